@@ -1,0 +1,188 @@
+"""ctypes front-end of the CPU oracle (oracle/sph_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: see oracle/sph_oracle.h.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER = range(9)
+F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_NBR_COUNT, F_FORCE_EXT = range(9, 16)
+F_WALL_POS, F_WALL_VOL = 32, 33
+_VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS}
+_WALL_FIELDS = {F_WALL_POS, F_WALL_VOL}
+
+
+class OrcConfig(ctypes.Structure):
+    _fields_ = [
+        ("box_min", ctypes.c_double * 3),
+        ("box_max", ctypes.c_double * 3),
+        ("particle_radius", ctypes.c_double),
+        ("gravity", ctypes.c_double),
+        ("delta_time", ctypes.c_double),
+        ("start_pos", ctypes.c_double * 3),
+        ("water_size", ctypes.c_double * 3),
+        ("boundary_handle", ctypes.c_int),
+        ("fs_couple", ctypes.c_int),
+        ("solver", ctypes.c_int),
+        ("num_threads", ctypes.c_int),
+    ]
+
+
+class OrcStepStats(ctypes.Structure):
+    _fields_ = [
+        ("n_div", ctypes.c_int),
+        ("n_dens", ctypes.c_int),
+        ("n_div_evals", ctypes.c_int),
+        ("div_first_err", ctypes.c_float),
+        ("div_err", ctypes.c_float),
+        ("dens_err", ctypes.c_float),
+        ("dt", ctypes.c_float),
+    ]
+
+
+def build(force=False):
+    """Compile liborc_f32.so / liborc_f64.so with gcc (oracle/Makefile)."""
+    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liborc_f32.so", "liborc_f64.so")):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+
+
+_libs = {}
+
+
+def _lib(precision):
+    if precision not in _libs:
+        build()
+        lib = ctypes.CDLL(os.path.join(_HERE, "liborc_%s.so" % precision))
+        lib.orc_create.restype = ctypes.c_void_p
+        lib.orc_create.argtypes = [ctypes.POINTER(OrcConfig)]
+        lib.orc_destroy.argtypes = [ctypes.c_void_p]
+        lib.orc_sizes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        lib.orc_get.restype = ctypes.c_long
+        lib.orc_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.orc_set.restype = ctypes.c_long
+        lib.orc_set.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.orc_get_scalar.restype = ctypes.c_double
+        lib.orc_get_scalar.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        for name in ("orc_build_grid", "orc_compute_rho", "orc_compute_alpha", "orc_compute_nbr_count"):
+            getattr(lib, name).argtypes = [ctypes.c_void_p]
+            getattr(lib, name).restype = None
+        lib.orc_step_wcsph.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_step_dfsph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
+        lib.orc_cubic_kernel.restype = ctypes.c_float
+        lib.orc_cubic_kernel.argtypes = [ctypes.c_float, ctypes.c_float]
+        lib.orc_cubic_kernel_derivative.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+        lib.orc_tait_pressure.restype = ctypes.c_float
+        lib.orc_tait_pressure.argtypes = [ctypes.c_float]
+        _libs[precision] = lib
+    return _libs[precision]
+
+
+def config_from_dict(config, solver=None, num_threads=1):
+    """Same JSON schema as the reference's config/*.json."""
+    scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
+    c = OrcConfig()
+    c.box_min[:] = [float(v) for v in scene["box_min"]]
+    c.box_max[:] = [float(v) for v in scene["box_max"]]
+    c.particle_radius = float(scene["particle_radius"])
+    c.gravity = float(scene["gravity"])
+    c.delta_time = float(sol["delta_time"])
+    c.start_pos[:] = [float(v) for v in fluid["start_pos"]]
+    c.water_size[:] = [float(v) for v in fluid["water_size"]]
+    c.boundary_handle = 1 if sol.get("boundary_handle", True) else 0
+    c.fs_couple = 1 if sol.get("fs_couple", True) else 0
+    name = solver or sol["name"]
+    c.solver = {"wcsph": 0, "dfsph": 1}[name]
+    c.num_threads = int(num_threads)
+    return c
+
+
+class Oracle:
+    """One simulation instance of the CPU restatement."""
+
+    def __init__(self, config, solver=None, num_threads=1, precision="f32"):
+        self._lib = _lib(precision)
+        self.cfg = config_from_dict(config, solver, num_threads)
+        self._h = self._lib.orc_create(ctypes.byref(self.cfg))
+        sz = (ctypes.c_int * 7)()
+        self._lib.orc_sizes(self._h, sz)
+        self.N, self.Nb, self.Nr = sz[0], sz[1], sz[2]
+        self.grid = (sz[3], sz[4], sz[5])
+        self.C = sz[6]
+        self.last_stats = OrcStepStats()
+
+    def close(self):
+        if self._h:
+            self._lib.orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _shape(self, field):
+        n = self.Nb if field in _WALL_FIELDS else self.N
+        return (n, 3) if field in _VEC_FIELDS else (n,)
+
+    def get(self, field):
+        out = np.empty(self._shape(field), dtype=np.float32)
+        n = self._lib.orc_get(self._h, field, out.ctypes.data)
+        assert n == out.size, (field, n, out.size)
+        return out
+
+    def set(self, field, values):
+        arr = np.ascontiguousarray(values, dtype=np.float32)
+        assert arr.shape == self._shape(field)
+        n = self._lib.orc_set(self._h, field, arr.ctypes.data)
+        assert n == arr.size
+
+    @property
+    def dt(self):
+        return self._lib.orc_get_scalar(self._h, 0)
+
+    @property
+    def particle_m(self):
+        return self._lib.orc_get_scalar(self._h, 2)
+
+    @property
+    def lost(self):
+        return int(self._lib.orc_get_scalar(self._h, 4))
+
+    def build_grid(self):
+        self._lib.orc_build_grid(self._h)
+
+    def compute_rho(self):
+        self._lib.orc_compute_rho(self._h)
+
+    def compute_alpha(self):
+        self._lib.orc_compute_alpha(self._h)
+
+    def compute_nbr_count(self):
+        self._lib.orc_compute_nbr_count(self._h)
+
+    def step_wcsph(self, nsteps=1):
+        self._lib.orc_step_wcsph(self._h, nsteps)
+
+    def step_dfsph(self, nsteps=1, max_dens_iter=0):
+        """Returns 1 if the (non-reference) density-iteration cap was hit."""
+        return self._lib.orc_step_dfsph(self._h, nsteps, max_dens_iter, ctypes.byref(self.last_stats))
+
+
+def cubic_kernel(r, h, precision="f32"):
+    return float(_lib(precision).orc_cubic_kernel(r, h))
+
+
+def cubic_kernel_derivative(rvec, h, precision="f32"):
+    r = np.ascontiguousarray(rvec, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    _lib(precision).orc_cubic_kernel_derivative(r.ctypes.data, h, out.ctypes.data)
+    return out
+
+
+def tait_pressure(rho, precision="f32"):
+    return float(_lib(precision).orc_tait_pressure(rho))

@@ -1,0 +1,984 @@
+/*
+ * sph_oracle.c -- CPU ORACLE (test infrastructure, see sph_oracle.h).  PARITY UNPINNED.
+ *
+ * Plain-C restatement of the reference's per-step SPH path, sweep by sweep, in the
+ * reference's own data flow: per-cell lists rebuilt every step, one 27-cell walk per
+ * sweep, separate accumulators per sweep, host-driven DFSPH loops.  Every function cites
+ * the reference file:line it restates (paths are relative to /root/reference).
+ *
+ * Arithmetic rules ([taichi-semantics]):
+ *   - fields and kernel locals are f32 (`real`), ints are i32;
+ *   - expressions made only of Python scalars are folded in f64, then rounded to f32;
+ *   - x ** n with integer n is exponentiation by squaring (r=1; while n: if n&1: r*=a; a*=a; n>>=1);
+ *   - vec.norm() = sqrt((x*x + y*y) + z*z); a.dot(b) = (ax*bx + ay*by) + az*bz;
+ *   - a % b on floats = a - b*floor(a/b);
+ *   - no FMA contraction, no re-association (build with -ffp-contract=off, no -ffast-math);
+ *   - cell-list order = single-thread append order: ascending particle index per cell.
+ * Deviations, all outside valid runs: a particle whose linear cell id is <0 or >=C is left
+ * out of the grid (reference: `> C`, ParticleSystem.py:393, id==C would write out of bounds)
+ * and keeps using the cell of its current position as walk centre (reference: stale
+ * belong_grid).  Residual means are accumulated in f64 in particle order (reference: f32
+ * atomics in nondeterministic order, dfsph_solver.py:140-141,276-277).
+ */
+#include "sph_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef ORC_REAL
+#define ORC_REAL float
+#endif
+typedef ORC_REAL real;
+
+#define R(x) ((real)(x))
+
+static inline real r_sqrt(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
+static inline real r_floor(real x) { return sizeof(real) == 4 ? (real)floorf((float)x) : (real)floor((double)x); }
+static inline real r_max(real a, real b) { return a > b ? a : b; }
+static inline real r_abs(real a) { return a < 0 ? -a : a; }
+
+struct Orc {
+    OrcConfig cfg;
+    int N, Nb, Nr;
+    int g[3], C;
+    int stride[3];         /* _3d_to_1d_tran = (1, gx*gz, gx)  ParticleSystem.py:102 */
+    /* constants, each rounded to f32 exactly where the reference would */
+    real h;                /* support_radius / kernel_h = 4r */
+    real m;                /* particle_m */
+    real d;                /* particle_diameter */
+    real rho0;             /* 1000 */
+    real gravity;
+    real visc_num;         /* 2*alpha*h*c_s folded in f64  solver_base.py:187 */
+    real visc_eps_h2;      /* eps*h*h folded in f64        solver_base.py:188 */
+    real tens_c;           /* -k/m*m folded in f64         solver_base.py:216 */
+    real neg_m;            /* -particle_m                  solver_base.py:189 */
+    real dt, dt2, ps_dt;   /* delta_time, delta_time_2, ps.delta_time (0-d f32 fields) */
+    real dt_cfl_num;       /* 0.4*r*2 folded in f64        dfsph_solver.py:112 */
+    int simulate_cnt;
+    int nt;
+    /* fluid particles */
+    real *pos, *vel, *acc;
+    int *cell3;            /* belong_grid */
+    /* wall particles */
+    real *bpos, *bvol;
+    int *bcell3;
+    /* cell lists: grids (fluid[+rigid] global indices) and boundary_grids (wall local indices) */
+    int *cstart, *citems;
+    int *bcstart, *bcitems;
+    /* solver fields */
+    real *rho, *pressure, *pgrad, *bacc, *visc, *tens;
+    real *alpha, *rho_adv, *rho_der, *vel_adv, *vel_adv_delta, *force_ext, *warm_k;
+    int *nbr_cnt;
+    long lost;
+};
+
+/* ---------------------------------------------------------------------------------------
+ * SPH kernels                                                         solver_base.py:74-103
+ * ------------------------------------------------------------------------------------- */
+static inline real pow3(real a) { return a * (a * a); }           /* r=a; a2=a*a; r=r*a2 */
+static inline real pow2(real a) { return a * a; }
+static inline real pow7(real a) { real a2 = a * a; real r3 = a * a2; real a4 = a2 * a2; return r3 * a4; }
+
+static const double ORC_PI = 3.141592653589793;
+
+/* solver_base.py:76-88 */
+static inline real cubic_kernel(real r, real h)
+{
+    real ret = 0;
+    real q = r / h;
+    real k = R(8) / (R(ORC_PI) * pow3(h));
+    if (R(0) <= q && q <= R(0.5)) {
+        real q2 = q * q;
+        real q3 = q2 * q;
+        ret = k * (R(6) * (q3 - q2) + R(1));
+    } else if (R(0.5) < q && q <= R(1)) {
+        ret = R(2) * k * pow3(R(1) - q);
+    } else {
+        ret = 0;
+    }
+    return ret;
+}
+
+/* solver_base.py:90-103 (keeps the reference's extra factor 6) */
+static inline void cubic_kernel_derivative(real rx, real ry, real rz, real h, real out[3])
+{
+    real r_norm = r_sqrt((rx * rx + ry * ry) + rz * rz);
+    real q = r_norm / h;
+    real k = R(48) / (R(ORC_PI) * pow3(h));
+    out[0] = out[1] = out[2] = 0;
+    if (R(1e-5) < q && q <= R(0.5)) {
+        real q2 = q * q;
+        real s = k * R(6) * (R(3) * q2 - R(2) * q);
+        real den = h * r_norm;
+        out[0] = s * rx / den;
+        out[1] = s * ry / den;
+        out[2] = s * rz / den;
+    } else if (R(0.5) < q && q <= R(1)) {
+        real s = -k * R(6) * pow2(R(1) - q);
+        real den = h * r_norm;
+        out[0] = s * rx / den;
+        out[1] = s * ry / den;
+        out[2] = s * rz / den;
+    }
+}
+
+float orc_cubic_kernel(float r, float h) { return (float)cubic_kernel(R(r), R(h)); }
+void orc_cubic_kernel_derivative(const float r[3], float h, float out[3])
+{
+    real o[3];
+    cubic_kernel_derivative(R(r[0]), R(r[1]), R(r[2]), R(h), o);
+    out[0] = (float)o[0]; out[1] = (float)o[1]; out[2] = (float)o[2];
+}
+/* wcsph_solver.py:86-90  (B=70000, gamma=7, rho_0=1000) */
+static inline real tait_pressure(real rho)
+{
+    real rho_i = r_max(rho, R(1000));
+    return R(70000) * (pow7(rho_i / R(1000)) - R(1.0));
+}
+float orc_tait_pressure(float rho) { return (float)tait_pressure(R(rho)); }
+
+/* ---------------------------------------------------------------------------------------
+ * grid helpers                                                    ParticleSystem.py:486-494
+ * ------------------------------------------------------------------------------------- */
+static inline void cell_of(const Orc *o, const real *p, int c[3])
+{
+    c[0] = (int)r_floor(p[0] / o->h);
+    c[1] = (int)r_floor(p[1] / o->h);
+    c[2] = (int)r_floor(p[2] / o->h);
+}
+static inline int cell_1d(const Orc *o, const int c[3])
+{
+    return c[0] * o->stride[0] + c[1] * o->stride[1] + c[2] * o->stride[2];
+}
+static inline int cell_valid(const Orc *o, int cx, int cy, int cz)
+{
+    /* ParticleSystem.py:453-456 */
+    if (cx >= o->g[0] || cy >= o->g[1] || cz >= o->g[2]) return 0;
+    if (cx < 0 || cy < 0 || cz < 0) return 0;
+    return 1;
+}
+
+/* counting sort by cell id, ascending index inside a cell (= single-thread append order) */
+static long build_lists(const Orc *o, int n, const real *pos, int *cell3, int *cstart, int *citems)
+{
+    int C = o->C;
+    long lost = 0;
+    memset(cstart, 0, sizeof(int) * (size_t)(C + 1));
+    int *ids = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+        int c[3];
+        cell_of(o, pos + 3 * i, c);
+        cell3[3 * i + 0] = c[0]; cell3[3 * i + 1] = c[1]; cell3[3 * i + 2] = c[2];
+        int id = cell_1d(o, c);
+        if (id < 0 || id >= C) { ids[i] = -1; ++lost; continue; }   /* ParticleSystem.py:393-395 */
+        ids[i] = id;
+        cstart[id + 1]++;
+    }
+    for (int c = 0; c < C; ++c) cstart[c + 1] += cstart[c];
+    int *fill = (int *)malloc(sizeof(int) * (size_t)C);
+    memcpy(fill, cstart, sizeof(int) * (size_t)C);
+    for (int i = 0; i < n; ++i)
+        if (ids[i] >= 0) citems[fill[ids[i]]++] = i;
+    free(fill);
+    free(ids);
+    return lost;
+}
+
+/* reset_grid + update_grid                               ParticleSystem.py:368-397 */
+void orc_build_grid(Orc *o)
+{
+    o->lost = build_lists(o, o->N, o->pos, o->cell3, o->cstart, o->citems);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * neighbour iteration macros.  They expand to the 27-cell walk of
+ * for_all_neighbor (ParticleSystem.py:447-469) / for_all_boundary_neighbor (:337-366):
+ * dx outermost, dz innermost, skip invalid cells, skip self, skip if |x_ij| > h.
+ * Inside BODY: j = neighbour index, (xij,yij,zij) = x_i - x_j.
+ * ------------------------------------------------------------------------------------- */
+#define FOR_FLUID_NEIGHBORS(o, i, ...)                                                         \
+    do {                                                                                       \
+        const real pix_ = (o)->pos[3 * (i)], piy_ = (o)->pos[3 * (i) + 1], piz_ = (o)->pos[3 * (i) + 2]; \
+        const int *cc_ = (o)->cell3 + 3 * (i);                                                 \
+        for (int dx_ = -1; dx_ <= 1; ++dx_)                                                    \
+            for (int dy_ = -1; dy_ <= 1; ++dy_)                                                \
+                for (int dz_ = -1; dz_ <= 1; ++dz_) {                                          \
+                    int cx_ = cc_[0] + dx_, cy_ = cc_[1] + dy_, cz_ = cc_[2] + dz_;            \
+                    if (!cell_valid((o), cx_, cy_, cz_)) continue;                             \
+                    int c1_ = cx_ * (o)->stride[0] + cy_ * (o)->stride[1] + cz_ * (o)->stride[2]; \
+                    for (int e_ = (o)->cstart[c1_]; e_ < (o)->cstart[c1_ + 1]; ++e_) {         \
+                        int j = (o)->citems[e_];                                               \
+                        if (j == (i)) continue;                                                \
+                        real xij = pix_ - (o)->pos[3 * j];                                     \
+                        real yij = piy_ - (o)->pos[3 * j + 1];                                 \
+                        real zij = piz_ - (o)->pos[3 * j + 2];                                 \
+                        if (r_sqrt((xij * xij + yij * yij) + zij * zij) > (o)->h) continue;    \
+                        __VA_ARGS__                                                            \
+                    }                                                                          \
+                }                                                                              \
+    } while (0)
+
+/* centre = fluid particle i (is_same_material = 0) */
+#define FOR_WALL_NEIGHBORS_OF_FLUID(o, i, ...)                                                 \
+    do {                                                                                       \
+        const real pix_ = (o)->pos[3 * (i)], piy_ = (o)->pos[3 * (i) + 1], piz_ = (o)->pos[3 * (i) + 2]; \
+        const int *cc_ = (o)->cell3 + 3 * (i);                                                 \
+        for (int dx_ = -1; dx_ <= 1; ++dx_)                                                    \
+            for (int dy_ = -1; dy_ <= 1; ++dy_)                                                \
+                for (int dz_ = -1; dz_ <= 1; ++dz_) {                                          \
+                    int cx_ = cc_[0] + dx_, cy_ = cc_[1] + dy_, cz_ = cc_[2] + dz_;            \
+                    if (!cell_valid((o), cx_, cy_, cz_)) continue;                             \
+                    int c1_ = cx_ * (o)->stride[0] + cy_ * (o)->stride[1] + cz_ * (o)->stride[2]; \
+                    for (int e_ = (o)->bcstart[c1_]; e_ < (o)->bcstart[c1_ + 1]; ++e_) {       \
+                        int j = (o)->bcitems[e_];                                              \
+                        real xij = pix_ - (o)->bpos[3 * j];                                    \
+                        real yij = piy_ - (o)->bpos[3 * j + 1];                                \
+                        real zij = piz_ - (o)->bpos[3 * j + 2];                                \
+                        if (r_sqrt((xij * xij + yij * yij) + zij * zij) > (o)->h) continue;    \
+                        __VA_ARGS__                                                            \
+                    }                                                                          \
+                }                                                                              \
+    } while (0)
+
+#define PARFOR _Pragma("omp parallel for schedule(static) num_threads(o->nt)")
+
+/* ---------------------------------------------------------------------------------------
+ * initialisation                                         ParticleSystem.py:78-103,129-195
+ * ------------------------------------------------------------------------------------- */
+static int boundary_particles_count(const OrcConfig *c)
+{
+    /* ParticleSystem.py:129-137, Python f64 */
+    double d = c->particle_radius * 2;
+    double bx = c->box_max[0] - c->box_min[0];
+    double by = c->box_max[1] - c->box_min[1];
+    double bz = c->box_max[2] - c->box_min[2];
+    int x_cnt = (int)(bx / d + 1);
+    int z_cnt = (int)(bz / d + 1);
+    int bottom = x_cnt * z_cnt;
+    int ring = x_cnt * z_cnt - (x_cnt - 2) * (z_cnt - 2);
+    int layer = (int)ceil((by - d) / d);
+    return layer * ring + bottom * 2;
+}
+
+static inline real fmod_py(real a, real b) { return a - b * r_floor(a / b); }
+
+/* ParticleSystem.py:139-195 */
+static void init_particle_pos(Orc *o)
+{
+    const OrcConfig *c = &o->cfg;
+    double dd = c->particle_radius * 2;
+    /* compile-time constants folded in f64, then f32 */
+    real x_num = R(c->water_size[0] / dd);
+    real z_num = R(c->water_size[2] / dd);
+    real xz_num = R((c->water_size[0] / dd) * (c->water_size[2] / dd));
+    real radius = R(c->particle_radius);
+    real sp[3] = { R(c->start_pos[0]), R(c->start_pos[1]), R(c->start_pos[2]) };
+    for (int i = 0; i < o->N; ++i) {
+        real fi = R(i);
+        real x = fmod_py(fi, x_num);                       /* :147 */
+        real z = fmod_py(r_floor(fi / x_num), z_num);      /* :148 */
+        int y = (int)(fi / xz_num);                        /* :149 */
+        o->pos[3 * i + 0] = x * radius * R(2) + sp[0];     /* :150 */
+        o->pos[3 * i + 1] = R(y) * radius * R(2) + sp[1];
+        o->pos[3 * i + 2] = z * radius * R(2) + sp[2];
+    }
+    /* walls: kernel-local f32 arithmetic on box                 :155-161 */
+    real d = o->d;
+    real boxx = R(c->box_max[0]) - R(c->box_min[0]);
+    real boxz = R(c->box_max[2]) - R(c->box_min[2]);
+    int x_cnt = (int)(boxx / d + R(1));
+    int z_cnt = (int)(boxz / d + R(1));
+    int xr = x_cnt - 1, zr = z_cnt - 1;
+    int bottom = x_cnt * z_cnt;
+    int ring = x_cnt * z_cnt - (x_cnt - 2) * (z_cnt - 2);
+    int Nb = o->Nb;
+    for (int i = 0; i < Nb; ++i) {
+        real x = 0, y = 0, z = 0;
+        if (i < bottom) {                                   /* :164-168 */
+            x = R(i % x_cnt) * d;
+            y = 0;
+            z = r_floor(R(i) / R(x_cnt)) * d;
+        } else if (i < Nb - bottom) {                       /* :169-189 */
+            int index = i - bottom;
+            int layer = (int)r_floor(R(index) / R(ring));
+            y = d * R(layer + 1);
+            index -= layer * ring;
+            index += 1;
+            if (index <= xr) {
+                x = R(index % xr) * d; z = 0;
+            } else if (index <= xr + zr) {
+                x = R(xr) * d; z = R((index - x_cnt) % zr) * d;
+            } else if (index <= 2 * xr + zr) {
+                x = R((2 * xr + zr - index) % xr + 1) * d; z = R(zr) * d;
+            } else if (index <= 2 * (xr + zr)) {
+                x = 0; z = R((2 * (xr + zr) - index) % zr + 1) * d;
+            }
+        } else {                                            /* :190-195 */
+            int index = i - (Nb - bottom);
+            x = R(index % x_cnt) * d;
+            y = R(c->box_max[1]);
+            z = R((int)(R(index) / R(x_cnt))) * d;
+        }
+        o->bpos[3 * i] = x; o->bpos[3 * i + 1] = y; o->bpos[3 * i + 2] = z;
+    }
+}
+
+/* compute_all_boundary_volume                            ParticleSystem.py:309-320 */
+static void compute_all_boundary_volume(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->Nb; ++i) {
+        real volume = 0;
+        const real pix = o->bpos[3 * i], piy = o->bpos[3 * i + 1], piz = o->bpos[3 * i + 2];
+        const int *cc = o->bcell3 + 3 * i;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    int cx = cc[0] + dx, cy = cc[1] + dy, cz = cc[2] + dz;
+                    if (!cell_valid(o, cx, cy, cz)) continue;
+                    int c1 = cx * o->stride[0] + cy * o->stride[1] + cz * o->stride[2];
+                    for (int e = o->bcstart[c1]; e < o->bcstart[c1 + 1]; ++e) {
+                        int j = o->bcitems[e];
+                        if (j == i) continue;                                   /* :362 */
+                        real xij = pix - o->bpos[3 * j], yij = piy - o->bpos[3 * j + 1], zij = piz - o->bpos[3 * j + 2];
+                        real q = r_sqrt((xij * xij + yij * yij) + zij * zij);
+                        if (q > o->h) continue;
+                        volume += cubic_kernel(q, o->h);                        /* :317-320 */
+                    }
+                }
+        o->bvol[i] = R(1.0) / volume;                                           /* :314 */
+    }
+}
+
+Orc *orc_create(const OrcConfig *cfg)
+{
+    Orc *o = (Orc *)calloc(1, sizeof(Orc));
+    o->cfg = *cfg;
+    const OrcConfig *c = &o->cfg;
+    double r = c->particle_radius;
+    double d = r * 2;                       /* ParticleSystem.py:81 */
+    double support = 4 * r;                 /* :82 */
+    double m = 1000 * (r * r * r) * 8;      /* :83 */
+    /* :85-86 left-to-right f64 */
+    o->N = (int)(c->water_size[0] / d * c->water_size[1] / d * c->water_size[2] / d);
+    o->Nb = boundary_particles_count(c);    /* :95 */
+    o->Nr = 0;
+    for (int a = 0; a < 3; ++a)             /* :100-101 */
+        o->g[a] = (int)ceil((c->box_max[a] - c->box_min[a]) / support) + 1;
+    o->stride[0] = 1; o->stride[1] = o->g[0] * o->g[2]; o->stride[2] = o->g[0];   /* :102 */
+    o->C = o->g[0] * o->g[1] * o->g[2];
+    o->h = R(support);
+    o->m = R(m);
+    o->d = R(d);
+    o->rho0 = R(1000);
+    o->gravity = R(c->gravity);
+    /* per-solver constants: wcsph_solver.py:17-22 vs solver_base.py:23-26 */
+    double c_s = c->solver == 0 ? 10 : 13;
+    double t_k = c->solver == 0 ? 0.2 : 0.5;
+    double kernel_h = r * 4;                /* solver_base.py:17 */
+    o->visc_num = R(2 * 0.08 * kernel_h * c_s);
+    o->visc_eps_h2 = R(0.01 * kernel_h * kernel_h);
+    o->tens_c = R(-t_k / m * m);
+    o->neg_m = R(-m);
+    o->dt = R(c->delta_time);
+    o->dt2 = R((real)R(c->delta_time) * (real)R(c->delta_time));   /* dfsph_solver.py:20: f32 field ** 2 */
+    o->ps_dt = 0;
+    o->dt_cfl_num = R(0.4 * r * 2);
+    o->nt = c->num_threads > 0 ? c->num_threads : 1;
+
+    size_t N = (size_t)(o->N > 0 ? o->N : 1), Nb = (size_t)(o->Nb > 0 ? o->Nb : 1);
+#define ALLOC(ptr, type, n) ptr = (type *)calloc((n), sizeof(type))
+    ALLOC(o->pos, real, 3 * N); ALLOC(o->vel, real, 3 * N); ALLOC(o->acc, real, 3 * N);
+    ALLOC(o->cell3, int, 3 * N);
+    ALLOC(o->bpos, real, 3 * Nb); ALLOC(o->bvol, real, Nb); ALLOC(o->bcell3, int, 3 * Nb);
+    ALLOC(o->cstart, int, (size_t)o->C + 1); ALLOC(o->citems, int, N);
+    ALLOC(o->bcstart, int, (size_t)o->C + 1); ALLOC(o->bcitems, int, Nb);
+    ALLOC(o->rho, real, N); ALLOC(o->pressure, real, N); ALLOC(o->pgrad, real, 3 * N);
+    ALLOC(o->bacc, real, 3 * N); ALLOC(o->visc, real, 3 * N); ALLOC(o->tens, real, 3 * N);
+    ALLOC(o->alpha, real, N); ALLOC(o->rho_adv, real, N); ALLOC(o->rho_der, real, N);
+    ALLOC(o->vel_adv, real, 3 * N); ALLOC(o->vel_adv_delta, real, 3 * N);
+    ALLOC(o->force_ext, real, 3 * N); ALLOC(o->warm_k, real, N);
+    ALLOC(o->nbr_cnt, int, N);
+#undef ALLOC
+    init_particle_pos(o);                                       /* ParticleSystem.py:119 */
+    /* init_particles_data                                         :225-247 */
+    build_lists(o, o->Nb, o->bpos, o->bcell3, o->bcstart, o->bcitems);   /* :237-238 */
+    orc_build_grid(o);                                                   /* :240-241 */
+    compute_all_boundary_volume(o);                                      /* :243 */
+    return o;
+}
+
+void orc_destroy(Orc *o)
+{
+    if (!o) return;
+    free(o->pos); free(o->vel); free(o->acc); free(o->cell3);
+    free(o->bpos); free(o->bvol); free(o->bcell3);
+    free(o->cstart); free(o->citems); free(o->bcstart); free(o->bcitems);
+    free(o->rho); free(o->pressure); free(o->pgrad); free(o->bacc); free(o->visc); free(o->tens);
+    free(o->alpha); free(o->rho_adv); free(o->rho_der); free(o->vel_adv); free(o->vel_adv_delta);
+    free(o->force_ext); free(o->warm_k); free(o->nbr_cnt);
+    free(o);
+}
+
+void orc_sizes(const Orc *o, int *out)
+{
+    out[0] = o->N; out[1] = o->Nb; out[2] = o->Nr;
+    out[3] = o->g[0]; out[4] = o->g[1]; out[5] = o->g[2]; out[6] = o->C;
+}
+
+static real *field_ptr(Orc *o, int field, long *count, int *is_int)
+{
+    *is_int = 0;
+    switch (field) {
+    case ORC_F_POS: *count = 3L * o->N; return o->pos;
+    case ORC_F_VEL: *count = 3L * o->N; return o->vel;
+    case ORC_F_ACC: *count = 3L * o->N; return o->acc;
+    case ORC_F_RHO: *count = o->N; return o->rho;
+    case ORC_F_PRESSURE: *count = o->N; return o->pressure;
+    case ORC_F_ALPHA: *count = o->N; return o->alpha;
+    case ORC_F_WARM_K: *count = o->N; return o->warm_k;
+    case ORC_F_RHO_ADV: *count = o->N; return o->rho_adv;
+    case ORC_F_RHO_DER: *count = o->N; return o->rho_der;
+    case ORC_F_VEL_ADV: *count = 3L * o->N; return o->vel_adv;
+    case ORC_F_VISCOSITY: *count = 3L * o->N; return o->visc;
+    case ORC_F_TENSION: *count = 3L * o->N; return o->tens;
+    case ORC_F_PGRAD: *count = 3L * o->N; return o->pgrad;
+    case ORC_F_BACC: *count = 3L * o->N; return o->bacc;
+    case ORC_F_FORCE_EXT: *count = 3L * o->N; return o->force_ext;
+    case ORC_F_WALL_POS: *count = 3L * o->Nb; return o->bpos;
+    case ORC_F_WALL_VOL: *count = o->Nb; return o->bvol;
+    case ORC_F_NBR_COUNT: *count = o->N; *is_int = 1; return NULL;
+    default: *count = -1; return NULL;
+    }
+}
+
+long orc_get(Orc *o, int field, float *out)
+{
+    long n; int is_int;
+    real *p = field_ptr(o, field, &n, &is_int);
+    if (n < 0) return -1;
+    if (is_int) { for (long i = 0; i < n; ++i) out[i] = (float)o->nbr_cnt[i]; return n; }
+    for (long i = 0; i < n; ++i) out[i] = (float)p[i];
+    return n;
+}
+
+long orc_set(Orc *o, int field, const float *in)
+{
+    long n; int is_int;
+    real *p = field_ptr(o, field, &n, &is_int);
+    if (n < 0 || is_int) return -1;
+    for (long i = 0; i < n; ++i) p[i] = R(in[i]);
+    return n;
+}
+
+double orc_get_scalar(const Orc *o, int which)
+{
+    switch (which) {
+    case 0: return (double)o->dt;
+    case 1: return (double)o->simulate_cnt;
+    case 2: return (double)o->m;
+    case 3: return (double)o->h;
+    case 4: return (double)o->lost;
+    default: return 0;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * shared sweeps                                                       solver_base.py:41-217
+ * ------------------------------------------------------------------------------------- */
+/* compute_all_rho                                                     solver_base.py:41-72 */
+void orc_compute_rho(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real rho = R(0.001);                                           /* :44 */
+        FOR_FLUID_NEIGHBORS(o, i, {
+            rho += o->m * cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);   /* :62 */
+        });
+        if (o->cfg.boundary_handle) {
+            real rho_boundary = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real q = r_sqrt((xij * xij + yij * yij) + zij * zij);
+                rho_boundary += o->bvol[j] * cubic_kernel(q, o->h);    /* :70-71 */
+            });
+            o->rho[i] = rho + rho_boundary * o->rho0;                  /* :49 */
+        } else {
+            o->rho[i] = rho;
+        }
+    }
+}
+
+/* solve_all_viscosity                                                solver_base.py:170-202 */
+static void solve_all_viscosity(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real vx = 0, vy = 0, vz = 0;
+        const real vix = o->vel[3 * i], viy = o->vel[3 * i + 1], viz = o->vel[3 * i + 2];
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real vijx = vix - o->vel[3 * j], vijy = viy - o->vel[3 * j + 1], vijz = viz - o->vel[3 * j + 2];
+            real shear = (vijx * xij + vijy * yij) + vijz * zij;        /* :183 */
+            if (shear < 0) {
+                real q = r_sqrt((xij * xij + yij * yij) + zij * zij);
+                real q2 = q * q;
+                real nu = o->visc_num / (o->rho[i] + o->rho[j]);        /* :187 */
+                real pi = -nu * shear / (q2 + o->visc_eps_h2);          /* :188 */
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->neg_m * pi;                                 /* :189 */
+                vx += s * gw[0]; vy += s * gw[1]; vz += s * gw[2];
+            }
+        });
+        o->visc[3 * i] = vx * o->m; o->visc[3 * i + 1] = vy * o->m; o->visc[3 * i + 2] = vz * o->m;   /* :175 */
+    }
+}
+
+/* solve_all_tension                                                  solver_base.py:204-217 */
+static void solve_all_tension(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real tx = 0, ty = 0, tz = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real w = cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);
+            real s = o->tens_c * w;                                     /* :216 */
+            tx += s * xij; ty += s * yij; tz += s * zij;
+        });
+        o->tens[3 * i] = tx * o->m; o->tens[3 * i + 1] = ty * o->m; o->tens[3 * i + 2] = tz * o->m;   /* :209 */
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * WCSPH                                                                    wcsph_solver.py
+ * ------------------------------------------------------------------------------------- */
+/* solve_all_pressure_gradient                                        wcsph_solver.py:70-129 */
+static void solve_all_pressure_gradient(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real rx = 0, ry = 0, rz = 0;
+        const real rho_i = o->rho[i];
+        const real rho_i_2 = rho_i * rho_i;                             /* :109 */
+        const real p_i = o->pressure[i];
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real p_j = o->pressure[j];
+            real rho_j = o->rho[j];
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real s = o->m * (p_i / rho_i_2 + p_j / (rho_j * rho_j));    /* :116 */
+            rx -= s * gw[0]; ry -= s * gw[1]; rz -= s * gw[2];
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->bvol[j] * p_i / rho_i_2;                    /* :99 */
+                bx -= s * gw[0]; by -= s * gw[1]; bz -= s * gw[2];
+            });
+            o->bacc[3 * i] = bx * o->rho0; o->bacc[3 * i + 1] = by * o->rho0; o->bacc[3 * i + 2] = bz * o->rho0;  /* :83 */
+        }
+        o->pgrad[3 * i] = rx; o->pgrad[3 * i + 1] = ry; o->pgrad[3 * i + 2] = rz;      /* :84 */
+    }
+}
+
+/* kinematic_phase                                                    wcsph_solver.py:40-63 */
+static void wcsph_kinematic_phase(Orc *o)
+{
+    real box_lo[3], box_hi[3];
+    for (int a = 0; a < 3; ++a) {
+        box_lo[a] = R(o->cfg.box_min[a]) + o->d;
+        box_hi[a] = R(o->cfg.box_max[a]) - o->d;
+    }
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            int k = 3 * i + a;
+            if (o->cfg.boundary_handle)
+                o->acc[k] += ((o->pgrad[k] + o->visc[k]) + o->tens[k]) + o->bacc[k];   /* :44-45 */
+            else
+                o->acc[k] += (o->pgrad[k] + o->visc[k]) + o->tens[k];                  /* :47 */
+            o->vel[k] += o->acc[k] * o->dt;                                            /* :50 */
+            o->vel[k] *= R(0.9998);                                                    /* :51 */
+            o->pos[k] += o->vel[k] * o->dt;                                            /* :52 */
+        }
+        if (!o->cfg.boundary_handle) {                                                 /* :54-63 */
+            for (int a = 0; a < 3; ++a) {
+                int k = 3 * i + a;
+                if (o->pos[k] <= box_lo[a]) { o->pos[k] = box_lo[a]; o->vel[k] *= R(-0.5); }
+                if (o->pos[k] >= box_hi[a]) { o->pos[k] = box_hi[a]; o->vel[k] *= R(-0.5); }
+            }
+        }
+    }
+}
+
+/* wcsph_solver.step                                                  wcsph_solver.py:25-38 */
+int orc_step_wcsph(Orc *o, int nsteps)
+{
+    for (int s = 0; s < nsteps; ++s) {
+        o->simulate_cnt += 1;                                          /* solver_base.py:137 */
+        orc_build_grid(o);                                             /* :139-141 */
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {                               /* reset(): solver_base.py:131-133 */
+            o->acc[3 * i] = o->gravity * R(0.0);
+            o->acc[3 * i + 1] = o->gravity * R(-1.0);
+            o->acc[3 * i + 2] = o->gravity * R(0.0);
+        }
+        orc_compute_rho(o);                                            /* wcsph_solver.py:34 */
+        PARFOR
+        for (int i = 0; i < o->N; ++i) o->pressure[i] = tait_pressure(o->rho[i]);   /* :66-68 */
+        solve_all_pressure_gradient(o);                                /* :36 */
+        solve_all_viscosity(o);                                        /* :37 */
+        solve_all_tension(o);                                          /* :38 */
+        wcsph_kinematic_phase(o);                                      /* :30 */
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * DFSPH                                                                    dfsph_solver.py
+ * ------------------------------------------------------------------------------------- */
+/* get_neighbour_count for every fluid particle                   ParticleSystem.py:424-445 */
+void orc_compute_nbr_count(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        int cnt = 0;
+        FOR_FLUID_NEIGHBORS(o, i, { (void)xij; (void)yij; (void)zij; cnt += 1; });
+        o->nbr_cnt[i] = cnt;
+    }
+}
+
+/* compute_all_alpha                                                   dfsph_solver.py:32-89 */
+void orc_compute_alpha(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real sx = 0, sy = 0, sz = 0;       /* sum_square   (:38, compute_sum)        */
+        real square_sum = 0;               /* square_sum   (:39, compute_square_sum) */
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real rx = o->m * gw[0], ry = o->m * gw[1], rz = o->m * gw[2];           /* :58, :70 */
+            sx += rx; sy += ry; sz += rz;
+            square_sum += (rx * rx + ry * ry) + rz * rz;                            /* :71 */
+        });
+        real denominator;
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0, bsq = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real c = o->bvol[j] * o->rho0;                                      /* :82, :88 */
+                real rx = c * gw[0], ry = c * gw[1], rz = c * gw[2];
+                bx += rx; by += ry; bz += rz;
+                bsq += (rx * rx + ry * ry) + rz * rz;
+            });
+            denominator = ((((sx * sx + sy * sy) + sz * sz) + square_sum) + bsq) + ((bx * bx + by * by) + bz * bz);  /* :45 */
+        } else {
+            denominator = ((sx * sx + sy * sy) + sz * sz) + square_sum;             /* :47 */
+        }
+        if (r_abs(denominator) < R(1e-6)) o->alpha[i] = 0;                          /* :48-51 */
+        else o->alpha[i] = o->rho[i] / denominator;
+    }
+}
+
+/* divergence_warm_start                                            dfsph_solver.py:314-355 */
+static void divergence_warm_start(Orc *o)
+{
+    real *nv = o->vel_adv_delta;   /* scratch: callbacks never read vel, so in-place == buffered */
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real ax = 0, ay = 0, az = 0;
+        const real k_i = o->warm_k[i] / o->dt;                                      /* :333 */
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real k_j = o->warm_k[j] / o->dt;                                        /* :334 */
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real s = o->m * (k_i / o->rho[i] + k_j / o->rho[j]);                    /* :337 */
+            ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->bvol[j] * k_i / o->rho[i];                              /* :354 */
+                bx += s * gw[0]; by += s * gw[1]; bz += s * gw[2];
+            });
+            nv[3 * i] = o->vel[3 * i] - (ax + bx * o->rho0) * o->dt;                /* :322 */
+            nv[3 * i + 1] = o->vel[3 * i + 1] - (ay + by * o->rho0) * o->dt;
+            nv[3 * i + 2] = o->vel[3 * i + 2] - (az + bz * o->rho0) * o->dt;
+        } else {
+            nv[3 * i] = o->vel[3 * i] - ax * o->dt;                                 /* :324 */
+            nv[3 * i + 1] = o->vel[3 * i + 1] - ay * o->dt;
+            nv[3 * i + 2] = o->vel[3 * i + 2] - az * o->dt;
+        }
+    }
+    memcpy(o->vel, nv, sizeof(real) * 3 * (size_t)o->N);
+    memset(o->warm_k, 0, sizeof(real) * (size_t)o->N);                              /* :325 */
+}
+
+/* derivative_iter_all_rho                                          dfsph_solver.py:252-300 */
+static real derivative_iter_all_rho(Orc *o)
+{
+    orc_compute_nbr_count(o);                                                       /* :258 */
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        if (o->nbr_cnt[i] < 20) { o->rho_der[i] = 0; continue; }                    /* :259-261 */
+        real rd = 0;
+        const real vix = o->vel[3 * i], viy = o->vel[3 * i + 1], viz = o->vel[3 * i + 2];
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real dvx = vix - o->vel[3 * j], dvy = viy - o->vel[3 * j + 1], dvz = viz - o->vel[3 * j + 2];
+            rd += o->m * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);               /* :287 */
+        });
+        if (o->cfg.boundary_handle) {
+            real rb = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                rb += o->bvol[j] * ((vix * gw[0] + viy * gw[1]) + viz * gw[2]);     /* :300 */
+            });
+            o->rho_der[i] = r_max(rd + rb * o->rho0, R(0.0));                       /* :267 */
+        } else {
+            o->rho_der[i] = r_max(rd, R(0.0));                                      /* :269 */
+        }
+    }
+    double avg = 0; long cnt = 0;                                                   /* :275-280 */
+    for (int i = 0; i < o->N; ++i)
+        if (o->rho_der[i] > 0) { cnt += 1; avg += (double)o->rho_der[i]; }
+    real ret = 0;
+    if (cnt > 0) ret = R(avg / (double)cnt);
+    return ret;
+}
+
+/* divergence_iter_all_vel_adv + sum_up_stiff                  dfsph_solver.py:302-312,357-391 */
+static void divergence_iter_all_vel_adv(Orc *o)
+{
+    real *nv = o->vel_adv_delta;
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real ax = 0, ay = 0, az = 0;
+        const real k_i = o->rho_der[i] * o->alpha[i] / o->dt;                       /* :363 */
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real k_j = o->rho_der[j] * o->alpha[j] / o->dt;                         /* :364 */
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real ks = k_i / o->rho[i] + k_j / o->rho[j];
+            if (ks > R(1e-5)) {                                                     /* :367 */
+                real s = o->m * ks;                                                 /* :369 */
+                ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+            }
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->bvol[j] * k_i / o->rho[i];                              /* :390 */
+                bx += s * gw[0]; by += s * gw[1]; bz += s * gw[2];
+            });
+            nv[3 * i] = o->vel[3 * i] - (ax + bx * o->rho0) * o->dt;                /* :310 */
+            nv[3 * i + 1] = o->vel[3 * i + 1] - (ay + by * o->rho0) * o->dt;
+            nv[3 * i + 2] = o->vel[3 * i + 2] - (az + bz * o->rho0) * o->dt;
+        } else {
+            nv[3 * i] = o->vel[3 * i] - ax * o->dt;                                 /* :312 */
+            nv[3 * i + 1] = o->vel[3 * i + 1] - ay * o->dt;
+            nv[3 * i + 2] = o->vel[3 * i + 2] - az * o->dt;
+        }
+    }
+    memcpy(o->vel, nv, sizeof(real) * 3 * (size_t)o->N);
+}
+
+static void sum_up_stiff(Orc *o)                                     /* dfsph_solver.py:381-384 */
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) o->warm_k[i] += o->rho_der[i] * o->alpha[i];
+}
+
+/* correct_divergence_error                                         dfsph_solver.py:393-416 */
+static void correct_divergence_error(Orc *o, OrcStepStats *st)
+{
+    real past = 0;
+    int iter_cnt = 0;
+    divergence_warm_start(o);                                                       /* :396-397 */
+    real err = derivative_iter_all_rho(o);                                          /* :398 */
+    st->n_div_evals = 1;
+    st->div_first_err = (float)err;
+    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {                  /* :400 (host f64 compare) */
+        divergence_iter_all_vel_adv(o);
+        sum_up_stiff(o);
+        past = err;
+        err = derivative_iter_all_rho(o);
+        st->n_div_evals += 1;
+        if (fabs((double)err - (double)past) < 1e-5) break;                         /* :410-412 (host f64) */
+        iter_cnt += 1;
+    }
+    st->n_div = iter_cnt;
+    st->div_err = (float)err;
+}
+
+/* compute_all_ext_force                                              dfsph_solver.py:91-96 */
+static void compute_all_ext_force(Orc *o)
+{
+    solve_all_tension(o);
+    solve_all_viscosity(o);
+    const real g[3] = { o->gravity * R(0), o->gravity * R(-1), o->gravity * R(0) };
+    PARFOR
+    for (int i = 0; i < o->N; ++i)
+        for (int a = 0; a < 3; ++a)
+            o->force_ext[3 * i + a] = (g[a] + o->tens[3 * i + a]) + o->visc[3 * i + a];   /* :96 */
+}
+
+/* compute_all_vel_adv                                               dfsph_solver.py:98-122 */
+static void compute_all_vel_adv(Orc *o)
+{
+    real max_vel = -INFINITY;
+    PARFOR
+    for (int i = 0; i < o->N; ++i)
+        for (int a = 0; a < 3; ++a)
+            o->vel_adv[3 * i + a] = o->vel[3 * i + a] + o->dt * o->force_ext[3 * i + a] / o->m;   /* :102 */
+    for (int i = 0; i < o->N; ++i) {
+        real x = o->vel_adv[3 * i], y = o->vel_adv[3 * i + 1], z = o->vel_adv[3 * i + 2];
+        real n = r_sqrt((x * x + y * y) + z * z);
+        if (n > max_vel) max_vel = n;                                               /* :103 */
+    }
+    real max_rigid_vel = 0;                                                         /* :104-110, no rigid */
+    max_vel += max_rigid_vel;
+    real max_delta_time = o->dt_cfl_num / max_vel * R(0.2);                         /* :112 */
+    if (max_delta_time > R(1e-3)) o->dt = R(1e-3);                                  /* :114-117 */
+    else o->dt = r_max(max_delta_time, R(1e-5));
+    o->dt2 = o->dt * o->dt;                                                         /* :118 */
+    o->ps_dt = o->dt;                                                               /* :119 */
+}
+
+/* compute_all_rho_adv                                              dfsph_solver.py:124-176 */
+static real compute_all_rho_adv(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real delta = 0;
+        const real vix = o->vel_adv[3 * i], viy = o->vel_adv[3 * i + 1], viz = o->vel_adv[3 * i + 2];
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real dvx = vix - o->vel_adv[3 * j], dvy = viy - o->vel_adv[3 * j + 1], dvz = viz - o->vel_adv[3 * j + 2];
+            delta += o->m * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);            /* :162 */
+        });
+        if (o->cfg.boundary_handle) {
+            real db = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                db += o->bvol[j] * ((vix * gw[0] + viy * gw[1]) + viz * gw[2]);     /* :176 */
+            });
+            o->rho_adv[i] = r_max(o->rho[i] + o->dt * (delta + db * o->rho0), o->rho0);   /* :135 */
+        } else {
+            o->rho_adv[i] = r_max(o->rho[i] + o->dt * delta, o->rho0);              /* :137 */
+        }
+    }
+    double rho_avg = 0; long cnt = 0;                                               /* :139-141 */
+    for (int i = 0; i < o->N; ++i)
+        if (!(o->rho_adv[i] == o->rho0)) { rho_avg += (double)o->rho_adv[i]; cnt += 1; }
+    real ret = R(1000.0);
+    if (cnt > 0) ret = R(rho_avg / (double)cnt);                                    /* :148-149 */
+    return ret;
+}
+
+/* iter_all_vel_adv                                                 dfsph_solver.py:178-219 */
+static void iter_all_vel_adv(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real ax = 0, ay = 0, az = 0;
+        const real k_i = (o->rho_adv[i] - o->rho0) * o->alpha[i] / o->dt2;          /* :199 */
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real k_j = (o->rho_adv[j] - o->rho0) * o->alpha[j] / o->dt2;            /* :200 */
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real s = o->m * (k_i / o->rho[i] + k_j / o->rho[j]);                    /* :203 */
+            ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->bvol[j] * k_i / o->rho[i];                              /* :219 */
+                bx += s * gw[0]; by += s * gw[1]; bz += s * gw[2];
+            });
+            o->vel_adv_delta[3 * i] = ax + bx * o->rho0;                            /* :187 */
+            o->vel_adv_delta[3 * i + 1] = ay + by * o->rho0;
+            o->vel_adv_delta[3 * i + 2] = az + bz * o->rho0;
+        } else {
+            o->vel_adv_delta[3 * i] = ax; o->vel_adv_delta[3 * i + 1] = ay; o->vel_adv_delta[3 * i + 2] = az;
+        }
+    }
+    PARFOR
+    for (int i = 0; i < 3 * o->N; ++i) o->vel_adv[i] -= o->vel_adv_delta[i] * o->dt;   /* :190-191 */
+}
+
+/* compute_all_position                                             dfsph_solver.py:235-250 */
+static void compute_all_position(Orc *o)
+{
+    real lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = R(o->cfg.box_min[a]) + R(o->cfg.particle_radius);
+        hi[a] = R(o->cfg.box_max[a]) - R(o->cfg.particle_radius);
+    }
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            int k = 3 * i + a;
+            o->pos[k] = o->pos[k] + o->dt * o->vel_adv[k] * R(0.9999);              /* :238 */
+            o->vel[k] = o->vel_adv[k] * R(0.9999);                                  /* :239 */
+        }
+        if (!o->cfg.boundary_handle) {                                              /* :241-250 */
+            for (int a = 0; a < 3; ++a) {
+                int k = 3 * i + a;
+                if (o->pos[k] <= lo[a]) { o->pos[k] = lo[a]; o->vel[k] *= R(-0.5); }
+                if (o->pos[k] >= hi[a]) { o->pos[k] = hi[a]; o->vel[k] *= R(-0.5); }
+            }
+        }
+    }
+}
+
+/* dfsph_solver.step                                                dfsph_solver.py:440-445 */
+int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last)
+{
+    int capped = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        OrcStepStats st;
+        memset(&st, 0, sizeof(st));
+        o->simulate_cnt += 1;                                          /* solver_base.py:137 */
+        orc_build_grid(o);                                             /* :139-141; reset() is a no-op, dfsph:418-421 */
+        orc_compute_rho(o);                                            /* initialize(): dfsph:423-426 */
+        orc_compute_alpha(o);
+        correct_divergence_error(o, &st);                              /* iterate(): :428-438 */
+        compute_all_ext_force(o);
+        compute_all_vel_adv(o);
+        {                                                              /* correct_density_error :221-233 */
+            real rho_avg = INFINITY;
+            int iter_cnt = 0;
+            while (iter_cnt < 2 || (double)rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {      /* :225 (host f64) */
+                if (max_dens_iter > 0 && iter_cnt >= max_dens_iter) { capped = 1; break; }
+                rho_avg = compute_all_rho_adv(o);
+                iter_all_vel_adv(o);
+                iter_cnt += 1;
+            }
+            st.n_dens = iter_cnt;
+            st.dens_err = (float)(rho_avg - o->rho0);
+        }
+        compute_all_position(o);
+        st.dt = (float)o->dt;
+        if (last) *last = st;
+    }
+    return capped;
+}

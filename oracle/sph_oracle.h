@@ -1,0 +1,88 @@
+/*
+ * sph_oracle.h -- CPU ORACLE for the SPH per-step path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the arithmetic in the reference
+ * (Jukgei/CFD_Taichi @ 2024_08_07): ParticleSystem.py, solver_base.py,
+ * wcsph_solver.py, dfsph_solver.py.  It is NOT Taichi and NOT the reference itself.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this
+ * path, and its runtime (taichi==1.6.0) is not installed in this image (plain
+ * ModuleNotFoundError; nothing was refused), so the restatement is pinned only by the
+ * analytic known-answer tests in tests/golden/kats.json.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (cfd_taichi_amd/) never links, imports or calls it.
+ *
+ * Conventions: all field arithmetic is f32 (ORC_REAL=float; build
+ * with -DORC_REAL=double for the f64 error-attribution variant), FP contraction off,
+ * Python-scalar sub-expressions are folded in f64 and then rounded to f32; cell lists
+ * are in the single-thread Taichi order: ascending particle index inside a cell.
+ */
+#ifndef SPH_ORACLE_H
+#define SPH_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcConfig {
+    double box_min[3];
+    double box_max[3];
+    double particle_radius;
+    double gravity;
+    double delta_time;
+    double start_pos[3];
+    double water_size[3];
+    int boundary_handle; /* 1 = Akinci wall particles (default), 0 = clamp walls */
+    int fs_couple;       /* unused until rigid coupling is restated */
+    int solver;          /* 0 = wcsph, 1 = dfsph */
+    int num_threads;     /* OpenMP threads for the sweeps; results do not depend on it */
+} OrcConfig;
+
+typedef struct OrcStepStats {
+    int n_div;          /* divergence-solver iteration count printed at dfsph_solver.py:416 */
+    int n_dens;         /* density-solver iteration count printed at dfsph_solver.py:233 */
+    int n_div_evals;    /* number of derivative_iter_all_rho evaluations this step */
+    float div_first_err;
+    float div_err;
+    float dens_err;     /* rho_avg - rho_0 */
+    float dt;           /* delta_time after the step */
+} OrcStepStats;
+
+/* field ids for orc_get / orc_set (fluid particles unless stated) */
+enum {
+    ORC_F_POS = 0, ORC_F_VEL = 1, ORC_F_ACC = 2, ORC_F_RHO = 3, ORC_F_PRESSURE = 4,
+    ORC_F_ALPHA = 5, ORC_F_WARM_K = 6, ORC_F_RHO_ADV = 7, ORC_F_RHO_DER = 8,
+    ORC_F_VEL_ADV = 9, ORC_F_VISCOSITY = 10, ORC_F_TENSION = 11, ORC_F_PGRAD = 12,
+    ORC_F_BACC = 13, ORC_F_NBR_COUNT = 14, ORC_F_FORCE_EXT = 15,
+    ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33
+};
+
+typedef struct Orc Orc;
+
+Orc *orc_create(const OrcConfig *cfg);
+void orc_destroy(Orc *o);
+/* out[0]=N fluid, out[1]=Nb wall, out[2]=Nr rigid, out[3..5]=grid_num, out[6]=C */
+void orc_sizes(const Orc *o, int *out7);
+/* copies the whole field as float (3 floats per particle for vectors); returns element count or -1 */
+long orc_get(Orc *o, int field, float *out);
+long orc_set(Orc *o, int field, const float *in);
+double orc_get_scalar(const Orc *o, int which); /* 0 dt, 1 simulate_cnt, 2 particle_m, 3 h */
+
+void orc_build_grid(Orc *o);               /* reset_grid + update_grid */
+void orc_compute_rho(Orc *o);              /* solver_base.compute_all_rho */
+void orc_compute_alpha(Orc *o);            /* dfsph compute_all_alpha (needs rho) */
+void orc_compute_nbr_count(Orc *o);        /* get_neighbour_count for all i -> ORC_F_NBR_COUNT */
+int orc_step_wcsph(Orc *o, int nsteps);
+/* max_dens_iter <= 0 means "no cap" like the reference */
+int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last);
+
+/* scalar kernels, for the known-answer tests */
+float orc_cubic_kernel(float r, float h);
+void orc_cubic_kernel_derivative(const float r[3], float h, float out[3]);
+float orc_tait_pressure(float rho);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
