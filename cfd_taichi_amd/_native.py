@@ -1,0 +1,258 @@
+"""ctypes binding of libsph_mi355x.so (include/sph_mi355x.h).
+
+The library is the product: there is no CPU fallback and nothing here imports oracle/.
+If the shared object is missing it is built with hipcc (cfd_taichi_amd/build.py); if that is
+impossible, or no gfx950 device is visible when a simulation is created, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SPH_OK = 0
+SPH_E_INVALID, SPH_E_HIP, SPH_E_NO_DEVICE, SPH_E_OVERFLOW, SPH_E_STATE = -1, -2, -3, -4, -5
+SOLVER_WCSPH, SOLVER_DFSPH = 0, 1
+SPECIES_FLUID, SPECIES_WALL, SPECIES_RIGID = 0, 1, 2
+F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER, F_VEL_ADV = range(10)
+F_NBR_COUNT = 14
+F_WALL_POS, F_WALL_VOL = 32, 33
+S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME = range(5)
+VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS}
+
+EXPORTS = [
+    "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
+    "sph_step_wcsph", "sph_step_dfsph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
+    "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
+    "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math",
+]
+
+
+class SphConfig(ctypes.Structure):
+    _fields_ = [
+        ("box_min", ctypes.c_double * 3),
+        ("box_max", ctypes.c_double * 3),
+        ("particle_radius", ctypes.c_double),
+        ("gravity", ctypes.c_double),
+        ("delta_time", ctypes.c_double),
+        ("start_pos", ctypes.c_double * 3),
+        ("water_size", ctypes.c_double * 3),
+        ("boundary_handle", ctypes.c_int32),
+        ("fs_couple", ctypes.c_int32),
+        ("solver", ctypes.c_int32),
+        ("device", ctypes.c_int32),
+        ("max_neighbors", ctypes.c_int32),
+        ("max_wall_neighbors", ctypes.c_int32),
+        ("max_density_iters", ctypes.c_int32),
+        ("slab_rank", ctypes.c_int32),
+        ("slab_count", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+class SphSizes(ctypes.Structure):
+    _fields_ = [
+        ("n_fluid", ctypes.c_int32),
+        ("n_wall", ctypes.c_int32),
+        ("n_rigid", ctypes.c_int32),
+        ("grid", ctypes.c_int32 * 3),
+        ("n_cells", ctypes.c_int32),
+        ("max_neighbors", ctypes.c_int32),
+        ("max_wall_neighbors", ctypes.c_int32),
+    ]
+
+
+class SphStepStats(ctypes.Structure):
+    _fields_ = [
+        ("n_div", ctypes.c_int32),
+        ("n_dens", ctypes.c_int32),
+        ("n_div_evals", ctypes.c_int32),
+        ("capped", ctypes.c_int32),
+        ("div_first_err", ctypes.c_float),
+        ("div_err", ctypes.c_float),
+        ("dens_err", ctypes.c_float),
+        ("dt", ctypes.c_float),
+        ("max_nbrs", ctypes.c_int32),
+        ("max_wall_nbrs", ctypes.c_int32),
+        ("lost", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load libsph_mi355x.so; raises RuntimeError if it cannot be found or built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError("%s is missing; run `python -m cfd_taichi_amd.build`" % path)
+        _build.build()
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise RuntimeError("cannot load %s (%s); the HIP extension is required, there is no CPU fallback" % (path, e))
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.sph_create.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(vp)]
+    lib.sph_create.restype = ci
+    lib.sph_destroy.argtypes = [vp]
+    lib.sph_destroy.restype = None
+    lib.sph_get_sizes.argtypes = [vp, ctypes.POINTER(SphSizes)]
+    lib.sph_last_error.argtypes = [vp]
+    lib.sph_last_error.restype = ctypes.c_char_p
+    lib.sph_upload.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
+    lib.sph_download.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
+    lib.sph_step_wcsph.argtypes = [vp, ci]
+    lib.sph_step_dfsph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
+    for name in ("sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_synchronize", "sph_profile_reset"):
+        getattr(lib, name).argtypes = [vp]
+    lib.sph_get_scalar.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    lib.sph_profile_enable.argtypes = [vp, ci]
+    lib.sph_profile_kernel_count.argtypes = []
+    lib.sph_profile_kernel_name.argtypes = [ci]
+    lib.sph_profile_kernel_name.restype = ctypes.c_char_p
+    lib.sph_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+    lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
+    _lib = lib
+    return lib
+
+
+class SphError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libsph_mi355x error %d: %s" % (code, message))
+        self.code = code
+
+
+def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0):
+    """Flatten a reference-style config dict (config/*.json schema) into SphConfig."""
+    scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
+    name = solver_name or sol["name"]
+    if name not in ("wcsph", "dfsph"):
+        raise ValueError("solver '%s' is outside the MI355X hot path (wcsph, dfsph)" % name)
+    c = SphConfig()
+    c.box_min[:] = [float(v) for v in scene["box_min"]]
+    c.box_max[:] = [float(v) for v in scene["box_max"]]
+    c.particle_radius = float(scene["particle_radius"])
+    c.gravity = float(scene["gravity"])
+    c.delta_time = float(sol["delta_time"])
+    c.start_pos[:] = [float(v) for v in fluid["start_pos"]]
+    c.water_size[:] = [float(v) for v in fluid["water_size"]]
+    c.boundary_handle = 1 if sol.get("boundary_handle", True) else 0   # solver_base.py:31
+    c.fs_couple = 1 if sol.get("fs_couple", True) else 0              # solver_base.py:32
+    c.solver = SOLVER_WCSPH if name == "wcsph" else SOLVER_DFSPH
+    c.device = int(device)
+    c.max_neighbors = int(max_neighbors)
+    c.max_wall_neighbors = int(max_wall_neighbors)
+    c.max_density_iters = int(max_density_iters)
+    return c
+
+
+class Simulation:
+    """Owns one SphHandle: device buffers of one ParticleSystem + one fluid solver."""
+
+    def __init__(self, cfg):
+        self._lib = load()
+        self.cfg = cfg
+        handle = ctypes.c_void_p()
+        rc = self._lib.sph_create(ctypes.byref(cfg), ctypes.byref(handle))
+        if rc != SPH_OK:
+            raise SphError(rc, (self._lib.sph_last_error(None) or b"").decode())
+        self._h = handle
+        sizes = SphSizes()
+        self._check(self._lib.sph_get_sizes(self._h, ctypes.byref(sizes)))
+        self.n_fluid, self.n_wall, self.n_rigid = sizes.n_fluid, sizes.n_wall, sizes.n_rigid
+        self.grid = tuple(sizes.grid)
+        self.n_cells = sizes.n_cells
+        self.max_neighbors, self.max_wall_neighbors = sizes.max_neighbors, sizes.max_wall_neighbors
+        self.last_stats = SphStepStats()
+
+    def _check(self, rc):
+        if rc != SPH_OK:
+            raise SphError(rc, (self._lib.sph_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, species, field):
+        n = self.n_wall if species == SPECIES_WALL else self.n_fluid
+        return (n, 3) if field in VECTOR_FIELDS else (n,)
+
+    def download(self, field, species=SPECIES_FLUID):
+        out = np.empty(self._shape(species, field), dtype=np.float32)
+        self._check(self._lib.sph_download(self._h, species, field, out.ctypes.data, out.size))
+        return out
+
+    def upload(self, field, values, species=SPECIES_FLUID):
+        arr = np.ascontiguousarray(values, dtype=np.float32)
+        if arr.shape != self._shape(species, field):
+            raise ValueError("expected shape %s, got %s" % (self._shape(species, field), arr.shape))
+        self._check(self._lib.sph_upload(self._h, species, field, arr.ctypes.data, arr.size))
+
+    def step_wcsph(self, nsteps=1):
+        self._check(self._lib.sph_step_wcsph(self._h, nsteps))
+
+    def step_dfsph(self, nsteps=1):
+        self._check(self._lib.sph_step_dfsph(self._h, nsteps, ctypes.byref(self.last_stats)))
+        return self.last_stats
+
+    def build_neighbors(self):
+        self._check(self._lib.sph_build_neighbors(self._h))
+
+    def compute_density(self):
+        self._check(self._lib.sph_compute_density(self._h))
+
+    def compute_alpha(self):
+        self._check(self._lib.sph_compute_alpha(self._h))
+
+    def scalar(self, which):
+        out = ctypes.c_double()
+        self._check(self._lib.sph_get_scalar(self._h, which, ctypes.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        self._check(self._lib.sph_synchronize(self._h))
+
+    # ---- profiling (HIP events on the handle's stream) ----
+    def profile_enable(self, on=True):
+        self._check(self._lib.sph_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.sph_profile_reset(self._h))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} for kernels launched while profiling was on."""
+        res = {}
+        for k in range(self._lib.sph_profile_kernel_count()):
+            ms, n = ctypes.c_double(), ctypes.c_int64()
+            self._check(self._lib.sph_profile_get(self._h, k, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                res[self._lib.sph_profile_kernel_name(k).decode()] = (ms.value, n.value)
+        return res
+
+
+def selftest_math(op, a, b, device=0):
+    lib = load()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty_like(a)
+    rc = lib.sph_selftest_math(device, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    if rc != SPH_OK:
+        raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
+    return out

@@ -1,0 +1,54 @@
+"""Builds libsph_mi355x.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+Flags that are part of the arithmetic contract (see csrc/sph_device.h):
+  -ffp-contract=off                          no FMA contraction: products and sums round separately
+  -fhip-fp32-correctly-rounded-divide-sqrt   IEEE f32 divide / sqrt on the device
+  (no -ffast-math, denormals kept)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libsph_mi355x.so")
+SOURCES = ["sph_mi355x.hip"]
+HEADERS = ["sph_device.h", "sph_kernels.h", os.path.join("..", "..", "include", "sph_mi355x.h")]
+
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libsph_mi355x.so cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + FLAGS + list(extra) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=["-Rpass-analysis=kernel-resource-usage"] if "--resources" in sys.argv else [])
+    print(LIB)

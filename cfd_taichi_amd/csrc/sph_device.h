@@ -1,0 +1,144 @@
+// sph_device.h -- shared structs and device-side SPH math for the gfx950 kernels.
+//
+// Arithmetic contract: every expression below is written with the association the reference
+// source text has (solver_base.py:74-103 and the per-pair callbacks of wcsph_solver.py /
+// dfsph_solver.py), evaluated in IEEE f32 with contraction off and correctly rounded
+// divide / sqrt (see build flags in cfd_taichi_amd/build.py).  tests/ checks the result
+// against the independent CPU restatement in oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sph {
+
+constexpr int kBlock = 256;
+
+// Launch-invariant constants, passed to kernels by value (lands in SGPRs).
+struct Consts {
+    float h;           // support radius = kernel_h = 4r            ParticleSystem.py:82, solver_base.py:17
+    float m;           // particle_m                                ParticleSystem.py:83
+    float d;           // particle_diameter
+    float rho0;        // 1000                                      solver_base.py:19
+    float gravity;
+    float kw;          // 8/(pi h^3)                                solver_base.py:79
+    float kg6;         // 48/(pi h^3) * 6                           solver_base.py:95,98
+    float neg_kg6;     // -48/(pi h^3) * 6                          solver_base.py:100
+    float r2_cut;      // largest f32 t with sqrtf(t) <= h: (|x_ij| > h) <=> (r2 > r2_cut)
+    float visc_num;    // 2*alpha*h*c_s (f64-folded)                solver_base.py:187
+    float visc_eps_h2; // eps*h*h (f64-folded)                      solver_base.py:188
+    float tens_c;      // -k/m*m (f64-folded)                       solver_base.py:216
+    float neg_m;       // -particle_m                               solver_base.py:189
+    float dt_cfl_num;  // 0.4*r*2 (f64-folded)                      dfsph_solver.py:112
+    float clamp_lo[3]; // clamp walls (boundary_handle == 0)        wcsph_solver.py:54-63, dfsph_solver.py:241-250
+    float clamp_hi[3];
+    int gx, gy, gz, C; // grid_num, cell count                      ParticleSystem.py:100-103
+    int sy, sz;        // _3d_to_1d_tran = (1, gx*gz, gx)           ParticleSystem.py:102
+    int boundary_handle;
+    int n;             // particles resident in the arrays
+    int stride;        // neighbour-list row stride (>= n, multiple of 64)
+    int kmax, kbmax;   // neighbour-list rows (fluid, wall)
+};
+
+// Run-time scalars that live in device memory (0-d fields of the reference).
+struct DevScalars {
+    float dt;          // solver.delta_time[None]
+    float dt2;         // solver.delta_time_2[None]
+    float ps_dt;       // ps.delta_time[None]
+    float mean;        // result of the last mean reduction (divergence error / rho_adv average)
+    float vmax;        // result of the last max reduction
+    int overflow;      // neighbour list overflow flag
+    int max_nbrs;
+    int max_wall_nbrs;
+    int lost;          // particles outside the grid
+    int pad[7];
+};
+
+struct F3 {
+    float x, y, z;
+};
+
+// solver_base.py:76-88
+__device__ __forceinline__ float cubic_w(const Consts &c, float r)
+{
+    float ret = 0.0f;
+    float q = r / c.h;
+    if (0.0f <= q && q <= 0.5f) {
+        float q2 = q * q;
+        float q3 = q2 * q;
+        ret = c.kw * (6.0f * (q3 - q2) + 1.0f);
+    } else if (0.5f < q && q <= 1.0f) {
+        float t = 1.0f - q;
+        ret = 2.0f * c.kw * (t * (t * t));
+    }
+    return ret;
+}
+
+// solver_base.py:90-103 (with the reference's factor 6)
+__device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float dz, float r_norm)
+{
+    F3 o = {0.0f, 0.0f, 0.0f};
+    float q = r_norm / c.h;
+    if (1e-5f < q && q <= 0.5f) {
+        float q2 = q * q;
+        float s = c.kg6 * (3.0f * q2 - 2.0f * q);
+        float den = c.h * r_norm;
+        o.x = s * dx / den;
+        o.y = s * dy / den;
+        o.z = s * dz / den;
+    } else if (0.5f < q && q <= 1.0f) {
+        float t = 1.0f - q;
+        float s = c.neg_kg6 * (t * t);
+        float den = c.h * r_norm;
+        o.x = s * dx / den;
+        o.y = s * dy / den;
+        o.z = s * dz / den;
+    }
+    return o;
+}
+
+// ti.max(a, b) as the oracle restates it: a > b ? a : b (keeps the sign-of-zero behaviour identical)
+__device__ __forceinline__ float rmax(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// wcsph_solver.py:86-90, x**7 by squaring
+__device__ __forceinline__ float tait_pressure(float rho)
+{
+    float rho_i = rmax(rho, 1000.0f);
+    float a = rho_i / 1000.0f;
+    float a2 = a * a;
+    float r3 = a * a2;
+    float a4 = a2 * a2;
+    return 70000.0f * (r3 * a4 - 1.0f);
+}
+
+// ---- wave / block reductions (wave64; fixed lane order => deterministic) -------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+}  // namespace sph

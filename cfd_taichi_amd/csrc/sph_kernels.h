@@ -1,0 +1,699 @@
+// sph_kernels.h -- gfx950 kernels of the SPH step: counting-sort cell list, neighbour-list build,
+// and the list-driven WCSPH / DFSPH sweeps.  Included once by sph_mi355x.hip.
+//
+// Data layout in HBM (all arrays cell-sorted, x fastest / z / y like the reference's cell stride,
+// ParticleSystem.py:102; ties inside a cell broken by original particle id so that every
+// neighbour sum runs in the single-thread Taichi order):
+//   float4 P[n]   = (x, y, z, s)   s = per-sweep scalar of that particle (rho, k/rho, ...)
+//   float4 V[n]   = (vx, vy, vz, a)
+//   uint32 nl[k*stride + i]        k-th fluid neighbour of particle i (row-major by k: coalesced per k)
+//   uint32 nlb[k*stride + i]       k-th wall neighbour of particle i
+//   int    cnt[i] = kf | kb << 16
+// One thread per particle; a wave's 64 lanes are 64 consecutive sorted particles (about 8 cells),
+// so gathers of P[j]/V[j] hit the same few cache lines across lanes.
+#pragma once
+#include "sph_device.h"
+
+namespace sph {
+
+// ======================================================================================
+// counting sort by cell                      ParticleSystem.py:368-397 (reset_grid + update_grid)
+// ======================================================================================
+__device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, float z, int &cx, int &cy, int &cz)
+{
+    // get_particle_grid_index_3d / _1d                       ParticleSystem.py:486-494
+    cx = (int)floorf(x / c.h);
+    cy = (int)floorf(y / c.h);
+    cz = (int)floorf(z / c.h);
+    int id = cx + cy * c.sy + cz * c.sz;
+    if (id < 0 || id >= c.C) id = c.C;   // "lost" bucket (reference prints and skips, :393-395)
+    return id;
+}
+
+__global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, int *__restrict__ cell_of,
+                                                       int *__restrict__ rank, int *__restrict__ cell_count)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= c.n) return;
+    float4 p = P[s];
+    int cx, cy, cz;
+    int id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+    cell_of[s] = id;
+    rank[s] = atomicAdd(&cell_count[id], 1);
+}
+
+// exclusive scan, three launches: per-tile scan, scan of tile sums, add-back
+constexpr int kScanTile = 1024;   // 256 threads x 4
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(const int *__restrict__ in, int *__restrict__ out,
+                                                       int *__restrict__ tile_sums, int n)
+{
+    __shared__ int wsum[kBlock / 64];
+    int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
+    int tsum = v[0] + v[1] + v[2] + v[3];
+    // inclusive wave scan of tsum
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    int excl = woff + inc - tsum;
+    int run = excl;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = woff + inc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sums, int ntiles)
+{
+    // single block; serial over chunks of 256 with a carry (ntiles is small: cells / 1024)
+    __shared__ int wsum[kBlock / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += kBlock) {
+        int i = base + threadIdx.x;
+        int v = (i < ntiles) ? tile_sums[i] : 0;
+        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int carry = carry_s;
+        if (i < ntiles) tile_sums[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / kScanTile];
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter(Consts c, const int *__restrict__ cell_of, const int *__restrict__ rank,
+                                                    const int *__restrict__ cell_start, int *__restrict__ slot_src)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= c.n) return;
+    slot_src[cell_start[cell_of[s]] + rank[s]] = s;
+}
+
+// Canonical order inside a cell = ascending original id (the single-thread append order of
+// update_grid_fluid_particles, ParticleSystem.py:389-397), then gather the state into it.
+__global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__restrict__ cell_of, const int *__restrict__ cell_start,
+                                                         const int *__restrict__ slot_src, const float4 *__restrict__ Pin,
+                                                         const float4 *__restrict__ Vin, const float *__restrict__ warm_in,
+                                                         const int *__restrict__ id_in, float4 *__restrict__ Pout,
+                                                         float4 *__restrict__ Vout, float *__restrict__ warm_out,
+                                                         int *__restrict__ id_out)
+{
+    int d = blockIdx.x * kBlock + threadIdx.x;
+    if (d >= c.n) return;
+    int src = slot_src[d];
+    int cell = cell_of[src];
+    int a = cell_start[cell], b = cell_start[cell + 1];
+    int key = id_in[src];
+    int r = 0;
+    for (int e = a; e < b; ++e) r += (id_in[slot_src[e]] < key) ? 1 : 0;
+    int dst = a + r;
+    Pout[dst] = Pin[src];
+    Vout[dst] = Vin[src];
+    if (warm_in) warm_out[dst] = warm_in[src];
+    id_out[dst] = key;
+}
+
+// ======================================================================================
+// neighbour-list build: the 27-cell walk of for_all_neighbor / for_all_boundary_neighbor
+// (ParticleSystem.py:447-469, 337-366), done once per step because positions are frozen
+// between the grid rebuild and the integrator.
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
+                                                     const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
+                                                     uint32_t *__restrict__ nl, uint32_t *__restrict__ nlb,
+                                                     int *__restrict__ cnt, DevScalars *__restrict__ ds)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    int kf = 0, kb = 0;
+    if (i == 0) ds->lost = cell_start[c.C + 1] - cell_start[c.C];   // size of the "outside the grid" bucket
+    if (i < c.n) {
+        float4 pi = P[i];
+        int cx, cy, cz;
+        cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    int x = cx + dx, y = cy + dy, z = cz + dz;
+                    if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
+                    if (x < 0 || y < 0 || z < 0) continue;
+                    int cid = x + y * c.sy + z * c.sz;
+                    int a = cell_start[cid], b = cell_start[cid + 1];
+                    for (int j = a; j < b; ++j) {
+                        if (j == i) continue;                            // :461
+                        float4 pj = P[j];
+                        float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                        float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                        if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
+                        if (kf < c.kmax) nl[(size_t)kf * c.stride + i] = (uint32_t)j;
+                        ++kf;
+                    }
+                    if (c.boundary_handle) {
+                        int wa = wcell_start[cid], wb = wcell_start[cid + 1];
+                        for (int j = wa; j < wb; ++j) {
+                            float4 pj = WP[j];
+                            float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                            if (r2 > c.r2_cut) continue;                 // :364
+                            if (kb < c.kbmax) nlb[(size_t)kb * c.stride + i] = (uint32_t)j;
+                            ++kb;
+                        }
+                    }
+                }
+        int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
+        cnt[i] = kfc | (kbc << 16);
+    }
+    int mf = wave_max(kf), mb = wave_max(kb);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&ds->max_nbrs, mf);
+        atomicMax(&ds->max_wall_nbrs, mb);
+        if (mf > c.kmax || mb > c.kbmax) atomicOr(&ds->overflow, 1);
+    }
+}
+
+// ======================================================================================
+// helpers for the list-driven sweeps
+// ======================================================================================
+#define SPH_SWEEP_PROLOGUE                                   \
+    int i = blockIdx.x * kBlock + threadIdx.x;               \
+    const bool live = i < c.n;                               \
+    const int ii = live ? i : 0;                             \
+    const int cw = live ? cnt[ii] : 0;                       \
+    const int kf = cw & 0xffff, kb = cw >> 16;               \
+    const float4 pi = P[ii];
+
+// block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
+__device__ __forceinline__ void block_partial_mean(double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
+{
+    __shared__ double s_sum[kBlock / 64];
+    __shared__ int s_cnt[kBlock / 64];
+    double ws = wave_sum(flag ? v : 0.0);
+    int wc = wave_sum(flag);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[w] = ws; s_cnt[w] = wc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0; int n = 0;
+        for (int k = 0; k < kBlock / 64; ++k) { t += s_sum[k]; n += s_cnt[k]; }
+        psum[blockIdx.x] = t;
+        pcnt[blockIdx.x] = n;
+    }
+}
+
+__device__ __forceinline__ void block_partial_max(float v, float *__restrict__ pmax)
+{
+    __shared__ float s_max[kBlock / 64];
+    float wm = wave_max(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_max[w] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = s_max[0];
+        for (int k = 1; k < kBlock / 64; ++k) t = fmaxf(t, s_max[k]);
+        pmax[blockIdx.x] = t;
+    }
+}
+
+// final, fixed-order reduction of the block partials; one block.
+// mean = cnt > 0 ? sum / cnt : dflt       (dfsph_solver.py:148-149, 278-279)
+__global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                          float dflt, DevScalars *__restrict__ ds)
+{
+    __shared__ double s_sum[kBlock];
+    __shared__ long long s_cnt[kBlock];
+    double t = 0.0; long long n = 0;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+    s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ds->mean = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : dflt;
+}
+
+// max |v*| over the block partials, then the CFL time step       dfsph_solver.py:100-119
+__global__ __launch_bounds__(kBlock) void k_finalize_dt(Consts c, const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds)
+{
+    __shared__ float s_max[kBlock];
+    float t = -INFINITY;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) t = fmaxf(t, pmax[k]);
+    s_max[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float max_vel = s_max[0];
+        float max_rigid_vel = 0.0f;                                   // :104-110 (no rigid body)
+        max_vel += max_rigid_vel;
+        float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112
+        float dt;
+        if (max_delta_time > 1e-3f) dt = 1e-3f;                       // :114-117
+        else dt = rmax(max_delta_time, 1e-5f);
+        ds->vmax = max_vel;
+        ds->dt = dt;
+        ds->dt2 = dt * dt;                                            // :118
+        ds->ps_dt = dt;                                               // :119
+    }
+}
+
+// ======================================================================================
+// W1 / D1: density (+ alpha)          solver_base.py:41-72, dfsph_solver.py:32-89, wcsph_solver.py:66-68
+//   WCSPH: writes Pout = (pos, rho), Vout = (vel, p/rho^2), rho[], pressure[]
+//   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, rho[], alpha[]
+// ======================================================================================
+template <bool DFSPH>
+__global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                    const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                    const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                    const float *__restrict__ warm, const DevScalars *__restrict__ ds,
+                                                    float *__restrict__ rho_out, float *__restrict__ aux_out,
+                                                    float4 *__restrict__ Pout, float4 *__restrict__ Vout)
+{
+    SPH_SWEEP_PROLOGUE
+    float rho = 0.001f;                                      // solver_base.py:44
+    float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
+    for (int k = 0; k < kf; ++k) {
+        uint32_t j = nl[(size_t)k * c.stride + ii];
+        float4 pj = P[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        rho += c.m * cubic_w(c, r);                          // solver_base.py:62
+        if (DFSPH) {
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float rx = c.m * g.x, ry = c.m * g.y, rz = c.m * g.z;   // dfsph_solver.py:58,70
+            sx += rx; sy += ry; sz += rz;
+            sq += (rx * rx + ry * ry) + rz * rz;             // :71
+        }
+    }
+    float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
+    for (int k = 0; k < kb; ++k) {
+        uint32_t j = nlb[(size_t)k * c.stride + ii];
+        float4 pj = WP[j];                                   // (x, y, z, V_b)
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        rho_b += pj.w * cubic_w(c, r);                       // solver_base.py:70-71
+        if (DFSPH) {
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float cc = pj.w * c.rho0;                        // dfsph_solver.py:82,88
+            float rx = cc * g.x, ry = cc * g.y, rz = cc * g.z;
+            bx += rx; by += ry; bz += rz;
+            bsq += (rx * rx + ry * ry) + rz * rz;
+        }
+    }
+    float rho_i = c.boundary_handle ? rho + rho_b * c.rho0 : rho;   // solver_base.py:49,51
+    if (!live) return;
+    rho_out[i] = rho_i;
+    if (DFSPH) {
+        float den;
+        if (c.boundary_handle)
+            den = ((((sx * sx + sy * sy) + sz * sz) + sq) + bsq) + ((bx * bx + by * by) + bz * bz);   // :45
+        else
+            den = ((sx * sx + sy * sy) + sz * sz) + sq;                                               // :47
+        float alpha = fabsf(den) < 1e-6f ? 0.0f : rho_i / den;                                        // :48-51
+        aux_out[i] = alpha;
+        float dt = ds->dt;
+        float k_i = warm[i] / dt;                            // dfsph_solver.py:333
+        Pout[i] = make_float4(pi.x, pi.y, pi.z, k_i / rho_i);
+    } else {
+        float p = tait_pressure(rho_i);                      // wcsph_solver.py:86-90
+        aux_out[i] = p;
+        float4 vi = V[i];
+        Pout[i] = make_float4(pi.x, pi.y, pi.z, rho_i);
+        Vout[i] = make_float4(vi.x, vi.y, vi.z, p / (rho_i * rho_i));   // :109,116
+    }
+}
+
+// ======================================================================================
+// W2: WCSPH pressure gradient + wall pressure + viscosity + tension + kinematic phase
+//     wcsph_solver.py:70-129, solver_base.py:170-217, wcsph_solver.py:40-63
+//   reads P = (pos, rho), V = (vel, p/rho^2); writes the next state Pn = (pos', .), Vn = (vel', .), acc
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                        const float *__restrict__ pressure, float4 *__restrict__ Pn,
+                                                        float4 *__restrict__ Vn, float4 *__restrict__ acc_out)
+{
+    SPH_SWEEP_PROLOGUE
+    const float4 vi = V[ii];
+    const float rho_i = pi.w;
+    const float a_i = vi.w;                                  // p_i / rho_i_2
+    float gx = 0.f, gy = 0.f, gz = 0.f;                      // pressure gradient
+    float wx = 0.f, wy = 0.f, wz = 0.f;                      // viscosity
+    float tx = 0.f, ty = 0.f, tz = 0.f;                      // tension
+    for (int k = 0; k < kf; ++k) {
+        uint32_t j = nl[(size_t)k * c.stride + ii];
+        float4 pj = P[j];
+        float4 vj = V[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float s = c.m * (a_i + vj.w);                        // wcsph_solver.py:116
+        gx -= s * g.x; gy -= s * g.y; gz -= s * g.z;
+        float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
+        float shear = dot3(vx, vy, vz, dx, dy, dz);          // solver_base.py:183
+        if (shear < 0.f) {
+            float q2 = r * r;
+            float nu = c.visc_num / (rho_i + pj.w);          // :187
+            float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
+            float sv = c.neg_m * pi_;                        // :189
+            wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+        }
+        float st = c.tens_c * cubic_w(c, r);                 // :216
+        tx += st * dx; ty += st * dy; tz += st * dz;
+    }
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    if (c.boundary_handle) {
+        const float p_i = live ? pressure[ii] : 0.f;
+        const float rho_i_2 = rho_i * rho_i;
+        for (int k = 0; k < kb; ++k) {
+            uint32_t j = nlb[(size_t)k * c.stride + ii];
+            float4 pj = WP[j];
+            float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            float r = norm3(dx, dy, dz);
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float s = pj.w * p_i / rho_i_2;                  // wcsph_solver.py:99
+            bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
+        }
+    }
+    if (!live) return;
+    float pg[3] = {gx, gy, gz};
+    float vis[3] = {wx * c.m, wy * c.m, wz * c.m};           // solver_base.py:175
+    float ten[3] = {tx * c.m, ty * c.m, tz * c.m};           // solver_base.py:209
+    float bac[3] = {bx * c.rho0, by * c.rho0, bz * c.rho0};  // wcsph_solver.py:83
+    float acc[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};   // solver_base.py:131-133
+    float pos[3] = {pi.x, pi.y, pi.z};
+    float vel[3] = {vi.x, vi.y, vi.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (c.boundary_handle) acc[a] += ((pg[a] + vis[a]) + ten[a]) + bac[a];   // wcsph_solver.py:44-45
+        else acc[a] += (pg[a] + vis[a]) + ten[a];                                // :47
+        vel[a] += acc[a] * dt;                                                   // :50
+        vel[a] *= 0.9998f;                                                       // :51
+        pos[a] += vel[a] * dt;                                                   // :52
+    }
+    if (!c.boundary_handle) {                                                    // :54-63
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (pos[a] <= c.clamp_lo[a]) { pos[a] = c.clamp_lo[a]; vel[a] *= -0.5f; }
+            if (pos[a] >= c.clamp_hi[a]) { pos[a] = c.clamp_hi[a]; vel[a] *= -0.5f; }
+        }
+    }
+    Pn[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
+    Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
+    acc_out[i] = make_float4(acc[0], acc[1], acc[2], 0.f);
+}
+
+// ======================================================================================
+// D2 / D4 / D7: "pressure-like" velocity corrections.  All three are
+//   v_i -= dt * ( sum_F m (k_i/rho_i + k_j/rho_j) gradW + rho0 * sum_B (V_b k_i / rho_i) gradW )
+// with k from warm_start_k (D2, dfsph_solver.py:314-355), rho_derivative*alpha (D4, :302-312,
+// 357-391, with the 1e-5 gate and sum_up_stiff :381-384) or (rho_adv-rho0)*alpha (D7, :178-219).
+// P.w of every particle holds k/rho, written by the sweep before.
+// ======================================================================================
+enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
+                                                    const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
+                                                    const int *__restrict__ cnt, const float *__restrict__ rho,
+                                                    const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
+                                                    float *__restrict__ warm, const DevScalars *__restrict__ ds,
+                                                    const float4 *__restrict__ Vin, float4 *__restrict__ Vout)
+{
+    SPH_SWEEP_PROLOGUE
+    const float dt = ds->dt;
+    const float rho_i = rho[ii];
+    float k_i;
+    if (MODE == CORR_WARM) k_i = warm[ii] / dt;                                   // :333
+    else if (MODE == CORR_DIV) k_i = src[ii] * alpha[ii] / dt;                    // :363
+    else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
+    const float kr_i = k_i / rho_i;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < kf; ++k) {
+        uint32_t j = nl[(size_t)k * c.stride + ii];
+        float4 pj = P[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float ks = kr_i + pj.w;
+        if (MODE != CORR_DIV || ks > 1e-5f) {                                     // :367
+            float s = c.m * ks;                                                   // :337 / :369 / :203
+            ax += s * g.x; ay += s * g.y; az += s * g.z;
+        }
+    }
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    for (int k = 0; k < kb; ++k) {
+        uint32_t j = nlb[(size_t)k * c.stride + ii];
+        float4 pj = WP[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219
+        bx += s * g.x; by += s * g.y; bz += s * g.z;
+    }
+    if (!live) return;
+    float4 v = Vin[i];
+    if (c.boundary_handle) {
+        // :322 / :310 ; for D7 :187 then :191 -- same association: (a + b*rho0) * dt
+        v.x -= (ax + bx * c.rho0) * dt;
+        v.y -= (ay + by * c.rho0) * dt;
+        v.z -= (az + bz * c.rho0) * dt;
+    } else {
+        v.x -= ax * dt; v.y -= ay * dt; v.z -= az * dt;                           // :324 / :312 / :189
+    }
+    Vout[i] = v;
+    if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
+    if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
+}
+
+// ======================================================================================
+// D3 / D6: divergence residual and predicted density.
+//   D3 (dfsph_solver.py:252-300): drho_i = cnt<20 ? 0 : max(sum_F m (v_i-v_j).gradW + rho0 sum_B V_b v_i.gradW, 0)
+//   D6 (dfsph_solver.py:124-176): rho*_i = max(rho_i + dt (same sums with v*), rho0)
+// Writes Pout.w = k/rho for the correction sweep that follows and the block partials of the mean.
+// ======================================================================================
+template <bool DENS>
+__global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                     const float *__restrict__ rho, const float *__restrict__ alpha,
+                                                     const DevScalars *__restrict__ ds, float *__restrict__ out,
+                                                     float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt)
+{
+    SPH_SWEEP_PROLOGUE
+    const float4 vi = V[ii];
+    float acc = 0.f;
+    const bool skip = !DENS && kf < 20;                                           // :258-261
+    const int kfe = skip ? 0 : kf, kbe = skip ? 0 : kb;
+    for (int k = 0; k < kfe; ++k) {
+        uint32_t j = nl[(size_t)k * c.stride + ii];
+        float4 pj = P[j];
+        float4 vj = V[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);  // :287 / :162
+    }
+    float accb = 0.f;
+    for (int k = 0; k < kbe; ++k) {
+        uint32_t j = nlb[(size_t)k * c.stride + ii];
+        float4 pj = WP[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
+    }
+    float val = 0.f;
+    int flag = 0;
+    if (live) {
+        const float rho_i = rho[i];
+        float kr;
+        if (DENS) {
+            const float dt = ds->dt;
+            if (c.boundary_handle) val = rmax(rho_i + dt * (acc + accb * c.rho0), c.rho0);   // :135
+            else val = rmax(rho_i + dt * acc, c.rho0);                                        // :137
+            flag = !(val == c.rho0);                                                          // :139
+            kr = ((val - c.rho0) * alpha[i] / ds->dt2) / rho_i;                               // :199,203
+        } else {
+            if (skip) val = 0.f;
+            else if (c.boundary_handle) val = rmax(acc + accb * c.rho0, 0.0f);                // :267
+            else val = rmax(acc, 0.0f);                                                       // :269
+            flag = val > 0.f;                                                                 // :275
+            kr = (val * alpha[i] / ds->dt) / rho_i;                                           // :363,367
+        }
+        out[i] = val;
+        Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
+    }
+    block_partial_mean((double)val, flag, psum, pcnt);
+}
+
+// ======================================================================================
+// D5: tension + viscosity + external force + v* and max |v*|
+//     solver_base.py:170-217, dfsph_solver.py:91-103
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                      const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
+                                                      const float *__restrict__ rho, const DevScalars *__restrict__ ds,
+                                                      float4 *__restrict__ VAout, float *__restrict__ pmax)
+{
+    SPH_SWEEP_PROLOGUE
+    (void)kb;
+    const float4 vi = V[ii];
+    const float rho_i = rho[ii];
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    for (int k = 0; k < kf; ++k) {
+        uint32_t j = nl[(size_t)k * c.stride + ii];
+        float4 pj = P[j];
+        float4 vj = V[j];
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        tx += st * dx; ty += st * dy; tz += st * dz;
+        float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
+        float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
+        if (shear < 0.f) {
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float q2 = r * r;
+            float nu = c.visc_num / (rho_i + rho[j]);        // :187
+            float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
+            float sv = c.neg_m * pi_;                        // :189
+            wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+        }
+    }
+    float vn = -INFINITY;
+    if (live) {
+        const float dt = ds->dt;
+        float ten[3] = {tx * c.m, ty * c.m, tz * c.m};       // :209
+        float vis[3] = {wx * c.m, wy * c.m, wz * c.m};       // :175
+        float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
+        float v[3] = {vi.x, vi.y, vi.z};
+        float va[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float f = (g[a] + ten[a]) + vis[a];              // dfsph_solver.py:96
+            va[a] = v[a] + dt * f / c.m;                     // :102
+        }
+        VAout[i] = make_float4(va[0], va[1], va[2], 0.f);
+        vn = norm3(va[0], va[1], va[2]);                     // :103
+    }
+    block_partial_max(vn, pmax);
+}
+
+// D8: compute_all_position                                  dfsph_solver.py:235-250
+__global__ __launch_bounds__(kBlock) void k_dfsph_integrate(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ VA,
+                                                            const DevScalars *__restrict__ ds, float4 *__restrict__ Pn,
+                                                            float4 *__restrict__ Vn)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n) return;
+    const float dt = ds->dt;
+    float4 p = P[i], va = VA[i];
+    float pos[3] = {p.x, p.y, p.z};
+    float v[3] = {va.x, va.y, va.z};
+    float vel[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        pos[a] = pos[a] + dt * v[a] * 0.9999f;               // :238
+        vel[a] = v[a] * 0.9999f;                             // :239
+    }
+    if (!c.boundary_handle) {                                // :241-250
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (pos[a] <= c.clamp_lo[a]) { pos[a] = c.clamp_lo[a]; vel[a] *= -0.5f; }
+            if (pos[a] >= c.clamp_hi[a]) { pos[a] = c.clamp_hi[a]; vel[a] *= -0.5f; }
+        }
+    }
+    Pn[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
+    Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
+}
+
+// ======================================================================================
+// original-order <-> sorted-order transfers for the C-ABI (field.to_numpy / from_numpy)
+// ======================================================================================
+__global__ __launch_bounds__(kBlock) void k_unsort_vec(int n, const float4 *__restrict__ src, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 v = src[s];
+    int o = id[s];
+    dst[3 * o] = v.x; dst[3 * o + 1] = v.y; dst[3 * o + 2] = v.z;
+}
+__global__ __launch_bounds__(kBlock) void k_unsort_scalar(int n, const float *__restrict__ src, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    dst[id[s]] = src[s];
+}
+__global__ __launch_bounds__(kBlock) void k_unsort_count(int n, const int *__restrict__ cnt, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    dst[id[s]] = (float)(cnt[s] & 0xffff);
+}
+__global__ __launch_bounds__(kBlock) void k_sort_in_vec(int n, const float *__restrict__ src, const int *__restrict__ id, float4 *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    int o = id[s];
+    dst[s] = make_float4(src[3 * o], src[3 * o + 1], src[3 * o + 2], 0.f);
+}
+__global__ __launch_bounds__(kBlock) void k_sort_in_scalar(int n, const float *__restrict__ src, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    dst[s] = src[id[s]];
+}
+
+// device arithmetic self-test (sph_selftest_math)
+__global__ void k_selftest(Consts c, int op, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b[i];
+    float r;
+    if (op == 0) r = x / y;
+    else if (op == 1) r = sqrtf(x);
+    else if (op == 2) { c.h = y; r = cubic_w(c, x); }
+    else {
+        float dz = 0.25f * x;
+        float rn = norm3(x, y, dz);
+        F3 g = grad_w(c, x, y, dz, rn);
+        r = op == 3 ? g.x : (op == 4 ? g.y : g.z);
+    }
+    out[i] = r;
+}
+
+}  // namespace sph

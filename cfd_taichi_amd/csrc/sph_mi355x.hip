@@ -1,0 +1,927 @@
+// sph_mi355x.hip -- host side of libsph_mi355x.so: scene construction, buffer ownership, the per-step
+// launch sequences for WCSPH and DFSPH, and the C-ABI of include/sph_mi355x.h.
+//
+// There is no CPU fallback: without a HIP device sph_create fails with SPH_E_NO_DEVICE.
+#include "../../include/sph_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sph_kernels.h"
+
+using namespace sph;
+
+namespace {
+
+enum KernelId {
+    K_HASH = 0, K_SCAN, K_SCATTER, K_ORDER_GATHER, K_BUILD_NL, K_W_DENSITY, K_W_FORCE, K_D_DENSITY_ALPHA,
+    K_D_WARM, K_D_DIV_RESIDUAL, K_D_DIV_CORRECT, K_D_EXT, K_D_DENS_RESIDUAL, K_D_DENS_CORRECT, K_D_INTEGRATE,
+    K_FINALIZE, K_TRANSFER, K_COUNT
+};
+const char *kKernelNames[K_COUNT] = {
+    "hash_count", "scan", "scatter", "order_gather", "build_nl", "wcsph_density", "wcsph_force", "dfsph_density_alpha",
+    "dfsph_warm_start", "dfsph_div_residual", "dfsph_div_correct", "dfsph_ext_force", "dfsph_dens_residual",
+    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer"};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct SphHandle {
+    SphConfig cfg;
+    Consts c;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int N = 0, Nb = 0, Nr = 0;
+    int nblocks = 0;
+    float dt_wcsph = 0.f;
+    int simulate_cnt = 0;
+    bool nl_valid = false;      // neighbour list matches the current positions
+    bool density_valid = false;
+
+    // device state (sorted order); index [cur] is the live one
+    float4 *P[2] = {nullptr, nullptr};
+    float4 *V[2] = {nullptr, nullptr};
+    float4 *VA[2] = {nullptr, nullptr};   // dfsph v* ping-pong; VA[0] doubles as wcsph acc
+    float *warm[2] = {nullptr, nullptr};
+    int *id[2] = {nullptr, nullptr};
+    int pcur = 0, vcur = 0, vacur = 0, wcur = 0, icur = 0;
+
+    float *rho = nullptr, *aux = nullptr /* pressure | alpha */, *drho = nullptr, *rho_adv = nullptr;
+    int *cnt = nullptr;
+    uint32_t *nl = nullptr, *nlb = nullptr;
+    int *cell_of = nullptr, *rank = nullptr, *slot_src = nullptr;
+    int *cell_count = nullptr, *cell_start = nullptr, *tile_sums = nullptr;
+    int ntiles = 0;
+    float4 *WP = nullptr;        // wall particles, cell-sorted: (x, y, z, V_b)
+    int *wcell_start = nullptr;
+    double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
+    DevScalars *ds = nullptr;    // device
+    DevScalars *ds_host = nullptr;   // pinned mirror
+    float *staging = nullptr;    // 3*max(N,Nb) floats, device
+    // host copies of the wall particles in original order (for download)
+    std::vector<float> wall_pos_host, wall_vol_host;
+
+    // profiling
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int kid; };
+    std::vector<Ev> ev_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[K_COUNT] = {0};
+    int64_t prof_n[K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(SphHandle *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(h, SPH_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+hipEvent_t take_event(SphHandle *h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+struct ProfScope {
+    SphHandle *h; int kid; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(SphHandle *h_, int kid_) : h(h_), kid(kid_)
+    {
+        if (h->profiling) { a = take_event(h); b = take_event(h); (void)hipEventRecord(a, h->stream); }
+    }
+    ~ProfScope()
+    {
+        if (h->profiling) { (void)hipEventRecord(b, h->stream); h->ev_pending.push_back({a, b, kid}); }
+    }
+};
+
+void drain_profile(SphHandle *h)
+{
+    if (h->ev_pending.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { h->prof_ms[e.kid] += ms; h->prof_n[e.kid] += 1; }
+        h->ev_pool.push_back(e.a); h->ev_pool.push_back(e.b);
+    }
+    h->ev_pending.clear();
+}
+
+inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// ---------------------------------------------------------------------------------------------
+// host-side scene construction (one-time; mirrors ParticleSystem.__init__)
+// ---------------------------------------------------------------------------------------------
+inline float fmod_py(float a, float b) { return a - b * floorf(a / b); }   // Taichi float %: a - b*floor(a/b)
+
+// host twin of cubic_w for the one-time wall volumes (ParticleSystem.py:309-320)
+inline float host_cubic_w(float r, float h, float kw)
+{
+    float ret = 0.0f;
+    float q = r / h;
+    if (0.0f <= q && q <= 0.5f) {
+        float q2 = q * q;
+        float q3 = q2 * q;
+        ret = kw * (6.0f * (q3 - q2) + 1.0f);
+    } else if (0.5f < q && q <= 1.0f) {
+        float t = 1.0f - q;
+        ret = 2.0f * kw * (t * (t * t));
+    }
+    return ret;
+}
+
+struct HostScene {
+    std::vector<float> fluid_pos;                 // 3N, original order
+    std::vector<float> wall_pos, wall_vol;        // original order
+    std::vector<float4> wall_sorted;              // cell-sorted (x,y,z,V)
+    std::vector<int> wcell_start;                 // C+1
+};
+
+int build_scene(SphHandle *h, HostScene &sc)
+{
+    const SphConfig &cf = h->cfg;
+    Consts &c = h->c;
+    const double r = cf.particle_radius;
+    const double d = r * 2;                        // ParticleSystem.py:81
+    const double support = 4 * r;                  // :82
+    const double m = 1000 * (r * r * r) * 8;       // :83
+    if (!(r > 0)) return fail(h, SPH_E_INVALID, "particle_radius must be > 0");
+    // :85-86, Python f64, left to right
+    h->N = (int)(cf.water_size[0] / d * cf.water_size[1] / d * cf.water_size[2] / d);
+    {   // compute_boundary_particles_count, :129-137 (Python f64)
+        double bx = cf.box_max[0] - cf.box_min[0], by = cf.box_max[1] - cf.box_min[1], bz = cf.box_max[2] - cf.box_min[2];
+        int x_cnt = (int)(bx / d + 1), z_cnt = (int)(bz / d + 1);
+        int bottom = x_cnt * z_cnt;
+        int ring = x_cnt * z_cnt - (x_cnt - 2) * (z_cnt - 2);
+        int layer = (int)std::ceil((by - d) / d);
+        h->Nb = layer * ring + bottom * 2;
+    }
+    h->Nr = 0;
+    int g[3];
+    for (int a = 0; a < 3; ++a) g[a] = (int)std::ceil((cf.box_max[a] - cf.box_min[a]) / support) + 1;   // :100-101
+    if (h->N <= 0) return fail(h, SPH_E_INVALID, "scene has no fluid particles");
+    long long C = (long long)g[0] * g[1] * g[2];
+    if (C <= 0 || C > 0x7ffffff0LL) return fail(h, SPH_E_INVALID, "grid too large");
+
+    memset(&c, 0, sizeof(c));
+    c.h = (float)support;
+    c.m = (float)m;
+    c.d = (float)d;
+    c.rho0 = 1000.0f;
+    c.gravity = (float)cf.gravity;
+    const float pi_f = (float)3.141592653589793;
+    const float h3 = c.h * (c.h * c.h);            // ti.pow(h, 3) by squaring
+    c.kw = 8.0f / (pi_f * h3);                     // solver_base.py:79
+    const float kg = 48.0f / (pi_f * h3);          // :95
+    c.kg6 = kg * 6.0f;
+    c.neg_kg6 = -kg * 6.0f;
+    {   // r2_cut: largest f32 t with sqrtf(t) <= h, so that (sqrt(r2) > h) == (r2 > r2_cut) exactly
+        float t = c.h * c.h;
+        while (sqrtf(t) > c.h) t = nextafterf(t, 0.0f);
+        while (sqrtf(nextafterf(t, INFINITY)) <= c.h) t = nextafterf(t, INFINITY);
+        c.r2_cut = t;
+    }
+    const double c_s = cf.solver == SPH_SOLVER_WCSPH ? 10 : 13;      // wcsph_solver.py:18 vs solver_base.py:24
+    const double t_k = cf.solver == SPH_SOLVER_WCSPH ? 0.2 : 0.5;    // wcsph_solver.py:20 vs solver_base.py:26
+    const double kernel_h = r * 4;                                    // solver_base.py:17
+    c.visc_num = (float)(2 * 0.08 * kernel_h * c_s);
+    c.visc_eps_h2 = (float)(0.01 * kernel_h * kernel_h);
+    c.tens_c = (float)(-t_k / m * m);
+    c.neg_m = (float)(-m);
+    c.dt_cfl_num = (float)(0.4 * r * 2);
+    const float clamp_off = cf.solver == SPH_SOLVER_WCSPH ? c.d : (float)r;   // wcsph_solver.py:57 vs dfsph_solver.py:244
+    for (int a = 0; a < 3; ++a) {
+        c.clamp_lo[a] = (float)cf.box_min[a] + clamp_off;
+        c.clamp_hi[a] = (float)cf.box_max[a] - clamp_off;
+    }
+    c.gx = g[0]; c.gy = g[1]; c.gz = g[2]; c.C = (int)C;
+    c.sy = g[0] * g[2]; c.sz = g[0];               // :102
+    c.boundary_handle = cf.boundary_handle ? 1 : 0;
+    c.n = h->N;
+    c.stride = (h->N + 63) / 64 * 64;
+    c.kmax = cf.max_neighbors > 0 ? cf.max_neighbors : 64;
+    c.kbmax = cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64;
+    if (c.kmax > 0xffff || c.kbmax > 0x7fff) return fail(h, SPH_E_INVALID, "neighbour capacity too large");
+
+    // ---- fluid lattice, init_particle_pos :142-151 (f32 index arithmetic, constants f64-folded) ----
+    const int N = h->N;
+    sc.fluid_pos.resize(3 * (size_t)N);
+    {
+        const float x_num = (float)(cf.water_size[0] / d);
+        const float z_num = (float)(cf.water_size[2] / d);
+        const float xz_num = (float)((cf.water_size[0] / d) * (cf.water_size[2] / d));
+        const float radius = (float)r;
+        const float sp[3] = {(float)cf.start_pos[0], (float)cf.start_pos[1], (float)cf.start_pos[2]};
+        for (int i = 0; i < N; ++i) {
+            float fi = (float)i;
+            float x = fmod_py(fi, x_num);
+            float z = fmod_py(floorf(fi / x_num), z_num);
+            int y = (int)(fi / xz_num);
+            sc.fluid_pos[3 * (size_t)i + 0] = x * radius * 2.0f + sp[0];
+            sc.fluid_pos[3 * (size_t)i + 1] = (float)y * radius * 2.0f + sp[1];
+            sc.fluid_pos[3 * (size_t)i + 2] = z * radius * 2.0f + sp[2];
+        }
+    }
+    // ---- wall particles, init_particle_pos :155-195 (kernel-local f32) ----
+    const int Nb = h->Nb;
+    sc.wall_pos.assign(3 * (size_t)(Nb > 0 ? Nb : 1), 0.f);
+    sc.wall_vol.assign((size_t)(Nb > 0 ? Nb : 1), 0.f);
+    {
+        const float dd = c.d;
+        const float boxx = (float)cf.box_max[0] - (float)cf.box_min[0];
+        const float boxz = (float)cf.box_max[2] - (float)cf.box_min[2];
+        const int x_cnt = (int)(boxx / dd + 1.0f), z_cnt = (int)(boxz / dd + 1.0f);
+        const int xr = x_cnt - 1, zr = z_cnt - 1;
+        const int bottom = x_cnt * z_cnt;
+        const int ring = x_cnt * z_cnt - (x_cnt - 2) * (z_cnt - 2);
+        if (Nb > 0 && (xr <= 0 || zr <= 0 || ring <= 0)) return fail(h, SPH_E_INVALID, "box too small for wall particles");
+        for (int i = 0; i < Nb; ++i) {
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (i < bottom) {
+                x = (float)(i % x_cnt) * dd;
+                z = floorf((float)i / (float)x_cnt) * dd;
+            } else if (i < Nb - bottom) {
+                int index = i - bottom;
+                int layer = (int)floorf((float)index / (float)ring);
+                y = dd * (float)(layer + 1);
+                index -= layer * ring;
+                index += 1;
+                if (index <= xr) { x = (float)(index % xr) * dd; z = 0.f; }
+                else if (index <= xr + zr) { x = (float)xr * dd; z = (float)((index - x_cnt) % zr) * dd; }
+                else if (index <= 2 * xr + zr) { x = (float)((2 * xr + zr - index) % xr + 1) * dd; z = (float)zr * dd; }
+                else if (index <= 2 * (xr + zr)) { x = 0.f; z = (float)((2 * (xr + zr) - index) % zr + 1) * dd; }
+            } else {
+                int index = i - (Nb - bottom);
+                x = (float)(index % x_cnt) * dd;
+                y = (float)cf.box_max[1];
+                z = (float)((int)((float)index / (float)x_cnt)) * dd;
+            }
+            sc.wall_pos[3 * (size_t)i] = x; sc.wall_pos[3 * (size_t)i + 1] = y; sc.wall_pos[3 * (size_t)i + 2] = z;
+        }
+    }
+    // ---- static wall cell list (reset/update_boundary_grids :322-335), canonical order ----
+    std::vector<int> wcell(Nb > 0 ? Nb : 1), wc3(3 * (size_t)(Nb > 0 ? Nb : 1));
+    sc.wcell_start.assign((size_t)c.C + 1, 0);
+    for (int i = 0; i < Nb; ++i) {
+        int cx = (int)floorf(sc.wall_pos[3 * (size_t)i] / c.h);
+        int cy = (int)floorf(sc.wall_pos[3 * (size_t)i + 1] / c.h);
+        int cz = (int)floorf(sc.wall_pos[3 * (size_t)i + 2] / c.h);
+        int id = cx + cy * c.sy + cz * c.sz;
+        if (id < 0 || id >= c.C) return fail(h, SPH_E_INVALID, "wall particle %d falls outside the grid", i);
+        wcell[i] = id; wc3[3 * (size_t)i] = cx; wc3[3 * (size_t)i + 1] = cy; wc3[3 * (size_t)i + 2] = cz;
+        sc.wcell_start[(size_t)id + 1]++;
+    }
+    for (int k = 0; k < c.C; ++k) sc.wcell_start[(size_t)k + 1] += sc.wcell_start[k];
+    std::vector<int> fill(sc.wcell_start.begin(), sc.wcell_start.end() - 1), order(Nb > 0 ? Nb : 1);
+    for (int i = 0; i < Nb; ++i) order[fill[wcell[i]]++] = i;
+    // ---- wall volumes, compute_all_boundary_volume :309-320 ----
+    for (int i = 0; i < Nb; ++i) {
+        float volume = 0.f;
+        const float pix = sc.wall_pos[3 * (size_t)i], piy = sc.wall_pos[3 * (size_t)i + 1], piz = sc.wall_pos[3 * (size_t)i + 2];
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    int x = wc3[3 * (size_t)i] + dx, y = wc3[3 * (size_t)i + 1] + dy, z = wc3[3 * (size_t)i + 2] + dz;
+                    if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
+                    if (x < 0 || y < 0 || z < 0) continue;
+                    int cid = x + y * c.sy + z * c.sz;
+                    for (int e = sc.wcell_start[cid]; e < sc.wcell_start[(size_t)cid + 1]; ++e) {
+                        int j = order[e];
+                        if (j == i) continue;
+                        float ddx = pix - sc.wall_pos[3 * (size_t)j], ddy = piy - sc.wall_pos[3 * (size_t)j + 1], ddz = piz - sc.wall_pos[3 * (size_t)j + 2];
+                        float q = sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
+                        if (q > c.h) continue;
+                        volume += host_cubic_w(q, c.h, c.kw);
+                    }
+                }
+        sc.wall_vol[i] = 1.0f / volume;                                 // :314
+    }
+    sc.wall_sorted.resize(Nb > 0 ? Nb : 1);
+    for (int e = 0; e < Nb; ++e) {
+        int j = order[e];
+        sc.wall_sorted[e] = make_float4(sc.wall_pos[3 * (size_t)j], sc.wall_pos[3 * (size_t)j + 1], sc.wall_pos[3 * (size_t)j + 2], sc.wall_vol[j]);
+    }
+    return SPH_OK;
+}
+
+template <class T>
+int dalloc(SphHandle *h, T **p, size_t count)
+{
+    HIP_TRY(h, hipMalloc((void **)p, sizeof(T) * (count > 0 ? count : 1)));
+    return SPH_OK;
+}
+
+int alloc_device(SphHandle *h, const HostScene &sc)
+{
+    const Consts &c = h->c;
+    const size_t n = (size_t)c.stride;
+    int rc;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dalloc(h, &h->P[k], n))) return rc;
+        if ((rc = dalloc(h, &h->V[k], n))) return rc;
+        if ((rc = dalloc(h, &h->VA[k], n))) return rc;
+        if ((rc = dalloc(h, &h->warm[k], n))) return rc;
+        if ((rc = dalloc(h, &h->id[k], n))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->P[k], 0, sizeof(float4) * n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->V[k], 0, sizeof(float4) * n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->VA[k], 0, sizeof(float4) * n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->warm[k], 0, sizeof(float) * n, h->stream));
+    }
+    if ((rc = dalloc(h, &h->rho, n))) return rc;
+    if ((rc = dalloc(h, &h->aux, n))) return rc;
+    if ((rc = dalloc(h, &h->drho, n))) return rc;
+    if ((rc = dalloc(h, &h->rho_adv, n))) return rc;
+    if ((rc = dalloc(h, &h->cnt, n))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->rho, 0, sizeof(float) * n, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->aux, 0, sizeof(float) * n, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->drho, 0, sizeof(float) * n, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rho_adv, 0, sizeof(float) * n, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->cnt, 0, sizeof(int) * n, h->stream));
+    if ((rc = dalloc(h, &h->nl, n * (size_t)c.kmax))) return rc;
+    if ((rc = dalloc(h, &h->nlb, n * (size_t)c.kbmax))) return rc;
+    if ((rc = dalloc(h, &h->cell_of, n))) return rc;
+    if ((rc = dalloc(h, &h->rank, n))) return rc;
+    if ((rc = dalloc(h, &h->slot_src, n))) return rc;
+    const size_t ncell = (size_t)c.C + 2;
+    h->ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
+    if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
+    if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
+    if ((rc = dalloc(h, &h->tile_sums, (size_t)h->ntiles))) return rc;
+    if ((rc = dalloc(h, &h->WP, (size_t)h->Nb))) return rc;
+    if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
+    h->nblocks = (c.n + kBlock - 1) / kBlock;
+    if ((rc = dalloc(h, &h->psum, (size_t)h->nblocks))) return rc;
+    if ((rc = dalloc(h, &h->pcnt, (size_t)h->nblocks))) return rc;
+    if ((rc = dalloc(h, &h->pmax, (size_t)h->nblocks))) return rc;
+    if ((rc = dalloc(h, &h->ds, 1))) return rc;
+    HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
+    size_t stg = 3 * (size_t)(h->N > h->Nb ? h->N : h->Nb);
+    if ((rc = dalloc(h, &h->staging, stg))) return rc;
+
+    // upload the scene
+    std::vector<float4> p4((size_t)h->N);
+    std::vector<int> ids((size_t)h->N);
+    for (int i = 0; i < h->N; ++i) {
+        p4[i] = make_float4(sc.fluid_pos[3 * (size_t)i], sc.fluid_pos[3 * (size_t)i + 1], sc.fluid_pos[3 * (size_t)i + 2], 0.f);
+        ids[i] = i;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->P[0], p4.data(), sizeof(float4) * p4.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->id[0], ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, h->stream));
+    if (h->Nb > 0)
+        HIP_TRY(h, hipMemcpyAsync(h->WP, sc.wall_sorted.data(), sizeof(float4) * (size_t)h->Nb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->wcell_start, sc.wcell_start.data(), sizeof(int) * ((size_t)c.C + 1), hipMemcpyHostToDevice, h->stream));
+    memset(h->ds_host, 0, sizeof(DevScalars));
+    h->ds_host->dt = (float)h->cfg.delta_time;                       // solver_base.py:16
+    h->ds_host->dt2 = h->ds_host->dt * h->ds_host->dt;               // dfsph_solver.py:20
+    h->ds_host->ps_dt = 0.f;                                         // ParticleSystem.py:37
+    HIP_TRY(h, hipMemcpyAsync(h->ds, h->ds_host, sizeof(DevScalars), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->dt_wcsph = (float)h->cfg.delta_time;
+    return SPH_OK;
+}
+
+int read_scalars(SphHandle *h)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->ds_host, h->ds, sizeof(DevScalars), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step stages
+// ---------------------------------------------------------------------------------------------
+// solver_base.step() prologue: reset_grid + update_grid (solver_base.py:136-143) as a counting sort,
+// then the neighbour lists.
+int stage_sort_and_lists(SphHandle *h)
+{
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(c.n), b(kBlock);
+    const size_t ncell = (size_t)c.C + 2;
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    {
+        ProfScope ps(h, K_HASH);
+        HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * ncell, s));
+        hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->cell_of, h->rank, h->cell_count);
+    }
+    {
+        ProfScope ps(h, K_SCAN);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->cell_count, h->cell_start, h->tile_sums, (int)ncell);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles);
+        hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->cell_start, h->tile_sums, (int)ncell);
+    }
+    {
+        ProfScope ps(h, K_SCATTER);
+        hipLaunchKernelGGL(k_scatter, g, b, 0, s, c, h->cell_of, h->rank, h->cell_start, h->slot_src);
+    }
+    {
+        ProfScope ps(h, K_ORDER_GATHER);
+        hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
+                           dfsph ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
+                           h->warm[1 - h->wcur], h->id[1 - h->icur]);
+        h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
+        if (dfsph) h->wcur ^= 1;
+    }
+    {
+        ProfScope ps(h, K_BUILD_NL);
+        // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
+        HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
+        hipLaunchKernelGGL(k_build_nl, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->nl, h->nlb, h->cnt, h->ds);
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = true;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+int check_overflow(SphHandle *h)
+{
+    // ds_host must be fresh
+    if (h->ds_host->overflow) {
+        (void)hipMemsetAsync(&h->ds->overflow, 0, sizeof(int), h->stream);
+        return fail(h, SPH_E_OVERFLOW, "neighbour list overflow: %d fluid / %d wall neighbours, capacity %d / %d (raise max_neighbors)",
+                    h->ds_host->max_nbrs, h->ds_host->max_wall_nbrs, h->c.kmax, h->c.kbmax);
+    }
+    return SPH_OK;
+}
+
+int stage_density(SphHandle *h)
+{
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(c.n), b(kBlock);
+    if (h->cfg.solver == SPH_SOLVER_DFSPH) {
+        ProfScope ps(h, K_D_DENSITY_ALPHA);
+        hipLaunchKernelGGL(k_density<true>, g, b, 0, s, c, h->P[h->pcur], (const float4 *)nullptr, h->WP, h->nl, h->nlb, h->cnt,
+                           h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], (float4 *)nullptr);
+        h->pcur ^= 1;     // P[pcur] = (pos, (warm_k/dt)/rho)
+    } else {
+        ProfScope ps(h, K_W_DENSITY);
+        hipLaunchKernelGGL(k_density<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                           (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->density_valid = true;
+    return SPH_OK;
+}
+
+int step_wcsph_once(SphHandle *h)
+{
+    int rc;
+    h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
+    if ((rc = stage_density(h))) return rc;                 // wcsph_solver.py:34-35
+    const Consts &c = h->c;
+    {
+        ProfScope ps(h, K_W_FORCE);                          // wcsph_solver.py:36-38 + kinematic_phase :40-63
+        hipLaunchKernelGGL(k_wcsph_force, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
+                           h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0]);
+        h->pcur ^= 1; h->vcur ^= 1;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+// derivative_iter_all_rho (dfsph_solver.py:252-300): residual sweep + mean; returns the mean through *err
+int dfsph_div_residual(SphHandle *h, float *err)
+{
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    {
+        ProfScope ps(h, K_D_DIV_RESIDUAL);
+        hipLaunchKernelGGL(k_residual<false>, grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+                           h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt);
+        h->pcur ^= 1;     // P.w = (drho*alpha/dt)/rho
+    }
+    {
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, s, h->psum, h->pcnt, h->nblocks, 0.0f, h->ds);
+    }
+    int rc = read_scalars(h);
+    if (rc) return rc;
+    *err = h->ds_host->mean;
+    return SPH_OK;
+}
+
+int step_dfsph_once(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(c.n), b(kBlock);
+    memset(st, 0, sizeof(*st));
+    h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
+    if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
+    // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
+    {
+        ProfScope ps(h, K_D_WARM);                           // :396-397
+        hipLaunchKernelGGL(k_correct<CORR_WARM>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                           (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
+        h->vcur ^= 1;
+    }
+    float err = 0.f, past = 0.f;
+    if ((rc = dfsph_div_residual(h, &err))) return rc;      // :398
+    if ((rc = check_overflow(h))) return rc;                // first read-back of the step: list overflow?
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->n_div_evals = 1;
+    st->div_first_err = err;
+    int iter_cnt = 0;
+    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {    // :400
+        {
+            ProfScope ps(h, K_D_DIV_CORRECT);                // :402 + sum_up_stiff :404-405
+            hipLaunchKernelGGL(k_correct<CORR_DIV>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                               h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
+            h->vcur ^= 1;
+        }
+        past = err;
+        if ((rc = dfsph_div_residual(h, &err))) return rc;  // :408
+        st->n_div_evals += 1;
+        if (std::fabs((double)err - (double)past) < 1e-5) break;       // :410-412
+        iter_cnt += 1;
+    }
+    st->n_div = iter_cnt;
+    st->div_err = err;
+    // ---- compute_all_ext_force + compute_all_vel_adv, :91-122 ----
+    {
+        ProfScope ps(h, K_D_EXT);
+        hipLaunchKernelGGL(k_dfsph_ext, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->rho, h->ds, h->VA[h->vacur], h->pmax);
+    }
+    {
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_dt, dim3(1), b, 0, s, c, h->pmax, h->nblocks, h->ds);
+    }
+    // ---- correct_density_error, :221-233 ----
+    {
+        const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
+        double rho_avg = INFINITY;
+        int it = 0;
+        while (it < 2 || rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {       // :225
+            if (it >= cap) { st->capped = 1; break; }
+            {
+                ProfScope ps(h, K_D_DENS_RESIDUAL);          // compute_all_rho_adv :124-152
+                hipLaunchKernelGGL(k_residual<true>, g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
+                                   h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt);
+                h->pcur ^= 1;
+            }
+            {
+                ProfScope ps(h, K_FINALIZE);
+                hipLaunchKernelGGL(k_finalize_mean, dim3(1), b, 0, s, h->psum, h->pcnt, h->nblocks, 1000.0f, h->ds);
+            }
+            {
+                ProfScope ps(h, K_D_DENS_CORRECT);           // iter_all_vel_adv :178-191
+                hipLaunchKernelGGL(k_correct<CORR_DENS>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                                   h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur]);
+                h->vacur ^= 1;
+            }
+            if ((rc = read_scalars(h))) return rc;
+            rho_avg = (double)h->ds_host->mean;
+            it += 1;
+        }
+        st->n_dens = it;
+        st->dens_err = (float)(rho_avg - 1000.0);
+    }
+    {
+        ProfScope ps(h, K_D_INTEGRATE);                      // compute_all_position :235-250
+        hipLaunchKernelGGL(k_dfsph_integrate, g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->ds, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        h->pcur ^= 1; h->vcur ^= 1;
+    }
+    HIP_TRY(h, hipGetLastError());
+    st->dt = h->ds_host->dt;
+    st->lost = h->ds_host->lost;
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+int field_floats(SphHandle *h, int species, int field, size_t *count, bool *vec)
+{
+    *vec = false;
+    if (species == SPH_SPECIES_FLUID) {
+        switch (field) {
+        case SPH_F_POS: case SPH_F_VEL: case SPH_F_ACC: case SPH_F_VEL_ADV:
+            *vec = true; *count = 3 * (size_t)h->N; return SPH_OK;
+        case SPH_F_RHO: case SPH_F_PRESSURE: case SPH_F_ALPHA: case SPH_F_WARM_K: case SPH_F_RHO_ADV: case SPH_F_RHO_DER:
+        case SPH_F_NBR_COUNT:
+            *count = (size_t)h->N; return SPH_OK;
+        default: break;
+        }
+    } else if (species == SPH_SPECIES_WALL) {
+        if (field == SPH_F_WALL_POS) { *vec = true; *count = 3 * (size_t)h->Nb; return SPH_OK; }
+        if (field == SPH_F_WALL_VOL) { *count = (size_t)h->Nb; return SPH_OK; }
+    }
+    return fail(h, SPH_E_INVALID, "unknown species/field %d/%d", species, field);
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+const char *sph_last_error(SphHandle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sph_create(const SphConfig *cfg, SphHandle **out)
+{
+    if (!cfg || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->solver != SPH_SOLVER_WCSPH && cfg->solver != SPH_SOLVER_DFSPH)
+        return fail(nullptr, SPH_E_INVALID, "unknown solver %d", cfg->solver);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SPH_E_NO_DEVICE, "no HIP device available (%s); libsph_mi355x has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, SPH_E_INVALID, "device %d out of range [0,%d)", cfg->device, ndev);
+    SphHandle *h = new SphHandle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    int rc = SPH_OK;
+    do {
+        if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipStreamCreate failed"); break; }
+        HostScene sc;
+        if ((rc = build_scene(h, sc))) break;
+        if ((rc = alloc_device(h, sc))) break;
+        h->wall_pos_host = sc.wall_pos;
+        h->wall_vol_host = sc.wall_vol;
+    } while (0);
+    if (rc) {
+        g_create_error = h->err;
+        sph_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SPH_OK;
+}
+
+void sph_destroy(SphHandle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(h->P[k]); (void)hipFree(h->V[k]); (void)hipFree(h->VA[k]); (void)hipFree(h->warm[k]); (void)hipFree(h->id[k]);
+    }
+    (void)hipFree(h->rho); (void)hipFree(h->aux); (void)hipFree(h->drho); (void)hipFree(h->rho_adv); (void)hipFree(h->cnt);
+    (void)hipFree(h->nl); (void)hipFree(h->nlb); (void)hipFree(h->cell_of); (void)hipFree(h->rank); (void)hipFree(h->slot_src);
+    (void)hipFree(h->cell_count); (void)hipFree(h->cell_start); (void)hipFree(h->tile_sums); (void)hipFree(h->WP);
+    (void)hipFree(h->wcell_start); (void)hipFree(h->psum); (void)hipFree(h->pcnt); (void)hipFree(h->pmax); (void)hipFree(h->ds);
+    (void)hipFree(h->staging);
+    if (h->ds_host) (void)hipHostFree(h->ds_host);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int sph_get_sizes(SphHandle *h, SphSizes *out)
+{
+    if (!h || !out) return SPH_E_INVALID;
+    out->n_fluid = h->N; out->n_wall = h->Nb; out->n_rigid = h->Nr;
+    out->grid[0] = h->c.gx; out->grid[1] = h->c.gy; out->grid[2] = h->c.gz;
+    out->n_cells = h->c.C;
+    out->max_neighbors = h->c.kmax; out->max_wall_neighbors = h->c.kbmax;
+    return SPH_OK;
+}
+
+int sph_upload(SphHandle *h, int species, int field, const float *host, size_t n_floats)
+{
+    if (!h || !host) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t count; bool vec;
+    int rc = field_floats(h, species, field, &count, &vec);
+    if (rc) return rc;
+    if (count != n_floats) return fail(h, SPH_E_INVALID, "field %d holds %zu floats, got %zu", field, count, n_floats);
+    if (species != SPH_SPECIES_FLUID || !(field == SPH_F_POS || field == SPH_F_VEL || field == SPH_F_WARM_K))
+        return fail(h, SPH_E_INVALID, "field %d is read-only", field);
+    if (field == SPH_F_WARM_K && h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "warm_start_k needs a dfsph handle");
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->staging, host, sizeof(float) * count, hipMemcpyHostToDevice, s));
+    ProfScope ps(h, K_TRANSFER);
+    const dim3 g = grid_for(h->N), b(kBlock);
+    if (field == SPH_F_POS) hipLaunchKernelGGL(k_sort_in_vec, g, b, 0, s, h->N, h->staging, h->id[h->icur], h->P[h->pcur]);
+    else if (field == SPH_F_VEL) hipLaunchKernelGGL(k_sort_in_vec, g, b, 0, s, h->N, h->staging, h->id[h->icur], h->V[h->vcur]);
+    else hipLaunchKernelGGL(k_sort_in_scalar, g, b, 0, s, h->N, h->staging, h->id[h->icur], h->warm[h->wcur]);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+int sph_download(SphHandle *h, int species, int field, float *host, size_t n_floats)
+{
+    if (!h || !host) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t count; bool vec;
+    int rc = field_floats(h, species, field, &count, &vec);
+    if (rc) return rc;
+    if (count != n_floats) return fail(h, SPH_E_INVALID, "field %d holds %zu floats, got %zu", field, count, n_floats);
+    if (species == SPH_SPECIES_WALL) {
+        const std::vector<float> &src = field == SPH_F_WALL_POS ? h->wall_pos_host : h->wall_vol_host;
+        memcpy(host, src.data(), sizeof(float) * count);
+        return SPH_OK;
+    }
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(h->N), b(kBlock);
+    const int *id = h->id[h->icur];
+    {
+        ProfScope ps(h, K_TRANSFER);
+        switch (field) {
+        case SPH_F_POS: hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->P[h->pcur], id, h->staging); break;
+        case SPH_F_VEL: hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->V[h->vcur], id, h->staging); break;
+        case SPH_F_ACC:
+            if (dfsph) return fail(h, SPH_E_STATE, "acc is a wcsph field (dfsph never fills it, dfsph_solver.py:418-421)");
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break;
+        case SPH_F_VEL_ADV:
+            if (!dfsph) return fail(h, SPH_E_STATE, "vel_adv is a dfsph field");
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[h->vacur], id, h->staging); break;
+        case SPH_F_RHO: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->rho, id, h->staging); break;
+        case SPH_F_PRESSURE:
+            if (dfsph) return fail(h, SPH_E_STATE, "pressure is a wcsph field");
+            hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->aux, id, h->staging); break;
+        case SPH_F_ALPHA:
+            if (!dfsph) return fail(h, SPH_E_STATE, "alpha is a dfsph field");
+            hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->aux, id, h->staging); break;
+        case SPH_F_WARM_K:
+            if (!dfsph) return fail(h, SPH_E_STATE, "warm_start_k is a dfsph field");
+            hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->warm[h->wcur], id, h->staging); break;
+        case SPH_F_RHO_ADV: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->rho_adv, id, h->staging); break;
+        case SPH_F_RHO_DER: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->drho, id, h->staging); break;
+        case SPH_F_NBR_COUNT: hipLaunchKernelGGL(k_unsort_count, g, b, 0, s, h->N, h->cnt, id, h->staging); break;
+        default: return fail(h, SPH_E_INVALID, "field %d cannot be downloaded", field);
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(host, h->staging, sizeof(float) * count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return SPH_OK;
+}
+
+int sph_build_neighbors(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = stage_sort_and_lists(h);
+    if (rc) return rc;
+    if ((rc = read_scalars(h))) return rc;
+    return check_overflow(h);
+}
+
+int sph_compute_density(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if (!h->nl_valid && (rc = sph_build_neighbors(h))) return rc;
+    if (h->density_valid) return SPH_OK;
+    if ((rc = stage_density(h))) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+int sph_compute_alpha(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "alpha needs a dfsph handle");
+    return sph_compute_density(h);   // the fused sweep produces rho and alpha together
+}
+
+int sph_step_wcsph(SphHandle *h, int nsteps)
+{
+    if (!h) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "handle was created for dfsph");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int k = 0; k < nsteps; ++k) {
+        int rc = step_wcsph_once(h);
+        if (rc) return rc;
+    }
+    // overflow is sticky within a call: one read-back per call keeps the steps asynchronous
+    int rc = read_scalars(h);
+    if (rc) return rc;
+    return check_overflow(h);
+}
+
+int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last)
+{
+    if (!h) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "handle was created for wcsph");
+    HIP_TRY(h, hipSetDevice(h->device));
+    SphStepStats st;
+    memset(&st, 0, sizeof(st));
+    for (int k = 0; k < nsteps; ++k) {
+        int rc = step_dfsph_once(h, &st);
+        if (rc) return rc;
+    }
+    if (last) *last = st;
+    return SPH_OK;
+}
+
+int sph_get_scalar(SphHandle *h, int which, double *out)
+{
+    if (!h || !out) return SPH_E_INVALID;
+    switch (which) {
+    case SPH_S_DELTA_TIME:
+        if (h->cfg.solver == SPH_SOLVER_WCSPH) { *out = (double)h->dt_wcsph; return SPH_OK; }
+        else { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->dt; return SPH_OK; }
+    case SPH_S_SIMULATE_CNT: *out = (double)h->simulate_cnt; return SPH_OK;
+    case SPH_S_PARTICLE_M: *out = (double)h->c.m; return SPH_OK;
+    case SPH_S_SUPPORT_RADIUS: *out = (double)h->c.h; return SPH_OK;
+    case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
+    default: return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
+    }
+}
+
+int sph_synchronize(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+int sph_profile_enable(SphHandle *h, int on)
+{
+    if (!h) return SPH_E_INVALID;
+    drain_profile(h);
+    h->profiling = on != 0;
+    return SPH_OK;
+}
+
+int sph_profile_reset(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    drain_profile(h);
+    for (int k = 0; k < K_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
+    return SPH_OK;
+}
+
+int sph_profile_kernel_count(void) { return K_COUNT; }
+const char *sph_profile_kernel_name(int kid) { return (kid >= 0 && kid < K_COUNT) ? kKernelNames[kid] : ""; }
+
+int sph_profile_get(SphHandle *h, int kid, double *total_ms, int64_t *launches)
+{
+    if (!h || kid < 0 || kid >= K_COUNT) return SPH_E_INVALID;
+    drain_profile(h);
+    if (total_ms) *total_ms = h->prof_ms[kid];
+    if (launches) *launches = h->prof_n[kid];
+    return SPH_OK;
+}
+
+int sph_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SPH_E_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev || !a || !b || !out) return fail(nullptr, SPH_E_INVALID, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SPH_E_HIP, "hipSetDevice failed");
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    int rc = SPH_OK;
+    if (hipMalloc((void **)&da, n * 4) != hipSuccess || hipMalloc((void **)&db, n * 4) != hipSuccess || hipMalloc((void **)&dout, n * 4) != hipSuccess)
+        rc = fail(nullptr, SPH_E_HIP, "hipMalloc failed");
+    if (!rc) {
+        (void)hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+        Consts c;
+        memset(&c, 0, sizeof(c));
+        c.h = 0.1f;
+        const float pi_f = (float)3.141592653589793;
+        const float h3 = c.h * (c.h * c.h);
+        c.kw = 8.0f / (pi_f * h3);
+        const float kg = 48.0f / (pi_f * h3);
+        c.kg6 = kg * 6.0f; c.neg_kg6 = -kg * 6.0f;
+        hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c, op, da, db, dout, n);
+        if (hipDeviceSynchronize() != hipSuccess) rc = fail(nullptr, SPH_E_HIP, "selftest kernel failed");
+        else (void)hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

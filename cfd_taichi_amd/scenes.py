@@ -1,0 +1,59 @@
+"""Synthetic dam-break scenes in the reference's config/*.json schema:
+deterministic lattice, zero initial velocity, no RNG.  `python -m cfd_taichi_amd.scenes` writes
+them under config/."""
+import copy
+import json
+import os
+
+_BASE = {
+    "scene": {"box_min": [0.0, 0.0, 0.0], "box_max": None, "particle_radius": 0.025, "gravity": 9.8,
+              "is_output_gif": False, "is_output_ply": False, "is_simulate": True},
+    "solver": {"name": None, "delta_time": None, "iter_cnt": 1, "boundary_handle": True},
+    "fluid": {"start_pos": [0.1, 0.1, 0.1], "water_size": None},
+}
+
+
+def _scene(name, dt, box_max, water_size, start_pos=(0.1, 0.1, 0.1), boundary_handle=True):
+    c = copy.deepcopy(_BASE)
+    c["scene"]["box_max"] = list(box_max)
+    c["solver"]["name"] = name
+    c["solver"]["delta_time"] = dt
+    c["solver"]["boundary_handle"] = boundary_handle
+    c["fluid"]["water_size"] = list(water_size)
+    c["fluid"]["start_pos"] = list(start_pos)
+    return c
+
+
+SCENES = {
+    # config 1: reference config/breaking_dam_30k.json geometry, solver overridden to wcsph (BASELINE.json)
+    "breaking_dam_30k_wcsph": lambda: _scene("wcsph", 2.5e-4, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
+    "breaking_dam_30k_dfsph": lambda: _scene("dfsph", 2.5e-4, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
+    # reference config/dfsph_config_backup.json geometry (N = 5879)
+    "dfsph_small": lambda: _scene("dfsph", 1e-3, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    "wcsph_small": lambda: _scene("wcsph", 2.5e-4, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    # a tiny column resting on the floor next to a wall: exercises wall neighbours from step 1
+    "wcsph_tiny_wall": lambda: _scene("wcsph", 2.5e-4, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
+    "dfsph_tiny_wall": lambda: _scene("dfsph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
+    "wcsph_tiny_clamp": lambda: _scene("wcsph", 2.5e-4, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.1, 0.1, 0.1), boundary_handle=False),
+    "dfsph_tiny_clamp": lambda: _scene("dfsph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.1, 0.1, 0.1), boundary_handle=False),
+    # config 2-4
+    "wcsph_250k": lambda: _scene("wcsph", 2.5e-4, [10.0, 6.0, 2.7], [2.5, 5.0, 2.5]),
+    "dfsph_1m": lambda: _scene("dfsph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
+    "dfsph_10m": lambda: _scene("dfsph", 1e-3, [40.0, 15.0, 10.2], [10.0, 12.5, 10.0]),
+}
+
+
+def get(name):
+    return SCENES[name]()
+
+
+def write_all(directory):
+    os.makedirs(directory, exist_ok=True)
+    for name in SCENES:
+        with open(os.path.join(directory, name + ".json"), "w") as f:
+            json.dump(get(name), f, indent=2)
+            f.write("\n")
+
+
+if __name__ == "__main__":
+    write_all(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config"))

@@ -1,0 +1,34 @@
+"""solver_base: what the fluid solvers share at the Python level (solver_base.py:5-39,136-143).
+The shared sweeps (density, viscosity, tension, kernels) are HIP code in csrc/sph_kernels.h."""
+from . import _native as nat
+from .fields import DeviceField, ScalarField
+
+
+class solver_base:
+    _kind = None   # "wcsph" | "dfsph"
+
+    def __init__(self, particle_system, config):
+        solver_config = config.get("solver")
+        scene_config = config.get("scene")
+        self.ps = particle_system
+        self._sim = particle_system._attach_solver(self._kind)
+        self.particle_count = particle_system.particle_num
+        self.kernel_h = self.ps.particle_radius * 4          # solver_base.py:17
+        self.rho_0 = 1000                                    # :19
+        self.gravity = scene_config.get("gravity")           # :20
+        self.v_decay_proportion = 0.5
+        self.viscosity_epsilon = 0.01                        # :23-26 (wcsph overrides c_s and k)
+        self.viscosity_c_s = 13
+        self.viscosity_alpha = 0.08
+        self.tension_k = 0.5
+        self.boundary_handle = 1 if solver_config.get("boundary_handle", True) else 0   # :31
+        self.fs_couple = 1 if solver_config.get("fs_couple", True) else 0               # :32
+        self.artificial_friction = 0.9999                    # :37
+        self.delta_time = ScalarField(lambda: self._sim.scalar(nat.S_DELTA_TIME))        # :15-16
+        self.simulate_cnt = ScalarField(lambda: int(self._sim.scalar(nat.S_SIMULATE_CNT)))   # :21
+        self.rho = DeviceField(self, nat.F_RHO)               # :14
+        print("\033[32m[Solver]: {}\033[0m".format(solver_config.get("name")))   # :39
+
+    def compute_all_rho(self):
+        """solver_base.compute_all_rho (:41-51) as a stand-alone stage (rebuilds the lists if needed)."""
+        self._sim.compute_density()

@@ -1,0 +1,161 @@
+/*
+ * sph_mi355x.h -- C-ABI of the MI355X-native SPH step library (libsph_mi355x.so).
+ *
+ * The reference (Jukgei/CFD_Taichi @ 2024_08_07) has no FFI: its per-step path is Python
+ * driving Taichi-JIT kernels, and the only caller contract is main.py:64-71,165-173
+ * (`ParticleSystem(config)`, `<name>_solver(ps, config)`, `solver.step()`,
+ * `solver.delta_time[None]`, `ps.fluid_particles.pos.to_numpy()`).  This header is what a
+ * ctypes binding for that path binds instead; each entry point names the reference
+ * interface it replaces.  Plain pointers and sizes only, no torch / HIP types.
+ *
+ * Conventions: every call returns SPH_OK (0) or a negative SPH_E_* code and never throws;
+ * sph_last_error() gives the message of the last failing call on that handle (or of the
+ * last failing sph_create when handle == NULL).  One host thread per handle, one HIP
+ * stream per handle, no global state.  Host pointers are borrowed for the call only.
+ * Particle data crosses the ABI in ORIGINAL particle order (the order of
+ * ParticleSystem.init_particle_pos, ParticleSystem.py:142-151), f32, 3 floats per vector.
+ */
+#ifndef SPH_MI355X_H
+#define SPH_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_OK 0
+#define SPH_E_INVALID (-1)   /* bad argument / size mismatch */
+#define SPH_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
+#define SPH_E_NO_DEVICE (-3) /* no gfx950 device visible: the library has no CPU fallback */
+#define SPH_E_OVERFLOW (-4)  /* a neighbour list / cell overflowed its capacity; state is unchanged for that step */
+#define SPH_E_STATE (-5)     /* call not valid for this handle (e.g. dfsph step on a wcsph handle) */
+
+#define SPH_SOLVER_WCSPH 0
+#define SPH_SOLVER_DFSPH 1
+
+/* config/X.json of the reference, flattened (utils.py:3-11 reads it,
+ * ParticleSystem.py:31-103 and solver_base.py:7-39 consume it).  Doubles carry the Python
+ * scalars unrounded; the library rounds to f32 exactly where Taichi would. */
+typedef struct SphConfig {
+    double box_min[3];          /* scene.box_min */
+    double box_max[3];          /* scene.box_max */
+    double particle_radius;     /* scene.particle_radius */
+    double gravity;             /* scene.gravity */
+    double delta_time;          /* solver.delta_time */
+    double start_pos[3];        /* fluid.start_pos */
+    double water_size[3];       /* fluid.water_size */
+    int32_t boundary_handle;    /* solver.boundary_handle (default 1: Akinci wall particles) */
+    int32_t fs_couple;          /* solver.fs_couple (default 1) */
+    int32_t solver;             /* SPH_SOLVER_* (solver.name) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t max_neighbors;      /* fluid neighbour-list rows per particle; 0 = default (64) */
+    int32_t max_wall_neighbors; /* wall neighbour-list rows per particle; 0 = default (64) */
+    int32_t max_density_iters;  /* cap on correct_density_error (reference has none, dfsph_solver.py:225); 0 = default (100); reported in SphStepStats.capped */
+    int32_t slab_rank;          /* multi-GPU x-slab rank, 0 for single GPU */
+    int32_t slab_count;         /* number of slabs (world size), 0 or 1 for single GPU */
+    int32_t reserved[7];
+} SphConfig;
+
+typedef struct SphSizes {
+    int32_t n_fluid;            /* ps.particle_num                 ParticleSystem.py:85 */
+    int32_t n_wall;             /* ps.boundary_particles_num       ParticleSystem.py:95 */
+    int32_t n_rigid;            /* ps.rigid_particles_num */
+    int32_t grid[3];            /* ps.grid_num                     ParticleSystem.py:101 */
+    int32_t n_cells;
+    int32_t max_neighbors;
+    int32_t max_wall_neighbors;
+} SphSizes;
+
+/* what dfsph_solver.py prints at :233 and :416, plus health counters */
+typedef struct SphStepStats {
+    int32_t n_div;              /* divergence iterations */
+    int32_t n_dens;             /* density iterations */
+    int32_t n_div_evals;        /* derivative_iter_all_rho evaluations */
+    int32_t capped;             /* 1 if max_density_iters stopped the density loop */
+    float div_first_err;
+    float div_err;
+    float dens_err;             /* rho_avg - rho_0 */
+    float dt;                   /* delta_time after the step */
+    int32_t max_nbrs;           /* largest fluid-neighbour count seen in the last list build */
+    int32_t max_wall_nbrs;
+    int32_t lost;               /* particles outside the grid (reference prints an error, ParticleSystem.py:393-395) */
+    int32_t reserved;
+} SphStepStats;
+
+/* species for upload / download */
+#define SPH_SPECIES_FLUID 0
+#define SPH_SPECIES_WALL 1
+#define SPH_SPECIES_RIGID 2
+
+/* fields (fluid unless stated).  Vectors are 3 floats per particle. */
+#define SPH_F_POS 0        /* fluid_particles.pos   (upload + download) */
+#define SPH_F_VEL 1        /* fluid_particles.vel   (upload + download) */
+#define SPH_F_ACC 2        /* fluid_particles.acc   (wcsph only, download) */
+#define SPH_F_RHO 3        /* solver.rho */
+#define SPH_F_PRESSURE 4   /* wcsph solver.pressure */
+#define SPH_F_ALPHA 5      /* dfsph solver.alpha */
+#define SPH_F_WARM_K 6     /* dfsph solver.warm_start_k (upload + download) */
+#define SPH_F_RHO_ADV 7    /* dfsph solver.rho_adv */
+#define SPH_F_RHO_DER 8    /* dfsph solver.rho_derivative */
+#define SPH_F_VEL_ADV 9    /* dfsph solver.vel_adv */
+#define SPH_F_NBR_COUNT 14 /* ps.get_neighbour_count(i), as float */
+#define SPH_F_WALL_POS 32  /* boundary_particles.pos    (species WALL) */
+#define SPH_F_WALL_VOL 33  /* boundary_particles.volume (species WALL) */
+
+/* scalars for sph_get_scalar */
+#define SPH_S_DELTA_TIME 0     /* solver.delta_time[None] */
+#define SPH_S_SIMULATE_CNT 1   /* solver.simulate_cnt[None] */
+#define SPH_S_PARTICLE_M 2     /* ps.particle_m */
+#define SPH_S_SUPPORT_RADIUS 3 /* ps.support_radius */
+#define SPH_S_PS_DELTA_TIME 4  /* ps.delta_time[None] */
+
+typedef struct SphHandle SphHandle;
+
+/* replaces ParticleSystem(config) + <name>_solver(ps, config)   main.py:64-68.
+ * Builds the fluid lattice and the wall particles (ParticleSystem.py:139-195), the static
+ * wall cell list and wall volumes (:309-335), and allocates every device buffer. */
+int sph_create(const SphConfig *cfg, SphHandle **out);
+void sph_destroy(SphHandle *h);
+int sph_get_sizes(SphHandle *h, SphSizes *out);
+const char *sph_last_error(SphHandle *h);
+
+/* replaces field.from_numpy / field.to_numpy on ps.fluid_particles.* and solver.*   main.py:159,190.
+ * n_floats must equal the field's float count. */
+int sph_upload(SphHandle *h, int species, int field, const float *host, size_t n_floats);
+int sph_download(SphHandle *h, int species, int field, float *host, size_t n_floats);
+
+/* replaces wcsph_solver.step() x nsteps   wcsph_solver.py:25-30 (asynchronous; sph_download /
+ * sph_synchronize wait for it) */
+int sph_step_wcsph(SphHandle *h, int nsteps);
+/* replaces dfsph_solver.step() x nsteps   dfsph_solver.py:440-445; `last` (may be NULL) gets the
+ * last step's statistics */
+int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last);
+/* stages of the step, for parity tests against the oracle's stages:
+ * ps.reset_grid()+update_grid() (+ neighbour-list build), solver.compute_all_rho(), dfsph compute_all_alpha() */
+int sph_build_neighbors(SphHandle *h);
+int sph_compute_density(SphHandle *h);
+int sph_compute_alpha(SphHandle *h);
+
+int sph_get_scalar(SphHandle *h, int which, double *out);
+int sph_synchronize(SphHandle *h);
+
+/* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
+ * Enabling it records an event pair around every launch; totals are read back per kernel id. */
+int sph_profile_enable(SphHandle *h, int on);
+int sph_profile_reset(SphHandle *h);
+int sph_profile_kernel_count(void);
+const char *sph_profile_kernel_name(int kernel_id);
+int sph_profile_get(SphHandle *h, int kernel_id, double *total_ms, int64_t *launches);
+
+/* device arithmetic self-test: out[i] = op(a[i], b[i]) evaluated on the GPU with the same
+ * compiler flags as the sweeps (op 0: a/b, 1: sqrt(a), 2: cubic_kernel(a, h=b), 3..5:
+ * component op-3 of cubic_kernel_derivative((a, b, 0.25*a), h=0.1)).  Used by tests to prove
+ * the device's f32 divide/sqrt are correctly rounded like the oracle's. */
+int sph_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

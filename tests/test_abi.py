@@ -1,0 +1,79 @@
+"""CPU suite: the C-ABI library builds/loads, exports every symbol include/sph_mi355x.h declares,
+and the product fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from cfd_taichi_amd import _native, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "sph_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == sorted(_native.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts(tmp_path):
+    """ctypes mirrors vs the header, as seen by a C compiler."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "sph_mi355x.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu\\n", sizeof(SphConfig), sizeof(SphStepStats), sizeof(SphSizes),'
+                   ' offsetof(SphConfig, boundary_handle));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == [ctypes.sizeof(_native.SphConfig), ctypes.sizeof(_native.SphStepStats),
+                                     ctypes.sizeof(_native.SphSizes), _native.SphConfig.boundary_handle.offset]
+
+
+def test_profile_kernel_names():
+    lib = _native.load()
+    names = [lib.sph_profile_kernel_name(k).decode() for k in range(lib.sph_profile_kernel_count())]
+    assert "build_nl" in names and "dfsph_div_residual" in names and len(set(names)) == len(names)
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-GPU failure mode")
+def test_no_gpu_is_a_loud_error():
+    cfg = _native.config_from_dict(scenes.get("wcsph_tiny_wall"))
+    with pytest.raises(_native.SphError) as e:
+        _native.Simulation(cfg)
+    assert e.value.code == _native.SPH_E_NO_DEVICE
+
+
+def test_out_of_scope_solver_rejected():
+    cfg = scenes.get("wcsph_tiny_wall")
+    cfg["solver"]["name"] = "pbf"
+    with pytest.raises(ValueError):
+        _native.config_from_dict(cfg)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "cfd_taichi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "sph_oracle" not in text and "liborc" not in text, f
