@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- million particle-steps/s of the DFSPH dam break on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one dfsph_solver.step() (grid rebuild, density/alpha, divergence solve, external
+forces, adaptive dt, density solve, integration) over the whole particle set, which is resident in
+HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel: algorithmic bytes per launch / its mean launch
+                duration, measured live with HIP events on the library's stream (a separate,
+                profiled pass after the timed region); `traffic` is the per-launch HBM byte count from
+                the rocprofv3 PMC passes committed under profiles/ (null if absent).
+  cpu_baseline  the CPU oracle ("port": restatement of the ti.cpu path, not Taichi) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+# algorithmic bytes per particle per launch
+ALGO_BYTES = {
+    "dfsph_density_alpha": 24, "dfsph_warm_start": 48, "dfsph_div_residual": 32, "dfsph_div_correct": 56,
+    "dfsph_ext_force": 40, "dfsph_dens_residual": 32, "dfsph_dens_correct": 48, "dfsph_integrate": 48,
+    "wcsph_density": 16, "wcsph_force": 52, "hash_count": 16, "order_gather": 64, "build_nl": 0,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None, help="scene name from cfd_taichi_amd.scenes (default dfsph_1m)")
+    ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event profiled pass (0 = skip roofline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_name, solver_kind):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+    from cfd_taichi_amd import scenes
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cfg = scenes.get(scene_name)
+    o = orc.Oracle(cfg, num_threads=cores)
+    if solver_kind == "dfsph":
+        o.step_dfsph(1, 100)                 # step 1 from rest is atypical (zero divergence residual): untimed
+        timed = 2
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            o.step_dfsph(1, 100)
+        dt = time.perf_counter() - t0
+        sample = "steps 2-3 of %s (N=%d, n_div=%d, n_dens=%d) after 1 untimed step" % (
+            scene_name, o.N, o.last_stats.n_div, o.last_stats.n_dens)
+    else:
+        o.step_wcsph(1)
+        timed = 3
+        t0 = time.perf_counter()
+        o.step_wcsph(timed)
+        dt = time.perf_counter() - t0
+        sample = "steps 2-4 of %s (N=%d) after 1 untimed step" % (scene_name, o.N)
+    value = o.N * timed / dt / 1e6
+    o.close()
+    return {"value": value, "unit": "Mparticle-steps/s", "cores": cores, "kind": "port",
+            "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt}
+
+
+def load_traffic(kernel):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        return data.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from cfd_taichi_amd import _native as nat
+    from cfd_taichi_amd import scenes
+
+    scene_name = args.workload or "dfsph_1m"
+    cfg = scenes.get(scene_name)
+    solver_kind = cfg["solver"]["name"]
+    sim = nat.Simulation(nat.config_from_dict(cfg, device=local_rank))
+    n_local = sim.n_fluid
+
+    def run(nsteps, stats=None):
+        if solver_kind == "dfsph":
+            for _ in range(nsteps):
+                st = sim.step_dfsph(1)
+                if stats is not None:
+                    stats.append((st.n_div, st.n_dens, st.n_div_evals))
+        else:
+            sim.step_wcsph(nsteps)
+
+    def fence():
+        sim.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    run(args.warmup)
+    fence()
+    stats = []
+    t0 = time.perf_counter()
+    run(args.steps, stats)
+    sim.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+
+    total_particles = n_local * world       # replicas: every rank advances its own dam break (weak scaling)
+    value = total_particles * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "million particle-steps/sec (DFSPH dam-break)" if solver_kind == "dfsph" else "million particle-steps/sec (WCSPH dam-break)",
+        "value": value, "unit": "Mparticle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": scene_name, "solver": solver_kind, "particles_per_gpu": n_local, "wall_particles": sim.n_wall,
+                   "grid": list(sim.grid), "parallelism": "1 GPU" if world == 1 else "%d independent replicas (x-slab halo exchange not built yet)" % world},
+    }
+    if stats:
+        nd = [s[0] for s in stats]; ns = [s[1] for s in stats]; ne = [s[2] for s in stats]
+        out["config"].update({"n_div_mean": sum(nd) / len(nd), "n_dens_mean": sum(ns) / len(ns), "n_div_evals_mean": sum(ne) / len(ne)})
+        algo_step = 272 + 88 * (sum(nd) / len(nd)) + 80 * (sum(ns) / len(ns))
+        out["config"]["algorithmic_bytes_per_particle_step"] = algo_step
+        out["step_hbm_frac_algorithmic"] = algo_step * n_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS
+
+    # ---- roofline leg: HIP-event timing of every kernel in a separate profiled pass ----
+    if rank == 0 and args.profile_steps > 0:
+        sim.profile_reset()
+        sim.profile_enable(True)
+        run(args.profile_steps)
+        sim.synchronize()
+        prof = sim.profile()
+        sim.profile_enable(False)
+        tot = sum(ms for ms, _ in prof.values())
+        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0}
+        dom = max(sweeps, key=lambda k: sweeps[k][0])
+        ms, n = prof[dom]
+        avg_s = ms / n / 1e3
+        algo = ALGO_BYTES[dom] * n_local
+        achieved = algo / avg_s / 1e9
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom),
+                           "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
+                           "share_of_gpu_time": ms / tot if tot else None}
+        out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.profile_steps,
+                                          "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind)
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

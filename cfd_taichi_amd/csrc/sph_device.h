@@ -57,42 +57,41 @@ struct F3 {
     float x, y, z;
 };
 
-// solver_base.py:76-88
+// solver_base.py:76-88.  Branch-free form: both polynomial pieces are cheap, the select keeps the
+// value of the branch the reference would have taken (identical f32 operations per piece).
 __device__ __forceinline__ float cubic_w(const Consts &c, float r)
 {
-    float ret = 0.0f;
     float q = r / c.h;
-    if (0.0f <= q && q <= 0.5f) {
-        float q2 = q * q;
-        float q3 = q2 * q;
-        ret = c.kw * (6.0f * (q3 - q2) + 1.0f);
-    } else if (0.5f < q && q <= 1.0f) {
-        float t = 1.0f - q;
-        ret = 2.0f * c.kw * (t * (t * t));
-    }
-    return ret;
+    float q2 = q * q;
+    float q3 = q2 * q;
+    float w1 = c.kw * (6.0f * (q3 - q2) + 1.0f);          // 0 <= q <= 0.5
+    float t = 1.0f - q;
+    float w2 = 2.0f * c.kw * (t * (t * t));               // 0.5 < q <= 1
+    bool in1 = (0.0f <= q) && (q <= 0.5f);
+    bool in2 = (0.5f < q) && (q <= 1.0f);
+    return in1 ? w1 : (in2 ? w2 : 0.0f);
 }
 
-// solver_base.py:90-103 (with the reference's factor 6)
+// solver_base.py:90-103 (with the reference's factor 6).  The two branches differ only in the
+// scalar s; selecting s first leaves ONE set of three IEEE divides per pair instead of two
+// divergent sets.
 __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float dz, float r_norm)
 {
-    F3 o = {0.0f, 0.0f, 0.0f};
     float q = r_norm / c.h;
-    if (1e-5f < q && q <= 0.5f) {
-        float q2 = q * q;
-        float s = c.kg6 * (3.0f * q2 - 2.0f * q);
-        float den = c.h * r_norm;
-        o.x = s * dx / den;
-        o.y = s * dy / den;
-        o.z = s * dz / den;
-    } else if (0.5f < q && q <= 1.0f) {
-        float t = 1.0f - q;
-        float s = c.neg_kg6 * (t * t);
-        float den = c.h * r_norm;
-        o.x = s * dx / den;
-        o.y = s * dy / den;
-        o.z = s * dz / den;
-    }
+    float q2 = q * q;
+    float s1 = c.kg6 * (3.0f * q2 - 2.0f * q);            // 1e-5 < q <= 0.5
+    float t = 1.0f - q;
+    float s2 = c.neg_kg6 * (t * t);                       // 0.5 < q <= 1
+    bool in1 = (1e-5f < q) && (q <= 0.5f);
+    bool in2 = (0.5f < q) && (q <= 1.0f);
+    float s = in1 ? s1 : s2;
+    float den = c.h * r_norm;
+    F3 o;
+    float ox = s * dx / den, oy = s * dy / den, oz = s * dz / den;
+    bool in = in1 || in2;
+    o.x = in ? ox : 0.0f;
+    o.y = in ? oy : 0.0f;
+    o.z = in ? oz : 0.0f;
     return o;
 }
 

@@ -16,6 +16,26 @@
 
 namespace sph {
 
+// ---- XCD-aware block mapping -------------------------------------------------------------------
+// Hardware deals workgroups round-robin over the 8 XCDs (blocks b and b+8 share an XCD and its
+// private 4 MiB L2).  Remap so that each XCD sweeps one CONTIGUOUS eighth of the sorted particle
+// array: its L2 then only has to hold the few cell layers around its own sweep front instead of
+// a slice of everything.  Bijective for any grid size (speed only, never correctness).
+__device__ __forceinline__ int xcd_block(int orig, int nwg)
+{
+    int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// Neighbour lists are stored per 64-particle wave tile, four rows interleaved per lane:
+//   entry (i, k) lives at ((i/64)*kmax + (k & ~3))*64 + (i%64)*4 + (k & 3)
+// so a lane fetches neighbours k..k+3 with ONE 16-byte load, a wave's load is 1 KiB contiguous, and
+// the whole tile (kmax * 256 B) is one contiguous chunk that the wave streams front to back.
+__device__ __forceinline__ size_t nl_index(int i, int k, int kmax)
+{
+    return ((size_t)(i >> 6) * kmax + (k & ~3)) * 64 + (size_t)(i & 63) * 4 + (k & 3);
+}
+
 // ======================================================================================
 // counting sort by cell                      ParticleSystem.py:368-397 (reset_grid + update_grid)
 // ======================================================================================
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      uint32_t *__restrict__ nl, uint32_t *__restrict__ nlb,
                                                      int *__restrict__ cnt, DevScalars *__restrict__ ds)
 {
-    int i = blockIdx.x * kBlock + threadIdx.x;
+    int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
     if (i == 0) ds->lost = cell_start[c.C + 1] - cell_start[c.C];   // size of the "outside the grid" bucket
     if (i < c.n) {
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                         float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
-                        if (kf < c.kmax) nl[(size_t)kf * c.stride + i] = (uint32_t)j;
+                        if (kf < c.kmax) nl[nl_index(i, kf, c.kmax)] = (uint32_t)j;
                         ++kf;
                     }
                     if (c.boundary_handle) {
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                             float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                             float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                             if (r2 > c.r2_cut) continue;                 // :364
-                            if (kb < c.kbmax) nlb[(size_t)kb * c.stride + i] = (uint32_t)j;
+                            if (kb < c.kbmax) nlb[nl_index(i, kb, c.kbmax)] = (uint32_t)j;
                             ++kb;
                         }
                     }
@@ -203,15 +223,54 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
 // helpers for the list-driven sweeps
 // ======================================================================================
 #define SPH_SWEEP_PROLOGUE                                   \
-    int i = blockIdx.x * kBlock + threadIdx.x;               \
+    const int blk = xcd_block(blockIdx.x, gridDim.x);        \
+    int i = blk * kBlock + threadIdx.x;                      \
     const bool live = i < c.n;                               \
     const int ii = live ? i : 0;                             \
     const int cw = live ? cnt[ii] : 0;                       \
     const int kf = cw & 0xffff, kb = cw >> 16;               \
-    const float4 pi = P[ii];
+    const float4 pi = P[ii];                                 \
+    const uint32_t *nlp = nl + nl_index(ii, 0, c.kmax);      \
+    const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbmax) : nullptr;
+
+// Walk of a neighbour list in groups of four: one 16-byte index load, four independent float4
+// gathers in flight, the next group's indices requested before the four bodies run.  Bodies run in
+// list order, so every accumulator sees its terms in the canonical order.  Rows past a particle's
+// count hold stale but valid indices (the buffer is zero-initialised, only ever holds indices < n,
+// and one spare tile pads the end), so the speculative loads are always in bounds.
+template <class Body>
+__device__ __forceinline__ void for_nbrs_p(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A, Body body)
+{
+    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = jn;
+        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
+        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        body(a0);
+        if (kk + 1 < cnt) body(a1);
+        if (kk + 2 < cnt) body(a2);
+        if (kk + 3 < cnt) body(a3);
+    }
+}
+template <class Body>
+__device__ __forceinline__ void for_nbrs_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
+                                            const float4 *__restrict__ B, Body body)
+{
+    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = jn;
+        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
+        const float4 b0 = B[jj.x], b1 = B[jj.y], b2 = B[jj.z], b3 = B[jj.w];
+        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        body(a0, b0);
+        if (kk + 1 < cnt) body(a1, b1);
+        if (kk + 2 < cnt) body(a2, b2);
+        if (kk + 3 < cnt) body(a3, b3);
+    }
+}
 
 // block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
-__device__ __forceinline__ void block_partial_mean(double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
+__device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
 {
     __shared__ double s_sum[kBlock / 64];
     __shared__ int s_cnt[kBlock / 64];
@@ -223,12 +282,12 @@ __device__ __forceinline__ void block_partial_mean(double v, int flag, double *_
     if (threadIdx.x == 0) {
         double t = 0.0; int n = 0;
         for (int k = 0; k < kBlock / 64; ++k) { t += s_sum[k]; n += s_cnt[k]; }
-        psum[blockIdx.x] = t;
-        pcnt[blockIdx.x] = n;
+        psum[blk] = t;
+        pcnt[blk] = n;
     }
 }
 
-__device__ __forceinline__ void block_partial_max(float v, float *__restrict__ pmax)
+__device__ __forceinline__ void block_partial_max(int blk, float v, float *__restrict__ pmax)
 {
     __shared__ float s_max[kBlock / 64];
     float wm = wave_max(v);
@@ -238,7 +297,7 @@ __device__ __forceinline__ void block_partial_max(float v, float *__restrict__ p
     if (threadIdx.x == 0) {
         float t = s_max[0];
         for (int k = 1; k < kBlock / 64; ++k) t = fmaxf(t, s_max[k]);
-        pmax[blockIdx.x] = t;
+        pmax[blk] = t;
     }
 }
 
@@ -290,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_dt(Consts c, const float *_
 // ======================================================================================
 // W1 / D1: density (+ alpha)          solver_base.py:41-72, dfsph_solver.py:32-89, wcsph_solver.py:66-68
 //   WCSPH: writes Pout = (pos, rho), Vout = (vel, p/rho^2), rho[], pressure[]
-//   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, rho[], alpha[]
+//   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, Vout = (vel, rho), rho[], alpha[]
 // ======================================================================================
 template <bool DFSPH>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
@@ -303,9 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     SPH_SWEEP_PROLOGUE
     float rho = 0.001f;                                      // solver_base.py:44
     float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
-    for (int k = 0; k < kf; ++k) {
-        uint32_t j = nl[(size_t)k * c.stride + ii];
-        float4 pj = P[j];
+    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         rho += c.m * cubic_w(c, r);                          // solver_base.py:62
@@ -315,11 +372,9 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             sx += rx; sy += ry; sz += rz;
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
-    }
+    });
     float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
-    for (int k = 0; k < kb; ++k) {
-        uint32_t j = nlb[(size_t)k * c.stride + ii];
-        float4 pj = WP[j];                                   // (x, y, z, V_b)
+    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         rho_b += pj.w * cubic_w(c, r);                       // solver_base.py:70-71
@@ -330,10 +385,11 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             bx += rx; by += ry; bz += rz;
             bsq += (rx * rx + ry * ry) + rz * rz;
         }
-    }
+    });
     float rho_i = c.boundary_handle ? rho + rho_b * c.rho0 : rho;   // solver_base.py:49,51
     if (!live) return;
     rho_out[i] = rho_i;
+    const float4 vi = V[i];
     if (DFSPH) {
         float den;
         if (c.boundary_handle)
@@ -345,10 +401,10 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
         float dt = ds->dt;
         float k_i = warm[i] / dt;                            // dfsph_solver.py:333
         Pout[i] = make_float4(pi.x, pi.y, pi.z, k_i / rho_i);
+        Vout[i] = make_float4(vi.x, vi.y, vi.z, rho_i);      // velocity buffers carry rho in .w (read by D5)
     } else {
         float p = tait_pressure(rho_i);                      // wcsph_solver.py:86-90
         aux_out[i] = p;
-        float4 vi = V[i];
         Pout[i] = make_float4(pi.x, pi.y, pi.z, rho_i);
         Vout[i] = make_float4(vi.x, vi.y, vi.z, p / (rho_i * rho_i));   // :109,116
     }
@@ -372,10 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
     float gx = 0.f, gy = 0.f, gz = 0.f;                      // pressure gradient
     float wx = 0.f, wy = 0.f, wz = 0.f;                      // viscosity
     float tx = 0.f, ty = 0.f, tz = 0.f;                      // tension
-    for (int k = 0; k < kf; ++k) {
-        uint32_t j = nl[(size_t)k * c.stride + ii];
-        float4 pj = P[j];
-        float4 vj = V[j];
+    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -392,20 +445,18 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
         }
         float st = c.tens_c * cubic_w(c, r);                 // :216
         tx += st * dx; ty += st * dy; tz += st * dz;
-    }
+    });
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (c.boundary_handle) {
         const float p_i = live ? pressure[ii] : 0.f;
         const float rho_i_2 = rho_i * rho_i;
-        for (int k = 0; k < kb; ++k) {
-            uint32_t j = nlb[(size_t)k * c.stride + ii];
-            float4 pj = WP[j];
+        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w(c, dx, dy, dz, r);
             float s = pj.w * p_i / rho_i_2;                  // wcsph_solver.py:99
             bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
-        }
+        });
     }
     if (!live) return;
     float pg[3] = {gx, gy, gz};
@@ -440,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
 //   v_i -= dt * ( sum_F m (k_i/rho_i + k_j/rho_j) gradW + rho0 * sum_B (V_b k_i / rho_i) gradW )
 // with k from warm_start_k (D2, dfsph_solver.py:314-355), rho_derivative*alpha (D4, :302-312,
 // 357-391, with the 1e-5 gate and sum_up_stiff :381-384) or (rho_adv-rho0)*alpha (D7, :178-219).
-// P.w of every particle holds k/rho, written by the sweep before.
+// P.w of every particle holds k/rho, written by the sweep before.  Vout.w carries rho.
 // ======================================================================================
 enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
 
@@ -461,9 +512,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
     const float kr_i = k_i / rho_i;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int k = 0; k < kf; ++k) {
-        uint32_t j = nl[(size_t)k * c.stride + ii];
-        float4 pj = P[j];
+    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -472,17 +521,15 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             float s = c.m * ks;                                                   // :337 / :369 / :203
             ax += s * g.x; ay += s * g.y; az += s * g.z;
         }
-    }
+    });
     float bx = 0.f, by = 0.f, bz = 0.f;
-    for (int k = 0; k < kb; ++k) {
-        uint32_t j = nlb[(size_t)k * c.stride + ii];
-        float4 pj = WP[j];
+    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
         float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219
         bx += s * g.x; by += s * g.y; bz += s * g.z;
-    }
+    });
     if (!live) return;
     float4 v = Vin[i];
     if (c.boundary_handle) {
@@ -493,6 +540,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     } else {
         v.x -= ax * dt; v.y -= ay * dt; v.z -= az * dt;                           // :324 / :312 / :189
     }
+    v.w = rho_i;
     Vout[i] = v;
     if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
     if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
@@ -516,25 +564,19 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     const float4 vi = V[ii];
     float acc = 0.f;
     const bool skip = !DENS && kf < 20;                                           // :258-261
-    const int kfe = skip ? 0 : kf, kbe = skip ? 0 : kb;
-    for (int k = 0; k < kfe; ++k) {
-        uint32_t j = nl[(size_t)k * c.stride + ii];
-        float4 pj = P[j];
-        float4 vj = V[j];
+    for_nbrs_pv(nlp, skip ? 0 : kf, P, V, [&](const float4 pj, const float4 vj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
         acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);  // :287 / :162
-    }
+    });
     float accb = 0.f;
-    for (int k = 0; k < kbe; ++k) {
-        uint32_t j = nlb[(size_t)k * c.stride + ii];
-        float4 pj = WP[j];
+    for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
-    }
+    });
     float val = 0.f;
     int flag = 0;
     if (live) {
@@ -556,28 +598,26 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         out[i] = val;
         Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
     }
-    block_partial_mean((double)val, flag, psum, pcnt);
+    block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // ======================================================================================
 // D5: tension + viscosity + external force + v* and max |v*|
-//     solver_base.py:170-217, dfsph_solver.py:91-103
+//     solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
 // ======================================================================================
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
-                                                      const float *__restrict__ rho, const DevScalars *__restrict__ ds,
-                                                      float4 *__restrict__ VAout, float *__restrict__ pmax)
+                                                      const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
+                                                      float *__restrict__ pmax)
 {
+    const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
-    (void)kb;
+    (void)kb; (void)nlbp;
     const float4 vi = V[ii];
-    const float rho_i = rho[ii];
+    const float rho_i = vi.w;
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
-    for (int k = 0; k < kf; ++k) {
-        uint32_t j = nl[(size_t)k * c.stride + ii];
-        float4 pj = P[j];
-        float4 vj = V[j];
+    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
@@ -587,12 +627,12 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
         if (shear < 0.f) {
             F3 g = grad_w(c, dx, dy, dz, r);
             float q2 = r * r;
-            float nu = c.visc_num / (rho_i + rho[j]);        // :187
+            float nu = c.visc_num / (rho_i + vj.w);          // :187
             float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
             float sv = c.neg_m * pi_;                        // :189
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
-    }
+    });
     float vn = -INFINITY;
     if (live) {
         const float dt = ds->dt;
@@ -606,10 +646,10 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             float f = (g[a] + ten[a]) + vis[a];              // dfsph_solver.py:96
             va[a] = v[a] + dt * f / c.m;                     // :102
         }
-        VAout[i] = make_float4(va[0], va[1], va[2], 0.f);
+        VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
         vn = norm3(va[0], va[1], va[2]);                     // :103
     }
-    block_partial_max(vn, pmax);
+    block_partial_max(blk, vn, pmax);
 }
 
 // D8: compute_all_position                                  dfsph_solver.py:235-250
@@ -639,6 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_integrate(Consts c, const floa
     Pn[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
     Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
 }
+
 
 // ======================================================================================
 // original-order <-> sorted-order transfers for the C-ABI (field.to_numpy / from_numpy)

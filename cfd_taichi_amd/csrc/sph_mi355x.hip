@@ -220,8 +220,8 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.boundary_handle = cf.boundary_handle ? 1 : 0;
     c.n = h->N;
     c.stride = (h->N + 63) / 64 * 64;
-    c.kmax = cf.max_neighbors > 0 ? cf.max_neighbors : 64;
-    c.kbmax = cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64;
+    c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
+    c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64) + 3) & ~3;
     if (c.kmax > 0xffff || c.kbmax > 0x7fff) return fail(h, SPH_E_INVALID, "neighbour capacity too large");
 
     // ---- fluid lattice, init_particle_pos :142-151 (f32 index arithmetic, constants f64-folded) ----
@@ -358,8 +358,11 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     HIP_TRY(h, hipMemsetAsync(h->drho, 0, sizeof(float) * n, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rho_adv, 0, sizeof(float) * n, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->cnt, 0, sizeof(int) * n, h->stream));
-    if ((rc = dalloc(h, &h->nl, n * (size_t)c.kmax))) return rc;
-    if ((rc = dalloc(h, &h->nlb, n * (size_t)c.kbmax))) return rc;
+    // one spare 64-particle tile at the end: the software-pipelined walks read one row ahead
+    if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kmax))) return rc;
+    if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbmax))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->nl, 0, sizeof(uint32_t) * (n + 64) * (size_t)c.kmax, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->nlb, 0, sizeof(uint32_t) * (n + 64) * (size_t)c.kbmax, h->stream));
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
@@ -473,9 +476,9 @@ int stage_density(SphHandle *h)
     const dim3 g = grid_for(c.n), b(kBlock);
     if (h->cfg.solver == SPH_SOLVER_DFSPH) {
         ProfScope ps(h, K_D_DENSITY_ALPHA);
-        hipLaunchKernelGGL(k_density<true>, g, b, 0, s, c, h->P[h->pcur], (const float4 *)nullptr, h->WP, h->nl, h->nlb, h->cnt,
-                           h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], (float4 *)nullptr);
-        h->pcur ^= 1;     // P[pcur] = (pos, (warm_k/dt)/rho)
+        hipLaunchKernelGGL(k_density<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                           h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        h->pcur ^= 1; h->vcur ^= 1;    // P = (pos, (warm_k/dt)/rho), V = (vel, rho)
     } else {
         ProfScope ps(h, K_W_DENSITY);
         hipLaunchKernelGGL(k_density<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
@@ -570,7 +573,7 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     // ---- compute_all_ext_force + compute_all_vel_adv, :91-122 ----
     {
         ProfScope ps(h, K_D_EXT);
-        hipLaunchKernelGGL(k_dfsph_ext, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->rho, h->ds, h->VA[h->vacur], h->pmax);
+        hipLaunchKernelGGL(k_dfsph_ext, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax);
     }
     {
         ProfScope ps(h, K_FINALIZE);
