@@ -42,16 +42,28 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None, help="scene name from cfd_taichi_amd.scenes (default dfsph_1m)")
-    ap.add_argument("--profile-steps", type=int, default=10, help="steps of the HIP-event profiled pass (0 = skip roofline)")
+    ap.add_argument("--profile-steps", type=int, default=1, help="0 = skip the HIP-event profiled replay (roofline leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
+
+
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (16 on a 1-GPU box)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
 
 
 def cpu_baseline(scene_name, solver_kind):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
     from cfd_taichi_amd import scenes
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     cfg = scenes.get(scene_name)
     o = orc.Oracle(cfg, num_threads=cores)
     if solver_kind == "dfsph":
@@ -161,11 +173,14 @@ def main():
         out["config"]["algorithmic_bytes_per_particle_step"] = algo_step
         out["step_hbm_frac_algorithmic"] = algo_step * n_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS
 
-    # ---- roofline leg: HIP-event timing of every kernel in a separate profiled pass ----
+    # ---- roofline leg: HIP-event timing of every kernel, replaying the SAME steps (warm-up + timed) on a
+    # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
     if rank == 0 and args.profile_steps > 0:
-        sim.profile_reset()
+        sim.close()
+        sim = nat.Simulation(nat.config_from_dict(cfg, device=local_rank))
         sim.profile_enable(True)
-        run(args.profile_steps)
+        nprof = args.warmup + args.steps
+        run(nprof)
         sim.synchronize()
         prof = sim.profile()
         sim.profile_enable(False)
@@ -179,8 +194,9 @@ def main():
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom),
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
-                           "share_of_gpu_time": ms / tot if tot else None}
-        out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.profile_steps,
+                           "share_of_gpu_time": ms / tot if tot else None,
+                           "note": "sweeps are f32-VALU bound (IEEE sqrt + 4 IEEE divides per pair), not HBM bound: see DESIGN.md section 4"}
+        out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind)

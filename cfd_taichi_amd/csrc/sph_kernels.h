@@ -167,6 +167,19 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
 // (ParticleSystem.py:447-469, 337-366), done once per step because positions are frozen
 // between the grid rebuild and the integrator.
 // ======================================================================================
+// Appends one index to a lane's list; a full group of four is written with one 16-byte store.
+__device__ __forceinline__ void nl_push(uint32_t j, uint4 &g, int &k, uint32_t *__restrict__ base, int kcap)
+{
+    const int s = k & 3;
+    if (s == 0) g.x = j; else if (s == 1) g.y = j; else if (s == 2) g.z = j; else g.w = j;
+    if (s == 3 && k < kcap) *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = g;
+    ++k;
+}
+__device__ __forceinline__ void nl_flush(const uint4 &g, int k, uint32_t *__restrict__ base, int kcap)
+{
+    if ((k & 3) != 0 && k < kcap) *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = g;   // tail slots: stale but valid indices
+}
+
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      uint32_t *__restrict__ nl, uint32_t *__restrict__ nlb,
@@ -179,6 +192,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         float4 pi = P[i];
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+        uint32_t *fbase = nl + nl_index(i, 0, c.kmax);
+        uint32_t *wbase = nlb + nl_index(i, 0, c.kbmax);
+        uint4 gf = make_uint4(0, 0, 0, 0), gw = make_uint4(0, 0, 0, 0);
         for (int dx = -1; dx <= 1; ++dx)
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dz = -1; dz <= 1; ++dz) {
@@ -193,8 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                         float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
-                        if (kf < c.kmax) nl[nl_index(i, kf, c.kmax)] = (uint32_t)j;
-                        ++kf;
+                        nl_push((uint32_t)j, gf, kf, fbase, c.kmax);
                     }
                     if (c.boundary_handle) {
                         int wa = wcell_start[cid], wb = wcell_start[cid + 1];
@@ -203,11 +218,12 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                             float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                             float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                             if (r2 > c.r2_cut) continue;                 // :364
-                            if (kb < c.kbmax) nlb[nl_index(i, kb, c.kbmax)] = (uint32_t)j;
-                            ++kb;
+                            nl_push((uint32_t)j, gw, kb, wbase, c.kbmax);
                         }
                     }
                 }
+        nl_flush(gf, kf, fbase, c.kmax);
+        nl_flush(gw, kb, wbase, c.kbmax);
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
         cnt[i] = kfc | (kbc << 16);
     }
