@@ -100,6 +100,54 @@ def load_traffic(kernel):
         return None
 
 
+def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group):
+    """Single-GPU handle, or this rank's slab of the sharded simulation."""
+    cfg = scenes.get(scene_name)
+    if world == 1:
+        return nat.Simulation(nat.config_from_dict(cfg, device=local_rank)), None
+    from cfd_taichi_amd.slab import SlabSimulation, TorchComm
+    slab = SlabSimulation.__new__(SlabSimulation)
+    c = nat.config_from_dict(cfg, device=local_rank, slab_rank=rank, slab_count=world)
+    slab.rank, slab.world = rank, world
+    slab.solver = cfg["solver"]["name"]
+    slab.sim = nat.Simulation(c)
+    slab.comm = TorchComm(rank, world, device=local_rank, capacity_bytes=128 << 20, group=transport_group)
+    slab.sim.set_comm(slab.comm.struct)
+    slab.n_fluid = slab.sim.n_fluid
+    return slab.sim, slab
+
+
+def pick_transport(dist, torch, rank, world, local_rank):
+    """RCCL (nccl backend) device-to-device halo exchange when it works; otherwise the same protocol over a gloo
+    side group with host staging.  Every rank takes the same decision (the probe result is all-reduced)."""
+    from cfd_taichi_amd.slab import TorchComm
+    gloo = dist.new_group(backend="gloo")
+    if os.environ.get("SPH_TRANSPORT", "nccl") == "gloo":
+        return gloo, "gloo (host staged, forced by SPH_TRANSPORT)"
+    ok = 1
+    try:
+        probe = TorchComm(rank, world, device=local_rank, capacity_bytes=1 << 16)
+        rl, rr = probe.exchange_counts(3, 5)
+        probe.bufs["send_left"][:64] = rank
+        probe.bufs["send_right"][:64] = rank
+        probe.exchange_buffers(64 if rank > 0 else 0, 64 if rank < world - 1 else 0, 64 if rank > 0 else 0, 64 if rank < world - 1 else 0)
+        torch.cuda.synchronize()
+        if rank > 0 and (rl != 5 or int(probe.bufs["recv_left"][0]) != rank - 1):
+            ok = 0
+        if rank < world - 1 and (rr != 3 or int(probe.bufs["recv_right"][0]) != rank + 1):
+            ok = 0
+        if probe.allreduce([1.0], 0) != [float(world)]:
+            ok = 0
+    except Exception as e:  # noqa: BLE001
+        print("[bench] rank %d: RCCL halo probe failed (%s); falling back to gloo host staging" % (rank, e), file=sys.stderr)
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=gloo)
+    if int(t.item()) == 1:
+        return None, "rccl p2p (device buffers over xGMI)"
+    return gloo, "gloo (host staged: RCCL probe failed)"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -112,19 +160,23 @@ def main():
 
     import torch
     dist = None
+    transport_group, transport = None, None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        transport_group, transport = pick_transport(dist, torch, rank, world, local_rank)
 
     from cfd_taichi_amd import _native as nat
     from cfd_taichi_amd import scenes
 
-    scene_name = args.workload or "dfsph_1m"
+    # N = 1: config 3 of BASELINE.json (dfsph_1m).  N > 1: config 4 (dfsph_10m), x-slabs with ghost exchange: the total
+    # work is fixed over N = 2, 4, 8 (strong scaling); 1.25 M particles per GPU at N = 8.
+    scene_name = args.workload or ("dfsph_1m" if world == 1 else "dfsph_10m")
     cfg = scenes.get(scene_name)
     solver_kind = cfg["solver"]["name"]
-    sim = nat.Simulation(nat.config_from_dict(cfg, device=local_rank))
-    n_local = sim.n_fluid
+    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group)
+    n_total = sim.n_fluid
 
     def run(nsteps, stats=None):
         if solver_kind == "dfsph":
@@ -155,35 +207,40 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
 
-    total_particles = n_local * world       # replicas: every rank advances its own dam break (weak scaling)
-    value = total_particles * args.steps / elapsed / 1e6
+    value = n_total * args.steps / elapsed / 1e6
+    slab_info = sim.slab_info() if world > 1 else None
 
     out = {
         "metric": "million particle-steps/sec (DFSPH dam-break)" if solver_kind == "dfsph" else "million particle-steps/sec (WCSPH dam-break)",
         "value": value, "unit": "Mparticle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": scene_name, "solver": solver_kind, "particles_per_gpu": n_local, "wall_particles": sim.n_wall,
-                   "grid": list(sim.grid), "parallelism": "1 GPU" if world == 1 else "%d independent replicas (x-slab halo exchange not built yet)" % world},
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
+                   "grid": list(sim.grid),
+                   "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s" % (world, transport)},
     }
+    if slab_info is not None:
+        out["config"]["rank0_slab"] = slab_info
+        out["config"]["rank0_comm"] = slab.comm.stats
     if stats:
         nd = [s[0] for s in stats]; ns = [s[1] for s in stats]; ne = [s[2] for s in stats]
         out["config"].update({"n_div_mean": sum(nd) / len(nd), "n_dens_mean": sum(ns) / len(ns), "n_div_evals_mean": sum(ne) / len(ne)})
         algo_step = 272 + 88 * (sum(nd) / len(nd)) + 80 * (sum(ns) / len(ns))
         out["config"]["algorithmic_bytes_per_particle_step"] = algo_step
-        out["step_hbm_frac_algorithmic"] = algo_step * n_local * args.steps / elapsed / 1e9 / HBM_PEAK_GBS
+        out["step_hbm_frac_algorithmic"] = algo_step * n_total * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world)
 
     # ---- roofline leg: HIP-event timing of every kernel, replaying the SAME steps (warm-up + timed) on a
     # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
         sim.close()
-        sim = nat.Simulation(nat.config_from_dict(cfg, device=local_rank))
+        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group)
         sim.profile_enable(True)
         nprof = args.warmup + args.steps
         run(nprof)
         sim.synchronize()
         prof = sim.profile()
         sim.profile_enable(False)
+        n_local = sim.slab_info()["owned"] + sim.slab_info()["ghosts"] if world > 1 else n_total
         tot = sum(ms for ms, _ in prof.values())
         sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0}
         dom = max(sweeps, key=lambda k: sweeps[k][0])
@@ -192,9 +249,9 @@ def main():
         algo = ALGO_BYTES[dom] * n_local
         achieved = algo / avg_s / 1e9
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom),
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom) if world == 1 and scene_name == "dfsph_1m" else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
-                           "share_of_gpu_time": ms / tot if tot else None,
+                           "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
                            "note": "sweeps are f32-VALU bound (IEEE sqrt + 4 IEEE divides per pair), not HBM bound: see DESIGN.md section 4"}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}

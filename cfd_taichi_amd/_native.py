@@ -26,6 +26,7 @@ EXPORTS = [
     "sph_step_wcsph", "sph_step_dfsph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math",
+    "sph_set_comm", "sph_plan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
 ]
 
 
@@ -47,7 +48,8 @@ class SphConfig(ctypes.Structure):
         ("max_density_iters", ctypes.c_int32),
         ("slab_rank", ctypes.c_int32),
         ("slab_count", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 7),
+        ("slab_capacity", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 6),
     ]
 
 
@@ -76,6 +78,28 @@ class SphStepStats(ctypes.Structure):
         ("max_nbrs", ctypes.c_int32),
         ("max_wall_nbrs", ctypes.c_int32),
         ("lost", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+EXCHANGE_COUNTS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                      ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
+EXCHANGE_BUFFERS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.c_int32)
+
+
+class SphComm(ctypes.Structure):
+    _fields_ = [
+        ("user", ctypes.c_void_p),
+        ("exchange_counts", EXCHANGE_COUNTS_FN),
+        ("exchange_buffers", EXCHANGE_BUFFERS_FN),
+        ("allreduce", ALLREDUCE_FN),
+        ("send_left", ctypes.c_void_p),
+        ("send_right", ctypes.c_void_p),
+        ("recv_left", ctypes.c_void_p),
+        ("recv_right", ctypes.c_void_p),
+        ("capacity", ctypes.c_size_t),
+        ("on_host", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
     ]
 
@@ -122,6 +146,11 @@ def load(build_if_missing=True):
     lib.sph_profile_kernel_name.restype = ctypes.c_char_p
     lib.sph_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
+    lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
+    lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.sph_download_local.argtypes = [vp, ci, vp, ctypes.c_size_t]
+    lib.sph_download_ids.argtypes = [vp, vp, ctypes.c_size_t]
     _lib = lib
     return lib
 
@@ -132,7 +161,8 @@ class SphError(RuntimeError):
         self.code = code
 
 
-def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0):
+def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0,
+                     slab_rank=0, slab_count=0, slab_capacity=0):
     """Flatten a reference-style config dict (config/*.json schema) into SphConfig."""
     scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
     name = solver_name or sol["name"]
@@ -153,7 +183,21 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.max_neighbors = int(max_neighbors)
     c.max_wall_neighbors = int(max_wall_neighbors)
     c.max_density_iters = int(max_density_iters)
+    c.slab_rank, c.slab_count, c.slab_capacity = int(slab_rank), int(slab_count), int(slab_capacity)
     return c
+
+
+def plan_slabs(cfg, slab_count):
+    """Host-only: (cuts, counts) of the equal-count x-slab decomposition of the scene's initial lattice."""
+    lib = load()
+    c = SphConfig.from_buffer_copy(cfg)
+    c.slab_count = int(slab_count)
+    cuts = (ctypes.c_int32 * (slab_count + 1))()
+    counts = (ctypes.c_int32 * slab_count)()
+    rc = lib.sph_plan_slabs(ctypes.byref(c), cuts, counts)
+    if rc != SPH_OK:
+        raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
+    return list(cuts), list(counts)
 
 
 class Simulation:
@@ -228,6 +272,31 @@ class Simulation:
 
     def synchronize(self):
         self._check(self._lib.sph_synchronize(self._h))
+
+    # ---- multi-GPU slab handles ----
+    def set_comm(self, comm):
+        self._comm = comm            # keep the callbacks and buffers alive
+        self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
+
+    def slab_info(self):
+        out = (ctypes.c_int32 * 5)()
+        self._check(self._lib.sph_slab_info(self._h, out))
+        return {"owned": out[0], "ghosts": out[1], "x_lo": out[2], "x_hi": out[3], "capacity": out[4]}
+
+    def download_local(self, field):
+        """(ids, values) of every resident particle in device order; ids < 0 are ghosts (~id)."""
+        info = self.slab_info()
+        n = info["owned"] + info["ghosts"]
+        ids = np.empty(n, dtype=np.int32)
+        self._check(self._lib.sph_download_ids(self._h, ids.ctypes.data, n))
+        out = np.empty((n, 3) if field in VECTOR_FIELDS else (n,), dtype=np.float32)
+        self._check(self._lib.sph_download_local(self._h, field, out.ctypes.data, out.size))
+        return ids, out
+
+    def download_owned(self, field):
+        ids, vals = self.download_local(field)
+        keep = ids >= 0
+        return ids[keep], vals[keep]
 
     # ---- profiling (HIP events on the handle's stream) ----
     def profile_enable(self, on=True):

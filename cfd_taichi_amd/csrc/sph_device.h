@@ -50,7 +50,9 @@ struct DevScalars {
     int max_nbrs;
     int max_wall_nbrs;
     int lost;          // particles outside the grid
-    int pad[7];
+    int pad[3];
+    double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
+    long long cnt;
 };
 
 struct F3 {

@@ -50,14 +50,17 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
     return id;
 }
 
-__global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, int *__restrict__ cell_of,
-                                                       int *__restrict__ rank, int *__restrict__ cell_count)
+// `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost go to the trash
+// bucket C+1 and fall off the end of the sorted arrays.
+__global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, const int *__restrict__ dead,
+                                                       int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count)
 {
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= c.n) return;
     float4 p = P[s];
     int cx, cy, cz;
     int id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+    if (dead && dead[s]) id = c.C + 1;
     cell_of[s] = id;
     rank[s] = atomicAdd(&cell_count[id], 1);
 }
@@ -152,14 +155,18 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
     int src = slot_src[d];
     int cell = cell_of[src];
     int a = cell_start[cell], b = cell_start[cell + 1];
-    int key = id_in[src];
+    int raw = id_in[src];
+    int key = raw < 0 ? ~raw : raw;          // ghosts carry ~id; order by the true id
     int r = 0;
-    for (int e = a; e < b; ++e) r += (id_in[slot_src[e]] < key) ? 1 : 0;
+    for (int e = a; e < b; ++e) {
+        int o = id_in[slot_src[e]];
+        r += ((o < 0 ? ~o : o) < key) ? 1 : 0;
+    }
     int dst = a + r;
     Pout[dst] = Pin[src];
     Vout[dst] = Vin[src];
     if (warm_in) warm_out[dst] = warm_in[src];
-    id_out[dst] = key;
+    id_out[dst] = raw;
 }
 
 // ======================================================================================
@@ -182,13 +189,15 @@ __device__ __forceinline__ void nl_flush(const uint4 &g, int k, uint32_t *__rest
 
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
-                                                     uint32_t *__restrict__ nl, uint32_t *__restrict__ nlb,
-                                                     int *__restrict__ cnt, DevScalars *__restrict__ ds)
+                                                     const int *__restrict__ id, uint32_t *__restrict__ nl,
+                                                     uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds)
 {
     int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
     if (i == 0) ds->lost = cell_start[c.C + 1] - cell_start[c.C];   // size of the "outside the grid" bucket
-    if (i < c.n) {
+    if (i < c.n && id[i] < 0) {
+        cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
+    } else if (i < c.n) {
         float4 pi = P[i];
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     const bool live = i < c.n;                               \
     const int ii = live ? i : 0;                             \
     const int cw = live ? cnt[ii] : 0;                       \
-    const int kf = cw & 0xffff, kb = cw >> 16;               \
+    const int kf = cw & 0xffff, kb = (cw >> 16) & 0x7fff;    \
+    const bool ghost = cw < 0;                               \
+    (void)ghost;                                             \
     const float4 pi = P[ii];                                 \
     const uint32_t *nlp = nl + nl_index(ii, 0, c.kmax);      \
     const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbmax) : nullptr;
@@ -317,10 +328,10 @@ __device__ __forceinline__ void block_partial_max(int blk, float v, float *__res
     }
 }
 
-// final, fixed-order reduction of the block partials; one block.
-// mean = cnt > 0 ? sum / cnt : dflt       (dfsph_solver.py:148-149, 278-279)
+// final, fixed-order reduction of the block partials; one block.  The host forms
+// mean = cnt > 0 ? sum / cnt : default   (dfsph_solver.py:148-149, 278-279) after all-reducing (sum, cnt) when sharded.
 __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                          float dflt, DevScalars *__restrict__ ds)
+                                                          DevScalars *__restrict__ ds)
 {
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
@@ -332,11 +343,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restri
         if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) ds->mean = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : dflt;
+    if (threadIdx.x == 0) { ds->sum = s_sum[0]; ds->cnt = s_cnt[0]; }
 }
 
-// max |v*| over the block partials, then the CFL time step       dfsph_solver.py:100-119
-__global__ __launch_bounds__(kBlock) void k_finalize_dt(Consts c, const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds)
+// max |v*| over the block partials                              dfsph_solver.py:100-103
+__global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds)
 {
     __shared__ float s_max[kBlock];
     float t = -INFINITY;
@@ -347,19 +358,22 @@ __global__ __launch_bounds__(kBlock) void k_finalize_dt(Consts c, const float *_
         if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        float max_vel = s_max[0];
-        float max_rigid_vel = 0.0f;                                   // :104-110 (no rigid body)
-        max_vel += max_rigid_vel;
-        float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112
-        float dt;
-        if (max_delta_time > 1e-3f) dt = 1e-3f;                       // :114-117
-        else dt = rmax(max_delta_time, 1e-5f);
-        ds->vmax = max_vel;
-        ds->dt = dt;
-        ds->dt2 = dt * dt;                                            // :118
-        ds->ps_dt = dt;                                               // :119
-    }
+    if (threadIdx.x == 0) ds->vmax = s_max[0];
+}
+
+// the CFL time step from ds->vmax (global maximum)              dfsph_solver.py:104-119
+__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds)
+{
+    float max_vel = ds->vmax;
+    float max_rigid_vel = 0.0f;                                   // :104-110 (no rigid body)
+    max_vel += max_rigid_vel;
+    float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112
+    float dt;
+    if (max_delta_time > 1e-3f) dt = 1e-3f;                       // :114-117
+    else dt = rmax(max_delta_time, 1e-5f);
+    ds->dt = dt;
+    ds->dt2 = dt * dt;                                            // :118
+    ds->ps_dt = dt;                                               // :119
 }
 
 // ======================================================================================
@@ -602,13 +616,13 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             const float dt = ds->dt;
             if (c.boundary_handle) val = rmax(rho_i + dt * (acc + accb * c.rho0), c.rho0);   // :135
             else val = rmax(rho_i + dt * acc, c.rho0);                                        // :137
-            flag = !(val == c.rho0);                                                          // :139
+            flag = !(val == c.rho0) && !ghost;                                                // :139
             kr = ((val - c.rho0) * alpha[i] / ds->dt2) / rho_i;                               // :199,203
         } else {
             if (skip) val = 0.f;
             else if (c.boundary_handle) val = rmax(acc + accb * c.rho0, 0.0f);                // :267
             else val = rmax(acc, 0.0f);                                                       // :269
-            flag = val > 0.f;                                                                 // :275
+            flag = val > 0.f && !ghost;                                                       // :275
             kr = (val * alpha[i] / ds->dt) / rho_i;                                           // :363,367
         }
         out[i] = val;
@@ -663,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             va[a] = v[a] + dt * f / c.m;                     // :102
         }
         VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
-        vn = norm3(va[0], va[1], va[2]);                     // :103
+        if (!ghost) vn = norm3(va[0], va[1], va[2]);         // :103
     }
     block_partial_max(blk, vn, pmax);
 }

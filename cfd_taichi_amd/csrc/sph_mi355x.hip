@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <vector>
 
 #include "sph_kernels.h"
+#include "sph_slab_kernels.h"
 
 using namespace sph;
 
@@ -22,12 +24,12 @@ namespace {
 enum KernelId {
     K_HASH = 0, K_SCAN, K_SCATTER, K_ORDER_GATHER, K_BUILD_NL, K_W_DENSITY, K_W_FORCE, K_D_DENSITY_ALPHA,
     K_D_WARM, K_D_DIV_RESIDUAL, K_D_DIV_CORRECT, K_D_EXT, K_D_DENS_RESIDUAL, K_D_DENS_CORRECT, K_D_INTEGRATE,
-    K_FINALIZE, K_TRANSFER, K_COUNT
+    K_FINALIZE, K_TRANSFER, K_SLAB, K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "hash_count", "scan", "scatter", "order_gather", "build_nl", "wcsph_density", "wcsph_force", "dfsph_density_alpha",
     "dfsph_warm_start", "dfsph_div_residual", "dfsph_div_correct", "dfsph_ext_force", "dfsph_dens_residual",
-    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer"};
+    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange"};
 
 thread_local std::string g_create_error;
 
@@ -69,6 +71,23 @@ struct SphHandle {
     float *staging = nullptr;    // 3*max(N,Nb) floats, device
     // host copies of the wall particles in original order (for download)
     std::vector<float> wall_pos_host, wall_vol_host;
+
+    // multi-GPU x-slab state (slab_count > 1)
+    bool slab = false;
+    int slab_rank = 0, nslab = 1;
+    SlabGeom geom = {0, 0, 0, 0};
+    int ncap = 0;                 // capacity (particles) of every per-particle array
+    int n_owned = 0, n_ghost = 0, n_dead = 0;
+    bool comm_set = false;
+    SphComm comm = {};
+    void *dsend[2] = {nullptr, nullptr}, *drecv[2] = {nullptr, nullptr};   // device-side message buffers
+    bool own_dev_comm = false;
+    int *dead = nullptr;
+    int *edge_off[4] = {nullptr, nullptr, nullptr, nullptr};    // 0 ghost-left, 1 send-left, 2 send-right, 3 ghost-right
+    int *edge_list[4] = {nullptr, nullptr, nullptr, nullptr};
+    int edge_count[4] = {0, 0, 0, 0};
+    int *counters = nullptr, *counters_host = nullptr;
+    std::vector<int> init_ids;    // original ids of the particles this handle owns at t = 0
 
     // profiling
     bool profiling = false;
@@ -151,6 +170,38 @@ inline float host_cubic_w(float r, float h, float kw)
     return ret;
 }
 
+// Equal-count cuts along the cell x index, computed identically on every rank from the full lattice:
+// slab k owns cell columns [cut[k], cut[k+1]).
+bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, int nslab, std::vector<int> &col, std::vector<int> &cut,
+                    std::string &why)
+{
+    std::vector<long long> hist((size_t)gx, 0);
+    col.resize((size_t)N);
+    for (int i = 0; i < N; ++i) {
+        int cx = (int)floorf(pos[3 * (size_t)i] / hcell);
+        cx = cx < 0 ? 0 : (cx >= gx ? gx - 1 : cx);
+        col[i] = cx;
+        hist[cx]++;
+    }
+    cut.assign((size_t)nslab + 1, 0);
+    cut[nslab] = gx;
+    long long pre = 0;      // particles with column < x
+    int k = 1;
+    for (int x = 0; x < gx && k < nslab; ++x) {
+        while (k < nslab && pre >= (long long)k * N / nslab) { cut[k] = x; ++k; }
+        pre += hist[x];
+    }
+    for (; k < nslab; ++k) cut[k] = gx;
+    for (int q = 1; q <= nslab; ++q)
+        if (cut[q] < cut[q - 1] + 2) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "slab %d would be narrower than 2 cell columns: too many slabs for this scene", q - 1);
+            why = buf;
+            return false;
+        }
+    return true;
+}
+
 struct HostScene {
     std::vector<float> fluid_pos;                 // 3N, original order
     std::vector<float> wall_pos, wall_vol;        // original order
@@ -218,7 +269,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.gx = g[0]; c.gy = g[1]; c.gz = g[2]; c.C = (int)C;
     c.sy = g[0] * g[2]; c.sz = g[0];               // :102
     c.boundary_handle = cf.boundary_handle ? 1 : 0;
-    c.n = h->N;
+    c.n = h->N;                                    // refined below for slab handles
     c.stride = (h->N + 63) / 64 * 64;
     c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
     c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64) + 3) & ~3;
@@ -242,6 +293,35 @@ int build_scene(SphHandle *h, HostScene &sc)
             sc.fluid_pos[3 * (size_t)i + 1] = (float)y * radius * 2.0f + sp[1];
             sc.fluid_pos[3 * (size_t)i + 2] = z * radius * 2.0f + sp[2];
         }
+    }
+    // ---- ownership: everything on one GPU, or the particles of this rank's x-slab ----
+    h->slab = cf.slab_count > 1;
+    h->init_ids.resize((size_t)N);
+    for (int i = 0; i < N; ++i) h->init_ids[i] = i;
+    h->n_owned = N;
+    h->ncap = N;
+    if (h->slab) {
+        h->slab_rank = cf.slab_rank; h->nslab = cf.slab_count;
+        if (h->slab_rank < 0 || h->slab_rank >= h->nslab) return fail(h, SPH_E_INVALID, "slab_rank %d out of range [0,%d)", h->slab_rank, h->nslab);
+        std::vector<int> col, cut;
+        std::string why;
+        if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why)) return fail(h, SPH_E_INVALID, "%s", why.c_str());
+        h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
+        h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
+        std::vector<float> own_pos; std::vector<int> own_id;
+        for (int i = 0; i < N; ++i)
+            if (col[i] >= h->geom.x_lo && col[i] < h->geom.x_hi) {
+                own_id.push_back(i);
+                own_pos.push_back(sc.fluid_pos[3 * (size_t)i]); own_pos.push_back(sc.fluid_pos[3 * (size_t)i + 1]); own_pos.push_back(sc.fluid_pos[3 * (size_t)i + 2]);
+            }
+        sc.fluid_pos.swap(own_pos);
+        h->init_ids.swap(own_id);
+        h->n_owned = (int)h->init_ids.size();
+        long long cap = cf.slab_capacity > 0 ? cf.slab_capacity : (long long)(1.75 * N / h->nslab) + 262144;
+        if (cap < h->n_owned) cap = h->n_owned;
+        h->ncap = (int)std::min<long long>(cap, 0x7fffff00LL);
+        c.n = h->n_owned;
+        c.stride = (h->ncap + 63) / 64 * 64;
     }
     // ---- wall particles, init_particle_pos :155-195 (kernel-local f32) ----
     const int Nb = h->Nb;
@@ -366,7 +446,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
-    const size_t ncell = (size_t)c.C + 2;
+    const size_t ncell = (size_t)c.C + 3;
     h->ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
     if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
     if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
@@ -374,23 +454,33 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->WP, (size_t)h->Nb))) return rc;
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
-    if ((rc = dalloc(h, &h->psum, (size_t)h->nblocks))) return rc;
-    if ((rc = dalloc(h, &h->pcnt, (size_t)h->nblocks))) return rc;
-    if ((rc = dalloc(h, &h->pmax, (size_t)h->nblocks))) return rc;
+    const size_t nblocks_cap = (n + kBlock - 1) / kBlock;
+    if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
+    if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
+    if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
+    if (h->slab) {
+        if ((rc = dalloc(h, &h->dead, n))) return rc;
+        HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * n, h->stream));
+        for (int k = 0; k < 4; ++k) {
+            if ((rc = dalloc(h, &h->edge_off[k], (size_t)c.gy * c.gz + 1))) return rc;
+            if ((rc = dalloc(h, &h->edge_list[k], n))) return rc;
+        }
+        if ((rc = dalloc(h, &h->counters, 4))) return rc;
+        HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * 4, hipHostMallocDefault));
+    }
     if ((rc = dalloc(h, &h->ds, 1))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
-    size_t stg = 3 * (size_t)(h->N > h->Nb ? h->N : h->Nb);
+    size_t stg = 3 * std::max(n, (size_t)h->Nb);
     if ((rc = dalloc(h, &h->staging, stg))) return rc;
 
     // upload the scene
-    std::vector<float4> p4((size_t)h->N);
-    std::vector<int> ids((size_t)h->N);
-    for (int i = 0; i < h->N; ++i) {
+    std::vector<float4> p4((size_t)h->n_owned);
+    for (int i = 0; i < h->n_owned; ++i)
         p4[i] = make_float4(sc.fluid_pos[3 * (size_t)i], sc.fluid_pos[3 * (size_t)i + 1], sc.fluid_pos[3 * (size_t)i + 2], 0.f);
-        ids[i] = i;
+    if (h->n_owned > 0) {
+        HIP_TRY(h, hipMemcpyAsync(h->P[0], p4.data(), sizeof(float4) * p4.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->id[0], h->init_ids.data(), sizeof(int) * h->init_ids.size(), hipMemcpyHostToDevice, h->stream));
     }
-    HIP_TRY(h, hipMemcpyAsync(h->P[0], p4.data(), sizeof(float4) * p4.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->id[0], ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, h->stream));
     if (h->Nb > 0)
         HIP_TRY(h, hipMemcpyAsync(h->WP, sc.wall_sorted.data(), sizeof(float4) * (size_t)h->Nb, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->wcell_start, sc.wcell_start.data(), sizeof(int) * ((size_t)c.C + 1), hipMemcpyHostToDevice, h->stream));
@@ -412,21 +502,140 @@ int read_scalars(SphHandle *h)
 }
 
 // ---------------------------------------------------------------------------------------------
+// multi-GPU slab transport.  The library packs/unpacks on the device; the caller's
+// callbacks move the bytes (RCCL send/recv over xGMI in production, gloo in the tests).
+// ---------------------------------------------------------------------------------------------
+int comm_fail(SphHandle *h, const char *what, int rc) { return fail(h, SPH_E_STATE, "comm callback %s failed (%d)", what, rc); }
+
+int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
+{
+    const SphComm &cm = h->comm;
+    if (sl > cm.capacity || sr > cm.capacity || rl > cm.capacity || rr > cm.capacity)
+        return fail(h, SPH_E_OVERFLOW, "halo message of %zu bytes exceeds the comm buffer capacity %zu", std::max(std::max(sl, sr), std::max(rl, rr)), cm.capacity);
+    if (cm.on_host) {
+        if (sl) HIP_TRY(h, hipMemcpyAsync(cm.send_left, h->dsend[0], sl, hipMemcpyDeviceToHost, h->stream));
+        if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
+    int rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);
+    if (rc) return comm_fail(h, "exchange_buffers", rc);
+    if (cm.on_host) {
+        if (rl) HIP_TRY(h, hipMemcpyAsync(h->drecv[0], cm.recv_left, rl, hipMemcpyHostToDevice, h->stream));
+        if (rr) HIP_TRY(h, hipMemcpyAsync(h->drecv[1], cm.recv_right, rr, hipMemcpyHostToDevice, h->stream));
+    }
+    return SPH_OK;
+}
+
+int read_counters(SphHandle *h)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+// Start of a step on a slab handle: migrate particles that left [x_lo, x_hi), then re-send both edge cell
+// columns as ghosts.  Old ghosts and leavers are only MARKED dead; the counting sort drops them.
+int slab_exchange_particles(SphHandle *h)
+{
+    if (!h->comm_set) return fail(h, SPH_E_STATE, "slab handle needs sph_set_comm before stepping");
+    Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 b(kBlock);
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    float *warm = dfsph ? h->warm[h->wcur] : nullptr;
+    const int cap_rec = (int)std::min<size_t>(h->comm.capacity / 32, 0x7fffffff);
+    const int n_prev = c.n;
+    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * 4, s));
+    {
+        ProfScope ps(h, K_SLAB);
+        hipLaunchKernelGGL(k_classify_migrate, grid_for(n_prev), b, 0, s, c, h->geom, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur],
+                           h->dead, (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters);
+    }
+    int rc;
+    if ((rc = read_counters(h))) return rc;
+    const int mL = h->counters_host[0], mR = h->counters_host[1], ndead = h->counters_host[2];
+    if (mL > cap_rec || mR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d migrating particles exceed the comm buffer (%d records)", mL, mR, cap_rec);
+    int32_t rL = 0, rR = 0;
+    if ((rc = h->comm.exchange_counts(h->comm.user, mL, mR, &rL, &rR))) return comm_fail(h, "exchange_counts", rc);
+    if ((long long)n_prev + rL + rR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by migration", h->ncap);
+    if ((rc = slab_xfer(h, 32 * (size_t)mL, 32 * (size_t)mR, 32 * (size_t)rL, 32 * (size_t)rR))) return rc;
+    {
+        ProfScope ps(h, K_SLAB);
+        if (rL) hipLaunchKernelGGL(k_append_records, grid_for(rL), b, 0, s, (const float4 *)h->drecv[0], rL, n_prev, 0, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+        if (rR) hipLaunchKernelGGL(k_append_records, grid_for(rR), b, 0, s, (const float4 *)h->drecv[1], rR, n_prev + rL, 0, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+    }
+    const int n_in = n_prev + rL + rR;
+    c.n = n_in;
+    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * 2, s));
+    {
+        ProfScope ps(h, K_SLAB);
+        hipLaunchKernelGGL(k_classify_ghost, grid_for(n_in), b, 0, s, c, h->geom, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
+                           (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters);
+    }
+    if ((rc = read_counters(h))) return rc;
+    const int gL = h->counters_host[0], gR = h->counters_host[1];
+    if (gL > cap_rec || gR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d ghost particles exceed the comm buffer (%d records)", gL, gR, cap_rec);
+    int32_t hL = 0, hR = 0;
+    if ((rc = h->comm.exchange_counts(h->comm.user, gL, gR, &hL, &hR))) return comm_fail(h, "exchange_counts", rc);
+    if ((long long)n_in + hL + hR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by ghosts", h->ncap);
+    if ((rc = slab_xfer(h, 32 * (size_t)gL, 32 * (size_t)gR, 32 * (size_t)hL, 32 * (size_t)hR))) return rc;
+    {
+        ProfScope ps(h, K_SLAB);
+        if (hL) hipLaunchKernelGGL(k_append_records, grid_for(hL), b, 0, s, (const float4 *)h->drecv[0], hL, n_in, 1, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+        if (hR) hipLaunchKernelGGL(k_append_records, grid_for(hR), b, 0, s, (const float4 *)h->drecv[1], hR, n_in + hL, 1, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+    }
+    HIP_TRY(h, hipGetLastError());
+    c.n = n_in + hL + hR;                     // the sort runs over everything resident, dead slots included
+    h->n_dead = ndead;
+    h->n_owned = h->n_owned - mL - mR + rL + rR;
+    h->n_ghost = hL + hR;
+    h->edge_count[0] = hL; h->edge_count[1] = gL; h->edge_count[2] = gR; h->edge_count[3] = hR;
+    return SPH_OK;
+}
+
+// refresh one field of the ghosts after the sweep that produced it (mode: see k_pack_field)
+int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho)
+{
+    hipStream_t s = h->stream;
+    const dim3 b(kBlock);
+    const size_t fl = mode == 0 ? 1 : (mode == 1 ? 3 : 2);
+    const int nsl = h->edge_count[1], nsr = h->edge_count[2], nrl = h->edge_count[0], nrr = h->edge_count[3];
+    {
+        ProfScope ps(h, K_SLAB);
+        if (nsl) hipLaunchKernelGGL(k_pack_field, grid_for(nsl), b, 0, s, h->edge_list[1], nsl, mode, P, V, (float *)h->dsend[0]);
+        if (nsr) hipLaunchKernelGGL(k_pack_field, grid_for(nsr), b, 0, s, h->edge_list[2], nsr, mode, P, V, (float *)h->dsend[1]);
+    }
+    int rc = slab_xfer(h, 4 * fl * nsl, 4 * fl * nsr, 4 * fl * nrl, 4 * fl * nrr);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, K_SLAB);
+        if (nrl) hipLaunchKernelGGL(k_unpack_field, grid_for(nrl), b, 0, s, h->edge_list[0], nrl, mode, (const float *)h->drecv[0], P, V, rho);
+        if (nrr) hipLaunchKernelGGL(k_unpack_field, grid_for(nrr), b, 0, s, h->edge_list[3], nrr, mode, (const float *)h->drecv[1], P, V, rho);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // step stages
 // ---------------------------------------------------------------------------------------------
 // solver_base.step() prologue: reset_grid + update_grid (solver_base.py:136-143) as a counting sort,
 // then the neighbour lists.
 int stage_sort_and_lists(SphHandle *h)
 {
-    const Consts &c = h->c;
+    int rc;
+    if (h->slab && (rc = slab_exchange_particles(h))) return rc;
+    Consts &c = h->c;
     hipStream_t s = h->stream;
-    const dim3 g = grid_for(c.n), b(kBlock);
-    const size_t ncell = (size_t)c.C + 2;
+    dim3 g = grid_for(c.n);
+    const dim3 b(kBlock);
+    const size_t ncell = (size_t)c.C + 3;       // cells, "outside the grid" bucket C, trash bucket C+1, end
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     {
         ProfScope ps(h, K_HASH);
         HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * ncell, s));
-        hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->cell_of, h->rank, h->cell_count);
+        hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->slab ? h->dead : (const int *)nullptr, h->cell_of, h->rank,
+                           h->cell_count);
     }
     {
         ProfScope ps(h, K_SCAN);
@@ -446,11 +655,28 @@ int stage_sort_and_lists(SphHandle *h)
         h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
         if (dfsph) h->wcur ^= 1;
     }
+    if (h->slab) {
+        // dead slots are now the tail of the sorted arrays: drop them
+        c.n -= h->n_dead;
+        h->n_dead = 0;
+        h->nblocks = (c.n + kBlock - 1) / kBlock;
+        g = grid_for(c.n);
+        HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * (size_t)c.n, s));
+        ProfScope ps(h, K_SLAB);
+        const int layer[4] = {h->geom.has_left ? h->geom.x_lo - 1 : -1, h->geom.has_left ? h->geom.x_lo : -1,
+                              h->geom.has_right ? h->geom.x_hi - 1 : -1, h->geom.has_right ? h->geom.x_hi : -1};
+        for (int k = 0; k < 4; ++k) {
+            if (layer[k] < 0) continue;
+            hipLaunchKernelGGL(k_layer_offsets, dim3(1), b, 0, s, c, h->cell_start, layer[k], h->edge_off[k]);
+            hipLaunchKernelGGL(k_layer_list, grid_for(c.gy * c.gz), b, 0, s, c, h->cell_start, layer[k], h->edge_off[k], h->edge_list[k]);
+        }
+    }
     {
         ProfScope ps(h, K_BUILD_NL);
         // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
         HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
-        hipLaunchKernelGGL(k_build_nl, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->nl, h->nlb, h->cnt, h->ds);
+        hipLaunchKernelGGL(k_build_nl, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb,
+                           h->cnt, h->ds);
     }
     HIP_TRY(h, hipGetLastError());
     h->nl_valid = true;
@@ -474,7 +700,8 @@ int stage_density(SphHandle *h)
     const Consts &c = h->c;
     hipStream_t s = h->stream;
     const dim3 g = grid_for(c.n), b(kBlock);
-    if (h->cfg.solver == SPH_SOLVER_DFSPH) {
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    if (dfsph) {
         ProfScope ps(h, K_D_DENSITY_ALPHA);
         hipLaunchKernelGGL(k_density<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
                            h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur]);
@@ -486,6 +713,10 @@ int stage_density(SphHandle *h)
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
+    if (h->slab) {   // ghosts need (k/rho, rho) resp. (rho, p/rho^2) from their owners
+        int rc = slab_exchange_field(h, 2, h->P[h->pcur], h->V[h->vcur], dfsph ? h->rho : nullptr);
+        if (rc) return rc;
+    }
     h->density_valid = true;
     return SPH_OK;
 }
@@ -509,6 +740,34 @@ int step_wcsph_once(SphHandle *h)
     return SPH_OK;
 }
 
+// (sum, count) of the block partials -> mean on the host, all-reduced over the slabs when sharded
+int reduce_mean(SphHandle *h, float dflt, float *mean)
+{
+    {
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds);
+    }
+    int rc = read_scalars(h);
+    if (rc) return rc;
+    double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
+    if (h->slab && (rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
+    *mean = v[1] > 0.0 ? (float)(v[0] / v[1]) : dflt;       // dfsph_solver.py:148-149, 278-279
+    return SPH_OK;
+}
+
+// every slab must see a list overflow at the same point, or the others would wait in a collective forever
+int check_overflow_all(SphHandle *h)
+{
+    int ovf = h->ds_host->overflow;
+    if (h->slab) {
+        double v[1] = {(double)ovf};
+        int rc = h->comm.allreduce(h->comm.user, v, 1, 1);
+        if (rc) return comm_fail(h, "allreduce", rc);
+        if (v[0] > 0.0 && !ovf) return fail(h, SPH_E_OVERFLOW, "neighbour list overflow on another slab");
+    }
+    return check_overflow(h);
+}
+
 // derivative_iter_all_rho (dfsph_solver.py:252-300): residual sweep + mean; returns the mean through *err
 int dfsph_div_residual(SphHandle *h, float *err)
 {
@@ -520,26 +779,22 @@ int dfsph_div_residual(SphHandle *h, float *err)
                            h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt);
         h->pcur ^= 1;     // P.w = (drho*alpha/dt)/rho
     }
-    {
-        ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, s, h->psum, h->pcnt, h->nblocks, 0.0f, h->ds);
-    }
-    int rc = read_scalars(h);
-    if (rc) return rc;
-    *err = h->ds_host->mean;
-    return SPH_OK;
+    int rc;
+    if (h->slab && (rc = slab_exchange_field(h, 0, h->P[h->pcur], nullptr, nullptr))) return rc;
+    return reduce_mean(h, 0.0f, err);
 }
 
 int step_dfsph_once(SphHandle *h, SphStepStats *st)
 {
     int rc;
-    const Consts &c = h->c;
     hipStream_t s = h->stream;
-    const dim3 g = grid_for(c.n), b(kBlock);
+    const dim3 b(kBlock);
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;                                   // solver_base.py:137
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
     if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
+    const Consts &c = h->c;                                 // c.n is final for this step now
+    const dim3 g = grid_for(c.n);
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
     {
         ProfScope ps(h, K_D_WARM);                           // :396-397
@@ -547,11 +802,13 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
                            (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
         h->vcur ^= 1;
     }
+    if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
     float err = 0.f, past = 0.f;
     if ((rc = dfsph_div_residual(h, &err))) return rc;      // :398
-    if ((rc = check_overflow(h))) return rc;                // first read-back of the step: list overflow?
+    if ((rc = check_overflow_all(h))) return rc;            // first read-back of the step: list overflow?
     st->max_nbrs = h->ds_host->max_nbrs;
     st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
     st->n_div_evals = 1;
     st->div_first_err = err;
     int iter_cnt = 0;
@@ -562,8 +819,9 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
                                h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
             h->vcur ^= 1;
         }
+        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
         past = err;
-        if ((rc = dfsph_div_residual(h, &err))) return rc;  // :408
+        if ((rc = dfsph_div_residual(h, &err))) return rc;             // :408
         st->n_div_evals += 1;
         if (std::fabs((double)err - (double)past) < 1e-5) break;       // :410-412
         iter_cnt += 1;
@@ -577,7 +835,19 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     }
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_dt, dim3(1), b, 0, s, c, h->pmax, h->nblocks, h->ds);
+        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, h->nblocks, h->ds);
+    }
+    if (h->slab) {
+        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[h->vacur], nullptr))) return rc;
+        if ((rc = read_scalars(h))) return rc;
+        double v[1] = {(double)h->ds_host->vmax};
+        if ((rc = h->comm.allreduce(h->comm.user, v, 1, 1))) return comm_fail(h, "allreduce", rc);
+        h->ds_host->vmax = (float)v[0];
+        HIP_TRY(h, hipMemcpyAsync(&h->ds->vmax, &h->ds_host->vmax, sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    {
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds);   // :112-119
     }
     // ---- correct_density_error, :221-233 ----
     {
@@ -592,9 +862,10 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
                                    h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt);
                 h->pcur ^= 1;
             }
+            if (h->slab && (rc = slab_exchange_field(h, 0, h->P[h->pcur], nullptr, nullptr))) return rc;
             {
                 ProfScope ps(h, K_FINALIZE);
-                hipLaunchKernelGGL(k_finalize_mean, dim3(1), b, 0, s, h->psum, h->pcnt, h->nblocks, 1000.0f, h->ds);
+                hipLaunchKernelGGL(k_finalize_mean, dim3(1), b, 0, s, h->psum, h->pcnt, h->nblocks, h->ds);
             }
             {
                 ProfScope ps(h, K_D_DENS_CORRECT);           // iter_all_vel_adv :178-191
@@ -602,8 +873,15 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
                                    h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur]);
                 h->vacur ^= 1;
             }
+            if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->VA[h->vacur], nullptr))) return rc;
             if ((rc = read_scalars(h))) return rc;
-            rho_avg = (double)h->ds_host->mean;
+            double sum = h->ds_host->sum, cnt = (double)h->ds_host->cnt;
+            if (h->slab) {
+                double v[2] = {sum, cnt};
+                if ((rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
+                sum = v[0]; cnt = v[1];
+            }
+            rho_avg = (double)(cnt > 0.0 ? (float)(sum / cnt) : 1000.0f);   // :148-149
             it += 1;
         }
         st->n_dens = it;
@@ -616,7 +894,6 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     }
     HIP_TRY(h, hipGetLastError());
     st->dt = h->ds_host->dt;
-    st->lost = h->ds_host->lost;
     h->nl_valid = false;
     h->density_valid = false;
     return SPH_OK;
@@ -699,6 +976,10 @@ void sph_destroy(SphHandle *h)
     (void)hipFree(h->cell_count); (void)hipFree(h->cell_start); (void)hipFree(h->tile_sums); (void)hipFree(h->WP);
     (void)hipFree(h->wcell_start); (void)hipFree(h->psum); (void)hipFree(h->pcnt); (void)hipFree(h->pmax); (void)hipFree(h->ds);
     (void)hipFree(h->staging);
+    (void)hipFree(h->dead); (void)hipFree(h->counters);
+    for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
+    if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
+    if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -724,6 +1005,7 @@ int sph_upload(SphHandle *h, int species, int field, const float *host, size_t n
     if (count != n_floats) return fail(h, SPH_E_INVALID, "field %d holds %zu floats, got %zu", field, count, n_floats);
     if (species != SPH_SPECIES_FLUID || !(field == SPH_F_POS || field == SPH_F_VEL || field == SPH_F_WARM_K))
         return fail(h, SPH_E_INVALID, "field %d is read-only", field);
+    if (h->slab) return fail(h, SPH_E_STATE, "sph_upload is not available on a slab handle");
     if (field == SPH_F_WARM_K && h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "warm_start_k needs a dfsph handle");
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->staging, host, sizeof(float) * count, hipMemcpyHostToDevice, s));
@@ -752,6 +1034,7 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
         memcpy(host, src.data(), sizeof(float) * count);
         return SPH_OK;
     }
+    if (h->slab) return fail(h, SPH_E_STATE, "slab handle: use sph_download_local + sph_download_ids (device order, owned and ghost particles)");
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     hipStream_t s = h->stream;
     const dim3 g = grid_for(h->N), b(kBlock);
@@ -789,6 +1072,106 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
     return SPH_OK;
 }
 
+int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts)
+{
+    // host-only: runs the same scene construction as sph_create on a throw-away handle, no device needed
+    if (!cfg || !cuts || !counts || cfg->slab_count < 1) return fail(nullptr, SPH_E_INVALID, "bad argument");
+    SphHandle tmp;
+    tmp.cfg = *cfg;
+    HostScene sc;
+    const int nslab = cfg->slab_count;
+    tmp.cfg.slab_count = 1;                  // build the full lattice
+    tmp.cfg.slab_rank = 0;
+    int rc = build_scene(&tmp, sc);
+    if (rc) { g_create_error = tmp.err; return rc; }
+    std::vector<int> col, cut;
+    std::string why;
+    if (!plan_slab_cuts(sc.fluid_pos, tmp.N, tmp.c.h, tmp.c.gx, nslab, col, cut, why)) return fail(nullptr, SPH_E_INVALID, "%s", why.c_str());
+    for (int k = 0; k <= nslab; ++k) cuts[k] = cut[k];
+    for (int k = 0; k < nslab; ++k) counts[k] = 0;
+    for (int i = 0; i < tmp.N; ++i)
+        for (int k = 0; k < nslab; ++k)
+            if (col[i] >= cut[k] && col[i] < cut[k + 1]) { counts[k]++; break; }
+    return SPH_OK;
+}
+
+int sph_set_comm(SphHandle *h, const SphComm *comm)
+{
+    if (!h || !comm) return SPH_E_INVALID;
+    if (!h->slab) return fail(h, SPH_E_STATE, "sph_set_comm needs a handle created with slab_count > 1");
+    if (!comm->exchange_counts || !comm->exchange_buffers || !comm->allreduce) return fail(h, SPH_E_INVALID, "SphComm callbacks must all be set");
+    if (!comm->send_left || !comm->send_right || !comm->recv_left || !comm->recv_right || comm->capacity < 4096)
+        return fail(h, SPH_E_INVALID, "SphComm buffers missing or smaller than 4 KiB");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); h->own_dev_comm = false; }
+    h->comm = *comm;
+    if (comm->on_host) {
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(h, hipMalloc(&h->dsend[k], comm->capacity));
+            HIP_TRY(h, hipMalloc(&h->drecv[k], comm->capacity));
+        }
+        h->own_dev_comm = true;
+    } else {
+        h->dsend[0] = comm->send_left; h->dsend[1] = comm->send_right;
+        h->drecv[0] = comm->recv_left; h->drecv[1] = comm->recv_right;
+    }
+    h->comm_set = true;
+    return SPH_OK;
+}
+
+int sph_slab_info(SphHandle *h, int32_t *out)
+{
+    if (!h || !out) return SPH_E_INVALID;
+    out[0] = h->n_owned; out[1] = h->slab ? h->c.n - h->n_owned : 0;
+    out[2] = h->geom.x_lo; out[3] = h->slab ? h->geom.x_hi : h->c.gx; out[4] = h->ncap;
+    return SPH_OK;
+}
+
+int sph_download_ids(SphHandle *h, int32_t *host, size_t n)
+{
+    if (!h || !host) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (n != (size_t)h->c.n) return fail(h, SPH_E_INVALID, "%d particles resident, got room for %zu", h->c.n, n);
+    HIP_TRY(h, hipMemcpyAsync(host, h->id[h->icur], sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+int sph_download_local(SphHandle *h, int field, float *host, size_t n_floats)
+{
+    if (!h || !host) return SPH_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    const size_t n = (size_t)h->c.n;
+    const float4 *vec = nullptr; const float *sca = nullptr;
+    switch (field) {
+    case SPH_F_POS: vec = h->P[h->pcur]; break;
+    case SPH_F_VEL: vec = h->V[h->vcur]; break;
+    case SPH_F_VEL_ADV: if (dfsph) vec = h->VA[h->vacur]; break;
+    case SPH_F_ACC: if (!dfsph) vec = h->VA[0]; break;
+    case SPH_F_RHO: sca = h->rho; break;
+    case SPH_F_PRESSURE: if (!dfsph) sca = h->aux; break;
+    case SPH_F_ALPHA: if (dfsph) sca = h->aux; break;
+    case SPH_F_WARM_K: if (dfsph) sca = h->warm[h->wcur]; break;
+    case SPH_F_RHO_ADV: sca = h->rho_adv; break;
+    case SPH_F_RHO_DER: sca = h->drho; break;
+    default: break;
+    }
+    if (!vec && !sca) return fail(h, SPH_E_INVALID, "field %d cannot be downloaded from this handle", field);
+    const size_t want = vec ? 3 * n : n;
+    if (n_floats != want) return fail(h, SPH_E_INVALID, "field %d holds %zu floats locally, got %zu", field, want, n_floats);
+    if (vec) {
+        ProfScope ps(h, K_TRANSFER);
+        hipLaunchKernelGGL(k_copy_vec_local, grid_for((int)n), dim3(kBlock), 0, h->stream, (int)n, vec, h->staging);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(host, h->staging, sizeof(float) * want, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(host, sca, sizeof(float) * want, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
 int sph_build_neighbors(SphHandle *h)
 {
     if (!h) return SPH_E_INVALID;
@@ -796,7 +1179,7 @@ int sph_build_neighbors(SphHandle *h)
     int rc = stage_sort_and_lists(h);
     if (rc) return rc;
     if ((rc = read_scalars(h))) return rc;
-    return check_overflow(h);
+    return check_overflow_all(h);
 }
 
 int sph_compute_density(SphHandle *h)
@@ -830,7 +1213,7 @@ int sph_step_wcsph(SphHandle *h, int nsteps)
     // overflow is sticky within a call: one read-back per call keeps the steps asynchronous
     int rc = read_scalars(h);
     if (rc) return rc;
-    return check_overflow(h);
+    return check_overflow_all(h);
 }
 
 int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last)

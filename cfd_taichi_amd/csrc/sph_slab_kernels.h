@@ -1,0 +1,182 @@
+// sph_slab_kernels.h -- device side of the multi-GPU x-slab decomposition:
+// particle migration, ghost-layer packing, ordered edge lists and per-sweep ghost field refresh.
+//
+// Particle record on the wire: 32 bytes = (x, y, z, vx) (vy, vz, warm_start_k, id bits).
+// Ghost particles carry id' = ~id (negative) in the id array; the sort orders by the true id, so the
+// order inside a cell -- and with it every neighbour sum -- is the same on every decomposition.
+#pragma once
+#include "sph_device.h"
+
+namespace sph {
+
+__device__ __forceinline__ int id_key(int id) { return id < 0 ? ~id : id; }
+
+struct SlabGeom {
+    int x_lo, x_hi;        // owned cell columns [x_lo, x_hi)
+    int has_left, has_right;
+};
+
+__device__ __forceinline__ void write_record(float4 *__restrict__ buf, int slot, float4 p, float4 v, float warm, int id)
+{
+    buf[2 * (size_t)slot] = make_float4(p.x, p.y, p.z, v.x);
+    buf[2 * (size_t)slot + 1] = make_float4(v.y, v.z, warm, __int_as_float(id));
+}
+
+// (1) previous ghosts die; owned particles that left the slab are packed for the neighbour and die here.
+__global__ __launch_bounds__(kBlock) void k_classify_migrate(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                             const float *__restrict__ warm, const int *__restrict__ id,
+                                                             int *__restrict__ dead, float4 *__restrict__ send_left,
+                                                             float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= c.n) return;
+    int pid = id[s];
+    if (pid < 0) { dead[s] = 1; atomicAdd(&counters[2], 1); return; }
+    float4 p = P[s];
+    int cx = (int)floorf(p.x / c.h);
+    int d = 0;
+    if (g.has_left && cx < g.x_lo) {
+        int slot = atomicAdd(&counters[0], 1);
+        if (slot < cap_records) write_record(send_left, slot, p, V[s], warm ? warm[s] : 0.f, pid);
+        d = 1;
+    } else if (g.has_right && cx >= g.x_hi) {
+        int slot = atomicAdd(&counters[1], 1);
+        if (slot < cap_records) write_record(send_right, slot, p, V[s], warm ? warm[s] : 0.f, pid);
+        d = 1;
+    }
+    dead[s] = d;
+    if (d) atomicAdd(&counters[2], 1);
+}
+
+// (2)/(4) received records are appended behind the resident particles
+__global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restrict__ buf, int count, int base, int as_ghost,
+                                                           float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ warm,
+                                                           int *__restrict__ id, int *__restrict__ dead)
+{
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count) return;
+    float4 a = buf[2 * (size_t)r], b = buf[2 * (size_t)r + 1];
+    int pid = __float_as_int(b.w);
+    P[base + r] = make_float4(a.x, a.y, a.z, 0.f);
+    V[base + r] = make_float4(a.w, b.x, b.y, 0.f);
+    if (warm) warm[base + r] = b.z;
+    id[base + r] = as_ghost ? ~pid : pid;
+    dead[base + r] = 0;
+}
+
+// (3) owned particles in the two edge cell columns are copied to the neighbours as ghosts
+__global__ __launch_bounds__(kBlock) void k_classify_ghost(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                           const float *__restrict__ warm, const int *__restrict__ id,
+                                                           const int *__restrict__ dead, float4 *__restrict__ send_left,
+                                                           float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= c.n) return;
+    if (dead[s]) return;
+    int pid = id[s];
+    if (pid < 0) return;
+    float4 p = P[s];
+    int cx = (int)floorf(p.x / c.h);
+    if (g.has_left && cx == g.x_lo) {
+        int slot = atomicAdd(&counters[0], 1);
+        if (slot < cap_records) write_record(send_left, slot, p, V[s], warm ? warm[s] : 0.f, pid);
+    }
+    if (g.has_right && cx == g.x_hi - 1) {
+        int slot = atomicAdd(&counters[1], 1);
+        if (slot < cap_records) write_record(send_right, slot, p, V[s], warm ? warm[s] : 0.f, pid);
+    }
+}
+
+// Ordered list of the sorted slots that live in cell column `layer_cx`: cells ascending (y, then z), slots
+// ascending inside a cell.  The sender's list for its edge column and the receiver's list for the matching ghost
+// column enumerate the same particles in the same order, because both sides sort by (cell, true id).
+__global__ __launch_bounds__(kBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, int layer_cx, int *__restrict__ off)
+{
+    // single block: exclusive scan of the per-cell counts of the column, chunks of 256 with a carry
+    __shared__ int wsum[kBlock / 64];
+    __shared__ int carry_s;
+    const int ncol = c.gy * c.gz;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < ncol; base += kBlock) {
+        int k = base + threadIdx.x;
+        int v = 0;
+        if (k < ncol && layer_cx >= 0 && layer_cx < c.gx) {
+            int y = k / c.gz, z = k - y * c.gz;
+            int cid = layer_cx + y * c.sy + z * c.sz;
+            v = cell_start[cid + 1] - cell_start[cid];
+        }
+        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < w; ++q) woff += wsum[q];
+        int carry = carry_s;
+        if (k < ncol) off[k] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[ncol] = carry_s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__restrict__ cell_start, int layer_cx, const int *__restrict__ off,
+                                                       int *__restrict__ list)
+{
+    int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= c.gy * c.gz || layer_cx < 0 || layer_cx >= c.gx) return;
+    int y = k / c.gz, z = k - y * c.gz;
+    int cid = layer_cx + y * c.sy + z * c.sz;
+    int a = cell_start[cid], b = cell_start[cid + 1];
+    int o = off[k];
+    for (int s = a; s < b; ++s) list[o + (s - a)] = s;
+}
+
+// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats)
+__global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ list, int count, int mode, const float4 *__restrict__ P,
+                                                       const float4 *__restrict__ V, float *__restrict__ out)
+{
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count) return;
+    int s = list[r];
+    if (mode == 0) out[r] = P[s].w;
+    else if (mode == 1) { float4 v = V[s]; out[3 * (size_t)r] = v.x; out[3 * (size_t)r + 1] = v.y; out[3 * (size_t)r + 2] = v.z; }
+    else { out[2 * (size_t)r] = P[s].w; out[2 * (size_t)r + 1] = V[s].w; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__ list, int count, int mode, const float *__restrict__ in,
+                                                         float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ rho)
+{
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count) return;
+    int s = list[r];
+    if (mode == 0) P[s].w = in[r];
+    else if (mode == 1) { V[s].x = in[3 * (size_t)r]; V[s].y = in[3 * (size_t)r + 1]; V[s].z = in[3 * (size_t)r + 2]; }
+    else {
+        P[s].w = in[2 * (size_t)r];
+        float b = in[2 * (size_t)r + 1];
+        V[s].w = b;
+        if (rho) rho[s] = b;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unsort_ids(int n, const int *__restrict__ id, int *__restrict__ out)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s < n) out[s] = id[s];
+}
+__global__ __launch_bounds__(kBlock) void k_copy_vec_local(int n, const float4 *__restrict__ src, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    float4 v = src[s];
+    dst[3 * (size_t)s] = v.x; dst[3 * (size_t)s + 1] = v.y; dst[3 * (size_t)s + 2] = v.z;
+}
+
+}  // namespace sph

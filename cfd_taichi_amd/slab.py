@@ -1,0 +1,174 @@
+"""Multi-GPU x-slab decomposition: the host side (the reference is single-device).
+
+One process per GPU.  Each rank creates a slab handle (`slab_rank`, `slab_count` in SphConfig); the native
+library does all packing, sorting and ghost bookkeeping on the device and calls back into this module for
+the transport:
+
+  * ghost / migrating particles and per-sweep ghost fields: point-to-point with the left and right slab
+    neighbour only (`batch_isend_irecv`) -- with the `nccl` backend (= RCCL) these are device buffers sent
+    over the direct xGMI link of each neighbour pair; with `gloo` they are pinned host buffers (tests);
+  * message sizes: one tiny all-gather of (send_left, send_right) counts per particle exchange;
+  * residual sums and the CFL maximum: one small all-reduce each.
+
+    dist.init_process_group("nccl")
+    sim = SlabSimulation(config, rank, world, device=local_rank)
+    sim.step(10)
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+
+
+class TorchComm:
+    """SphComm callbacks on top of torch.distributed (backend nccl = RCCL, or gloo)."""
+
+    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world, self.group = rank, world, group
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world - 1 else None
+        self.on_host = dist.get_backend(group) != "nccl"
+        self.device = torch.device("cpu") if self.on_host else torch.device("cuda", device)
+        kw = {"pin_memory": True} if (self.on_host and torch.cuda.is_available()) else {}
+        self.capacity = int(capacity_bytes)
+        self.bufs = {k: torch.empty(self.capacity, dtype=torch.uint8, device=self.device, **kw)
+                     for k in ("send_left", "send_right", "recv_left", "recv_right")}
+        self.error = None
+        self.stats = {"exchange_counts": 0, "exchange_buffers": 0, "allreduce": 0, "bytes_sent": 0}
+        self._cb_counts = nat.EXCHANGE_COUNTS_FN(self._exchange_counts)
+        self._cb_buffers = nat.EXCHANGE_BUFFERS_FN(self._exchange_buffers)
+        self._cb_allreduce = nat.ALLREDUCE_FN(self._allreduce)
+        self.struct = nat.SphComm()
+        self.struct.user = None
+        self.struct.exchange_counts = self._cb_counts
+        self.struct.exchange_buffers = self._cb_buffers
+        self.struct.allreduce = self._cb_allreduce
+        for k, t in self.bufs.items():
+            setattr(self.struct, k, t.data_ptr())
+        self.struct.capacity = self.capacity
+        self.struct.on_host = 1 if self.on_host else 0
+
+    # ---- transport primitives (also called directly by the CPU tests) -------------------------
+    def exchange_counts(self, send_left, send_right):
+        """Returns (recv_left, recv_right): what the left neighbour sends right, and vice versa."""
+        torch, dist = self.torch, self.dist
+        mine = torch.tensor([send_left, send_right], dtype=torch.int32, device=self.device)
+        allc = torch.empty(2 * self.world, dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        allc = allc.cpu().view(self.world, 2)
+        recv_left = int(allc[self.left, 1]) if self.left is not None else 0
+        recv_right = int(allc[self.right, 0]) if self.right is not None else 0
+        return recv_left, recv_right
+
+    def exchange_buffers(self, sl, sr, rl, rr):
+        dist = self.dist
+        ops = []
+        if self.left is not None:
+            if sl:
+                ops.append(dist.P2POp(dist.isend, self.bufs["send_left"][:sl], self.left, self.group))
+            if rl:
+                ops.append(dist.P2POp(dist.irecv, self.bufs["recv_left"][:rl], self.left, self.group))
+        if self.right is not None:
+            if sr:
+                ops.append(dist.P2POp(dist.isend, self.bufs["send_right"][:sr], self.right, self.group))
+            if rr:
+                ops.append(dist.P2POp(dist.irecv, self.bufs["recv_right"][:rr], self.right, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if not self.on_host:
+                self.torch.cuda.current_stream(self.device).synchronize()   # the library continues on its own stream
+        self.stats["bytes_sent"] += sl + sr
+
+    def allreduce(self, values, op):
+        torch, dist = self.torch, self.dist
+        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().tolist()
+
+    # ---- C callbacks ---------------------------------------------------------------------------
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # noqa: BLE001 - must not propagate through the C frame
+            self.error = e
+            return 1
+
+    def _exchange_counts(self, user, send_left, send_right, recv_left, recv_right):
+        def run():
+            self.stats["exchange_counts"] += 1
+            rl, rr = self.exchange_counts(send_left, send_right)
+            recv_left[0], recv_right[0] = rl, rr
+        return self._guard(run)
+
+    def _exchange_buffers(self, user, sl, sr, rl, rr):
+        def run():
+            self.stats["exchange_buffers"] += 1
+            self.exchange_buffers(sl, sr, rl, rr)
+        return self._guard(run)
+
+    def _allreduce(self, user, values, n, op):
+        def run():
+            self.stats["allreduce"] += 1
+            out = self.allreduce([values[i] for i in range(n)], op)
+            for i in range(n):
+                values[i] = out[i]
+        return self._guard(run)
+
+
+class SlabSimulation:
+    """One rank's share of a sharded simulation: a slab handle plus its transport."""
+
+    def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, **native_opts):
+        self.rank, self.world = rank, world
+        cfg = nat.config_from_dict(config, solver_name=solver_name, device=device, slab_rank=rank, slab_count=world,
+                                   slab_capacity=slab_capacity, **native_opts)
+        self.solver = "wcsph" if cfg.solver == nat.SOLVER_WCSPH else "dfsph"
+        self.sim = nat.Simulation(cfg)
+        self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes)
+        self.sim.set_comm(self.comm.struct)
+        self.n_fluid = self.sim.n_fluid
+
+    def step(self, nsteps=1):
+        try:
+            if self.solver == "dfsph":
+                st = None
+                for _ in range(nsteps):
+                    st = self.sim.step_dfsph(1)
+                return st
+            self.sim.step_wcsph(nsteps)
+            return None
+        except nat.SphError:
+            if self.comm.error is not None:
+                raise self.comm.error
+            raise
+
+    def owned(self, field):
+        return self.sim.download_owned(field)
+
+    def gather(self, field, dst=0):
+        """All owned particles of all ranks assembled in original particle order on rank `dst` (else None)."""
+        dist = self.comm.dist
+        ids, vals = self.owned(field)
+        parts = [None] * self.world if self.rank == dst else None
+        dist.gather_object((ids, vals), parts, dst=dst)
+        if self.rank != dst:
+            return None
+        shape = (self.n_fluid,) + vals.shape[1:]
+        out = np.full(shape, np.nan, dtype=np.float32)
+        seen = np.zeros(self.n_fluid, dtype=np.int32)
+        for pid, pv in parts:
+            out[pid] = pv
+            np.add.at(seen, pid, 1)
+        if not np.all(seen == 1):
+            raise RuntimeError("slab ownership is not a partition: %d particles missing, %d duplicated" %
+                               (int((seen == 0).sum()), int((seen > 1).sum())))
+        return out
+
+    def close(self):
+        self.sim.close()

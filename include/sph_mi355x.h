@@ -55,7 +55,8 @@ typedef struct SphConfig {
     int32_t max_density_iters;  /* cap on correct_density_error (reference has none, dfsph_solver.py:225); 0 = default (100); reported in SphStepStats.capped */
     int32_t slab_rank;          /* multi-GPU x-slab rank, 0 for single GPU */
     int32_t slab_count;         /* number of slabs (world size), 0 or 1 for single GPU */
-    int32_t reserved[7];
+    int32_t slab_capacity;      /* particles (owned + ghosts) a slab handle can hold; 0 = default (1.75 N / slab_count + 256k) */
+    int32_t reserved[6];
 } SphConfig;
 
 typedef struct SphSizes {
@@ -148,6 +149,41 @@ int sph_profile_reset(SphHandle *h);
 int sph_profile_kernel_count(void);
 const char *sph_profile_kernel_name(int kernel_id);
 int sph_profile_get(SphHandle *h, int kernel_id, double *total_ms, int64_t *launches);
+
+/* ---- multi-GPU: x-slab decomposition (new capability, the reference is single-device) ----
+ * One process per GPU.  A handle created with slab_count > 1 owns the particles whose cell x-index lies in its slab
+ * [x_lo, x_hi) plus one ghost cell layer on each side.  Every step it (1) migrates particles that left the slab,
+ * (2) re-sends its two edge layers as ghosts, and after every sweep whose output the neighbours read (3) refreshes that
+ * field on the ghosts; residual sums and the CFL maximum are all-reduced.  The library packs / unpacks on the device and
+ * calls back into the host for the transport, so the same code runs over RCCL (device buffers) or any host transport.
+ *
+ * Buffers: four byte buffers of `capacity` bytes each, owned by the caller (e.g. torch tensors): send/recv x left/right.
+ * With on_host = 0 they are device pointers (RCCL over xGMI reads/writes them directly); with on_host = 1 they are host
+ * pointers and the library stages through them with hipMemcpy (used by the gloo tests).
+ * Callbacks return 0 on success; they are invoked on the calling thread, with the handle's stream idle. */
+typedef struct SphComm {
+    void *user;
+    /* send my counts to the left / right neighbour and receive theirs (absent neighbour: recv 0) */
+    int (*exchange_counts)(void *user, int32_t send_left, int32_t send_right, int32_t *recv_left, int32_t *recv_right);
+    /* send the first send_*_bytes of the send buffers, receive exactly recv_*_bytes into the recv buffers */
+    int (*exchange_buffers)(void *user, size_t send_left_bytes, size_t send_right_bytes, size_t recv_left_bytes, size_t recv_right_bytes);
+    /* in-place all-reduce of n doubles over all slabs; op 0 = sum, 1 = max */
+    int (*allreduce)(void *user, double *values, int32_t n, int32_t op);
+    void *send_left, *send_right, *recv_left, *recv_right;
+    size_t capacity;
+    int32_t on_host;
+    int32_t reserved;
+} SphComm;
+
+int sph_set_comm(SphHandle *h, const SphComm *comm);
+/* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the equal-count slabs of the
+ * scene's initial lattice, counts[k] = particles slab k owns at t = 0 */
+int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);
+/* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity */
+int sph_slab_info(SphHandle *h, int32_t *out5);
+/* local (device-order) access for slab handles: all resident particles, owned and ghost; ids < 0 mark ghosts (~id) */
+int sph_download_local(SphHandle *h, int field, float *host, size_t n_floats);
+int sph_download_ids(SphHandle *h, int32_t *host, size_t n);
 
 /* device arithmetic self-test: out[i] = op(a[i], b[i]) evaluated on the GPU with the same
  * compiler flags as the sweeps (op 0: a/b, 1: sqrt(a), 2: cubic_kernel(a, h=b), 3..5:
