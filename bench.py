@@ -161,11 +161,17 @@ def main():
     import torch
     dist = None
     transport_group, transport = None, None
+    rehearsal = os.environ.get("SPH_BENCH_REHEARSAL") == "1"   # all ranks on GPU 0 over gloo: lets a 1-GPU box exercise this file
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        transport_group, transport = pick_transport(dist, torch, rank, world, local_rank)
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+            transport_group, transport = None, "gloo (rehearsal on one GPU)"
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            transport_group, transport = pick_transport(dist, torch, rank, world, local_rank)
 
     from cfd_taichi_amd import _native as nat
     from cfd_taichi_amd import scenes
@@ -202,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()

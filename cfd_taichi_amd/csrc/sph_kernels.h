@@ -50,17 +50,17 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
     return id;
 }
 
-// `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost go to the trash
-// bucket C+1 and fall off the end of the sorted arrays.
+// `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost take no part in
+// the sort; the sorted arrays simply end after the live particles.
 __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, const int *__restrict__ dead,
                                                        int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count)
 {
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= c.n) return;
+    if (dead && dead[s]) { cell_of[s] = -1; return; }
     float4 p = P[s];
     int cx, cy, cz;
     int id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
-    if (dead && dead[s]) id = c.C + 1;
     cell_of[s] = id;
     rank[s] = atomicAdd(&cell_count[id], 1);
 }
@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(Consts c, const int *__restr
 {
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= c.n) return;
-    slot_src[cell_start[cell_of[s]] + rank[s]] = s;
+    int cell = cell_of[s];
+    if (cell < 0) return;                       // dead slot (multi-GPU)
+    slot_src[cell_start[cell] + rank[s]] = s;
 }
 
 // Canonical order inside a cell = ascending original id (the single-thread append order of
@@ -158,9 +160,13 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
     int raw = id_in[src];
     int key = raw < 0 ? ~raw : raw;          // ghosts carry ~id; order by the true id
     int r = 0;
-    for (int e = a; e < b; ++e) {
-        int o = id_in[slot_src[e]];
-        r += ((o < 0 ? ~o : o) < key) ? 1 : 0;
+    if (cell < c.C) {
+        for (int e = a; e < b; ++e) {
+            int o = id_in[slot_src[e]];
+            r += ((o < 0 ? ~o : o) < key) ? 1 : 0;
+        }
+    } else {
+        r = d - a;                              // "outside the grid" bucket: nobody walks it, keep arrival order
     }
     int dst = a + r;
     Pout[dst] = Pin[src];

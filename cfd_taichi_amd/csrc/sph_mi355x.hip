@@ -446,7 +446,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
-    const size_t ncell = (size_t)c.C + 3;
+    const size_t ncell = (size_t)c.C + 2;
     h->ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
     if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
     if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
@@ -629,7 +629,7 @@ int stage_sort_and_lists(SphHandle *h)
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
     const dim3 b(kBlock);
-    const size_t ncell = (size_t)c.C + 3;       // cells, "outside the grid" bucket C, trash bucket C+1, end
+    const size_t ncell = (size_t)c.C + 2;       // cells, "outside the grid" bucket C, end
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     {
         ProfScope ps(h, K_HASH);
@@ -647,6 +647,13 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_SCATTER);
         hipLaunchKernelGGL(k_scatter, g, b, 0, s, c, h->cell_of, h->rank, h->cell_start, h->slot_src);
     }
+    if (h->slab) {
+        // dead slots took no part in the sort: the sorted arrays end after the live particles
+        c.n -= h->n_dead;
+        h->n_dead = 0;
+        h->nblocks = (c.n + kBlock - 1) / kBlock;
+        g = grid_for(c.n);
+    }
     {
         ProfScope ps(h, K_ORDER_GATHER);
         hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
@@ -656,11 +663,6 @@ int stage_sort_and_lists(SphHandle *h)
         if (dfsph) h->wcur ^= 1;
     }
     if (h->slab) {
-        // dead slots are now the tail of the sorted arrays: drop them
-        c.n -= h->n_dead;
-        h->n_dead = 0;
-        h->nblocks = (c.n + kBlock - 1) / kBlock;
-        g = grid_for(c.n);
         HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * (size_t)c.n, s));
         ProfScope ps(h, K_SLAB);
         const int layer[4] = {h->geom.has_left ? h->geom.x_lo - 1 : -1, h->geom.has_left ? h->geom.x_lo : -1,
