@@ -108,7 +108,8 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB
+    # SPH_LIB selects an alternative build of the same library (A/B experiments); default is the in-tree build
+    return os.environ.get("SPH_LIB") or _build.LIB
 
 
 def load(build_if_missing=True):
@@ -117,6 +118,8 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = library_path()
+    if not os.path.exists(path) and os.environ.get("SPH_LIB"):
+        raise RuntimeError("SPH_LIB=%s does not exist" % path)
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError("%s is missing; run `python -m cfd_taichi_amd.build`" % path)

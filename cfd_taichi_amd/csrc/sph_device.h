@@ -24,6 +24,7 @@ struct Consts {
     float kg6;         // 48/(pi h^3) * 6                           solver_base.py:95,98
     float neg_kg6;     // -48/(pi h^3) * 6                          solver_base.py:100
     float r2_cut;      // largest f32 t with sqrtf(t) <= h: (|x_ij| > h) <=> (r2 > r2_cut)
+    float rh;          // RN(1/h), for the exact division by the constant h
     float visc_num;    // 2*alpha*h*c_s (f64-folded)                solver_base.py:187
     float visc_eps_h2; // eps*h*h (f64-folded)                      solver_base.py:188
     float tens_c;      // -k/m*m (f64-folded)                       solver_base.py:216
@@ -59,11 +60,56 @@ struct F3 {
     float x, y, z;
 };
 
+// ---- correctly rounded f32 division at a fraction of the generic expansion ----------------------
+// The sweeps need RN(a/b) (the oracle's IEEE divide), four times per pair.  hipcc's generic expansion is
+// ~10 instructions + VCC hazard nops each (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup).
+//
+// (1) Division by the constant h: with y = RN(1/h), q0 = RN(a*y), e = a - h*q0 (exact, fma),
+//     q = RN(q0 + e*y) is the correctly rounded quotient (Markstein's theorem; h's significand is not all
+//     ones).  3 instructions.
+// (2) Three numerators over one denominator: exactly the Newton-Raphson sequence LLVM emits for `/`
+//     (fma0..fma4 + fmas) minus the v_div_scale / v_div_fixup range handling, with the reciprocal refinement
+//     shared.  Operands here are h*r in [1e-7, 1e-2] and s*dx, far inside the range where v_div_scale is
+//     the identity, so the result is bit-identical to `/`.  3 + 3*5 instructions instead of 3*10 + nops.
+// tests/test_parity_gpu.py checks both against the oracle's plain divisions bit for bit.
+__device__ __forceinline__ float div_by_h(const Consts &c, float a)
+{
+#ifdef SPH_GENERIC_DIV
+    return a / c.h;
+#endif
+    float q0 = a * c.rh;
+    float e = __builtin_fmaf(-q0, c.h, a);
+    return __builtin_fmaf(e, c.rh, q0);
+}
+struct Recip {
+    float d, y;
+};
+__device__ __forceinline__ Recip recip_prepare(float d)
+{
+    float y0 = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, y0, 1.0f);
+    Recip r;
+    r.d = d;
+    r.y = __builtin_fmaf(e, y0, y0);
+    return r;
+}
+__device__ __forceinline__ float div_shared(float a, const Recip &r)
+{
+#ifdef SPH_GENERIC_DIV
+    return a / r.d;
+#endif
+    float q0 = a * r.y;
+    float r0 = __builtin_fmaf(-r.d, q0, a);
+    float q1 = __builtin_fmaf(r0, r.y, q0);
+    float r1 = __builtin_fmaf(-r.d, q1, a);
+    return __builtin_fmaf(r1, r.y, q1);
+}
+
 // solver_base.py:76-88.  Branch-free form: both polynomial pieces are cheap, the select keeps the
 // value of the branch the reference would have taken (identical f32 operations per piece).
 __device__ __forceinline__ float cubic_w(const Consts &c, float r)
 {
-    float q = r / c.h;
+    float q = div_by_h(c, r);                             // r / h
     float q2 = q * q;
     float q3 = q2 * q;
     float w1 = c.kw * (6.0f * (q3 - q2) + 1.0f);          // 0 <= q <= 0.5
@@ -79,7 +125,7 @@ __device__ __forceinline__ float cubic_w(const Consts &c, float r)
 // divergent sets.
 __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float dz, float r_norm)
 {
-    float q = r_norm / c.h;
+    float q = div_by_h(c, r_norm);                        // r_norm / h
     float q2 = q * q;
     float s1 = c.kg6 * (3.0f * q2 - 2.0f * q);            // 1e-5 < q <= 0.5
     float t = 1.0f - q;
@@ -87,9 +133,9 @@ __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float 
     bool in1 = (1e-5f < q) && (q <= 0.5f);
     bool in2 = (0.5f < q) && (q <= 1.0f);
     float s = in1 ? s1 : s2;
-    float den = c.h * r_norm;
+    const Recip den = recip_prepare(c.h * r_norm);
     F3 o;
-    float ox = s * dx / den, oy = s * dy / den, oz = s * dz / den;
+    float ox = div_shared(s * dx, den), oy = div_shared(s * dy, den), oz = div_shared(s * dz, den);   // s*d / (h*r_norm)
     bool in = in1 || in2;
     o.x = in ? ox : 0.0f;
     o.y = in ? oy : 0.0f;

@@ -244,6 +244,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     const float pi_f = (float)3.141592653589793;
     const float h3 = c.h * (c.h * c.h);            // ti.pow(h, 3) by squaring
     c.kw = 8.0f / (pi_f * h3);                     // solver_base.py:79
+    c.rh = 1.0f / c.h;
     const float kg = 48.0f / (pi_f * h3);          // :95
     c.kg6 = kg * 6.0f;
     c.neg_kg6 = -kg * 6.0f;
@@ -1302,6 +1303,7 @@ int sph_selftest_math(int device, int op, const float *a, const float *b, float 
         const float pi_f = (float)3.141592653589793;
         const float h3 = c.h * (c.h * c.h);
         c.kw = 8.0f / (pi_f * h3);
+        c.rh = 1.0f / c.h;
         const float kg = 48.0f / (pi_f * h3);
         c.kg6 = kg * 6.0f; c.neg_kg6 = -kg * 6.0f;
         hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, c, op, da, db, dout, n);

@@ -47,13 +47,14 @@ def test_device_divide_sqrt_are_ieee():
 
 def test_device_kernel_functions_match_oracle():
     rng = np.random.default_rng(11)
-    r = np.concatenate([rng.uniform(0, 0.12, 20000), [0.0, 0.05, 0.1, 0.1000001, 1e-7]]).astype(np.float32)
+    # the device divides by h and by h*r with shortened exact sequences (sph_device.h): cover the whole support densely
+    r = np.concatenate([rng.uniform(0, 0.12, 200000), 10.0 ** rng.uniform(-9, -1, 20000), [0.0, 0.05, 0.1, 0.1000001, 1e-7, 1e-12]]).astype(np.float32)
     h = np.full_like(r, 0.1)
     w = nat.selftest_math(2, r, h)
     w_ref = np.array([orc.cubic_kernel(float(x), 0.1) for x in r], dtype=np.float32)
     assert_same(w, w_ref, "cubic_kernel")
-    x = rng.uniform(-0.07, 0.07, 5000).astype(np.float32)
-    y = rng.uniform(-0.07, 0.07, 5000).astype(np.float32)
+    x = np.concatenate([rng.uniform(-0.07, 0.07, 60000), 10.0 ** rng.uniform(-8, -2, 5000), [0.0, 0.05, 1e-7]]).astype(np.float32)
+    y = np.concatenate([rng.uniform(-0.07, 0.07, 60000), -(10.0 ** rng.uniform(-8, -2, 5000)), [0.0, 0.0, 0.0]]).astype(np.float32)
     g = [nat.selftest_math(3 + k, x, y) for k in range(3)]
     ref = np.array([orc.cubic_kernel_derivative([a, b, np.float32(0.25) * a], 0.1) for a, b in zip(x, y)], dtype=np.float32)
     for k in range(3):
