@@ -31,7 +31,7 @@ def run_slabs(tmp_path, scene, world, steps):
 
 
 @pytest.mark.parametrize("scene,world,steps", [("dfsph_small", 2, 25), ("dfsph_small", 3, 25), ("wcsph_small", 2, 60),
-                                               ("breaking_dam_30k_dfsph", 4, 8)])
+                                               ("breaking_dam_30k_dfsph", 4, 8), ("dfsph_1m", 2, 4)])
 def test_slabs_match_single_gpu(tmp_path, scene, world, steps):
     r = run_slabs(tmp_path, scene, world, steps)
     assert r["pos_rel_err"] <= 1e-5 and r["vel_rel_err"] <= 1e-5, r
