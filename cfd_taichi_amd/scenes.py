@@ -43,6 +43,30 @@ SCENES = {
 }
 
 
+def _with_solid(cfg, mesh, scale, pos_offset, attitude_offset, rho_0, active=True):
+    cfg["solver"]["fs_couple"] = True
+    cfg["solid"] = {"mesh": mesh, "voxel_radius": 0.025, "rho_0": rho_0, "scale": scale, "pos_offset": list(pos_offset),
+                    "attitude_offset": list(attitude_offset), "fill": True, "active": active}
+    return cfg
+
+
+_CUBE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "cube1.stl")
+
+SCENES.update({
+    # config 5 family: DFSPH + one rigid box (the geometry of the reference's obj/cube1.STL: 0.8 x 0.5 x 1.0)
+    # small: the box stands next to the water column, 0.05 above the floor: coupling and wall contact from the first steps
+    "dfsph_rigid_small": lambda: _with_solid(_scene("dfsph", 1e-3, [2.5, 2.0, 1.5], [0.6, 1.0, 1.2], start_pos=(0.1, 0.1, 0.15)),
+                                             _CUBE, 0.5, [0.75, 0.1, 0.5], [0.0, 0.0, 0.0], 2000),
+    "dfsph_rigid_tilted": lambda: _with_solid(_scene("dfsph", 1e-3, [2.5, 2.0, 1.5], [0.6, 1.0, 1.2], start_pos=(0.1, 0.1, 0.15)),
+                                              _CUBE, 0.5, [1.0, 0.4, 0.5], [20.0, 0.0, 35.0], 500),
+    # reference config/coupling_demo.json geometry with the solver switched to dfsph (BASELINE config 5 is its x3.3 scale-up)
+    "coupling_demo_dfsph": lambda: _with_solid(_scene("dfsph", 1e-4, [5.0, 7.0, 2.5], [1.5, 2.0, 2.3]),
+                                               _CUBE, 1.0, [2.5, 0.9, 0.7], [0.0, 0.0, 90.0], 5000),
+    "dfsph_rigid_2m": lambda: _with_solid(_scene("dfsph", 1e-3, [16.0, 12.0, 8.0], [5.0, 6.6, 7.6]),
+                                          _CUBE, 3.3, [8.25, 2.97, 2.31], [0.0, 0.0, 90.0], 5000),
+})
+
+
 def get(name):
     return SCENES[name]()
 

@@ -14,7 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER = range(9)
 F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_NBR_COUNT, F_FORCE_EXT = range(9, 16)
 F_WALL_POS, F_WALL_VOL = 32, 33
-_VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS}
+F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
+_VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT}
+_RIGID_FIELDS = {F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS}
 _WALL_FIELDS = {F_WALL_POS, F_WALL_VOL}
 
 
@@ -31,6 +33,19 @@ class OrcConfig(ctypes.Structure):
         ("fs_couple", ctypes.c_int),
         ("solver", ctypes.c_int),
         ("num_threads", ctypes.c_int),
+    ]
+
+
+class OrcRigid(ctypes.Structure):
+    _fields_ = [
+        ("n_particles", ctypes.c_int),
+        ("n_vertices", ctypes.c_int),
+        ("points", ctypes.c_void_p),
+        ("vertices", ctypes.c_void_p),
+        ("rho_0", ctypes.c_double),
+        ("pos_offset", ctypes.c_double * 3),
+        ("attitude_offset_deg", ctypes.c_double * 3),
+        ("active", ctypes.c_int),
     ]
 
 
@@ -62,6 +77,10 @@ def _lib(precision):
         lib = ctypes.CDLL(os.path.join(_HERE, "liborc_%s.so" % precision))
         lib.orc_create.restype = ctypes.c_void_p
         lib.orc_create.argtypes = [ctypes.POINTER(OrcConfig)]
+        lib.orc_create_rigid.restype = ctypes.c_void_p
+        lib.orc_create_rigid.argtypes = [ctypes.POINTER(OrcConfig), ctypes.POINTER(OrcRigid)]
+        lib.orc_rigid_step.argtypes = [ctypes.c_void_p]
+        lib.orc_rigid_step.restype = None
         lib.orc_destroy.argtypes = [ctypes.c_void_p]
         lib.orc_sizes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         lib.orc_get.restype = ctypes.c_long
@@ -106,10 +125,27 @@ def config_from_dict(config, solver=None, num_threads=1):
 class Oracle:
     """One simulation instance of the CPU restatement."""
 
-    def __init__(self, config, solver=None, num_threads=1, precision="f32"):
+    def __init__(self, config, solver=None, num_threads=1, precision="f32", rigid=None):
+        """rigid: dict(points=(Nr,3) f32, vertices=(Nv,3) f32, rho_0, pos_offset, attitude_offset (degrees), active)"""
         self._lib = _lib(precision)
         self.cfg = config_from_dict(config, solver, num_threads)
-        self._h = self._lib.orc_create(ctypes.byref(self.cfg))
+        self.Nv = 0
+        if rigid is None:
+            self._h = self._lib.orc_create(ctypes.byref(self.cfg))
+        else:
+            pts = np.ascontiguousarray(rigid["points"], dtype=np.float32)
+            vts = np.ascontiguousarray(rigid["vertices"], dtype=np.float32)
+            rg = OrcRigid()
+            rg.n_particles, rg.n_vertices = len(pts), len(vts)
+            rg.points, rg.vertices = pts.ctypes.data, vts.ctypes.data
+            rg.rho_0 = float(rigid["rho_0"])
+            rg.pos_offset[:] = [float(v) for v in rigid["pos_offset"]]
+            rg.attitude_offset_deg[:] = [float(v) for v in rigid["attitude_offset"]]
+            rg.active = 1 if rigid.get("active", False) else 0
+            self._h = self._lib.orc_create_rigid(ctypes.byref(self.cfg), ctypes.byref(rg))
+            if not self._h:
+                raise ValueError("oracle: rigid coupling is restated for dfsph only")
+            self.Nv = len(vts)
         sz = (ctypes.c_int * 7)()
         self._lib.orc_sizes(self._h, sz)
         self.N, self.Nb, self.Nr = sz[0], sz[1], sz[2]
@@ -126,7 +162,7 @@ class Oracle:
         self.close()
 
     def _shape(self, field):
-        n = self.Nb if field in _WALL_FIELDS else self.N
+        n = self.Nb if field in _WALL_FIELDS else (self.Nr if field in _RIGID_FIELDS else (self.Nv if field == F_RIGID_VERT else self.N))
         return (n, 3) if field in _VEC_FIELDS else (n,)
 
     def get(self, field):
@@ -152,6 +188,14 @@ class Oracle:
     @property
     def lost(self):
         return int(self._lib.orc_get_scalar(self._h, 4))
+
+    def rigid_step(self):
+        self._lib.orc_rigid_step(self._h)
+
+    def rigid_scalars(self):
+        g = lambda k: self._lib.orc_get_scalar(self._h, k)   # noqa: E731
+        return {"centroid": [g(10), g(11), g(12)], "omega": [g(13), g(14), g(15)], "vel": [g(16), g(17), g(18)], "mass": g(19),
+                "inertia_inv": [g(20 + k) for k in range(9)]}
 
     def build_grid(self):
         self._lib.orc_build_grid(self._h)

@@ -75,6 +75,17 @@ struct Orc {
     real *alpha, *rho_adv, *rho_der, *vel_adv, *vel_adv_delta, *force_ext, *warm_k;
     int *nbr_cnt;
     long lost;
+    /* rigid body (config 5): particles sampled from the mesh, ParticleSystem.py:41-64 */
+    int Nv;                /* mesh vertices */
+    int exist_rigid, active_rigid;
+    real rigid_rho;
+    real *rpos, *rvol, *rmass, *rforce, *rvert;
+    int *rcell3;
+    real centroid[3], inertia_inv[9];
+    real r_vel[3], r_acc[3], r_omega[3], r_alpha[3];   /* rigid_particles.vel/acc/omega/alpha: always filled uniformly */
+    /* rigid_solver state, rigid_solver.py:6-31 */
+    real rs_dt, rs_omega[3], rs_attitude[3], rs_mass;
+    int rs_run_once, rs_cnt;
 };
 
 /* ---------------------------------------------------------------------------------------
@@ -192,7 +203,35 @@ static long build_lists(const Orc *o, int n, const real *pos, int *cell3, int *c
 /* reset_grid + update_grid                               ParticleSystem.py:368-397 */
 void orc_build_grid(Orc *o)
 {
-    o->lost = build_lists(o, o->N, o->pos, o->cell3, o->cstart, o->citems);
+    if (!(o->exist_rigid && o->active_rigid)) {
+        o->lost = build_lists(o, o->N, o->pos, o->cell3, o->cstart, o->citems);
+        return;
+    }
+    /* fluid entries first (ascending), then rigid entries (ascending, global index i + N + Nb): the order of
+     * update_grid_fluid_particles followed by update_grid_rigid_particles */
+    int C = o->C, N = o->N, Nr = o->Nr;
+    long lost = 0;
+    memset(o->cstart, 0, sizeof(int) * (size_t)(C + 1));
+    int *ids = (int *)malloc(sizeof(int) * (size_t)(N + Nr + 1));
+    for (int i = 0; i < N + Nr; ++i) {
+        int c[3];
+        const real *p = i < N ? o->pos + 3 * i : o->rpos + 3 * (i - N);
+        int *c3 = i < N ? o->cell3 + 3 * i : o->rcell3 + 3 * (i - N);
+        cell_of(o, p, c);
+        c3[0] = c[0]; c3[1] = c[1]; c3[2] = c[2];
+        int id = cell_1d(o, c);
+        if (id < 0 || id >= C) { ids[i] = -1; ++lost; continue; }
+        ids[i] = id;
+        o->cstart[id + 1]++;
+    }
+    for (int c = 0; c < C; ++c) o->cstart[c + 1] += o->cstart[c];
+    int *fill = (int *)malloc(sizeof(int) * (size_t)C);
+    memcpy(fill, o->cstart, sizeof(int) * (size_t)C);
+    for (int i = 0; i < N + Nr; ++i)
+        if (ids[i] >= 0) o->citems[fill[ids[i]]++] = i < N ? i : i + o->Nb;
+    free(fill);
+    free(ids);
+    o->lost = lost;
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -214,10 +253,15 @@ void orc_build_grid(Orc *o)
                     for (int e_ = (o)->cstart[c1_]; e_ < (o)->cstart[c1_ + 1]; ++e_) {         \
                         int j = (o)->citems[e_];                                               \
                         if (j == (i)) continue;                                                \
-                        real xij = pix_ - (o)->pos[3 * j];                                     \
-                        real yij = piy_ - (o)->pos[3 * j + 1];                                 \
-                        real zij = piz_ - (o)->pos[3 * j + 2];                                 \
+                        /* get_particle(): fluid [0,N), rigid [N+Nb, ...)  ParticleSystem.py:496-507 */ \
+                        const int jm_ = j < (o)->N ? 0 : 2;                                    \
+                        const int jl = jm_ == 0 ? j : j - (o)->N - (o)->Nb;                    \
+                        const real *pj_ = jm_ == 0 ? (o)->pos + 3 * j : (o)->rpos + 3 * jl;    \
+                        real xij = pix_ - pj_[0];                                              \
+                        real yij = piy_ - pj_[1];                                              \
+                        real zij = piz_ - pj_[2];                                              \
                         if (r_sqrt((xij * xij + yij * yij) + zij * zij) > (o)->h) continue;    \
+                        (void)jl;                                                              \
                         __VA_ARGS__                                                            \
                     }                                                                          \
                 }                                                                              \
@@ -422,6 +466,7 @@ void orc_destroy(Orc *o)
     free(o->rho); free(o->pressure); free(o->pgrad); free(o->bacc); free(o->visc); free(o->tens);
     free(o->alpha); free(o->rho_adv); free(o->rho_der); free(o->vel_adv); free(o->vel_adv_delta);
     free(o->force_ext); free(o->warm_k); free(o->nbr_cnt);
+    free(o->rpos); free(o->rvol); free(o->rmass); free(o->rforce); free(o->rvert); free(o->rcell3);
     free(o);
 }
 
@@ -453,6 +498,11 @@ static real *field_ptr(Orc *o, int field, long *count, int *is_int)
     case ORC_F_WALL_POS: *count = 3L * o->Nb; return o->bpos;
     case ORC_F_WALL_VOL: *count = o->Nb; return o->bvol;
     case ORC_F_NBR_COUNT: *count = o->N; *is_int = 1; return NULL;
+    case ORC_F_RIGID_POS: *count = 3L * o->Nr; return o->rpos;
+    case ORC_F_RIGID_VOL: *count = o->Nr; return o->rvol;
+    case ORC_F_RIGID_FORCE: *count = 3L * o->Nr; return o->rforce;
+    case ORC_F_RIGID_MASS: *count = o->Nr; return o->rmass;
+    case ORC_F_RIGID_VERT: *count = 3L * o->Nv; return o->rvert;
     default: *count = -1; return NULL;
     }
 }
@@ -484,7 +534,325 @@ double orc_get_scalar(const Orc *o, int which)
     case 2: return (double)o->m;
     case 3: return (double)o->h;
     case 4: return (double)o->lost;
+    case 10: case 11: case 12: return (double)o->centroid[which - 10];
+    case 13: case 14: case 15: return (double)o->rs_omega[which - 13];
+    case 16: case 17: case 18: return (double)o->r_vel[which - 16];
+    case 19: return (double)o->rs_mass;
+    case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: return (double)o->inertia_inv[which - 20];
     default: return 0;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------
+ * rigid body helpers (config 5)
+ * ------------------------------------------------------------------------------------- */
+static inline void cross3(const real a[3], const real b[3], real out[3])
+{
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void matvec3(const real m[9], const real v[3], real out[3])
+{
+    for (int r = 0; r < 3; ++r) out[r] = (m[3 * r] * v[0] + m[3 * r + 1] * v[1]) + m[3 * r + 2] * v[2];
+}
+static inline void matmul3(const real a[9], const real b[9], real out[9])
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = (a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c]) + a[3 * r + 2] * b[6 + c];
+}
+/* ti.math.inverse for 3x3 (Taichi matrix.py, recalled; [taichi-semantics, unverifiable here]):
+ * inv[j][i] = (1/det) * (E(i+1,j+1) E(i+2,j+2) - E(i+2,j+1) E(i+1,j+2)), indices mod 3 */
+static void inverse3(const real m[9], real out[9])
+{
+#define E_(x, y) m[3 * ((x) % 3) + ((y) % 3)]
+    real det = (m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2])) + m[6] * (m[1] * m[5] - m[4] * m[2]);
+    real inv_det = R(1.0) / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[3 * j + i] = inv_det * (E_(i + 1, j + 1) * E_(i + 2, j + 2) - E_(i + 2, j + 1) * E_(i + 1, j + 2));
+#undef E_
+}
+/* ti.math.rotation3d(ang_x, ang_y, ang_z), upper-left 3x3 (Taichi mathimpl.py, recalled; unverifiable here:
+ * the rigid body's initial orientation is 'parity unpinned') */
+static void rotation3d(real ang_x, real ang_y, real ang_z, real m[9])
+{
+    real ca = sizeof(real) == 4 ? (real)cosf((float)ang_x) : (real)cos((double)ang_x);
+    real sa = sizeof(real) == 4 ? (real)sinf((float)ang_x) : (real)sin((double)ang_x);
+    real cb = sizeof(real) == 4 ? (real)cosf((float)ang_z) : (real)cos((double)ang_z);
+    real sb = sizeof(real) == 4 ? (real)sinf((float)ang_z) : (real)sin((double)ang_z);
+    real cy = sizeof(real) == 4 ? (real)cosf((float)ang_y) : (real)cos((double)ang_y);
+    real sy = sizeof(real) == 4 ? (real)sinf((float)ang_y) : (real)sin((double)ang_y);
+    m[0] = cb * cy + sb * sa * sy; m[1] = sb * ca; m[2] = -cb * sy + sb * sa * cy;
+    m[3] = -sb * cy + cb * sa * sy; m[4] = cb * ca; m[5] = sb * sy + cb * sa * cy;
+    m[6] = ca * sy; m[7] = -sa; m[8] = ca * cy;
+}
+
+/* predicted velocity of rigid particle j as the fluid sweeps see it:
+ * v_j = vel + acc*dt + cross(omega [+ alpha*dt], x_j - c)     dfsph_solver.py:292-293 / :168-169 */
+static inline void rigid_predicted_velocity(const Orc *o, int jl, int with_alpha, real out[3])
+{
+    real w[3], rel[3], vo[3];
+    for (int a = 0; a < 3; ++a) {
+        w[a] = with_alpha ? o->r_omega[a] + o->r_alpha[a] * o->dt : o->r_omega[a];
+        rel[a] = o->rpos[3 * jl + a] - o->centroid[a];
+    }
+    cross3(w, rel, vo);
+    for (int a = 0; a < 3; ++a) out[a] = (o->r_vel[a] + o->r_acc[a] * o->dt) + vo[a];
+}
+
+/* dfsph_solver.py:212  rigid_particles[j].force += ret * particle_m, accumulated per rigid particle over its fluid
+ * neighbours in cell-walk order (the reference uses atomics in thread order: any serialisation is valid) */
+static void rigid_accumulate_force(Orc *o)
+{
+    PARFOR
+    for (int r = 0; r < o->Nr; ++r) {
+        real fx = 0, fy = 0, fz = 0;
+        const real *pr = o->rpos + 3 * r;
+        const int *cc = o->rcell3 + 3 * r;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dz = -1; dz <= 1; ++dz) {
+                    int cx = cc[0] + dx, cy = cc[1] + dy, cz = cc[2] + dz;
+                    if (!cell_valid(o, cx, cy, cz)) continue;
+                    int c1 = cx * o->stride[0] + cy * o->stride[1] + cz * o->stride[2];
+                    for (int e = o->cstart[c1]; e < o->cstart[c1 + 1]; ++e) {
+                        int i = o->citems[e];
+                        if (i >= o->N) continue;                       /* fluid particles exert the force */
+                        real xij = o->pos[3 * i] - pr[0], yij = o->pos[3 * i + 1] - pr[1], zij = o->pos[3 * i + 2] - pr[2];
+                        if (r_sqrt((xij * xij + yij * yij) + zij * zij) > o->h) continue;
+                        real k_i = (o->rho_adv[i] - o->rho0) * o->alpha[i] / o->dt2;             /* :208 */
+                        real gw[3];
+                        cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                        real s = o->rvol[r] * o->rho0 * k_i / o->rho[i];                         /* :211 */
+                        fx += s * gw[0] * o->m; fy += s * gw[1] * o->m; fz += s * gw[2] * o->m;   /* :212 */
+                    }
+                }
+        o->rforce[3 * r] += fx; o->rforce[3 * r + 1] += fy; o->rforce[3 * r + 2] += fz;
+    }
+}
+
+/* init_rigid_particles_pos + init_rigid_particles_data          ParticleSystem.py:198-223, 249-295 */
+static void init_rigid(Orc *o, const OrcRigid *rg)
+{
+    const double pi = 3.141592653589793;
+    real att[3];
+    for (int a = 0; a < 3; ++a) att[a] = R(rg->attitude_offset_deg[a] / 180.0 * pi);            /* :52 */
+    real m[9];
+    rotation3d(att[0], att[2], att[1], m);                                                       /* :200 */
+    real off[3] = { R(rg->pos_offset[0]), R(rg->pos_offset[1]), R(rg->pos_offset[2]) };
+    for (int pass = 0; pass < 2; ++pass) {
+        int n = pass == 0 ? o->Nr : o->Nv;
+        real *dst = pass == 0 ? o->rpos : o->rvert;
+        const float *src = pass == 0 ? rg->points : rg->vertices;
+        for (int i = 0; i < n; ++i) {
+            real p[3] = { R(src[3 * i]), R(src[3 * i + 1]), R(src[3 * i + 2]) };
+            for (int r = 0; r < 3; ++r) {
+                real v = ((m[3 * r] * p[0] + m[3 * r + 1] * p[1]) + m[3 * r + 2] * p[2]) + R(0) * R(1);   /* mat4 @ (p, 1) :205-207 */
+                dst[3 * i + r] = v + off[r];                                                     /* :218, :223 */
+            }
+        }
+    }
+}
+
+static void init_rigid_data(Orc *o)
+{
+    /* volume = 1 / sum of W over SOLID neighbours of the fluid/rigid grid              :252-259, 301-307 */
+    for (int i = 0; i < o->Nr; ++i) {
+        real volume = 0;
+        if (o->active_rigid) {
+            const int gi = i + o->N + o->Nb;
+            const real *pi_ = o->rpos + 3 * i;
+            const int *cc = o->rcell3 + 3 * i;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        int cx = cc[0] + dx, cy = cc[1] + dy, cz = cc[2] + dz;
+                        if (!cell_valid(o, cx, cy, cz)) continue;
+                        int c1 = cx * o->stride[0] + cy * o->stride[1] + cz * o->stride[2];
+                        for (int e = o->cstart[c1]; e < o->cstart[c1 + 1]; ++e) {
+                            int j = o->citems[e];
+                            if (j == gi || j < o->N) continue;          /* self; fluid neighbours add 0 */
+                            const real *pj = o->rpos + 3 * (j - o->N - o->Nb);
+                            real x = pi_[0] - pj[0], y = pi_[1] - pj[1], z = pi_[2] - pj[2];
+                            real q = r_sqrt((x * x + y * y) + z * z);
+                            if (q > o->h) continue;
+                            volume += cubic_kernel(q, o->h);
+                        }
+                    }
+        }
+        o->rvol[i] = volume < R(1e-6) ? R(0.0) : R(1.0) / volume;                                /* :255-259 */
+    }
+    for (int i = 0; i < o->Nr; ++i) o->rmass[i] = o->rigid_rho * o->rvol[i];                     /* :262-263 */
+    real c[3] = {0, 0, 0}, sum_mass = 0;                                                         /* :266-271 */
+    for (int i = 0; i < o->Nr; ++i) {
+        for (int a = 0; a < 3; ++a) c[a] += o->rpos[3 * i + a] * o->rmass[i];
+        sum_mass += o->rmass[i];
+    }
+    for (int a = 0; a < 3; ++a) o->centroid[a] = c[a] / sum_mass;
+    real Ixx = 0, Iyy = 0, Izz = 0, Ixy = 0, Ixz = 0, Iyz = 0;                                   /* :275-288 */
+    for (int i = 0; i < o->Nr; ++i) {
+        real x = o->rpos[3 * i] - o->centroid[0], y = o->rpos[3 * i + 1] - o->centroid[1], z = o->rpos[3 * i + 2] - o->centroid[2];
+        real mi = o->rmass[i];
+        Ixx += mi * (y * y + z * z);
+        Iyy += mi * (x * x + z * z);
+        Izz += mi * (x * x + y * y);
+        Ixy += -mi * (x * y);
+        Ixz += -mi * (x * z);
+        Iyz += -mi * (z * y);
+    }
+    real I[9] = { Ixx, Ixy, Ixz, Ixy, Iyy, Iyz, Ixz, Iyz, Izz };                                 /* :290 */
+    inverse3(I, o->inertia_inv);                                                                 /* :291 */
+}
+
+Orc *orc_create_rigid(const OrcConfig *cfg, const OrcRigid *rg)
+{
+    if (cfg->solver != 1 || !rg || rg->n_particles <= 0) return NULL;   /* the rigid branches are restated for dfsph only */
+    Orc *o = orc_create(cfg);
+    o->exist_rigid = 1;
+    o->active_rigid = rg->active ? 1 : 0;
+    o->Nr = rg->n_particles;
+    o->Nv = rg->n_vertices;
+    o->rigid_rho = R(rg->rho_0);
+    size_t Nr = (size_t)o->Nr, Nv = (size_t)(o->Nv > 0 ? o->Nv : 1);
+    o->rpos = (real *)calloc(3 * Nr, sizeof(real)); o->rvol = (real *)calloc(Nr, sizeof(real));
+    o->rmass = (real *)calloc(Nr, sizeof(real)); o->rforce = (real *)calloc(3 * Nr, sizeof(real));
+    o->rvert = (real *)calloc(3 * Nv, sizeof(real)); o->rcell3 = (int *)calloc(3 * Nr, sizeof(int));
+    free(o->citems);
+    o->citems = (int *)calloc((size_t)o->N + Nr + 1, sizeof(int));
+    init_rigid(o, rg);                                                  /* ParticleSystem.py:121 */
+    orc_build_grid(o);                                                  /* :240-241 (now with the rigid particles) */
+    init_rigid_data(o);                                                 /* :247 */
+    o->rs_dt = R(cfg->delta_time);                                      /* rigid_solver.py:13 */
+    return o;
+}
+
+/* rigid_solver.step                                                   rigid_solver.py:216-232 */
+void orc_rigid_step(Orc *o)
+{
+    if (!o->exist_rigid) return;
+    if (!o->rs_run_once) {                                              /* compute_sum_mass :156-162 */
+        real sm = 0;
+        for (int i = 0; i < o->Nr; ++i) sm += o->rmass[i];
+        o->rs_mass = sm;
+        o->rs_run_once = 1;
+    }
+    o->rs_cnt += 1;
+    if (o->ps_dt > R(0.0)) o->rs_dt = o->ps_dt;                         /* :223-224 */
+    const real dt = o->rs_dt;
+    /* compute_attitude :118-128 (sums in f64, ascending particle order; reference: f32 atomics) */
+    {
+        double t[3] = {0, 0, 0};
+        for (int i = 0; i < o->Nr; ++i) {
+            real rel[3] = { o->rpos[3 * i] - o->centroid[0], o->rpos[3 * i + 1] - o->centroid[1], o->rpos[3 * i + 2] - o->centroid[2] };
+            real tq[3];
+            cross3(rel, o->rforce + 3 * i, tq);
+            t[0] += (double)tq[0]; t[1] += (double)tq[1]; t[2] += (double)tq[2];
+        }
+        real torque[3] = { R(t[0]), R(t[1]), R(t[2]) }, alpha[3];
+        matvec3(o->inertia_inv, torque, alpha);
+        for (int a = 0; a < 3; ++a) {
+            o->rs_omega[a] += alpha[a] * dt;
+            o->rs_attitude[a] = o->rs_omega[a] * dt;
+            o->r_alpha[a] = alpha[a];                                   /* rigid_particles.alpha.fill */
+        }
+    }
+    /* rotation :130-141 */
+    {
+        real m[9], mt[9], tmp[9];
+        rotation3d(-o->rs_attitude[0], -o->rs_attitude[2], -o->rs_attitude[1], m);
+        for (int pass = 0; pass < 2; ++pass) {
+            int n = pass == 0 ? o->Nr : o->Nv;
+            real *arr = pass == 0 ? o->rpos : o->rvert;
+            for (int i = 0; i < n; ++i) {
+                real rel[3] = { arr[3 * i] - o->centroid[0], arr[3 * i + 1] - o->centroid[1], arr[3 * i + 2] - o->centroid[2] }, rot[3];
+                matvec3(m, rel, rot);
+                for (int a = 0; a < 3; ++a) arr[3 * i + a] = rot[a] + o->centroid[a];
+            }
+        }
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mt[3 * r + c] = m[3 * c + r];
+        matmul3(m, o->inertia_inv, tmp);
+        matmul3(tmp, mt, o->inertia_inv);                               /* :141 */
+    }
+    /* kinematic :33-104 */
+    {
+        double f[3] = {0, 0, 0};
+        for (int i = 0; i < o->Nr; ++i) {                               /* :36-38 */
+            f[0] += (double)o->rforce[3 * i]; f[1] += (double)o->rforce[3 * i + 1]; f[2] += (double)o->rforce[3 * i + 2];
+            o->rforce[3 * i] = o->rforce[3 * i + 1] = o->rforce[3 * i + 2] = 0;
+        }
+        real force[3] = { R(f[0]), R(f[1]), R(f[2]) };
+        const real g[3] = { o->gravity * R(0.0), o->gravity * R(-1.0), o->gravity * R(0.0) };
+        real vel[3], disp[3], ori[3];
+        for (int a = 0; a < 3; ++a) {
+            o->r_acc[a] = force[a] / o->rs_mass + g[a];                 /* :40-41 */
+            vel[a] = o->r_acc[a] * dt + o->r_vel[a];                    /* :43 */
+            disp[a] = vel[a] * dt;                                      /* :45 */
+            ori[a] = disp[a];
+        }
+        int ccount = 0;
+        double cp[3] = {0, 0, 0};
+        real cnorm[3] = {0, 0, 0};
+        /* ti.atomic_max / atomic_min on displacement[j] (:58, :67) run in thread order in the reference; restated as
+         * "all lower-wall maxima first, then all upper-wall minima" (identical unless one step hits both walls of an axis) */
+        real dmax[3] = {-INFINITY, -INFINITY, -INFINITY}, dmin[3] = {INFINITY, INFINITY, INFINITY};
+        const real lo[3] = { R(o->cfg.box_min[0]) + o->d, R(o->cfg.box_min[1]) + o->d, R(o->cfg.box_min[2]) + o->d };
+        const real hi[3] = { R(o->cfg.box_max[0]) - o->d, R(o->cfg.box_max[1]) - o->d, R(o->cfg.box_max[2]) - o->d };
+        for (int i = 0; i < o->Nr; ++i) {                               /* :53-76 */
+            const real *p = o->rpos + 3 * i;
+            real rel[3] = { p[0] + ori[0] - o->centroid[0], p[1] + ori[1] - o->centroid[1], p[2] + ori[2] - o->centroid[2] }, wr[3];
+            cross3(o->rs_omega, rel, wr);
+            for (int j = 0; j < 3; ++j) {
+                int collision = 0;
+                if (p[j] + ori[j] <= lo[j]) {
+                    dmax[j] = r_max(dmax[j], lo[j] - p[j]);             /* :58 */
+                    if (vel[j] + wr[j] < 0) { collision = 1; cnorm[j] = -1; }
+                }
+                if (p[j] + ori[j] >= hi[j]) {
+                    real cand = hi[j] - p[j];
+                    dmin[j] = cand < dmin[j] ? cand : dmin[j];          /* :67 */
+                    if (vel[j] + wr[j] > 0) { collision = 1; cnorm[j] = 1; }
+                }
+                if (collision == 1) { cp[0] += (double)p[0]; cp[1] += (double)p[1]; cp[2] += (double)p[2]; ccount += 1; }   /* :74-76 */
+            }
+        }
+        for (int j = 0; j < 3; ++j) {
+            disp[j] = r_max(disp[j], dmax[j]);
+            disp[j] = dmin[j] < disp[j] ? dmin[j] : disp[j];
+        }
+        if (ccount > 0) {                                               /* :80-94 */
+            real cpt[3], cv[3], wr[3];
+            for (int a = 0; a < 3; ++a) cpt[a] = (R(cp[a]) + ori[a]) / R(ccount) - o->centroid[a];
+            cross3(o->rs_omega, cpt, wr);
+            for (int a = 0; a < 3; ++a) cv[a] = vel[a] + wr[a];
+            /* compute_new_vel :106-116 */
+            const real mu_n = R(0.1);
+            const real mu_c = R(0.8 * (1 + 0.1));               /* mu_t * (1 + mu_n): Python scalars, folded in f64 */
+            real vdn = (cv[0] * cnorm[0] + cv[1] * cnorm[1]) + cv[2] * cnorm[2];
+            real vn[3], vt[3], vnew[3];
+            for (int a = 0; a < 3; ++a) { vn[a] = vdn * cnorm[a]; vt[a] = cv[a] - vn[a]; }
+            real nvn = r_sqrt((vn[0] * vn[0] + vn[1] * vn[1]) + vn[2] * vn[2]);
+            real nvt = r_sqrt((vt[0] * vt[0] + vt[1] * vt[1]) + vt[2] * vt[2]);
+            real a_ = r_max(R(1) - mu_c * nvn / nvt, R(0.0));
+            for (int a = 0; a < 3; ++a) vnew[a] = a_ * vt[a] + (-mu_n * vn[a]);
+            /* K = I/M - [r]x I^-1 [r]x ; j = K^-1 (v_new - v)        :88-94 */
+            real rx[9] = { 0, -cpt[2], cpt[1], cpt[2], 0, -cpt[0], -cpt[1], cpt[0], 0 };
+            real t1[9], t2[9], K[9], Kinv[9], dv[3], jimp[3], cj[3], dw[3];
+            matmul3(rx, o->inertia_inv, t1);
+            matmul3(t1, rx, t2);
+            for (int q = 0; q < 9; ++q) K[q] = ((q % 4 == 0) ? R(1) / o->rs_mass : R(0) / o->rs_mass) - t2[q];
+            inverse3(K, Kinv);
+            for (int a = 0; a < 3; ++a) dv[a] = vnew[a] - cv[a];
+            matvec3(Kinv, dv, jimp);
+            for (int a = 0; a < 3; ++a) vel[a] += jimp[a] / o->rs_mass;
+            cross3(cpt, jimp, cj);
+            matvec3(o->inertia_inv, cj, dw);
+            for (int a = 0; a < 3; ++a) o->rs_omega[a] += dw[a];
+        }
+        for (int a = 0; a < 3; ++a) { o->r_omega[a] = o->rs_omega[a]; o->r_vel[a] = vel[a]; }     /* :96-97 */
+        for (int i = 0; i < o->Nr; ++i) for (int a = 0; a < 3; ++a) o->rpos[3 * i + a] += disp[a];   /* :98-99 */
+        for (int i = 0; i < o->Nv; ++i) for (int a = 0; a < 3; ++a) o->rvert[3 * i + a] += disp[a];  /* :101-102 */
+        for (int a = 0; a < 3; ++a) o->centroid[a] += disp[a];                                    /* :104 */
     }
 }
 
@@ -498,7 +866,10 @@ void orc_compute_rho(Orc *o)
     for (int i = 0; i < o->N; ++i) {
         real rho = R(0.001);                                           /* :44 */
         FOR_FLUID_NEIGHBORS(o, i, {
-            rho += o->m * cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);   /* :62 */
+            if (jm_ == 0)
+                rho += o->m * cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);   /* :62 */
+            else if (o->cfg.fs_couple)
+                rho += o->rvol[jl] * cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h) * o->rho0;   /* :65 */
         });
         if (o->cfg.boundary_handle) {
             real rho_boundary = 0;
@@ -521,6 +892,24 @@ static void solve_all_viscosity(Orc *o)
         real vx = 0, vy = 0, vz = 0;
         const real vix = o->vel[3 * i], viy = o->vel[3 * i + 1], viz = o->vel[3 * i + 2];
         FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    real vijx = vix - o->r_vel[0], vijy = viy - o->r_vel[1], vijz = viz - o->r_vel[2];   /* :192 */
+                    real shear = (vijx * xij + vijy * yij) + vijz * zij;
+                    if (shear < 0 && jl < o->N) {     /* jl >= N would read rho[] out of bounds in the reference */
+                        real q = r_sqrt((xij * xij + yij * yij) + zij * zij);
+                        real q2 = q * q;
+                        /* quirk: rho[particle_j.index] reads the FLUID density at the rigid particle's local index (:198-199) */
+                        real nu = o->visc_num / (o->rho[i] + o->rho[jl]);
+                        real pi = -nu * shear / (q2 + o->visc_eps_h2);
+                        real gw[3];
+                        cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                        real s = R(-1000) * o->rvol[jl] * pi;                   /* :201 */
+                        vx += s * gw[0]; vy += s * gw[1]; vz += s * gw[2];
+                    }
+                }
+                continue;
+            }
             real vijx = vix - o->vel[3 * j], vijy = viy - o->vel[3 * j + 1], vijz = viz - o->vel[3 * j + 2];
             real shear = (vijx * xij + vijy * yij) + vijz * zij;        /* :183 */
             if (shear < 0) {
@@ -545,6 +934,7 @@ static void solve_all_tension(Orc *o)
     for (int i = 0; i < o->N; ++i) {
         real tx = 0, ty = 0, tz = 0;
         FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;                                     /* :214: fluid neighbours only */
             real w = cubic_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);
             real s = o->tens_c * w;                                     /* :216 */
             tx += s * xij; ty += s * yij; tz += s * zij;
@@ -649,7 +1039,28 @@ void orc_compute_nbr_count(Orc *o)
     PARFOR
     for (int i = 0; i < o->N; ++i) {
         int cnt = 0;
-        FOR_FLUID_NEIGHBORS(o, i, { (void)xij; (void)yij; (void)zij; cnt += 1; });
+        if (!(o->exist_rigid && o->active_rigid)) {
+            FOR_FLUID_NEIGHBORS(o, i, { (void)xij; (void)yij; (void)zij; cnt += 1; });
+        } else {
+            /* literal: skip when particle_j.index == i (LOCAL index), distance to fluid_particles.pos[particle_j.index] */
+            const int *cc = o->cell3 + 3 * i;
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        int cx = cc[0] + dx, cy = cc[1] + dy, cz = cc[2] + dz;
+                        if (!cell_valid(o, cx, cy, cz)) continue;
+                        int c1 = cx * o->stride[0] + cy * o->stride[1] + cz * o->stride[2];
+                        for (int e = o->cstart[c1]; e < o->cstart[c1 + 1]; ++e) {
+                            int j = o->citems[e];
+                            int jl = j < o->N ? j : j - o->N - o->Nb;
+                            if (jl == i) continue;                                  /* :440 */
+                            if (jl >= o->N) continue;     /* would index fluid_particles out of bounds in the reference */
+                            real x = o->pos[3 * i] - o->pos[3 * jl], y = o->pos[3 * i + 1] - o->pos[3 * jl + 1], z = o->pos[3 * i + 2] - o->pos[3 * jl + 2];
+                            if (r_sqrt((x * x + y * y) + z * z) > o->h) continue;   /* :442 */
+                            cnt += 1;
+                        }
+                    }
+        }
         o->nbr_cnt[i] = cnt;
     }
 }
@@ -663,8 +1074,10 @@ void orc_compute_alpha(Orc *o)
         real square_sum = 0;               /* square_sum   (:39, compute_square_sum) */
         FOR_FLUID_NEIGHBORS(o, i, {
             real gw[3];
+            if (jm_ != 0 && !o->cfg.fs_couple) continue;
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
-            real rx = o->m * gw[0], ry = o->m * gw[1], rz = o->m * gw[2];           /* :58, :70 */
+            const real cm = jm_ == 0 ? o->m : o->rvol[jl] * o->rho0;                /* :58,:70 / :62,:75 */
+            real rx = cm * gw[0], ry = cm * gw[1], rz = cm * gw[2];
             sx += rx; sy += ry; sz += rz;
             square_sum += (rx * rx + ry * ry) + rz * rz;                            /* :71 */
         });
@@ -697,8 +1110,16 @@ static void divergence_warm_start(Orc *o)
         real ax = 0, ay = 0, az = 0;
         const real k_i = o->warm_k[i] / o->dt;                                      /* :333 */
         FOR_FLUID_NEIGHBORS(o, i, {
-            real k_j = o->warm_k[j] / o->dt;                                        /* :334 */
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real s = o->rvol[jl] * o->rho0 * k_i / o->rho[i];               /* :345 */
+                    ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+                }
+                continue;
+            }
+            real k_j = o->warm_k[j] / o->dt;                                        /* :334 */
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real s = o->m * (k_i / o->rho[i] + k_j / o->rho[j]);                    /* :337 */
             ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
@@ -735,6 +1156,16 @@ static real derivative_iter_all_rho(Orc *o)
         const real vix = o->vel[3 * i], viy = o->vel[3 * i + 1], viz = o->vel[3 * i + 2];
         FOR_FLUID_NEIGHBORS(o, i, {
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real vj[3];
+                    rigid_predicted_velocity(o, jl, 0, vj);                         /* :292-293 */
+                    real dvx = vix - vj[0], dvy = viy - vj[1], dvz = viz - vj[2];
+                    rd += o->rvol[jl] * o->rho0 * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);   /* :294 */
+                }
+                continue;
+            }
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real dvx = vix - o->vel[3 * j], dvy = viy - o->vel[3 * j + 1], dvz = viz - o->vel[3 * j + 2];
             rd += o->m * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);               /* :287 */
@@ -768,8 +1199,16 @@ static void divergence_iter_all_vel_adv(Orc *o)
         real ax = 0, ay = 0, az = 0;
         const real k_i = o->rho_der[i] * o->alpha[i] / o->dt;                       /* :363 */
         FOR_FLUID_NEIGHBORS(o, i, {
-            real k_j = o->rho_der[j] * o->alpha[j] / o->dt;                         /* :364 */
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real s = o->rvol[jl] * o->rho0 * k_i / o->rho[i];               /* :377 */
+                    ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+                }
+                continue;
+            }
+            real k_j = o->rho_der[j] * o->alpha[j] / o->dt;                         /* :364 */
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real ks = k_i / o->rho[i] + k_j / o->rho[j];
             if (ks > R(1e-5)) {                                                     /* :367 */
@@ -850,7 +1289,16 @@ static void compute_all_vel_adv(Orc *o)
         real n = r_sqrt((x * x + y * y) + z * z);
         if (n > max_vel) max_vel = n;                                               /* :103 */
     }
-    real max_rigid_vel = 0;                                                         /* :104-110, no rigid */
+    real max_rigid_vel = 0;                                                         /* :104-110 */
+    for (int i = 0; i < o->Nr; ++i) {
+        real px = o->rpos[3 * i] - o->centroid[0], py = o->rpos[3 * i + 1] - o->centroid[1], pz = o->rpos[3 * i + 2] - o->centroid[2];
+        real cx = o->r_omega[1] * pz - o->r_omega[2] * py;
+        real cy = o->r_omega[2] * px - o->r_omega[0] * pz;
+        real cz = o->r_omega[0] * py - o->r_omega[1] * px;
+        real vn = r_sqrt((o->r_vel[0] * o->r_vel[0] + o->r_vel[1] * o->r_vel[1]) + o->r_vel[2] * o->r_vel[2]);
+        real v = vn + r_sqrt((cx * cx + cy * cy) + cz * cz);
+        if (v > max_rigid_vel) max_rigid_vel = v;
+    }
     max_vel += max_rigid_vel;
     real max_delta_time = o->dt_cfl_num / max_vel * R(0.2);                         /* :112 */
     if (max_delta_time > R(1e-3)) o->dt = R(1e-3);                                  /* :114-117 */
@@ -868,6 +1316,16 @@ static real compute_all_rho_adv(Orc *o)
         const real vix = o->vel_adv[3 * i], viy = o->vel_adv[3 * i + 1], viz = o->vel_adv[3 * i + 2];
         FOR_FLUID_NEIGHBORS(o, i, {
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real vj[3];
+                    rigid_predicted_velocity(o, jl, 1, vj);                         /* :168-169 (omega + alpha*dt) */
+                    real dvx = vix - vj[0], dvy = viy - vj[1], dvz = viz - vj[2];
+                    delta += o->rvol[jl] * o->rho0 * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);   /* :170 */
+                }
+                continue;
+            }
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real dvx = vix - o->vel_adv[3 * j], dvy = viy - o->vel_adv[3 * j + 1], dvz = viz - o->vel_adv[3 * j + 2];
             delta += o->m * ((dvx * gw[0] + dvy * gw[1]) + dvz * gw[2]);            /* :162 */
@@ -900,8 +1358,16 @@ static void iter_all_vel_adv(Orc *o)
         real ax = 0, ay = 0, az = 0;
         const real k_i = (o->rho_adv[i] - o->rho0) * o->alpha[i] / o->dt2;          /* :199 */
         FOR_FLUID_NEIGHBORS(o, i, {
-            real k_j = (o->rho_adv[j] - o->rho0) * o->alpha[j] / o->dt2;            /* :200 */
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real s = o->rvol[jl] * o->rho0 * k_i / o->rho[i];               /* :211 */
+                    ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
+                }
+                continue;
+            }
+            real k_j = (o->rho_adv[j] - o->rho0) * o->alpha[j] / o->dt2;            /* :200 */
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real s = o->m * (k_i / o->rho[i] + k_j / o->rho[j]);                    /* :203 */
             ax += s * gw[0]; ay += s * gw[1]; az += s * gw[2];
@@ -921,6 +1387,7 @@ static void iter_all_vel_adv(Orc *o)
             o->vel_adv_delta[3 * i] = ax; o->vel_adv_delta[3 * i + 1] = ay; o->vel_adv_delta[3 * i + 2] = az;
         }
     }
+    if (o->exist_rigid && o->active_rigid && o->cfg.fs_couple) rigid_accumulate_force(o);   /* :212 */
     PARFOR
     for (int i = 0; i < 3 * o->N; ++i) o->vel_adv[i] -= o->vel_adv_delta[i] * o->dt;   /* :190-191 */
 }

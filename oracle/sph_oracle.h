@@ -55,12 +55,25 @@ enum {
     ORC_F_ALPHA = 5, ORC_F_WARM_K = 6, ORC_F_RHO_ADV = 7, ORC_F_RHO_DER = 8,
     ORC_F_VEL_ADV = 9, ORC_F_VISCOSITY = 10, ORC_F_TENSION = 11, ORC_F_PGRAD = 12,
     ORC_F_BACC = 13, ORC_F_NBR_COUNT = 14, ORC_F_FORCE_EXT = 15,
-    ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33
+    ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33,
+    ORC_F_RIGID_POS = 48, ORC_F_RIGID_VOL = 49, ORC_F_RIGID_FORCE = 50, ORC_F_RIGID_MASS = 51, ORC_F_RIGID_VERT = 52
 };
+
+/* rigid body of config 5 (ParticleSystem.py:41-64): sample points and mesh vertices in the mesh frame */
+typedef struct OrcRigid {
+    int n_particles, n_vertices;
+    const float *points, *vertices;
+    double rho_0;
+    double pos_offset[3];
+    double attitude_offset_deg[3];
+    int active;
+} OrcRigid;
 
 typedef struct Orc Orc;
 
 Orc *orc_create(const OrcConfig *cfg);
+Orc *orc_create_rigid(const OrcConfig *cfg, const OrcRigid *rigid);   /* dfsph only */
+void orc_rigid_step(Orc *o);                                          /* rigid_solver.step, rigid_solver.py:216-232 */
 void orc_destroy(Orc *o);
 /* out[0]=N fluid, out[1]=Nb wall, out[2]=Nr rigid, out[3..5]=grid_num, out[6]=C */
 void orc_sizes(const Orc *o, int *out7);
