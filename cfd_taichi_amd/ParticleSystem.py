@@ -18,9 +18,13 @@ class ParticleSystem:
         self.config = config
         self._native_opts = dict(device=device, max_neighbors=max_neighbors, max_wall_neighbors=max_wall_neighbors,
                                  max_density_iters=max_density_iters)
-        if config.get("solid", {}):
-            # rigid coupling (config 5) is a later row of the scope table; fail loudly instead of ignoring the body
-            raise NotImplementedError("rigid-fluid coupling ('solid' block) is not built yet in cfd_taichi_amd")
+        self._rigid_input = None
+        if config.get("solid", {}):                                      # :35-64
+            from . import mesh as _mesh
+            self._rigid_input = _mesh.rigid_from_config(config)
+            self.rigid_pos_offset = config["solid"].get("pos_offset")
+            self.rigid_rho = config["solid"].get("rho_0")
+            self.voxel_radius = config["solid"].get("voxel_radius")
         scene, fluid = config["scene"], config["fluid"]
         self.particle_radius = scene["particle_radius"]                 # :80
         self.particle_diameter = self.particle_radius * 2               # :81
@@ -32,7 +36,7 @@ class ParticleSystem:
         self.box_min = np.asarray(scene["box_min"], dtype=np.float64)
         self.rigid_particles_num = 0
         name = config["solver"].get("name")
-        self._solver_kind = name if name in ("wcsph", "dfsph") else "wcsph"
+        self._solver_kind = name if name in ("wcsph", "dfsph") else ("dfsph" if self._rigid_input else "wcsph")
         self._sim = None
         self._make_sim(self._solver_kind)
         self.particle_num = self._sim.n_fluid                            # :85
@@ -52,8 +56,22 @@ class ParticleSystem:
         )
         self.rgba = ConstField(self.particle_num, [0.0, 0.26, 0.68, 1.0])   # :152
         self.rgb = ConstField(self.particle_num, [0.0, 0.28, 1.0])          # :117
-        self.exist_rigid = ScalarField(lambda: 0)                            # :39-40
-        self.active_rigid = ScalarField(lambda: 0)
+        has_rigid = self._rigid_input is not None
+        self.rigid_particles_num = self._sim.n_rigid if has_rigid else 0
+        self.exist_rigid = ScalarField(lambda: 1 if has_rigid else 0)                               # :39-40
+        self.active_rigid = ScalarField(lambda: 1 if has_rigid and self._rigid_input["active"] else 0)   # :63-64
+        if has_rigid:
+            self.rigid_vertex_count = self._sim.n_vertices
+            self.rigid_particles = ParticleFields(
+                pos=DeviceField(self, nat.F_RIGID_POS, nat.SPECIES_RIGID),
+                volume=DeviceField(self, nat.F_RIGID_VOL, nat.SPECIES_RIGID),
+                mass=DeviceField(self, nat.F_RIGID_MASS, nat.SPECIES_RIGID),
+                force=DeviceField(self, nat.F_RIGID_FORCE, nat.SPECIES_RIGID),
+                rgb=ConstField(self.rigid_particles_num, [1.0, 0.0, 0.0]),                          # :295
+            )
+            self.rigid_vertices = DeviceField(self, nat.F_RIGID_VERT, nat.SPECIES_RIGID)
+            self.rigid_centriod = ScalarField(lambda: np.asarray(self._sim.rigid_scalars()["centroid"], dtype=np.float32))
+            self.mesh_faces = self._rigid_input["faces"]
         self.delta_time = ScalarField(lambda: self._sim.scalar(nat.S_PS_DELTA_TIME))   # :37
         print("Boundary particle count: {}k".format(self.boundary_particles_num / 1000))   # :96
         print("Fluid particle count: {}k".format(self.particle_num / 1000))                # :124-127
@@ -64,7 +82,9 @@ class ParticleSystem:
     # ---- native handle management -------------------------------------------------------------
     def _make_sim(self, kind):
         cfg = nat.config_from_dict(self.config, solver_name=kind, **self._native_opts)
-        self._sim = nat.Simulation(cfg)
+        if self._rigid_input is not None and kind != "dfsph":
+            raise NotImplementedError("rigid-fluid coupling is built for the dfsph solver (BASELINE config 5) only")
+        self._sim = nat.Simulation(cfg, rigid=self._rigid_input)
         self._solver_kind = kind
 
     def _attach_solver(self, kind):
@@ -90,6 +110,10 @@ class ParticleSystem:
         """All particles at once: (N,) counts of fluid-grid entries within h (ParticleSystem.py:424-445)."""
         self._sim.build_neighbors()
         return self._sim.download(nat.F_NBR_COUNT).astype(np.int32)
+
+    def update_mesh_vextics(self):                        # :298-299 (sic)
+        """Current mesh vertices (Nv, 3), as main.py:196-200 needs them for the OBJ export."""
+        return self.rigid_vertices.to_numpy()
 
     def compute_boundary_particles_count(self):          # :129-137
         box = self.box_max - self.box_min

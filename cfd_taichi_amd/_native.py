@@ -18,8 +18,10 @@ SPECIES_FLUID, SPECIES_WALL, SPECIES_RIGID = 0, 1, 2
 F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER, F_VEL_ADV = range(10)
 F_NBR_COUNT = 14
 F_WALL_POS, F_WALL_VOL = 32, 33
+F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
+S_RIGID_CENTROID, S_RIGID_OMEGA, S_RIGID_VEL, S_RIGID_MASS, S_RIGID_INERTIA_INV = 10, 13, 16, 19, 20
 S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME = range(5)
-VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS}
+VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT}
 
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
@@ -27,6 +29,7 @@ EXPORTS = [
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math",
     "sph_set_comm", "sph_plan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
+    "sph_create_rigid", "sph_rigid_step",
 ]
 
 
@@ -50,6 +53,20 @@ class SphConfig(ctypes.Structure):
         ("slab_count", ctypes.c_int32),
         ("slab_capacity", ctypes.c_int32),
         ("reserved", ctypes.c_int32 * 6),
+    ]
+
+
+class SphRigid(ctypes.Structure):
+    _fields_ = [
+        ("n_particles", ctypes.c_int32),
+        ("n_vertices", ctypes.c_int32),
+        ("points", ctypes.c_void_p),
+        ("vertices", ctypes.c_void_p),
+        ("rho_0", ctypes.c_double),
+        ("pos_offset", ctypes.c_double * 3),
+        ("attitude_offset", ctypes.c_double * 3),
+        ("active", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -149,6 +166,8 @@ def load(build_if_missing=True):
     lib.sph_profile_kernel_name.restype = ctypes.c_char_p
     lib.sph_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
+    lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
+    lib.sph_rigid_step.argtypes = [vp]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
@@ -206,11 +225,26 @@ def plan_slabs(cfg, slab_count):
 class Simulation:
     """Owns one SphHandle: device buffers of one ParticleSystem + one fluid solver."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, rigid=None):
+        """rigid: dict(points, vertices, rho_0, pos_offset, attitude_offset (degrees), active) from mesh.rigid_from_config"""
         self._lib = load()
         self.cfg = cfg
         handle = ctypes.c_void_p()
-        rc = self._lib.sph_create(ctypes.byref(cfg), ctypes.byref(handle))
+        self.n_vertices = 0
+        if rigid is None:
+            rc = self._lib.sph_create(ctypes.byref(cfg), ctypes.byref(handle))
+        else:
+            pts = np.ascontiguousarray(rigid["points"], dtype=np.float32)
+            vts = np.ascontiguousarray(rigid["vertices"], dtype=np.float32)
+            rg = SphRigid()
+            rg.n_particles, rg.n_vertices = len(pts), len(vts)
+            rg.points, rg.vertices = pts.ctypes.data, vts.ctypes.data
+            rg.rho_0 = float(rigid["rho_0"])
+            rg.pos_offset[:] = [float(v) for v in rigid["pos_offset"]]
+            rg.attitude_offset[:] = [float(v) for v in rigid["attitude_offset"]]
+            rg.active = 1 if rigid.get("active", False) else 0
+            rc = self._lib.sph_create_rigid(ctypes.byref(cfg), ctypes.byref(rg), ctypes.byref(handle))
+            self.n_vertices = len(vts)
         if rc != SPH_OK:
             raise SphError(rc, (self._lib.sph_last_error(None) or b"").decode())
         self._h = handle
@@ -238,6 +272,9 @@ class Simulation:
             pass
 
     def _shape(self, species, field):
+        if species == SPECIES_RIGID:
+            n = self.n_vertices if field == F_RIGID_VERT else self.n_rigid
+            return (n, 3) if field in VECTOR_FIELDS else (n,)
         n = self.n_wall if species == SPECIES_WALL else self.n_fluid
         return (n, 3) if field in VECTOR_FIELDS else (n,)
 
@@ -258,6 +295,15 @@ class Simulation:
     def step_dfsph(self, nsteps=1):
         self._check(self._lib.sph_step_dfsph(self._h, nsteps, ctypes.byref(self.last_stats)))
         return self.last_stats
+
+    def rigid_step(self):
+        self._check(self._lib.sph_rigid_step(self._h))
+
+    def rigid_scalars(self):
+        g = self.scalar
+        return {"centroid": [g(S_RIGID_CENTROID + k) for k in range(3)], "omega": [g(S_RIGID_OMEGA + k) for k in range(3)],
+                "vel": [g(S_RIGID_VEL + k) for k in range(3)], "mass": g(S_RIGID_MASS),
+                "inertia_inv": [g(S_RIGID_INERTIA_INV + k) for k in range(9)]}
 
     def build_neighbors(self):
         self._check(self._lib.sph_build_neighbors(self._h))

@@ -51,7 +51,8 @@ struct DevScalars {
     int max_nbrs;
     int max_wall_nbrs;
     int lost;          // particles outside the grid
-    int pad[3];
+    float rigid_vmax;  // max over rigid particles of |vel| + |omega x (x - c)|   dfsph_solver.py:104-110
+    int pad[2];
     double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
     long long cnt;
 };

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
                                                          const float4 *__restrict__ Vin, const float *__restrict__ warm_in,
                                                          const int *__restrict__ id_in, float4 *__restrict__ Pout,
                                                          float4 *__restrict__ Vout, float *__restrict__ warm_out,
-                                                         int *__restrict__ id_out)
+                                                         int *__restrict__ id_out, float4 *__restrict__ pos_orig)
 {
     int d = blockIdx.x * kBlock + threadIdx.x;
     if (d >= c.n) return;
@@ -169,10 +169,71 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
         r = d - a;                              // "outside the grid" bucket: nobody walks it, keep arrival order
     }
     int dst = a + r;
-    Pout[dst] = Pin[src];
+    const float4 pp = Pin[src];
+    Pout[dst] = pp;
     Vout[dst] = Vin[src];
     if (warm_in) warm_out[dst] = warm_in[src];
     id_out[dst] = raw;
+    if (pos_orig) pos_orig[key] = pp;
+}
+
+// ---- rigid body (config 5) ------------------------------------------------------------------------
+// Rigid sample particles are a third species: every step they are cell-sorted like the fluid, and a fluid particle's
+// neighbour list holds them in the reference's order -- per cell: fluid entries, then rigid entries (update_grid appends
+// fluid first, ParticleSystem.py:383-386) -- tagged with bit 31.  vel / acc / omega / alpha are uniform over the body
+// (rigid_solver.py fills them, :41,96-97,128), so only (x, y, z, V_r) is per particle.
+constexpr uint32_t kRigidTag = 0x80000000u;
+
+struct RigidView {
+    const float4 *RP;         // cell-sorted rigid particles (x, y, z, V_r)
+    const int *rid;           // sorted slot -> rigid particle index
+    const int *rcell_start;   // rigid cell list
+    const float4 *pos_orig;   // fluid positions by ORIGINAL particle id   (get_neighbour_count quirk, ParticleSystem.py:440-442)
+    const float *rho_orig;    // fluid densities by ORIGINAL particle id   (viscosity quirk, solver_base.py:198-199)
+    float c[3], vel[3], acc[3], omega[3], alpha[3];
+    int n_fluid;
+};
+
+// predicted velocity of a rigid particle as the fluid sees it      dfsph_solver.py:292-293 / :168-169
+__device__ __forceinline__ F3 rigid_velocity(const RigidView &rv, float4 pj, float dt, bool with_alpha)
+{
+    float wx = with_alpha ? rv.omega[0] + rv.alpha[0] * dt : rv.omega[0];
+    float wy = with_alpha ? rv.omega[1] + rv.alpha[1] * dt : rv.omega[1];
+    float wz = with_alpha ? rv.omega[2] + rv.alpha[2] * dt : rv.omega[2];
+    float rx = pj.x - rv.c[0], ry = pj.y - rv.c[1], rz = pj.z - rv.c[2];
+    float cx = wy * rz - wz * ry, cy = wz * rx - wx * rz, cz = wx * ry - wy * rx;
+    F3 o;
+    o.x = (rv.vel[0] + rv.acc[0] * dt) + cx;
+    o.y = (rv.vel[1] + rv.acc[1] * dt) + cy;
+    o.z = (rv.vel[2] + rv.acc[2] * dt) + cz;
+    return o;
+}
+
+// fluid-list walkers that understand tagged rigid entries; body(pj, vj, j): j & kRigidTag marks a rigid neighbour,
+// then pj = (x, y, z, V_r) and vj is undefined
+template <bool RIGID, bool WITHV, class Body>
+__device__ __forceinline__ void for_fluid_nbrs(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
+                                               const float4 *__restrict__ B, const RigidView &rv, Body body)
+{
+    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = jn;
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = j[u] & ~kRigidTag;
+            a[u] = rg ? rv.RP[idx] : A[idx];
+            if (WITHV) b[u] = B[rg ? 0u : idx];
+            else b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        body(a[0], b[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], j[3]);
+    }
 }
 
 // ======================================================================================
@@ -193,10 +254,12 @@ __device__ __forceinline__ void nl_flush(const uint4 &g, int k, uint32_t *__rest
     if ((k & 3) != 0 && k < kcap) *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = g;   // tail slots: stale but valid indices
 }
 
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
-                                                     uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds)
+                                                     uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
+                                                     RigidView rv, int *__restrict__ ncount)
 {
     int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
@@ -210,6 +273,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         uint32_t *fbase = nl + nl_index(i, 0, c.kmax);
         uint32_t *wbase = nlb + nl_index(i, 0, c.kbmax);
         uint4 gf = make_uint4(0, 0, 0, 0), gw = make_uint4(0, 0, 0, 0);
+        int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
+        const int my_id = RIGID ? id[i] : 0;
         for (int dx = -1; dx <= 1; ++dx)
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dz = -1; dz <= 1; ++dz) {
@@ -225,6 +290,26 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
                         nl_push((uint32_t)j, gf, kf, fbase, c.kmax);
+                        if (RIGID) ++nq;
+                    }
+                    if (RIGID) {
+                        // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
+                        const int ra = rv.rcell_start[cid], rb = rv.rcell_start[cid + 1];
+                        for (int j = ra; j < rb; ++j) {
+                            const float4 pj = rv.RP[j];
+                            float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                            if (!(r2 > c.r2_cut)) nl_push((uint32_t)j | kRigidTag, gf, kf, fbase, c.kmax);
+                            // get_neighbour_count (:436-444): skips when particle_j.index == i (the rigid particle's LOCAL index) and
+                            // measures the distance to fluid_particles.pos[particle_j.index]
+                            const int jl = rv.rid[j];
+                            if (jl != my_id && jl < rv.n_fluid) {
+                                const float4 pq = rv.pos_orig[jl];
+                                float ex = pi.x - pq.x, ey = pi.y - pq.y, ez = pi.z - pq.z;
+                                float e2 = (ex * ex + ey * ey) + ez * ez;
+                                if (!(e2 > c.r2_cut)) ++nq;
+                            }
+                        }
                     }
                     if (c.boundary_handle) {
                         int wa = wcell_start[cid], wb = wcell_start[cid + 1];
@@ -241,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         nl_flush(gw, kb, wbase, c.kbmax);
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
         cnt[i] = kfc | (kbc << 16);
+        if (RIGID) ncount[i] = nq;
     }
     int mf = wave_max(kf), mb = wave_max(kb);
     if ((threadIdx.x & 63) == 0) {
@@ -371,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict
 __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds)
 {
     float max_vel = ds->vmax;
-    float max_rigid_vel = 0.0f;                                   // :104-110 (no rigid body)
+    float max_rigid_vel = ds->rigid_vmax;                         // :104-110 (0 without a rigid body)
     max_vel += max_rigid_vel;
     float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112
     float dt;
@@ -387,24 +473,28 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds)
 //   WCSPH: writes Pout = (pos, rho), Vout = (vel, p/rho^2), rho[], pressure[]
 //   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, Vout = (vel, rho), rho[], alpha[]
 // ======================================================================================
-template <bool DFSPH>
+template <bool DFSPH, bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                     const float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     float *__restrict__ rho_out, float *__restrict__ aux_out,
-                                                    float4 *__restrict__ Pout, float4 *__restrict__ Vout)
+                                                    float4 *__restrict__ Pout, float4 *__restrict__ Vout, RigidView rv,
+                                                    const int *__restrict__ id, float *__restrict__ rho_orig)
 {
     SPH_SWEEP_PROLOGUE
     float rho = 0.001f;                                      // solver_base.py:44
     float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
-    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        rho += c.m * cubic_w(c, r);                          // solver_base.py:62
+        const bool rg = RIGID && (j & kRigidTag);
+        if (rg) rho += pj.w * cubic_w(c, r) * c.rho0;        // solver_base.py:65  (V_j * W * rho_0)
+        else rho += c.m * cubic_w(c, r);                     // solver_base.py:62
         if (DFSPH) {
             F3 g = grad_w(c, dx, dy, dz, r);
-            float rx = c.m * g.x, ry = c.m * g.y, rz = c.m * g.z;   // dfsph_solver.py:58,70
+            const float cm = rg ? pj.w * c.rho0 : c.m;       // dfsph_solver.py:62,75 / :58,70
+            float rx = cm * g.x, ry = cm * g.y, rz = cm * g.z;
             sx += rx; sy += ry; sz += rz;
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
@@ -425,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     float rho_i = c.boundary_handle ? rho + rho_b * c.rho0 : rho;   // solver_base.py:49,51
     if (!live) return;
     rho_out[i] = rho_i;
+    if (RIGID) rho_orig[id[i]] = rho_i;
     const float4 vi = V[i];
     if (DFSPH) {
         float den;
@@ -531,13 +622,13 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
 // ======================================================================================
 enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
 
-template <int MODE>
+template <int MODE, bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
-                                                    const float4 *__restrict__ Vin, float4 *__restrict__ Vout)
+                                                    const float4 *__restrict__ Vin, float4 *__restrict__ Vout, RigidView rv)
 {
     SPH_SWEEP_PROLOGUE
     const float dt = ds->dt;
@@ -548,14 +639,19 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
     const float kr_i = k_i / rho_i;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
-        float ks = kr_i + pj.w;
-        if (MODE != CORR_DIV || ks > 1e-5f) {                                     // :367
-            float s = c.m * ks;                                                   // :337 / :369 / :203
+        if (RIGID && (j & kRigidTag)) {
+            float s = pj.w * c.rho0 * k_i / rho_i;                                // :345 / :377 / :211  (no 1e-5 gate)
             ax += s * g.x; ay += s * g.y; az += s * g.z;
+        } else {
+            float ks = kr_i + pj.w;
+            if (MODE != CORR_DIV || ks > 1e-5f) {                                 // :367
+                float s = c.m * ks;                                               // :337 / :369 / :203
+                ax += s * g.x; ay += s * g.y; az += s * g.z;
+            }
         }
     });
     float bx = 0.f, by = 0.f, bz = 0.f;
@@ -588,23 +684,31 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
 //   D6 (dfsph_solver.py:124-176): rho*_i = max(rho_i + dt (same sums with v*), rho0)
 // Writes Pout.w = k/rho for the correction sweep that follows and the block partials of the mean.
 // ======================================================================================
-template <bool DENS>
+template <bool DENS, bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                      const float *__restrict__ rho, const float *__restrict__ alpha,
                                                      const DevScalars *__restrict__ ds, float *__restrict__ out,
-                                                     float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt)
+                                                     float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
+                                                     RigidView rv, const int *__restrict__ ncount)
 {
     SPH_SWEEP_PROLOGUE
     const float4 vi = V[ii];
     float acc = 0.f;
-    const bool skip = !DENS && kf < 20;                                           // :258-261
-    for_nbrs_pv(nlp, skip ? 0 : kf, P, V, [&](const float4 pj, const float4 vj) {
+    const int nq = RIGID ? (live ? ncount[ii] : 0) : kf;                          // ps.get_neighbour_count(i)
+    const bool skip = !DENS && nq < 20;                                           // :258-261
+    const float dt_r = RIGID ? ds->dt : 0.f;
+    for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
-        acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);  // :287 / :162
+        if (RIGID && (j & kRigidTag)) {
+            const F3 w = rigid_velocity(rv, pj, dt_r, DENS);                      // :292-293 / :168-169
+            acc += pj.w * c.rho0 * dot3(vi.x - w.x, vi.y - w.y, vi.z - w.z, g.x, g.y, g.z);   // :294 / :170
+        } else {
+            acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);          // :287 / :162
+        }
     });
     float accb = 0.f;
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
@@ -641,10 +745,11 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
 // D5: tension + viscosity + external force + v* and max |v*|
 //     solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
 // ======================================================================================
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
-                                                      float *__restrict__ pmax)
+                                                      float *__restrict__ pmax, RigidView rv)
 {
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
@@ -653,9 +758,25 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
     const float rho_i = vi.w;
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
-    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
+        if (RIGID && (j & kRigidTag)) {
+            // solver_base.py:190-201: no tension from rigid neighbours; viscosity against the body velocity, with
+            // rho[particle_j.index] = the FLUID density at the rigid particle's local index (quirk, :198-199)
+            float vx = vi.x - rv.vel[0], vy = vi.y - rv.vel[1], vz = vi.z - rv.vel[2];
+            float shear = dot3(vx, vy, vz, dx, dy, dz);
+            const int jl = rv.rid[j & ~kRigidTag];
+            if (shear < 0.f && jl < rv.n_fluid) {
+                F3 g = grad_w(c, dx, dy, dz, r);
+                float q2 = r * r;
+                float nu = c.visc_num / (rho_i + rv.rho_orig[jl]);
+                float pi_ = -nu * shear / (q2 + c.visc_eps_h2);
+                float sv = -1000.0f * pj.w * pi_;                               // :201
+                wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+            }
+            return;
+        }
         float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
@@ -739,6 +860,12 @@ __global__ __launch_bounds__(kBlock) void k_unsort_count(int n, const int *__res
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= n) return;
     dst[id[s]] = (float)(cnt[s] & 0xffff);
+}
+__global__ __launch_bounds__(kBlock) void k_unsort_scalar_int(int n, const int *__restrict__ src, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    dst[id[s]] = (float)src[s];
 }
 __global__ __launch_bounds__(kBlock) void k_sort_in_vec(int n, const float *__restrict__ src, const int *__restrict__ id, float4 *__restrict__ dst)
 {

@@ -16,6 +16,7 @@
 
 #include "sph_kernels.h"
 #include "sph_slab_kernels.h"
+#include "sph_rigid_kernels.h"
 
 using namespace sph;
 
@@ -24,12 +25,12 @@ namespace {
 enum KernelId {
     K_HASH = 0, K_SCAN, K_SCATTER, K_ORDER_GATHER, K_BUILD_NL, K_W_DENSITY, K_W_FORCE, K_D_DENSITY_ALPHA,
     K_D_WARM, K_D_DIV_RESIDUAL, K_D_DIV_CORRECT, K_D_EXT, K_D_DENS_RESIDUAL, K_D_DENS_CORRECT, K_D_INTEGRATE,
-    K_FINALIZE, K_TRANSFER, K_SLAB, K_COUNT
+    K_FINALIZE, K_TRANSFER, K_SLAB, K_RIGID, K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "hash_count", "scan", "scatter", "order_gather", "build_nl", "wcsph_density", "wcsph_force", "dfsph_density_alpha",
     "dfsph_warm_start", "dfsph_div_residual", "dfsph_div_correct", "dfsph_ext_force", "dfsph_dens_residual",
-    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange"};
+    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange", "rigid"};
 
 thread_local std::string g_create_error;
 
@@ -88,6 +89,27 @@ struct SphHandle {
     int edge_count[4] = {0, 0, 0, 0};
     int *counters = nullptr, *counters_host = nullptr;
     std::vector<int> init_ids;    // original ids of the particles this handle owns at t = 0
+
+    // rigid body (config 5)
+    bool rigid = false;
+    int rigid_active = 0;
+    int Nv = 0;
+    float rigid_rho = 0.f;
+    float4 *RPos = nullptr;       // [Nr] rigid particles in their own index order: (x, y, z, V_r)
+    float4 *RPs = nullptr;        // [Nr] cell-sorted copy, rebuilt every step
+    int *rid = nullptr, *rcell_of = nullptr, *rrank = nullptr, *rslot = nullptr, *rcell_count = nullptr, *rcell_start = nullptr;
+    float *rforce = nullptr;      // [3 Nr] rigid_particles.force
+    float *rvert = nullptr;       // [3 Nv] mesh vertices
+    float4 *pos_orig = nullptr;   // fluid positions by original id   (get_neighbour_count quirk)
+    float *rho_orig = nullptr;    // fluid densities by original id   (viscosity quirk)
+    int *ncount = nullptr;        // ps.get_neighbour_count(i) with rigid entries
+    RigidReduce *rred = nullptr, *rred_host = nullptr;
+    std::vector<float> rvol_host, rmass_host;
+    float centroid[3] = {0, 0, 0}, inertia_inv[9] = {0}, r_vel[3] = {0, 0, 0}, r_acc[3] = {0, 0, 0}, r_omega[3] = {0, 0, 0},
+          r_alpha[3] = {0, 0, 0};
+    float rs_dt = 0.f, rs_omega[3] = {0, 0, 0}, rs_attitude[3] = {0, 0, 0}, rs_mass = 0.f;
+    bool rs_run_once = false;
+    int rs_cnt = 0;
 
     // profiling
     bool profiling = false;
@@ -618,6 +640,318 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
 }
 
 // ---------------------------------------------------------------------------------------------
+// rigid body of config 5: host-side construction and rigid_solver.step orchestration
+// ---------------------------------------------------------------------------------------------
+void cross3h(const float a[3], const float b[3], float out[3])
+{
+    out[0] = a[1] * b[2] - a[2] * b[1];
+    out[1] = a[2] * b[0] - a[0] * b[2];
+    out[2] = a[0] * b[1] - a[1] * b[0];
+}
+void matvec3h(const float m[9], const float v[3], float out[3])
+{
+    for (int r = 0; r < 3; ++r) out[r] = (m[3 * r] * v[0] + m[3 * r + 1] * v[1]) + m[3 * r + 2] * v[2];
+}
+void matmul3h(const float a[9], const float b[9], float out[9])
+{
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = (a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c]) + a[3 * r + 2] * b[6 + c];
+}
+// ti.math.inverse for a 3x3 matrix (cofactor form, [taichi-semantics, unverifiable here])
+void inverse3h(const float m[9], float out[9])
+{
+    auto E = [&](int x, int y) { return m[3 * (x % 3) + (y % 3)]; };
+    float det = (m[0] * (m[4] * m[8] - m[7] * m[5]) - m[3] * (m[1] * m[8] - m[7] * m[2])) + m[6] * (m[1] * m[5] - m[4] * m[2]);
+    float inv_det = 1.0f / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out[3 * j + i] = inv_det * (E(i + 1, j + 1) * E(i + 2, j + 2) - E(i + 2, j + 1) * E(i + 1, j + 2));
+}
+// ti.math.rotation3d(ang_x, ang_y, ang_z), 3x3 block ([taichi-semantics]: the body's orientation is 'parity unpinned')
+void rotation3dh(float ang_x, float ang_y, float ang_z, float m[9])
+{
+    float ca = cosf(ang_x), sa = sinf(ang_x), cb = cosf(ang_z), sb = sinf(ang_z), cy = cosf(ang_y), sy = sinf(ang_y);
+    m[0] = cb * cy + sb * sa * sy; m[1] = sb * ca; m[2] = -cb * sy + sb * sa * cy;
+    m[3] = -sb * cy + cb * sa * sy; m[4] = cb * ca; m[5] = sb * sy + cb * sa * cy;
+    m[6] = ca * sy; m[7] = -sa; m[8] = ca * cy;
+}
+
+RigidView rigid_view(const SphHandle *h)
+{
+    RigidView rv;
+    memset(&rv, 0, sizeof(rv));
+    rv.RP = h->RPs; rv.rid = h->rid; rv.rcell_start = h->rcell_start; rv.pos_orig = h->pos_orig; rv.rho_orig = h->rho_orig;
+    for (int a = 0; a < 3; ++a) {
+        rv.c[a] = h->centroid[a]; rv.vel[a] = h->r_vel[a]; rv.acc[a] = h->r_acc[a]; rv.omega[a] = h->r_omega[a]; rv.alpha[a] = h->r_alpha[a];
+    }
+    rv.n_fluid = h->N;
+    return rv;
+}
+
+inline bool rigid_coupled(const SphHandle *h) { return h->rigid && h->rigid_active && h->cfg.fs_couple; }
+
+// init_rigid_particles_pos + init_rigid_particles_data (ParticleSystem.py:198-223, 249-295), once, on the host
+int build_rigid(SphHandle *h, const SphRigid *rg)
+{
+    const Consts &c = h->c;
+    h->Nr = rg->n_particles; h->Nv = rg->n_vertices;
+    h->rigid_active = rg->active ? 1 : 0;
+    h->rigid_rho = (float)rg->rho_0;
+    const int Nr = h->Nr, Nv = h->Nv;
+    const double pi = 3.141592653589793;
+    float att[3], m[9], off[3];
+    for (int a = 0; a < 3; ++a) { att[a] = (float)(rg->attitude_offset[a] / 180.0 * pi); off[a] = (float)rg->pos_offset[a]; }   // :52
+    rotation3dh(att[0], att[2], att[1], m);                                                                                     // :200
+    std::vector<float> rpos(3 * (size_t)Nr), rvert(3 * (size_t)(Nv > 0 ? Nv : 1));
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n = pass == 0 ? Nr : Nv;
+        const float *src = pass == 0 ? rg->points : rg->vertices;
+        float *dst = pass == 0 ? rpos.data() : rvert.data();
+        for (int i = 0; i < n; ++i) {
+            const float p[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
+            for (int r = 0; r < 3; ++r) {
+                float v = ((m[3 * r] * p[0] + m[3 * r + 1] * p[1]) + m[3 * r + 2] * p[2]) + 0.0f * 1.0f;   // mat4 @ (p, 1), :205-207
+                dst[3 * i + r] = v + off[r];                                                                // :218, :223
+            }
+        }
+    }
+    // rigid cell list (canonical: ascending index inside a cell) for the one-time volume sums
+    std::vector<int> rc3(3 * (size_t)Nr), rcell(Nr), rstart((size_t)c.C + 1, 0);
+    for (int i = 0; i < Nr; ++i) {
+        int cx = (int)floorf(rpos[3 * (size_t)i] / c.h), cy = (int)floorf(rpos[3 * (size_t)i + 1] / c.h), cz = (int)floorf(rpos[3 * (size_t)i + 2] / c.h);
+        int id = cx + cy * c.sy + cz * c.sz;
+        if (id < 0 || id >= c.C) return fail(h, SPH_E_INVALID, "rigid particle %d starts outside the grid", i);
+        rc3[3 * (size_t)i] = cx; rc3[3 * (size_t)i + 1] = cy; rc3[3 * (size_t)i + 2] = cz;
+        rcell[i] = id;
+        rstart[(size_t)id + 1]++;
+    }
+    for (int k = 0; k < c.C; ++k) rstart[(size_t)k + 1] += rstart[k];
+    std::vector<int> fill(rstart.begin(), rstart.end() - 1), order(Nr);
+    for (int i = 0; i < Nr; ++i) order[fill[rcell[i]]++] = i;
+    h->rvol_host.assign(Nr, 0.f);
+    h->rmass_host.assign(Nr, 0.f);
+    for (int i = 0; i < Nr; ++i) {                                                     // :252-259
+        float volume = 0.f;
+        if (h->rigid_active) {
+            const float *pi_ = &rpos[3 * (size_t)i];
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dz = -1; dz <= 1; ++dz) {
+                        int x = rc3[3 * (size_t)i] + dx, y = rc3[3 * (size_t)i + 1] + dy, z = rc3[3 * (size_t)i + 2] + dz;
+                        if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
+                        if (x < 0 || y < 0 || z < 0) continue;
+                        int cid = x + y * c.sy + z * c.sz;
+                        for (int e = rstart[cid]; e < rstart[(size_t)cid + 1]; ++e) {
+                            int j = order[e];
+                            if (j == i) continue;
+                            float ddx = pi_[0] - rpos[3 * (size_t)j], ddy = pi_[1] - rpos[3 * (size_t)j + 1], ddz = pi_[2] - rpos[3 * (size_t)j + 2];
+                            float q = sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
+                            if (q > c.h) continue;
+                            volume += host_cubic_w(q, c.h, c.kw);
+                        }
+                    }
+        }
+        h->rvol_host[i] = volume < 1e-6f ? 0.0f : 1.0f / volume;
+    }
+    for (int i = 0; i < Nr; ++i) h->rmass_host[i] = h->rigid_rho * h->rvol_host[i];     // :262-263
+    float cs[3] = {0, 0, 0}, sum_mass = 0.f;                                            // :266-271
+    for (int i = 0; i < Nr; ++i) {
+        for (int a = 0; a < 3; ++a) cs[a] += rpos[3 * (size_t)i + a] * h->rmass_host[i];
+        sum_mass += h->rmass_host[i];
+    }
+    for (int a = 0; a < 3; ++a) h->centroid[a] = cs[a] / sum_mass;
+    float Ixx = 0, Iyy = 0, Izz = 0, Ixy = 0, Ixz = 0, Iyz = 0;                         // :275-288
+    for (int i = 0; i < Nr; ++i) {
+        float x = rpos[3 * (size_t)i] - h->centroid[0], y = rpos[3 * (size_t)i + 1] - h->centroid[1], z = rpos[3 * (size_t)i + 2] - h->centroid[2];
+        float mi = h->rmass_host[i];
+        Ixx += mi * (y * y + z * z);
+        Iyy += mi * (x * x + z * z);
+        Izz += mi * (x * x + y * y);
+        Ixy += -mi * (x * y);
+        Ixz += -mi * (x * z);
+        Iyz += -mi * (z * y);
+    }
+    const float I[9] = {Ixx, Ixy, Ixz, Ixy, Iyy, Iyz, Ixz, Iyz, Izz};
+    inverse3h(I, h->inertia_inv);                                                       // :291
+    h->rs_dt = (float)h->cfg.delta_time;                                                // rigid_solver.py:13
+    // device buffers
+    int rc;
+    const size_t nr = (size_t)Nr;
+    if ((rc = dalloc(h, &h->RPos, nr))) return rc;
+    if ((rc = dalloc(h, &h->RPs, nr))) return rc;
+    if ((rc = dalloc(h, &h->rid, nr))) return rc;
+    if ((rc = dalloc(h, &h->rcell_of, nr))) return rc;
+    if ((rc = dalloc(h, &h->rrank, nr))) return rc;
+    if ((rc = dalloc(h, &h->rslot, nr))) return rc;
+    if ((rc = dalloc(h, &h->rcell_count, (size_t)c.C + 2))) return rc;
+    if ((rc = dalloc(h, &h->rcell_start, (size_t)c.C + 2))) return rc;
+    if ((rc = dalloc(h, &h->rforce, 3 * nr))) return rc;
+    if ((rc = dalloc(h, &h->rvert, 3 * (size_t)(Nv > 0 ? Nv : 1)))) return rc;
+    if ((rc = dalloc(h, &h->pos_orig, (size_t)h->c.stride))) return rc;
+    if ((rc = dalloc(h, &h->rho_orig, (size_t)h->c.stride))) return rc;
+    if ((rc = dalloc(h, &h->ncount, (size_t)h->c.stride))) return rc;
+    if ((rc = dalloc(h, &h->rred, 1))) return rc;
+    HIP_TRY(h, hipHostMalloc((void **)&h->rred_host, sizeof(RigidReduce), hipHostMallocDefault));
+    std::vector<float4> rp4(nr);
+    for (int i = 0; i < Nr; ++i) rp4[i] = make_float4(rpos[3 * (size_t)i], rpos[3 * (size_t)i + 1], rpos[3 * (size_t)i + 2], h->rvol_host[i]);
+    HIP_TRY(h, hipMemcpyAsync(h->RPos, rp4.data(), sizeof(float4) * nr, hipMemcpyHostToDevice, h->stream));
+    if (Nv > 0) HIP_TRY(h, hipMemcpyAsync(h->rvert, rvert.data(), sizeof(float) * 3 * (size_t)Nv, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rforce, 0, sizeof(float) * 3 * nr, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)c.C + 2), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rho_orig, 0, sizeof(float) * (size_t)h->c.stride, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->ncount, 0, sizeof(int) * (size_t)h->c.stride, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    size_t stg_need = 3 * std::max(nr, (size_t)Nv);
+    if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb)) {
+        (void)hipFree(h->staging);
+        if ((rc = dalloc(h, &h->staging, stg_need))) return rc;
+    }
+    h->rigid = true;
+    return SPH_OK;
+}
+
+// per step: cell-sort the rigid sample particles (update_grid_rigid_particles, ParticleSystem.py:399-407)
+int stage_sort_rigid(SphHandle *h)
+{
+    Consts cr = h->c;
+    cr.n = h->Nr;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(h->Nr), b(kBlock);
+    const size_t ncell = (size_t)cr.C + 2;
+    ProfScope ps(h, K_RIGID);
+    HIP_TRY(h, hipMemsetAsync(h->rcell_count, 0, sizeof(int) * ncell, s));
+    hipLaunchKernelGGL(k_hash_count, g, b, 0, s, cr, h->RPos, (const int *)nullptr, h->rcell_of, h->rrank, h->rcell_count);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->rcell_count, h->rcell_start, h->tile_sums, (int)ncell);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles);
+    hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->rcell_start, h->tile_sums, (int)ncell);
+    hipLaunchKernelGGL(k_scatter, g, b, 0, s, cr, h->rcell_of, h->rrank, h->rcell_start, h->rslot);
+    hipLaunchKernelGGL(k_rigid_order, g, b, 0, s, h->Nr, h->rcell_of, h->rcell_start, h->rslot, h->RPos, h->RPs, h->rid);
+    HIP_TRY(h, hipGetLastError());
+    return SPH_OK;
+}
+
+RigidBodyState rigid_state(const SphHandle *h, const float vel[3], const float ori[3])
+{
+    RigidBodyState st;
+    memset(&st, 0, sizeof(st));
+    for (int a = 0; a < 3; ++a) {
+        st.c[a] = h->centroid[a]; st.omega[a] = h->rs_omega[a];
+        st.vel[a] = vel ? vel[a] : 0.f; st.ori[a] = ori ? ori[a] : 0.f;
+        st.lo[a] = (float)h->cfg.box_min[a] + h->c.d;                   // rigid_solver.py:56
+        st.hi[a] = (float)h->cfg.box_max[a] - h->c.d;                   // :65
+    }
+    return st;
+}
+
+int read_rigid_reduce(SphHandle *h)
+{
+    HIP_TRY(h, hipMemcpyAsync(h->rred_host, h->rred, sizeof(RigidReduce), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+// rigid_solver.step                                                      rigid_solver.py:216-232
+int rigid_step(SphHandle *h)
+{
+    hipStream_t s = h->stream;
+    const dim3 b(kBlock), gr = grid_for(h->Nr), gv = grid_for(h->Nv > 0 ? h->Nv : 1);
+    int rc;
+    if (!h->rs_run_once) {                                              // compute_sum_mass :156-162
+        float sm = 0.f;
+        for (int i = 0; i < h->Nr; ++i) sm += h->rmass_host[i];
+        h->rs_mass = sm;
+        h->rs_run_once = true;
+    }
+    h->rs_cnt += 1;
+    if (h->cfg.solver == SPH_SOLVER_DFSPH) {
+        if ((rc = read_scalars(h))) return rc;
+        if (h->ds_host->ps_dt > 0.0f) h->rs_dt = h->ds_host->ps_dt;     // :223-224
+    }
+    const float dt = h->rs_dt;
+    ProfScope ps(h, K_RIGID);
+    // compute_attitude :118-128 (+ the force sum of kinematic :35-38: the forces do not change in between)
+    hipLaunchKernelGGL(k_rigid_torque_force, dim3(1), b, 0, s, h->Nr, h->RPos, h->rforce, rigid_state(h, nullptr, nullptr), h->rred);
+    if ((rc = read_rigid_reduce(h))) return rc;
+    {
+        const float torque[3] = {(float)h->rred_host->torque[0], (float)h->rred_host->torque[1], (float)h->rred_host->torque[2]};
+        float alpha[3];
+        matvec3h(h->inertia_inv, torque, alpha);
+        for (int a = 0; a < 3; ++a) {
+            h->rs_omega[a] += alpha[a] * dt;
+            h->rs_attitude[a] = h->rs_omega[a] * dt;
+            h->r_alpha[a] = alpha[a];
+        }
+    }
+    // rotation :130-141
+    {
+        Mat3 R;
+        float mt[9], tmp[9], out[9];
+        rotation3dh(-h->rs_attitude[0], -h->rs_attitude[2], -h->rs_attitude[1], R.m);
+        const RigidBodyState st = rigid_state(h, nullptr, nullptr);
+        hipLaunchKernelGGL(k_rigid_rotate, gr, b, 0, s, h->Nr, h->RPos, (float *)nullptr, R, st);
+        if (h->Nv > 0) hipLaunchKernelGGL(k_rigid_rotate, gv, b, 0, s, h->Nv, (float4 *)nullptr, h->rvert, R, st);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mt[3 * r + c] = R.m[3 * c + r];
+        matmul3h(R.m, h->inertia_inv, tmp);
+        matmul3h(tmp, mt, out);
+        memcpy(h->inertia_inv, out, sizeof(out));
+    }
+    // kinematic :33-104
+    float vel[3], disp[3], ori[3];
+    {
+        const float force[3] = {(float)h->rred_host->force[0], (float)h->rred_host->force[1], (float)h->rred_host->force[2]};
+        const float g[3] = {h->c.gravity * 0.0f, h->c.gravity * -1.0f, h->c.gravity * 0.0f};
+        for (int a = 0; a < 3; ++a) {
+            h->r_acc[a] = force[a] / h->rs_mass + g[a];                 // :40-41
+            vel[a] = h->r_acc[a] * dt + h->r_vel[a];                    // :43
+            disp[a] = vel[a] * dt;                                      // :45
+            ori[a] = disp[a];
+        }
+    }
+    hipLaunchKernelGGL(k_rigid_collide, dim3(1), b, 0, s, h->Nr, h->RPos, rigid_state(h, vel, ori), h->rred);
+    if ((rc = read_rigid_reduce(h))) return rc;
+    const RigidReduce &rr = *h->rred_host;
+    for (int j = 0; j < 3; ++j) {
+        disp[j] = disp[j] > rr.dmax[j] ? disp[j] : rr.dmax[j];          // :58 (all lower-wall maxima, then the upper-wall minima)
+        disp[j] = rr.dmin[j] < disp[j] ? rr.dmin[j] : disp[j];          // :67
+    }
+    if (rr.ccount > 0) {                                                // :80-94
+        const float cnorm[3] = {(float)rr.cnorm[0], (float)rr.cnorm[1], (float)rr.cnorm[2]};
+        float cpt[3], cv[3], wr[3];
+        for (int a = 0; a < 3; ++a) cpt[a] = ((float)rr.cp[a] + ori[a]) / (float)rr.ccount - h->centroid[a];
+        cross3h(h->rs_omega, cpt, wr);
+        for (int a = 0; a < 3; ++a) cv[a] = vel[a] + wr[a];
+        const float mu_n = 0.1f, mu_c = (float)(0.8 * (1 + 0.1));        // compute_new_vel :106-116
+        float vdn = (cv[0] * cnorm[0] + cv[1] * cnorm[1]) + cv[2] * cnorm[2];
+        float vn[3], vt[3], vnew[3];
+        for (int a = 0; a < 3; ++a) { vn[a] = vdn * cnorm[a]; vt[a] = cv[a] - vn[a]; }
+        float nvn = sqrtf((vn[0] * vn[0] + vn[1] * vn[1]) + vn[2] * vn[2]);
+        float nvt = sqrtf((vt[0] * vt[0] + vt[1] * vt[1]) + vt[2] * vt[2]);
+        float a_ = 1.0f - mu_c * nvn / nvt;
+        a_ = a_ > 0.0f ? a_ : 0.0f;
+        for (int a = 0; a < 3; ++a) vnew[a] = a_ * vt[a] + (-mu_n * vn[a]);
+        const float rx[9] = {0, -cpt[2], cpt[1], cpt[2], 0, -cpt[0], -cpt[1], cpt[0], 0};
+        float t1[9], t2[9], K[9], Kinv[9], dv[3], jimp[3], cj[3], dw[3];
+        matmul3h(rx, h->inertia_inv, t1);
+        matmul3h(t1, rx, t2);
+        for (int q = 0; q < 9; ++q) K[q] = ((q % 4 == 0) ? 1.0f / h->rs_mass : 0.0f / h->rs_mass) - t2[q];
+        inverse3h(K, Kinv);
+        for (int a = 0; a < 3; ++a) dv[a] = vnew[a] - cv[a];
+        matvec3h(Kinv, dv, jimp);
+        for (int a = 0; a < 3; ++a) vel[a] += jimp[a] / h->rs_mass;
+        cross3h(cpt, jimp, cj);
+        matvec3h(h->inertia_inv, cj, dw);
+        for (int a = 0; a < 3; ++a) h->rs_omega[a] += dw[a];
+    }
+    for (int a = 0; a < 3; ++a) { h->r_omega[a] = h->rs_omega[a]; h->r_vel[a] = vel[a]; }   // :96-97
+    hipLaunchKernelGGL(k_rigid_translate, gr, b, 0, s, h->Nr, h->RPos, (float *)nullptr, disp[0], disp[1], disp[2], h->rforce);   // :98-99, :38
+    if (h->Nv > 0) hipLaunchKernelGGL(k_rigid_translate, gv, b, 0, s, h->Nv, (float4 *)nullptr, h->rvert, disp[0], disp[1], disp[2], (float *)nullptr);
+    for (int a = 0; a < 3; ++a) h->centroid[a] += disp[a];                                  // :104
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = false;
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // step stages
 // ---------------------------------------------------------------------------------------------
 // solver_base.step() prologue: reset_grid + update_grid (solver_base.py:136-143) as a counting sort,
@@ -659,7 +993,7 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_ORDER_GATHER);
         hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
                            dfsph ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
-                           h->warm[1 - h->wcur], h->id[1 - h->icur]);
+                           h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
         if (dfsph) h->wcur ^= 1;
     }
@@ -674,12 +1008,17 @@ int stage_sort_and_lists(SphHandle *h)
             hipLaunchKernelGGL(k_layer_list, grid_for(c.gy * c.gz), b, 0, s, c, h->cell_start, layer[k], h->edge_off[k], h->edge_list[k]);
         }
     }
+    if (rigid_coupled(h) && (rc = stage_sort_rigid(h))) return rc;
     {
         ProfScope ps(h, K_BUILD_NL);
         // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
         HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
-        hipLaunchKernelGGL(k_build_nl, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb,
-                           h->cnt, h->ds);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL(k_build_nl<true>, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
+                               h->nlb, h->cnt, h->ds, rigid_view(h), h->ncount);
+        else
+            hipLaunchKernelGGL(k_build_nl<false>, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
+                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr);
     }
     HIP_TRY(h, hipGetLastError());
     h->nl_valid = true;
@@ -706,13 +1045,20 @@ int stage_density(SphHandle *h)
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     if (dfsph) {
         ProfScope ps(h, K_D_DENSITY_ALPHA);
-        hipLaunchKernelGGL(k_density<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                           h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL((k_density<true, true>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view(h),
+                               h->id[h->icur], h->rho_orig);
+        else
+            hipLaunchKernelGGL((k_density<true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
+                               (const int *)nullptr, (float *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;    // P = (pos, (warm_k/dt)/rho), V = (vel, rho)
     } else {
         ProfScope ps(h, K_W_DENSITY);
-        hipLaunchKernelGGL(k_density<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                           (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        hipLaunchKernelGGL((k_density<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                           (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
+                           (const int *)nullptr, (float *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -778,8 +1124,13 @@ int dfsph_div_residual(SphHandle *h, float *err)
     hipStream_t s = h->stream;
     {
         ProfScope ps(h, K_D_DIV_RESIDUAL);
-        hipLaunchKernelGGL(k_residual<false>, grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
-                           h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl,
+                               h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount);
+        else
+            hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl,
+                               h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                               (const int *)nullptr);
         h->pcur ^= 1;     // P.w = (drho*alpha/dt)/rho
     }
     int rc;
@@ -801,8 +1152,12 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
     {
         ProfScope ps(h, K_D_WARM);                           // :396-397
-        hipLaunchKernelGGL(k_correct<CORR_WARM>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                           (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL((k_correct<CORR_WARM, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                               (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], rigid_view(h));
+        else
+            hipLaunchKernelGGL((k_correct<CORR_WARM, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                               (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], RigidView());
         h->vcur ^= 1;
     }
     if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
@@ -818,8 +1173,12 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {    // :400
         {
             ProfScope ps(h, K_D_DIV_CORRECT);                // :402 + sum_up_stiff :404-405
-            hipLaunchKernelGGL(k_correct<CORR_DIV>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                               h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur]);
+            if (rigid_coupled(h))
+                hipLaunchKernelGGL((k_correct<CORR_DIV, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                                   h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], rigid_view(h));
+            else
+                hipLaunchKernelGGL((k_correct<CORR_DIV, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                                   h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], RigidView());
             h->vcur ^= 1;
         }
         if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
@@ -834,7 +1193,18 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     // ---- compute_all_ext_force + compute_all_vel_adv, :91-122 ----
     {
         ProfScope ps(h, K_D_EXT);
-        hipLaunchKernelGGL(k_dfsph_ext, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL(k_dfsph_ext<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax,
+                               rigid_view(h));
+        else
+            hipLaunchKernelGGL(k_dfsph_ext<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax,
+                               RigidView());
+        if (h->rigid) {   // max_rigid_vel, dfsph_solver.py:104-110 (loops over the rigid particles whether or not the body is active)
+            RigidBodyState st = rigid_state(h, nullptr, nullptr);
+            for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];
+            const float vn = sqrtf((h->r_vel[0] * h->r_vel[0] + h->r_vel[1] * h->r_vel[1]) + h->r_vel[2] * h->r_vel[2]);
+            hipLaunchKernelGGL(k_rigid_vmax, dim3(1), b, 0, s, h->Nr, h->RPos, st, vn, h->ds);
+        }
     }
     {
         ProfScope ps(h, K_FINALIZE);
@@ -861,8 +1231,13 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
             if (it >= cap) { st->capped = 1; break; }
             {
                 ProfScope ps(h, K_D_DENS_RESIDUAL);          // compute_all_rho_adv :124-152
-                hipLaunchKernelGGL(k_residual<true>, g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
-                                   h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt);
+                if (rigid_coupled(h))
+                    hipLaunchKernelGGL((k_residual<true, true>), g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
+                                       h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount);
+                else
+                    hipLaunchKernelGGL((k_residual<true, false>), g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
+                                       h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                                       (const int *)nullptr);
                 h->pcur ^= 1;
             }
             if (h->slab && (rc = slab_exchange_field(h, 0, h->P[h->pcur], nullptr, nullptr))) return rc;
@@ -872,8 +1247,16 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
             }
             {
                 ProfScope ps(h, K_D_DENS_CORRECT);           // iter_all_vel_adv :178-191
-                hipLaunchKernelGGL(k_correct<CORR_DENS>, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                                   h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur]);
+                if (rigid_coupled(h)) {
+                    hipLaunchKernelGGL((k_correct<CORR_DENS, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho,
+                                       h->aux, h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur], rigid_view(h));
+                    // rigid_particles[j].force += ret * particle_m   (dfsph_solver.py:212)
+                    hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->cell_start, h->rho,
+                                       h->rho_adv, h->aux, h->ds, h->rforce);
+                } else {
+                    hipLaunchKernelGGL((k_correct<CORR_DENS, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho,
+                                       h->aux, h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur], RigidView());
+                }
                 h->vacur ^= 1;
             }
             if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->VA[h->vacur], nullptr))) return rc;
@@ -917,6 +1300,10 @@ int field_floats(SphHandle *h, int species, int field, size_t *count, bool *vec)
     } else if (species == SPH_SPECIES_WALL) {
         if (field == SPH_F_WALL_POS) { *vec = true; *count = 3 * (size_t)h->Nb; return SPH_OK; }
         if (field == SPH_F_WALL_VOL) { *count = (size_t)h->Nb; return SPH_OK; }
+    } else if (species == SPH_SPECIES_RIGID && h->rigid) {
+        if (field == SPH_F_RIGID_POS || field == SPH_F_RIGID_FORCE) { *vec = true; *count = 3 * (size_t)h->Nr; return SPH_OK; }
+        if (field == SPH_F_RIGID_VOL || field == SPH_F_RIGID_MASS) { *count = (size_t)h->Nr; return SPH_OK; }
+        if (field == SPH_F_RIGID_VERT) { *vec = true; *count = 3 * (size_t)h->Nv; return SPH_OK; }
     }
     return fail(h, SPH_E_INVALID, "unknown species/field %d/%d", species, field);
 }
@@ -964,6 +1351,32 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     return SPH_OK;
 }
 
+int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out)
+{
+    if (!cfg || !rigid || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
+    if (cfg->solver != SPH_SOLVER_DFSPH) return fail(nullptr, SPH_E_INVALID, "rigid coupling is built for dfsph (BASELINE config 5) only");
+    if (cfg->slab_count > 1) return fail(nullptr, SPH_E_INVALID, "rigid coupling is not available on slab handles");
+    if (rigid->n_particles <= 0 || !rigid->points) return fail(nullptr, SPH_E_INVALID, "rigid body has no sample points");
+    int rc = sph_create(cfg, out);
+    if (rc) return rc;
+    SphHandle *h = *out;
+    rc = build_rigid(h, rigid);
+    if (rc) {
+        g_create_error = h->err;
+        sph_destroy(h);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int sph_rigid_step(SphHandle *h)
+{
+    if (!h) return SPH_E_INVALID;
+    if (!h->rigid) return fail(h, SPH_E_STATE, "handle has no rigid body");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return rigid_step(h);
+}
+
 void sph_destroy(SphHandle *h)
 {
     if (!h) return;
@@ -980,6 +1393,10 @@ void sph_destroy(SphHandle *h)
     (void)hipFree(h->wcell_start); (void)hipFree(h->psum); (void)hipFree(h->pcnt); (void)hipFree(h->pmax); (void)hipFree(h->ds);
     (void)hipFree(h->staging);
     (void)hipFree(h->dead); (void)hipFree(h->counters);
+    (void)hipFree(h->RPos); (void)hipFree(h->RPs); (void)hipFree(h->rid); (void)hipFree(h->rcell_of); (void)hipFree(h->rrank);
+    (void)hipFree(h->rslot); (void)hipFree(h->rcell_count); (void)hipFree(h->rcell_start); (void)hipFree(h->rforce); (void)hipFree(h->rvert);
+    (void)hipFree(h->pos_orig); (void)hipFree(h->rho_orig); (void)hipFree(h->ncount); (void)hipFree(h->rred);
+    if (h->rred_host) (void)hipHostFree(h->rred_host);
     for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
     if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
     if (h->counters_host) (void)hipHostFree(h->counters_host);
@@ -991,7 +1408,7 @@ void sph_destroy(SphHandle *h)
 int sph_get_sizes(SphHandle *h, SphSizes *out)
 {
     if (!h || !out) return SPH_E_INVALID;
-    out->n_fluid = h->N; out->n_wall = h->Nb; out->n_rigid = h->Nr;
+    out->n_fluid = h->N; out->n_wall = h->Nb; out->n_rigid = h->rigid ? h->Nr : 0;
     out->grid[0] = h->c.gx; out->grid[1] = h->c.gy; out->grid[2] = h->c.gz;
     out->n_cells = h->c.C;
     out->max_neighbors = h->c.kmax; out->max_wall_neighbors = h->c.kbmax;
@@ -1037,6 +1454,22 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
         memcpy(host, src.data(), sizeof(float) * count);
         return SPH_OK;
     }
+    if (species == SPH_SPECIES_RIGID) {
+        if (field == SPH_F_RIGID_VOL || field == SPH_F_RIGID_MASS) {
+            memcpy(host, (field == SPH_F_RIGID_VOL ? h->rvol_host : h->rmass_host).data(), sizeof(float) * count);
+            return SPH_OK;
+        }
+        hipStream_t s = h->stream;
+        if (field == SPH_F_RIGID_POS) {
+            hipLaunchKernelGGL(k_copy_vec_local, grid_for(h->Nr), dim3(kBlock), 0, s, h->Nr, h->RPos, h->staging);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, hipMemcpyAsync(host, h->staging, sizeof(float) * count, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(h, hipMemcpyAsync(host, field == SPH_F_RIGID_FORCE ? h->rforce : h->rvert, sizeof(float) * count, hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(h, hipStreamSynchronize(s));
+        return SPH_OK;
+    }
     if (h->slab) return fail(h, SPH_E_STATE, "slab handle: use sph_download_local + sph_download_ids (device order, owned and ghost particles)");
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     hipStream_t s = h->stream;
@@ -1065,7 +1498,10 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
             hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->warm[h->wcur], id, h->staging); break;
         case SPH_F_RHO_ADV: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->rho_adv, id, h->staging); break;
         case SPH_F_RHO_DER: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->drho, id, h->staging); break;
-        case SPH_F_NBR_COUNT: hipLaunchKernelGGL(k_unsort_count, g, b, 0, s, h->N, h->cnt, id, h->staging); break;
+        case SPH_F_NBR_COUNT:
+            if (rigid_coupled(h)) hipLaunchKernelGGL(k_unsort_scalar_int, g, b, 0, s, h->N, h->ncount, id, h->staging);
+            else hipLaunchKernelGGL(k_unsort_count, g, b, 0, s, h->N, h->cnt, id, h->staging);
+            break;
         default: return fail(h, SPH_E_INVALID, "field %d cannot be downloaded", field);
         }
     }
@@ -1245,7 +1681,16 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PARTICLE_M: *out = (double)h->c.m; return SPH_OK;
     case SPH_S_SUPPORT_RADIUS: *out = (double)h->c.h; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
-    default: return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
+    default:
+        if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {
+            if (which < SPH_S_RIGID_OMEGA) *out = (double)h->centroid[which - SPH_S_RIGID_CENTROID];
+            else if (which < SPH_S_RIGID_VEL) *out = (double)h->rs_omega[which - SPH_S_RIGID_OMEGA];
+            else if (which < SPH_S_RIGID_MASS) *out = (double)h->r_vel[which - SPH_S_RIGID_VEL];
+            else if (which == SPH_S_RIGID_MASS) *out = (double)h->rs_mass;
+            else *out = (double)h->inertia_inv[which - SPH_S_RIGID_INERTIA_INV];
+            return SPH_OK;
+        }
+        return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
     }
 }
 

@@ -13,8 +13,10 @@ class DeviceField:
 
     @property
     def shape(self):
-        n = self._owner._sim.n_wall if self._species == nat.SPECIES_WALL else self._owner._sim.n_fluid
-        return (n,)
+        sim = self._owner._sim
+        if self._species == nat.SPECIES_RIGID:
+            return (sim.n_vertices if self._field == nat.F_RIGID_VERT else sim.n_rigid,)
+        return (sim.n_wall if self._species == nat.SPECIES_WALL else sim.n_fluid,)
 
     def to_numpy(self):
         return self._owner._sim.download(self._field, self._species)

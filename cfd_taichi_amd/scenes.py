@@ -58,7 +58,7 @@ SCENES.update({
     "dfsph_rigid_small": lambda: _with_solid(_scene("dfsph", 1e-3, [2.5, 2.0, 1.5], [0.6, 1.0, 1.2], start_pos=(0.1, 0.1, 0.15)),
                                              _CUBE, 0.5, [0.75, 0.1, 0.5], [0.0, 0.0, 0.0], 2000),
     "dfsph_rigid_tilted": lambda: _with_solid(_scene("dfsph", 1e-3, [2.5, 2.0, 1.5], [0.6, 1.0, 1.2], start_pos=(0.1, 0.1, 0.15)),
-                                              _CUBE, 0.5, [1.0, 0.4, 0.5], [20.0, 0.0, 35.0], 500),
+                                              _CUBE, 0.5, [0.8, 0.25, 0.45], [20.0, 0.0, 35.0], 500),
     # reference config/coupling_demo.json geometry with the solver switched to dfsph (BASELINE config 5 is its x3.3 scale-up)
     "coupling_demo_dfsph": lambda: _with_solid(_scene("dfsph", 1e-4, [5.0, 7.0, 2.5], [1.5, 2.0, 2.3]),
                                                _CUBE, 1.0, [2.5, 0.9, 0.7], [0.0, 0.0, 90.0], 5000),

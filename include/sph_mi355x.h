@@ -85,6 +85,21 @@ typedef struct SphStepStats {
     int32_t reserved;
 } SphStepStats;
 
+/* the `solid` block of the reference's config (ParticleSystem.py:41-64) after mesh loading: sample points
+ * (trimesh voxelized(pitch).fill().points in the reference; cfd_taichi_amd/mesh.py here) and mesh vertices, both in the
+ * mesh frame, before attitude_offset / pos_offset are applied */
+typedef struct SphRigid {
+    int32_t n_particles;
+    int32_t n_vertices;
+    const float *points;         /* 3 * n_particles */
+    const float *vertices;       /* 3 * n_vertices */
+    double rho_0;                /* solid.rho_0 */
+    double pos_offset[3];        /* solid.pos_offset */
+    double attitude_offset[3];   /* solid.attitude_offset, degrees */
+    int32_t active;              /* solid.active */
+    int32_t reserved;
+} SphRigid;
+
 /* species for upload / download */
 #define SPH_SPECIES_FLUID 0
 #define SPH_SPECIES_WALL 1
@@ -104,6 +119,11 @@ typedef struct SphStepStats {
 #define SPH_F_NBR_COUNT 14 /* ps.get_neighbour_count(i), as float */
 #define SPH_F_WALL_POS 32  /* boundary_particles.pos    (species WALL) */
 #define SPH_F_WALL_VOL 33  /* boundary_particles.volume (species WALL) */
+#define SPH_F_RIGID_POS 48    /* rigid_particles.pos    (species RIGID) */
+#define SPH_F_RIGID_VOL 49    /* rigid_particles.volume */
+#define SPH_F_RIGID_FORCE 50  /* rigid_particles.force */
+#define SPH_F_RIGID_MASS 51   /* rigid_particles.mass */
+#define SPH_F_RIGID_VERT 52   /* ps.rigid_vertices (mesh vertices, for OBJ export) */
 
 /* scalars for sph_get_scalar */
 #define SPH_S_DELTA_TIME 0     /* solver.delta_time[None] */
@@ -111,6 +131,11 @@ typedef struct SphStepStats {
 #define SPH_S_PARTICLE_M 2     /* ps.particle_m */
 #define SPH_S_SUPPORT_RADIUS 3 /* ps.support_radius */
 #define SPH_S_PS_DELTA_TIME 4  /* ps.delta_time[None] */
+#define SPH_S_RIGID_CENTROID 10   /* +0,1,2: ps.rigid_centriod[None] */
+#define SPH_S_RIGID_OMEGA 13      /* +0,1,2: rigid_solver.omega[None] */
+#define SPH_S_RIGID_VEL 16        /* +0,1,2: rigid_particles.vel (uniform over the body) */
+#define SPH_S_RIGID_MASS 19       /* rigid_solver.mass[None] */
+#define SPH_S_RIGID_INERTIA_INV 20 /* +0..8: ps.rigid_inertia_tensor_inv[None], row major */
 
 typedef struct SphHandle SphHandle;
 
@@ -118,6 +143,11 @@ typedef struct SphHandle SphHandle;
  * Builds the fluid lattice and the wall particles (ParticleSystem.py:139-195), the static
  * wall cell list and wall volumes (:309-335), and allocates every device buffer. */
 int sph_create(const SphConfig *cfg, SphHandle **out);
+/* the same with a rigid body: replaces ParticleSystem(config) with a `solid` block + rigid_solver(ps, config)   main.py:69-71.
+ * DFSPH only (BASELINE config 5); not available on slab handles. */
+int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out);
+/* replaces rigid_solver.step()   rigid_solver.py:216-232 */
+int sph_rigid_step(SphHandle *h);
 void sph_destroy(SphHandle *h);
 int sph_get_sizes(SphHandle *h, SphSizes *out);
 const char *sph_last_error(SphHandle *h);

@@ -796,6 +796,7 @@ void orc_rigid_step(Orc *o)
         /* ti.atomic_max / atomic_min on displacement[j] (:58, :67) run in thread order in the reference; restated as
          * "all lower-wall maxima first, then all upper-wall minima" (identical unless one step hits both walls of an axis) */
         real dmax[3] = {-INFINITY, -INFINITY, -INFINITY}, dmin[3] = {INFINITY, INFINITY, INFINITY};
+        int lo_hit[3] = {0, 0, 0}, hi_hit[3] = {0, 0, 0};   /* collision_norm[j] is written racily (:63, :72): upper wall wins here */
         const real lo[3] = { R(o->cfg.box_min[0]) + o->d, R(o->cfg.box_min[1]) + o->d, R(o->cfg.box_min[2]) + o->d };
         const real hi[3] = { R(o->cfg.box_max[0]) - o->d, R(o->cfg.box_max[1]) - o->d, R(o->cfg.box_max[2]) - o->d };
         for (int i = 0; i < o->Nr; ++i) {                               /* :53-76 */
@@ -806,17 +807,18 @@ void orc_rigid_step(Orc *o)
                 int collision = 0;
                 if (p[j] + ori[j] <= lo[j]) {
                     dmax[j] = r_max(dmax[j], lo[j] - p[j]);             /* :58 */
-                    if (vel[j] + wr[j] < 0) { collision = 1; cnorm[j] = -1; }
+                    if (vel[j] + wr[j] < 0) { collision = 1; lo_hit[j] = 1; }
                 }
                 if (p[j] + ori[j] >= hi[j]) {
                     real cand = hi[j] - p[j];
                     dmin[j] = cand < dmin[j] ? cand : dmin[j];          /* :67 */
-                    if (vel[j] + wr[j] > 0) { collision = 1; cnorm[j] = 1; }
+                    if (vel[j] + wr[j] > 0) { collision = 1; hi_hit[j] = 1; }
                 }
                 if (collision == 1) { cp[0] += (double)p[0]; cp[1] += (double)p[1]; cp[2] += (double)p[2]; ccount += 1; }   /* :74-76 */
             }
         }
         for (int j = 0; j < 3; ++j) {
+            cnorm[j] = hi_hit[j] ? R(1) : (lo_hit[j] ? R(-1) : R(0));
             disp[j] = r_max(disp[j], dmax[j]);
             disp[j] = dmin[j] < disp[j] ? dmin[j] : disp[j];
         }

@@ -1,0 +1,94 @@
+"""GPU suite, config 5: DFSPH with a two-way coupled rigid body (ParticleSystem 'solid' block + rigid_solver) against
+the oracle, bit for bit: rigid sample volumes / mass / inertia, the rigid-neighbour branches of every DFSPH sweep, the
+neighbour-count quirk, the force accumulated on the body and rigid_solver.step (rotation, wall impulse, translation)."""
+import numpy as np
+import pytest
+
+from cfd_taichi_amd import _native as nat
+from cfd_taichi_amd import mesh, scenes
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        scale = max(float(np.abs(b).max()), 1e-30)
+        raise AssertionError("%s differs at %d of %d entries, rel err %.3e, first %s: %r vs %r" % (
+            what, len(bad), a.size, float(np.abs(a.astype(np.float64) - b).max()) / scale, bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+
+
+def make(scene):
+    cfg = scenes.get(scene)
+    rg = mesh.rigid_from_config(cfg)
+    sim = nat.Simulation(nat.config_from_dict(cfg), rigid=rg)
+    o = orc.Oracle(cfg, num_threads=8, rigid=rg)
+    return cfg, sim, o
+
+
+@pytest.mark.parametrize("scene", ["dfsph_rigid_small", "dfsph_rigid_tilted"])
+def test_rigid_initialisation(scene):
+    cfg, sim, o = make(scene)
+    assert (sim.n_fluid, sim.n_wall, sim.n_rigid) == (o.N, o.Nb, o.Nr) and sim.n_rigid > 0
+    same(sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_POS), "rigid positions")
+    same(sim.download(nat.F_RIGID_VOL, nat.SPECIES_RIGID), o.get(orc.F_RIGID_VOL), "rigid volumes")
+    same(sim.download(nat.F_RIGID_MASS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_MASS), "rigid masses")
+    same(sim.download(nat.F_RIGID_VERT, nat.SPECIES_RIGID), o.get(orc.F_RIGID_VERT), "mesh vertices")
+    a, b = sim.rigid_scalars(), o.rigid_scalars()
+    same(np.float32(a["centroid"]), np.float32(b["centroid"]), "centroid")
+    same(np.float32(a["inertia_inv"]), np.float32(b["inertia_inv"]), "inverse inertia tensor")
+    sim.close(); o.close()
+
+
+def test_density_alpha_count_with_rigid_neighbours():
+    cfg, sim, o = make("dfsph_rigid_small")
+    sim.compute_alpha()
+    o.compute_rho(); o.compute_alpha(); o.compute_nbr_count()
+    same(sim.download(nat.F_NBR_COUNT), o.get(orc.F_NBR_COUNT), "neighbour count (with the rigid-entry quirk)")
+    same(sim.download(nat.F_RHO), o.get(orc.F_RHO), "rho")
+    same(sim.download(nat.F_ALPHA), o.get(orc.F_ALPHA), "alpha")
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("scene,steps", [("dfsph_rigid_small", 120), ("dfsph_rigid_tilted", 150)])
+def test_coupled_steps(scene, steps):
+    cfg, sim, o = make(scene)
+    moved = False
+    for s in range(steps):
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        so = o.last_stats
+        assert (st.n_div, st.n_dens, st.div_first_err, st.div_err, st.dens_err, st.dt) == (
+            so.n_div, so.n_dens, so.div_first_err, so.div_err, so.dens_err, so.dt), s
+        if s % 10 == 0:
+            same(sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), o.get(orc.F_RIGID_FORCE), "force on the body before rigid step %d" % s)
+        sim.rigid_step()
+        o.rigid_step()
+        a, b = sim.rigid_scalars(), o.rigid_scalars()
+        for k in ("centroid", "omega", "vel", "inertia_inv"):
+            same(np.float32(a[k]), np.float32(b[k]), "%s after step %d" % (k, s))
+        moved = moved or any(abs(v) > 1e-3 for v in a["omega"])
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "fluid positions")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "fluid velocities")
+    same(sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_POS), "rigid positions")
+    same(sim.download(nat.F_RIGID_VERT, nat.SPECIES_RIGID), o.get(orc.F_RIGID_VERT), "mesh vertices")
+    assert moved, "the body never picked up angular velocity: coupling not exercised"
+    sim.close(); o.close()
+
+
+def test_python_api_with_solid_block():
+    from cfd_taichi_amd import ParticleSystem, dfsph_solver, rigid_solver
+    cfg = scenes.get("dfsph_rigid_small")
+    ps = ParticleSystem(cfg)
+    solver = dfsph_solver(ps, cfg)
+    rs = rigid_solver(ps, cfg)
+    assert ps.exist_rigid[None] == 1 and ps.active_rigid[None] == 1 and ps.rigid_particles_num > 0
+    for _ in range(5):
+        solver.step()
+        if ps.active_rigid[None] == 1:          # main.py:169-171
+            rs.step()
+    assert ps.rigid_particles.pos.to_numpy().shape == (ps.rigid_particles_num, 3)
+    assert ps.update_mesh_vextics().shape == (8, 3)
+    assert ps.rigid_centriod[None].shape == (3,)
