@@ -104,7 +104,11 @@ def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group):
     """Single-GPU handle, or this rank's slab of the sharded simulation."""
     cfg = scenes.get(scene_name)
     if world == 1:
-        return nat.Simulation(nat.config_from_dict(cfg, device=local_rank)), None
+        rigid = None
+        if cfg.get("solid"):
+            from cfd_taichi_amd import mesh
+            rigid = mesh.rigid_from_config(cfg)
+        return nat.Simulation(nat.config_from_dict(cfg, device=local_rank), rigid=rigid), None
     from cfd_taichi_amd.slab import SlabSimulation, TorchComm
     slab = SlabSimulation.__new__(SlabSimulation)
     c = nat.config_from_dict(cfg, device=local_rank, slab_rank=rank, slab_count=world)
@@ -184,10 +188,14 @@ def main():
     sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group)
     n_total = sim.n_fluid
 
+    has_rigid = bool(cfg.get("solid")) and world == 1
+
     def run(nsteps, stats=None):
         if solver_kind == "dfsph":
             for _ in range(nsteps):
                 st = sim.step_dfsph(1)
+                if has_rigid:
+                    sim.rigid_step()          # main.py:169-171
                 if stats is not None:
                     stats.append((st.n_div, st.n_dens, st.n_div_evals))
         else:
@@ -261,7 +269,9 @@ def main():
                            "note": "sweeps are f32-VALU bound (IEEE sqrt + 4 IEEE divides per pair), not HBM bound: see DESIGN.md section 4"}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if has_rigid:
+        out["config"]["rigid_particles"] = sim.n_rigid
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid:
         out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind)
     sim.close()
     if dist is not None:
