@@ -20,7 +20,7 @@ F_NBR_COUNT = 14
 F_WALL_POS, F_WALL_VOL = 32, 33
 F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
 S_RIGID_CENTROID, S_RIGID_OMEGA, S_RIGID_VEL, S_RIGID_MASS, S_RIGID_INERTIA_INV = 10, 13, 16, 19, 20
-S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME = range(5)
+S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME, S_GRAPH_LAUNCHES = range(6)
 VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT}
 
 EXPORTS = [

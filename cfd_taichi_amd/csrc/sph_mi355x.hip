@@ -111,6 +111,11 @@ struct SphHandle {
     bool rs_run_once = false;
     int rs_cnt = 0;
 
+    // hipGraph replay of WCSPH step pairs (launch-bound at small N): one executable graph per buffer parity
+    hipGraphExec_t wcsph_graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool graphs_enabled = true;
+    long long graph_launches = 0;
+
     // profiling
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int kid; };
@@ -1384,6 +1389,7 @@ void sph_destroy(SphHandle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 8; ++k) if (h->wcsph_graph[k]) (void)hipGraphExecDestroy(h->wcsph_graph[k]);
     for (int k = 0; k < 2; ++k) {
         (void)hipFree(h->P[k]); (void)hipFree(h->V[k]); (void)hipFree(h->VA[k]); (void)hipFree(h->warm[k]); (void)hipFree(h->id[k]);
     }
@@ -1645,7 +1651,35 @@ int sph_step_wcsph(SphHandle *h, int nsteps)
     if (!h) return SPH_E_INVALID;
     if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "handle was created for dfsph");
     HIP_TRY(h, hipSetDevice(h->device));
-    for (int k = 0; k < nsteps; ++k) {
+    int k = 0;
+    // The WCSPH step is a fixed launch sequence with no host decision in it, so two steps (after which the ping-pong
+    // buffers are back in the same roles) are captured once into a hipGraph and replayed: at 30k particles the step is
+    // launch-bound and replay halves it.  Eager launches remain for odd remainders, profiling and slab handles.
+    if (h->graphs_enabled && !h->profiling && !h->slab && nsteps >= 2) {
+        while (nsteps - k >= 2) {
+            const int key = h->pcur | (h->vcur << 1) | (h->icur << 2);
+            if (!h->wcsph_graph[key]) {
+                hipGraph_t graph = nullptr;
+                const int sim_cnt = h->simulate_cnt;
+                if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { h->graphs_enabled = false; break; }
+                int rc = step_wcsph_once(h);
+                if (!rc) rc = step_wcsph_once(h);
+                hipError_t e = hipStreamEndCapture(h->stream, &graph);
+                h->simulate_cnt = sim_cnt;             // the capture launched nothing
+                if (rc || e != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); h->graphs_enabled = false; (void)hipGetLastError(); break; }
+                e = hipGraphInstantiate(&h->wcsph_graph[key], graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (e != hipSuccess) { h->wcsph_graph[key] = nullptr; h->graphs_enabled = false; (void)hipGetLastError(); break; }
+                if ((h->pcur | (h->vcur << 1) | (h->icur << 2)) != key) { h->graphs_enabled = false; break; }   // roles must return after 2 steps
+            }
+            HIP_TRY(h, hipGraphLaunch(h->wcsph_graph[key], h->stream));
+            h->graph_launches += 1;
+            h->simulate_cnt += 2;
+            h->nl_valid = false; h->density_valid = false;
+            k += 2;
+        }
+    }
+    for (; k < nsteps; ++k) {
         int rc = step_wcsph_once(h);
         if (rc) return rc;
     }
@@ -1680,6 +1714,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_SIMULATE_CNT: *out = (double)h->simulate_cnt; return SPH_OK;
     case SPH_S_PARTICLE_M: *out = (double)h->c.m; return SPH_OK;
     case SPH_S_SUPPORT_RADIUS: *out = (double)h->c.h; return SPH_OK;
+    case SPH_S_GRAPH_LAUNCHES: *out = (double)h->graph_launches; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {

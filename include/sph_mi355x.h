@@ -131,6 +131,7 @@ typedef struct SphRigid {
 #define SPH_S_PARTICLE_M 2     /* ps.particle_m */
 #define SPH_S_SUPPORT_RADIUS 3 /* ps.support_radius */
 #define SPH_S_PS_DELTA_TIME 4  /* ps.delta_time[None] */
+#define SPH_S_GRAPH_LAUNCHES 5 /* diagnostics: hipGraph replays issued by sph_step_wcsph (each replays two steps) */
 #define SPH_S_RIGID_CENTROID 10   /* +0,1,2: ps.rigid_centriod[None] */
 #define SPH_S_RIGID_OMEGA 13      /* +0,1,2: rigid_solver.omega[None] */
 #define SPH_S_RIGID_VEL 16        /* +0,1,2: rigid_particles.vel (uniform over the body) */
