@@ -1,0 +1,91 @@
+"""Headless runner: the reference's frame loop (main.py:95-206) without the GGUI window.
+
+    python -m cfd_taichi_amd.run --config config/dfsph_small.json [--solver dfsph] [--until 4.0 | --steps N] [--ply-dir output]
+
+Per frame: `iter_cnt` fluid steps, then `iter_cnt` rigid steps if a rigid body is active (main.py:165-171),
+t += iter_cnt * solver.delta_time[None] (:173); stops at t > 4.0 (:205) or after --steps frames.  With --ply-dir (or
+scene.is_output_ply) it writes ASCII PLY frames `output_%06d.ply` at scene.output_fps like main.py:189-195 (vertex
+xyz + the constant RGBA of ParticleSystem.py:152) and, when a rigid body exists, `obj_%06d.obj` of its mesh (:196-200)."""
+import argparse
+import importlib
+import os
+import time
+
+import numpy as np
+
+from . import ParticleSystem, rigid_solver, utils
+
+
+def write_ply_ascii(path, pos, rgba):
+    """ASCII PLY in the layout of ti.tools.PLYWriter.export_frame_ascii: float x y z red green blue alpha."""
+    n = len(pos)
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment created by cfd_taichi_amd\nelement vertex %d\n" % n)
+        for name in ("x", "y", "z", "red", "green", "blue", "alpha"):
+            f.write("property float %s\n" % name)
+        f.write("end_header\n")
+        np.savetxt(f, np.hstack([pos, rgba]), fmt="%.6f")
+
+
+def write_obj(path, vertices, faces):
+    with open(path, "w") as f:
+        for v in vertices:
+            f.write("v %.8f %.8f %.8f\n" % tuple(v))
+        for t in faces:
+            f.write("f %d %d %d\n" % tuple(int(k) + 1 for k in t))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--config", default="./default.json")          # main.py:14
+    ap.add_argument("--solver", default=None, help="override solver.name (wcsph | dfsph)")
+    ap.add_argument("--until", type=float, default=4.0, help="stop when simulated time exceeds this (main.py:205)")
+    ap.add_argument("--steps", type=int, default=0, help="stop after this many frames (0 = use --until)")
+    ap.add_argument("--ply-dir", default=None)
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    config = utils.read_config(args.config)
+    if args.solver:
+        config["solver"]["name"] = args.solver
+    scene_config, solver_config = config["scene"], config["solver"]
+    print("Simulation Start!")
+    start_time = time.time()
+    ps = ParticleSystem(config, device=args.device)
+    name = solver_config.get("name")
+    if name not in ("wcsph", "dfsph"):
+        raise SystemExit("solver '%s' is outside the MI355X hot path; pass --solver wcsph or --solver dfsph" % name)
+    module = importlib.import_module("cfd_taichi_amd." + name + "_solver")      # main.py:65-68
+    solver = getattr(module, name + "_solver")(ps, config)
+    rs = rigid_solver(ps, config) if config.get("solid", {}) else None           # :69-71
+    iter_cnt = solver_config.get("iter_cnt")
+    ply_dir = args.ply_dir or ("./output" if scene_config.get("is_output_ply", False) else None)
+    if ply_dir:
+        os.makedirs(ply_dir, exist_ok=True)
+    np_rgba = ps.rgba.to_numpy()
+    frame_time = 1.0 / scene_config.get("output_fps", 60)
+    frame_cnt, ply_cnt, t = 0, 0, 0.0
+    while True:
+        if frame_cnt > 100000:                                                   # :98
+            break
+        for _ in range(iter_cnt):
+            solver.step()
+        for _ in range(iter_cnt):
+            if rs and ps.active_rigid[None] == 1:
+                rs.step()
+        frame_cnt += 1
+        t += iter_cnt * solver.delta_time[None]
+        if ply_dir and (t / frame_time) > ply_cnt:                               # :189
+            write_ply_ascii(os.path.join(ply_dir, "output_%06d.ply" % ply_cnt), ps.fluid_particles.pos.to_numpy(), np_rgba)
+            if ps.exist_rigid[None] == 1:
+                write_obj(os.path.join(ply_dir, "obj_%06d.obj" % ply_cnt), ps.update_mesh_vextics(), ps.mesh_faces)
+            ply_cnt += 1
+        if (args.steps and frame_cnt >= args.steps) or t > args.until:           # :205
+            break
+    print("frames: %d, simulated time: %.6f s, PLY frames: %d" % (frame_cnt, t, ply_cnt))
+    print("Simulation time: {}".format(time.time() - start_time))               # :211
+    return frame_cnt, t, ply_cnt
+
+
+if __name__ == "__main__":
+    main()

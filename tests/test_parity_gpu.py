@@ -170,3 +170,18 @@ def test_neighbour_overflow_is_reported():
         sim.step_wcsph(1)
     assert e.value.code == nat.SPH_E_OVERFLOW
     sim.close()
+
+
+def test_headless_runner_writes_ply_and_obj(tmp_path):
+    import json
+    from cfd_taichi_amd import run
+    cfg = scenes.get("dfsph_rigid_small")
+    cfg["scene"]["output_fps"] = 500
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(cfg))
+    frames, t, plys = run.main(["--config", str(path), "--steps", "6", "--ply-dir", str(tmp_path / "out")])
+    assert frames == 6 and plys >= 2 and t > 0
+    head = (tmp_path / "out" / "output_000000.ply").read_text().splitlines()
+    assert head[0] == "ply" and head[3] == "element vertex 5759" and len(head) == 5759 + 12
+    obj = (tmp_path / "out" / "obj_000000.obj").read_text().splitlines()
+    assert sum(1 for l in obj if l.startswith("v ")) == 8 and sum(1 for l in obj if l.startswith("f ")) == 12
