@@ -185,3 +185,27 @@ def test_headless_runner_writes_ply_and_obj(tmp_path):
     assert head[0] == "ply" and head[3] == "element vertex 5759" and len(head) == 5759 + 12
     obj = (tmp_path / "out" / "obj_000000.obj").read_text().splitlines()
     assert sum(1 for l in obj if l.startswith("v ")) == 8 and sum(1 for l in obj if l.startswith("f ")) == 12
+
+
+@pytest.mark.parametrize("solver", ["wcsph", "dfsph"])
+def test_particles_outside_the_grid(solver):
+    """Escaped particles (the reference only prints an error, ParticleSystem.py:393-395): both sides keep them out of the
+    cell lists, still integrate them, and report how many there are."""
+    scene = "wcsph_tiny_wall" if solver == "wcsph" else "dfsph_tiny_wall"
+    sim, o = make(scene)
+    pos = o.get(orc.F_POS)
+    pos[0] = [-0.31, 0.2, 0.2]       # linear cell id < 0
+    pos[1] = [0.5, 7.5, 0.5]         # far above the grid: id >= C
+    pos[2] = [0.5, 0.5, -0.05]       # one negative component, id still valid (wraps into another cell): stays in the lists
+    pos[3] = [1.15, 0.5, 0.5]        # beyond box_max.x but inside the +1 cell margin
+    sim.upload(nat.F_POS, pos); o.set(orc.F_POS, pos)
+    for _ in range(5):
+        if solver == "wcsph":
+            sim.step_wcsph(1); o.step_wcsph(1)
+        else:
+            st = sim.step_dfsph(1); o.step_dfsph(1, 100)
+            assert st.lost == o.lost and st.lost >= 1
+        assert_same(sim.download(nat.F_POS), o.get(orc.F_POS), "pos")
+        assert_same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "vel")
+    assert_same(sim.download(nat.F_RHO), o.get(orc.F_RHO), "rho")
+    sim.close(); o.close()
