@@ -55,7 +55,21 @@ struct DevScalars {
     int pad[2];
     double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
     long long cnt;
+    // device-side control of the reference's host loops (correct_divergence_error dfsph_solver.py:393-416,
+    // correct_density_error :221-233) on a single GPU: kernels of an iteration that the loop would not have run exit at once
+    int div_active, div_it, div_evals, dens_active;
+    int dens_d7_active, dens_it, dens_cap, dens_capped;
+    float div_err, div_past, div_first, dens_avg;
 };
+
+enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3 };
+__device__ __forceinline__ bool gate_closed(const DevScalars *ds, int gate)
+{
+    if (gate == GATE_DIV) return ds->div_active == 0;
+    if (gate == GATE_DENS) return ds->dens_active == 0;
+    if (gate == GATE_DENS_D7) return ds->dens_d7_active == 0;
+    return false;
+}
 
 struct F3 {
     float x, y, z;

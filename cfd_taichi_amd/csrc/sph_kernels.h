@@ -283,14 +283,21 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     if (x < 0 || y < 0 || z < 0) continue;
                     int cid = x + y * c.sy + z * c.sz;
                     int a = cell_start[cid], b = cell_start[cid + 1];
-                    for (int j = a; j < b; ++j) {
-                        if (j == i) continue;                            // :461
-                        float4 pj = P[j];
-                        float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
-                        float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                        if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
-                        nl_push((uint32_t)j, gf, kf, fbase, c.kmax);
-                        if (RIGID) ++nq;
+                    // candidates four at a time: the loads are independent, only the accept/push order is sequential
+                    for (int j0 = a; j0 < b; j0 += 4) {
+                        float4 pc[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pc[u] = P[j0 + u < b ? j0 + u : a];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = j0 + u;
+                            if (j >= b || j == i) continue;                  // :461
+                            float ddx = pi.x - pc[u].x, ddy = pi.y - pc[u].y, ddz = pi.z - pc[u].z;
+                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                            if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
+                            nl_push((uint32_t)j, gf, kf, fbase, c.kmax);
+                            if (RIGID) ++nq;
+                        }
                     }
                     if (RIGID) {
                         // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
@@ -422,9 +429,13 @@ __device__ __forceinline__ void block_partial_max(int blk, float v, float *__res
 
 // final, fixed-order reduction of the block partials; one block.  The host forms
 // mean = cnt > 0 ? sum / cnt : default   (dfsph_solver.py:148-149, 278-279) after all-reducing (sum, cnt) when sharded.
+enum { FIN_PLAIN = 0, FIN_DIV_FIRST = 1, FIN_DIV_LOOP = 2, FIN_DENS = 3 };
+
 __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                          DevScalars *__restrict__ ds)
+                                                          DevScalars *__restrict__ ds, int mode)
 {
+    if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
+    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0) ds->dens_d7_active = 0; return; }
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
     double t = 0.0; long long n = 0;
@@ -435,7 +446,43 @@ __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restri
         if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { ds->sum = s_sum[0]; ds->cnt = s_cnt[0]; }
+    if (threadIdx.x != 0) return;
+    ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
+    if (mode == FIN_PLAIN) return;
+    // the reference's host logic, evaluated where the data is (same f64 compares as the Python host code)
+    if (mode == FIN_DIV_FIRST || mode == FIN_DIV_LOOP) {
+        const float err = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // dfsph_solver.py:278-279
+        int it = ds->div_it;
+        int active;
+        if (mode == FIN_DIV_FIRST) {                                     // :398-399
+            ds->div_first = err; ds->div_err = err; ds->div_evals = 1;
+            active = 1;
+        } else {                                                         // :406-414
+            const float past = ds->div_err;
+            ds->div_past = past; ds->div_err = err; ds->div_evals += 1;
+            if (fabs((double)err - (double)past) < 1e-5) active = 0;    // break before iter_cnt += 1
+            else { it += 1; active = 1; }
+        }
+        if (active) active = ((it < 1 || (double)err > 10.0) && it < 15) ? 1 : 0;   // :400
+        ds->div_it = it;
+        ds->div_active = active;
+    } else {
+        const float avg = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 1000.0f;  // :148-149
+        ds->dens_avg = avg;
+        ds->dens_d7_active = 1;                                          // iter_all_vel_adv of this iteration runs (:229)
+        const int it = ds->dens_it + 1;                                  // :231
+        ds->dens_it = it;
+        int active = (it < 2 || (double)avg - 1000.0 > 0.1 * 1000 * 0.01) ? 1 : 0;      // :225
+        if (active && it >= ds->dens_cap) { active = 0; ds->dens_capped = 1; }
+        ds->dens_active = active;
+    }
+}
+
+__global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
+{
+    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0;
+    ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
+    ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
 }
 
 // max |v*| over the block partials                              dfsph_solver.py:100-103
@@ -474,12 +521,12 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds)
 //   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, Vout = (vel, rho), rho[], alpha[]
 // ======================================================================================
 template <bool DFSPH, bool RIGID>
-__global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+__global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                     const float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     float *__restrict__ rho_out, float *__restrict__ aux_out,
-                                                    float4 *__restrict__ Pout, float4 *__restrict__ Vout, RigidView rv,
+                                                    float4 *__restrict__ Pout, float4 *Vout, RigidView rv,
                                                     const int *__restrict__ id, float *__restrict__ rho_orig)
 {
     SPH_SWEEP_PROLOGUE
@@ -628,8 +675,9 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
-                                                    const float4 *__restrict__ Vin, float4 *__restrict__ Vout, RigidView rv)
+                                                    const float4 *Vin, float4 *Vout, RigidView rv, int gate)
 {
+    if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     SPH_SWEEP_PROLOGUE
     const float dt = ds->dt;
     const float rho_i = rho[ii];
@@ -691,8 +739,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      const float *__restrict__ rho, const float *__restrict__ alpha,
                                                      const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
-                                                     RigidView rv, const int *__restrict__ ncount)
+                                                     RigidView rv, const int *__restrict__ ncount, int gate)
 {
+    if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
     const float4 vi = V[ii];
     float acc = 0.f;

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -114,6 +115,7 @@ struct SphHandle {
     // hipGraph replay of WCSPH step pairs (launch-bound at small N): one executable graph per buffer parity
     hipGraphExec_t wcsph_graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool graphs_enabled = true;
+    bool host_loops = false;        // SPH_HOST_LOOPS=1: run the DFSPH loops on the host even on a single GPU (A/B, debugging)
     long long graph_launches = 0;
 
     // profiling
@@ -1049,16 +1051,18 @@ int stage_density(SphHandle *h)
     const dim3 g = grid_for(c.n), b(kBlock);
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     if (dfsph) {
+        // DFSPH buffer roles for the whole step: P[pcur] = sorted positions (never written until the integrator),
+        // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
+        // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
         if (rigid_coupled(h))
             hipLaunchKernelGGL((k_density<true, true>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view(h),
+                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view(h),
                                h->id[h->icur], h->rho_orig);
         else
             hipLaunchKernelGGL((k_density<true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
+                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], RigidView(),
                                (const int *)nullptr, (float *)nullptr);
-        h->pcur ^= 1; h->vcur ^= 1;    // P = (pos, (warm_k/dt)/rho), V = (vel, rho)
     } else {
         ProfScope ps(h, K_W_DENSITY);
         hipLaunchKernelGGL((k_density<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
@@ -1068,7 +1072,7 @@ int stage_density(SphHandle *h)
     }
     HIP_TRY(h, hipGetLastError());
     if (h->slab) {   // ghosts need (k/rho, rho) resp. (rho, p/rho^2) from their owners
-        int rc = slab_exchange_field(h, 2, h->P[h->pcur], h->V[h->vcur], dfsph ? h->rho : nullptr);
+        int rc = slab_exchange_field(h, 2, dfsph ? h->P[1 - h->pcur] : h->P[h->pcur], h->V[h->vcur], dfsph ? h->rho : nullptr);
         if (rc) return rc;
     }
     h->density_valid = true;
@@ -1094,21 +1098,6 @@ int step_wcsph_once(SphHandle *h)
     return SPH_OK;
 }
 
-// (sum, count) of the block partials -> mean on the host, all-reduced over the slabs when sharded
-int reduce_mean(SphHandle *h, float dflt, float *mean)
-{
-    {
-        ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds);
-    }
-    int rc = read_scalars(h);
-    if (rc) return rc;
-    double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
-    if (h->slab && (rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
-    *mean = v[1] > 0.0 ? (float)(v[0] / v[1]) : dflt;       // dfsph_solver.py:148-149, 278-279
-    return SPH_OK;
-}
-
 // every slab must see a list overflow at the same point, or the others would wait in a collective forever
 int check_overflow_all(SphHandle *h)
 {
@@ -1122,89 +1111,88 @@ int check_overflow_all(SphHandle *h)
     return check_overflow(h);
 }
 
-// derivative_iter_all_rho (dfsph_solver.py:252-300): residual sweep + mean; returns the mean through *err
-int dfsph_div_residual(SphHandle *h, float *err)
+// ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
+void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+{
+    const Consts &c = h->c;
+    ProfScope ps(h, K_D_DIV_RESIDUAL);
+    if (rigid_coupled(h))
+        hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h),
+                           h->ncount, gate);
+    else
+        hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                           (const int *)nullptr, gate);
+}
+
+template <int MODE>
+void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate)
+{
+    const Consts &c = h->c;
+    ProfScope ps(h, kid);
+    if (rigid_coupled(h))
+        hipLaunchKernelGGL((k_correct<MODE, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view(h), gate);
+    else
+        hipLaunchKernelGGL((k_correct<MODE, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate);
+}
+
+void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
+{
+    const Consts &c = h->c;
+    ProfScope ps(h, K_D_DENS_RESIDUAL);
+    if (rigid_coupled(h))
+        hipLaunchKernelGGL((k_residual<true, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount,
+                           gate);
+    else
+        hipLaunchKernelGGL((k_residual<true, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                           (const int *)nullptr, gate);
+}
+
+void launch_finalize(SphHandle *h, int mode)
+{
+    ProfScope ps(h, K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode);
+}
+
+void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:212
+{
+    const Consts &c = h->c;
+    ProfScope ps(h, K_RIGID);
+    hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), dim3(kBlock), 0, h->stream, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->cell_start, h->rho,
+                       h->rho_adv, h->aux, h->ds, h->rforce, gate);
+}
+
+// host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
+int reduce_mean_host(SphHandle *h, float dflt, float *mean)
+{
+    launch_finalize(h, FIN_PLAIN);
+    int rc = read_scalars(h);
+    if (rc) return rc;
+    double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
+    if (h->slab && (rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
+    *mean = v[1] > 0.0 ? (float)(v[0] / v[1]) : dflt;       // dfsph_solver.py:148-149, 278-279
+    return SPH_OK;
+}
+
+// ext forces, v*, CFL dt                                    dfsph_solver.py:91-122
+int dfsph_ext_and_dt(SphHandle *h)
 {
     const Consts &c = h->c;
     hipStream_t s = h->stream;
-    {
-        ProfScope ps(h, K_D_DIV_RESIDUAL);
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl,
-                               h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount);
-        else
-            hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl,
-                               h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                               (const int *)nullptr);
-        h->pcur ^= 1;     // P.w = (drho*alpha/dt)/rho
-    }
+    const dim3 g = grid_for(c.n), b(kBlock);
     int rc;
-    if (h->slab && (rc = slab_exchange_field(h, 0, h->P[h->pcur], nullptr, nullptr))) return rc;
-    return reduce_mean(h, 0.0f, err);
-}
-
-int step_dfsph_once(SphHandle *h, SphStepStats *st)
-{
-    int rc;
-    hipStream_t s = h->stream;
-    const dim3 b(kBlock);
-    memset(st, 0, sizeof(*st));
-    h->simulate_cnt += 1;                                   // solver_base.py:137
-    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
-    if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
-    const Consts &c = h->c;                                 // c.n is final for this step now
-    const dim3 g = grid_for(c.n);
-    // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
-    {
-        ProfScope ps(h, K_D_WARM);                           // :396-397
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_correct<CORR_WARM, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                               (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], rigid_view(h));
-        else
-            hipLaunchKernelGGL((k_correct<CORR_WARM, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                               (const float *)nullptr, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], RigidView());
-        h->vcur ^= 1;
-    }
-    if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
-    float err = 0.f, past = 0.f;
-    if ((rc = dfsph_div_residual(h, &err))) return rc;      // :398
-    if ((rc = check_overflow_all(h))) return rc;            // first read-back of the step: list overflow?
-    st->max_nbrs = h->ds_host->max_nbrs;
-    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
-    st->lost = h->ds_host->lost;
-    st->n_div_evals = 1;
-    st->div_first_err = err;
-    int iter_cnt = 0;
-    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {    // :400
-        {
-            ProfScope ps(h, K_D_DIV_CORRECT);                // :402 + sum_up_stiff :404-405
-            if (rigid_coupled(h))
-                hipLaunchKernelGGL((k_correct<CORR_DIV, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                                   h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], rigid_view(h));
-            else
-                hipLaunchKernelGGL((k_correct<CORR_DIV, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
-                                   h->drho, h->warm[h->wcur], h->ds, h->V[h->vcur], h->V[1 - h->vcur], RigidView());
-            h->vcur ^= 1;
-        }
-        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
-        past = err;
-        if ((rc = dfsph_div_residual(h, &err))) return rc;             // :408
-        st->n_div_evals += 1;
-        if (std::fabs((double)err - (double)past) < 1e-5) break;       // :410-412
-        iter_cnt += 1;
-    }
-    st->n_div = iter_cnt;
-    st->div_err = err;
-    // ---- compute_all_ext_force + compute_all_vel_adv, :91-122 ----
     {
         ProfScope ps(h, K_D_EXT);
         if (rigid_coupled(h))
-            hipLaunchKernelGGL(k_dfsph_ext<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax,
-                               rigid_view(h));
+            hipLaunchKernelGGL(k_dfsph_ext<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, rigid_view(h));
         else
-            hipLaunchKernelGGL(k_dfsph_ext<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[h->vacur], h->pmax,
-                               RigidView());
-        if (h->rigid) {   // max_rigid_vel, dfsph_solver.py:104-110 (loops over the rigid particles whether or not the body is active)
+            hipLaunchKernelGGL(k_dfsph_ext<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, RigidView());
+        if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
             for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];
             const float vn = sqrtf((h->r_vel[0] * h->r_vel[0] + h->r_vel[1] * h->r_vel[1]) + h->r_vel[2] * h->r_vel[2]);
@@ -1216,7 +1204,7 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
         hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, h->nblocks, h->ds);
     }
     if (h->slab) {
-        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[h->vacur], nullptr))) return rc;
+        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
         if ((rc = read_scalars(h))) return rc;
         double v[1] = {(double)h->ds_host->vmax};
         if ((rc = h->comm.allreduce(h->comm.user, v, 1, 1))) return comm_fail(h, "allreduce", rc);
@@ -1227,67 +1215,140 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
         ProfScope ps(h, K_FINALIZE);
         hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds);   // :112-119
     }
-    // ---- correct_density_error, :221-233 ----
-    {
-        const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
-        double rho_avg = INFINITY;
-        int it = 0;
-        while (it < 2 || rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {       // :225
-            if (it >= cap) { st->capped = 1; break; }
-            {
-                ProfScope ps(h, K_D_DENS_RESIDUAL);          // compute_all_rho_adv :124-152
-                if (rigid_coupled(h))
-                    hipLaunchKernelGGL((k_residual<true, true>), g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
-                                       h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount);
-                else
-                    hipLaunchKernelGGL((k_residual<true, false>), g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->WP, h->nl, h->nlb, h->cnt,
-                                       h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                                       (const int *)nullptr);
-                h->pcur ^= 1;
-            }
-            if (h->slab && (rc = slab_exchange_field(h, 0, h->P[h->pcur], nullptr, nullptr))) return rc;
-            {
-                ProfScope ps(h, K_FINALIZE);
-                hipLaunchKernelGGL(k_finalize_mean, dim3(1), b, 0, s, h->psum, h->pcnt, h->nblocks, h->ds);
-            }
-            {
-                ProfScope ps(h, K_D_DENS_CORRECT);           // iter_all_vel_adv :178-191
-                if (rigid_coupled(h)) {
-                    hipLaunchKernelGGL((k_correct<CORR_DENS, true>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho,
-                                       h->aux, h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur], rigid_view(h));
-                    // rigid_particles[j].force += ret * particle_m   (dfsph_solver.py:212)
-                    hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->cell_start, h->rho,
-                                       h->rho_adv, h->aux, h->ds, h->rforce);
-                } else {
-                    hipLaunchKernelGGL((k_correct<CORR_DENS, false>), g, b, 0, s, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho,
-                                       h->aux, h->rho_adv, h->warm[h->wcur], h->ds, h->VA[h->vacur], h->VA[1 - h->vacur], RigidView());
-                }
-                h->vacur ^= 1;
-            }
-            if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->VA[h->vacur], nullptr))) return rc;
-            if ((rc = read_scalars(h))) return rc;
-            double sum = h->ds_host->sum, cnt = (double)h->ds_host->cnt;
-            if (h->slab) {
-                double v[2] = {sum, cnt};
-                if ((rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
-                sum = v[0]; cnt = v[1];
-            }
-            rho_avg = (double)(cnt > 0.0 ? (float)(sum / cnt) : 1000.0f);   // :148-149
-            it += 1;
-        }
-        st->n_dens = it;
-        st->dens_err = (float)(rho_avg - 1000.0);
-    }
-    {
-        ProfScope ps(h, K_D_INTEGRATE);                      // compute_all_position :235-250
-        hipLaunchKernelGGL(k_dfsph_integrate, g, b, 0, s, c, h->P[h->pcur], h->VA[h->vacur], h->ds, h->P[1 - h->pcur], h->V[1 - h->vcur]);
-        h->pcur ^= 1; h->vcur ^= 1;
-    }
+    return SPH_OK;
+}
+
+int dfsph_integrate(SphHandle *h)
+{
+    const Consts &c = h->c;
+    ProfScope ps(h, K_D_INTEGRATE);                          // compute_all_position :235-250
+    // new positions go to the scratch buffer (nobody reads it any more), new velocities in place
+    hipLaunchKernelGGL(k_dfsph_integrate, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->VA[0], h->ds, h->P[1 - h->pcur],
+                       h->V[h->vcur]);
+    h->pcur ^= 1;
     HIP_TRY(h, hipGetLastError());
-    st->dt = h->ds_host->dt;
     h->nl_valid = false;
     h->density_valid = false;
     return SPH_OK;
+}
+
+// One DFSPH step on a single GPU: the reference's two host loops run on the device (k_finalize_mean applies their
+// conditions; kernels of iterations that would not run exit at once), the host only reads the control block back
+// once per chunk of iterations.
+int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    hipStream_t s = h->stream;
+    const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
+    hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
+    // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
+    launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
+    launch_div_residual(h, GATE_NONE);                                               // :398
+    launch_finalize(h, FIN_DIV_FIRST);
+    bool first = true;
+    for (int done = 0; done < 15;) {
+        const int chunk = 5;
+        for (int k = 0; k < chunk && done < 15; ++k, ++done) {
+            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
+            launch_div_residual(h, GATE_DIV);                                                 // :408
+            launch_finalize(h, FIN_DIV_LOOP);
+        }
+        if ((rc = read_scalars(h))) return rc;
+        if (first) {
+            if ((rc = check_overflow_all(h))) return rc;     // first read-back of the step: list overflow?
+            first = false;
+        }
+        if (!h->ds_host->div_active) break;
+    }
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
+    st->n_div = h->ds_host->div_it;
+    st->n_div_evals = h->ds_host->div_evals;
+    st->div_first_err = h->ds_host->div_first;
+    st->div_err = h->ds_host->div_err;
+    if ((rc = dfsph_ext_and_dt(h))) return rc;
+    // ---- correct_density_error, :221-233 ----
+    for (int chunk = 2;; chunk = chunk < 8 ? chunk * 2 : 8) {
+        for (int k = 0; k < chunk; ++k) {
+            launch_dens_residual(h, GATE_DENS);                                      // :227
+            launch_finalize(h, FIN_DENS);
+            launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
+            if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
+        }
+        if ((rc = read_scalars(h))) return rc;
+        if (!h->ds_host->dens_active) break;
+    }
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->dens_err = (float)((double)h->ds_host->dens_avg - 1000.0);
+    st->dt = h->ds_host->dt;
+    return dfsph_integrate(h);
+}
+
+// The same step with the loops on the host (sharded runs: every residual needs an all-reduce and every sweep a ghost refresh)
+int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
+    if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
+    float err = 0.f, past = 0.f;
+    auto residual = [&](float *out) -> int {
+        launch_div_residual(h, GATE_NONE);
+        int r;
+        if (h->slab && (r = slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr))) return r;
+        return reduce_mean_host(h, 0.0f, out);
+    };
+    if ((rc = residual(&err))) return rc;                                            // :398
+    if ((rc = check_overflow_all(h))) return rc;
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
+    st->n_div_evals = 1;
+    st->div_first_err = err;
+    int iter_cnt = 0;
+    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {                  // :400
+        launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
+        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
+        past = err;
+        if ((rc = residual(&err))) return rc;                                        // :408
+        st->n_div_evals += 1;
+        if (std::fabs((double)err - (double)past) < 1e-5) break;                     // :410-412
+        iter_cnt += 1;
+    }
+    st->n_div = iter_cnt;
+    st->div_err = err;
+    if ((rc = dfsph_ext_and_dt(h))) return rc;
+    const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
+    double rho_avg = INFINITY;
+    int it = 0;
+    while (it < 2 || rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {                         // :225
+        if (it >= cap) { st->capped = 1; break; }
+        launch_dens_residual(h, GATE_NONE);
+        if (h->slab && (rc = slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr))) return rc;
+        float avg;
+        if ((rc = reduce_mean_host(h, 1000.0f, &avg))) return rc;
+        launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_NONE);
+        if (rigid_coupled(h)) launch_rigid_force(h, GATE_NONE);
+        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
+        rho_avg = (double)avg;
+        it += 1;
+    }
+    st->n_dens = it;
+    st->dens_err = (float)(rho_avg - 1000.0);
+    if ((rc = read_scalars(h))) return rc;
+    st->dt = h->ds_host->dt;
+    return dfsph_integrate(h);
+}
+
+int step_dfsph_once(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    memset(st, 0, sizeof(*st));
+    h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
+    if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
+    return (h->slab || h->host_loops) ? step_dfsph_host_loops(h, st) : step_dfsph_device_loops(h, st);
 }
 
 int field_floats(SphHandle *h, int species, int field, size_t *count, bool *vec)
@@ -1337,6 +1398,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     SphHandle *h = new SphHandle();
     h->cfg = *cfg;
     h->device = cfg->device;
+    { const char *e = getenv("SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
     int rc = SPH_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }
@@ -1491,7 +1553,7 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break;
         case SPH_F_VEL_ADV:
             if (!dfsph) return fail(h, SPH_E_STATE, "vel_adv is a dfsph field");
-            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[h->vacur], id, h->staging); break;
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break;
         case SPH_F_RHO: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->rho, id, h->staging); break;
         case SPH_F_PRESSURE:
             if (dfsph) return fail(h, SPH_E_STATE, "pressure is a wcsph field");
@@ -1592,7 +1654,7 @@ int sph_download_local(SphHandle *h, int field, float *host, size_t n_floats)
     switch (field) {
     case SPH_F_POS: vec = h->P[h->pcur]; break;
     case SPH_F_VEL: vec = h->V[h->vcur]; break;
-    case SPH_F_VEL_ADV: if (dfsph) vec = h->VA[h->vacur]; break;
+    case SPH_F_VEL_ADV: if (dfsph) vec = h->VA[0]; break;
     case SPH_F_ACC: if (!dfsph) vec = h->VA[0]; break;
     case SPH_F_RHO: sca = h->rho; break;
     case SPH_F_PRESSURE: if (!dfsph) sca = h->aux; break;

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(kBlock) void k_rigid_force(Consts c, int nr, const 
                                                         const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                         const float *__restrict__ rho, const float *__restrict__ rho_adv,
                                                         const float *__restrict__ alpha, const DevScalars *__restrict__ ds,
-                                                        float *__restrict__ force)
+                                                        float *__restrict__ force, int gate)
 {
+    if (gate_closed(ds, gate)) return;
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= nr) return;
     const float4 pr = RP[r];
