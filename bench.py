@@ -266,7 +266,7 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom) if world == 1 and scene_name == "dfsph_1m" else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
-                           "note": "sweeps are f32-VALU bound (IEEE sqrt + 4 IEEE divides per pair), not HBM bound: see DESIGN.md section 4"}
+                           "note": "gather sweep, not HBM-streaming bound: ~36 L1 line accesses per wave-gather and ~52 f32 VALU instr per pair share the time (PMC, DESIGN.md section 6c)"}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     if has_rigid:

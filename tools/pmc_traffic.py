@@ -23,13 +23,21 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name.split("(")[0]
 
 
-KERNEL_TO_PROFILE_NAME = {
-    "k_residual<false>": "dfsph_div_residual", "k_residual<true>": "dfsph_dens_residual",
-    "k_correct<0>": "dfsph_warm_start", "k_correct<1>": "dfsph_div_correct", "k_correct<2>": "dfsph_dens_correct",
-    "k_density<true>": "dfsph_density_alpha", "k_density<false>": "wcsph_density", "k_wcsph_force": "wcsph_force",
+KERNEL_TO_PROFILE_NAME = {     # first template argument decides the bench.py name; the RIGID flag does not
+    "k_residual<false": "dfsph_div_residual", "k_residual<true": "dfsph_dens_residual",
+    "k_correct<0": "dfsph_warm_start", "k_correct<1": "dfsph_div_correct", "k_correct<2": "dfsph_dens_correct",
+    "k_density<true": "dfsph_density_alpha", "k_density<false": "wcsph_density", "k_wcsph_force": "wcsph_force",
     "k_dfsph_ext": "dfsph_ext_force", "k_dfsph_integrate": "dfsph_integrate", "k_build_nl": "build_nl",
     "k_hash_count": "hash_count", "k_order_gather": "order_gather", "k_scatter": "scatter",
 }
+
+
+def profile_name(k):
+    head = k.split(",")[0].rstrip(">")
+    for key, name in KERNEL_TO_PROFILE_NAME.items():
+        if head == key or head.split("<")[0] == key:
+            return name
+    return k
 
 
 def collect(directory, counter):
@@ -62,7 +70,7 @@ def main():
             continue
         fr = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [])), 1) * 1024
         wr = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1) * 1024
-        kernels[KERNEL_TO_PROFILE_NAME.get(k, k)] = {
+        kernels[profile_name(k)] = {
             "kernel": k, "launches_sampled": len(fetch.get(k, [])),
             "fetch_bytes_raw_per_launch": fr, "write_bytes_per_launch": wr,
             "hbm_bytes_per_launch": fr * fetch_factor + wr,
