@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", default=None, help="scene name from cfd_taichi_amd.scenes (default dfsph_1m)")
     ap.add_argument("--profile-steps", type=int, default=1, help="0 = skip the HIP-event profiled replay (roofline leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
+                    help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
     return ap.parse_args()
 
 
@@ -100,7 +102,7 @@ def load_traffic(kernel):
         return None
 
 
-def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group):
+def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0):
     """Single-GPU handle, or this rank's slab of the sharded simulation."""
     cfg = scenes.get(scene_name)
     if world == 1:
@@ -111,7 +113,7 @@ def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group):
         return nat.Simulation(nat.config_from_dict(cfg, device=local_rank), rigid=rigid), None
     from cfd_taichi_amd.slab import SlabSimulation, TorchComm
     slab = SlabSimulation.__new__(SlabSimulation)
-    c = nat.config_from_dict(cfg, device=local_rank, slab_rank=rank, slab_count=world)
+    c = nat.config_from_dict(cfg, device=local_rank, slab_rank=rank, slab_count=world, slab_rebalance_every=rebalance)
     slab.rank, slab.world = rank, world
     slab.solver = cfg["solver"]["name"]
     slab.sim = nat.Simulation(c)
@@ -185,7 +187,7 @@ def main():
     scene_name = args.workload or ("dfsph_1m" if world == 1 else "dfsph_10m")
     cfg = scenes.get(scene_name)
     solver_kind = cfg["solver"]["name"]
-    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group)
+    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance)
     n_total = sim.n_fluid
 
     has_rigid = bool(cfg.get("solid")) and world == 1
@@ -231,7 +233,7 @@ def main():
         "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
                    "grid": list(sim.grid),
-                   "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s" % (world, transport)},
+                   "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s, cuts re-balanced every %d steps" % (world, transport, args.rebalance)},
     }
     if slab_info is not None:
         out["config"]["rank0_slab"] = slab_info
@@ -247,7 +249,7 @@ def main():
     # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
     if args.profile_steps > 0:
         sim.close()
-        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group)
+        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance)
         sim.profile_enable(True)
         nprof = args.warmup + args.steps
         run(nprof)

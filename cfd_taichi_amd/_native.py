@@ -28,7 +28,7 @@ EXPORTS = [
     "sph_step_wcsph", "sph_step_dfsph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math",
-    "sph_set_comm", "sph_plan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
+    "sph_set_comm", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
 
@@ -52,7 +52,8 @@ class SphConfig(ctypes.Structure):
         ("slab_rank", ctypes.c_int32),
         ("slab_count", ctypes.c_int32),
         ("slab_capacity", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 6),
+        ("slab_rebalance_every", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 5),
     ]
 
 
@@ -171,6 +172,7 @@ def load(build_if_missing=True):
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_download_local.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.sph_download_ids.argtypes = [vp, vp, ctypes.c_size_t]
     _lib = lib
@@ -184,7 +186,7 @@ class SphError(RuntimeError):
 
 
 def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0,
-                     slab_rank=0, slab_count=0, slab_capacity=0):
+                     slab_rank=0, slab_count=0, slab_capacity=0, slab_rebalance_every=0):
     """Flatten a reference-style config dict (config/*.json schema) into SphConfig."""
     scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
     name = solver_name or sol["name"]
@@ -206,6 +208,7 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.max_wall_neighbors = int(max_wall_neighbors)
     c.max_density_iters = int(max_density_iters)
     c.slab_rank, c.slab_count, c.slab_capacity = int(slab_rank), int(slab_count), int(slab_capacity)
+    c.slab_rebalance_every = int(slab_rebalance_every)
     return c
 
 
@@ -220,6 +223,19 @@ def plan_slabs(cfg, slab_count):
     if rc != SPH_OK:
         raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
     return list(cuts), list(counts)
+
+
+def replan_slabs(column_histogram, old_cuts):
+    """Host-only: the re-balancing rule of a slab run (new cuts from a per-column particle histogram)."""
+    lib = load()
+    gx, nslab = len(column_histogram), len(old_cuts) - 1
+    hist = (ctypes.c_int64 * gx)(*[int(v) for v in column_histogram])
+    old = (ctypes.c_int32 * (nslab + 1))(*[int(v) for v in old_cuts])
+    new = (ctypes.c_int32 * (nslab + 1))()
+    rc = lib.sph_replan_slabs(hist, gx, nslab, old, new)
+    if rc != SPH_OK:
+        raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
+    return list(new)
 
 
 class Simulation:
@@ -328,9 +344,10 @@ class Simulation:
         self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
 
     def slab_info(self):
-        out = (ctypes.c_int32 * 5)()
+        out = (ctypes.c_int32 * 8)()
         self._check(self._lib.sph_slab_info(self._h, out))
-        return {"owned": out[0], "ghosts": out[1], "x_lo": out[2], "x_hi": out[3], "capacity": out[4]}
+        return {"owned": out[0], "ghosts": out[1], "x_lo": out[2], "x_hi": out[3], "capacity": out[4], "recuts": out[5],
+                "rebalance_every": out[6]}
 
     def download_local(self, field):
         """(ids, values) of every resident particle in device order; ids < 0 are ghosts (~id)."""

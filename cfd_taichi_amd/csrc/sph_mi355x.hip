@@ -88,6 +88,9 @@ struct SphHandle {
     int *edge_off[4] = {nullptr, nullptr, nullptr, nullptr};    // 0 ghost-left, 1 send-left, 2 send-right, 3 ghost-right
     int *edge_list[4] = {nullptr, nullptr, nullptr, nullptr};
     int edge_count[4] = {0, 0, 0, 0};
+    std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
+    int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
+    int *col_hist = nullptr, *col_hist_host = nullptr;
     int *counters = nullptr, *counters_host = nullptr;
     std::vector<int> init_ids;    // original ids of the particles this handle owns at t = 0
 
@@ -176,7 +179,7 @@ void drain_profile(SphHandle *h)
     h->ev_pending.clear();
 }
 
-inline dim3 grid_for(int n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+inline dim3 grid_for(int n) { return dim3((unsigned)std::max(1, (n + kBlock - 1) / kBlock)); }   // an empty slab still launches one (idle) block
 
 // ---------------------------------------------------------------------------------------------
 // host-side scene construction (one-time; mirrors ParticleSystem.__init__)
@@ -199,6 +202,39 @@ inline float host_cubic_w(float r, float h, float kw)
     return ret;
 }
 
+// cut[k] = first column x with (particles in columns < x) >= k N / nslab
+void cuts_from_histogram(const std::vector<long long> &hist, long long N, int gx, int nslab, std::vector<int> &cut)
+{
+    cut.assign((size_t)nslab + 1, 0);
+    cut[nslab] = gx;
+    long long pre = 0;      // particles with column < x
+    int k = 1;
+    for (int x = 0; x < gx && k < nslab; ++x) {
+        while (k < nslab && pre >= (long long)k * N / nslab) { cut[k] = x; ++k; }
+        pre += hist[x];
+    }
+    for (; k < nslab; ++k) cut[k] = gx;
+}
+
+// Re-balancing ("re-chosen every M steps because a dam break migrates mass along x"):
+// new equal-count cuts from the current global column histogram, clamped so that (a) every slab keeps >= 2
+// columns and (b) a particle's new owner is its current rank or a direct neighbour -- the migration step only
+// talks to the left and right neighbour.  A particle resident on rank r sits in columns
+// [old[r] - 1, old[r+1]] (it may have crossed one column since the last exchange), hence
+// old[k-1] + 1 <= new[k] <= old[k+1] - 1.
+void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, const std::vector<int> &old_cut, std::vector<int> &cut)
+{
+    long long N = 0;
+    for (long long v : hist) N += v;
+    cuts_from_histogram(hist, N, gx, nslab, cut);
+    cut[0] = 0; cut[nslab] = gx;
+    for (int k = 1; k < nslab; ++k) {
+        int lo = std::max(old_cut[k - 1] + 1, cut[k - 1] + 2);
+        int hi = std::min(old_cut[k + 1] - 1, gx - 2 * (nslab - k));
+        cut[k] = std::min(std::max(cut[k], lo), hi);
+    }
+}
+
 // Equal-count cuts along the cell x index, computed identically on every rank from the full lattice:
 // slab k owns cell columns [cut[k], cut[k+1]).
 bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, int nslab, std::vector<int> &col, std::vector<int> &cut,
@@ -212,22 +248,15 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
         col[i] = cx;
         hist[cx]++;
     }
-    cut.assign((size_t)nslab + 1, 0);
-    cut[nslab] = gx;
-    long long pre = 0;      // particles with column < x
-    int k = 1;
-    for (int x = 0; x < gx && k < nslab; ++x) {
-        while (k < nslab && pre >= (long long)k * N / nslab) { cut[k] = x; ++k; }
-        pre += hist[x];
+    if (gx < 2 * nslab) {
+        char buf[160];
+        snprintf(buf, sizeof(buf), "%d slabs need at least %d cell columns along x, the grid has %d: too many slabs for this scene", nslab, 2 * nslab, gx);
+        why = buf;
+        return false;
     }
-    for (; k < nslab; ++k) cut[k] = gx;
-    for (int q = 1; q <= nslab; ++q)
-        if (cut[q] < cut[q - 1] + 2) {
-            char buf[160];
-            snprintf(buf, sizeof(buf), "slab %d would be narrower than 2 cell columns: too many slabs for this scene", q - 1);
-            why = buf;
-            return false;
-        }
+    cuts_from_histogram(hist, N, gx, nslab, cut);
+    for (int k = 1; k < nslab; ++k)     // every slab at least 2 columns wide (edge column + one more), even where the fluid is narrow
+        cut[k] = std::min(std::max(cut[k], cut[k - 1] + 2), gx - 2 * (nslab - k));
     return true;
 }
 
@@ -336,6 +365,8 @@ int build_scene(SphHandle *h, HostScene &sc)
         std::vector<int> col, cut;
         std::string why;
         if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why)) return fail(h, SPH_E_INVALID, "%s", why.c_str());
+        h->cuts = cut;
+        h->rebalance_every = cf.slab_rebalance_every > 0 ? cf.slab_rebalance_every : 0;
         h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
         h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
         std::vector<float> own_pos; std::vector<int> own_id;
@@ -497,6 +528,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         }
         if ((rc = dalloc(h, &h->counters, 4))) return rc;
         HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * 4, hipHostMallocDefault));
+        if ((rc = dalloc(h, &h->col_hist, (size_t)c.gx))) return rc;
+        HIP_TRY(h, hipHostMalloc((void **)&h->col_hist_host, sizeof(int) * (size_t)c.gx, hipHostMallocDefault));
     }
     if ((rc = dalloc(h, &h->ds, 1))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
@@ -560,6 +593,38 @@ int read_counters(SphHandle *h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SPH_OK;
+}
+
+// Every `slab_rebalance_every` steps: global per-column particle histogram (one all-reduce of gx counts), new
+// equal-count cuts on every rank alike.  Only the cuts change here; the migration that follows moves the
+// particles of the shifted columns to the neighbour that now owns them.  Results do not depend on the cuts
+// (every sum runs in (cell, id) order), so re-balancing is invisible in the output.
+int slab_rebalance(SphHandle *h)
+{
+    if (!h->comm_set) return fail(h, SPH_E_STATE, "slab handle needs sph_set_comm before stepping");
+    Consts &c = h->c;
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemsetAsync(h->col_hist, 0, sizeof(int) * (size_t)c.gx, s));
+    {
+        ProfScope ps(h, K_SLAB);
+        hipLaunchKernelGGL(k_column_histogram, grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->id[h->icur], h->col_hist);
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->col_hist_host, h->col_hist, sizeof(int) * (size_t)c.gx, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<double> v((size_t)c.gx);
+    for (int x = 0; x < c.gx; ++x) v[x] = (double)h->col_hist_host[x];
+    int rc = h->comm.allreduce(h->comm.user, v.data(), c.gx, 0);
+    if (rc) return comm_fail(h, "allreduce", rc);
+    std::vector<long long> hist((size_t)c.gx);
+    for (int x = 0; x < c.gx; ++x) hist[x] = (long long)v[x];
+    std::vector<int> cut;
+    replan_slab_cuts(hist, c.gx, h->nslab, h->cuts, cut);
+    if (cut != h->cuts) {
+        h->cuts = cut;
+        h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
+        ++h->n_recuts;
+    }
     return SPH_OK;
 }
 
@@ -966,7 +1031,13 @@ int rigid_step(SphHandle *h)
 int stage_sort_and_lists(SphHandle *h)
 {
     int rc;
-    if (h->slab && (rc = slab_exchange_particles(h))) return rc;
+    if (h->slab) {
+        if (h->rebalance_every > 0 && ++h->steps_since_rebalance >= h->rebalance_every) {
+            h->steps_since_rebalance = 0;
+            if ((rc = slab_rebalance(h))) return rc;
+        }
+        if ((rc = slab_exchange_particles(h))) return rc;
+    }
     Consts &c = h->c;
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
@@ -1468,6 +1539,7 @@ void sph_destroy(SphHandle *h)
     for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
     if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1602,6 +1674,20 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts)
     return SPH_OK;
 }
 
+int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts)
+{
+    if (!column_histogram || !old_cuts || !new_cuts || grid_x < 2 || slab_count < 1 || grid_x < 2 * slab_count)
+        return fail(nullptr, SPH_E_INVALID, "bad argument");
+    for (int k = 0; k < slab_count; ++k)
+        if (old_cuts[k + 1] < old_cuts[k] + 2 || old_cuts[0] != 0 || old_cuts[slab_count] != grid_x)
+            return fail(nullptr, SPH_E_INVALID, "old cuts must start at 0, end at grid_x and leave every slab >= 2 columns");
+    std::vector<long long> hist(column_histogram, column_histogram + grid_x);
+    std::vector<int> oldc(old_cuts, old_cuts + slab_count + 1), cut;
+    replan_slab_cuts(hist, grid_x, slab_count, oldc, cut);
+    for (int k = 0; k <= slab_count; ++k) new_cuts[k] = cut[k];
+    return SPH_OK;
+}
+
 int sph_set_comm(SphHandle *h, const SphComm *comm)
 {
     if (!h || !comm) return SPH_E_INVALID;
@@ -1631,6 +1717,7 @@ int sph_slab_info(SphHandle *h, int32_t *out)
     if (!h || !out) return SPH_E_INVALID;
     out[0] = h->n_owned; out[1] = h->slab ? h->c.n - h->n_owned : 0;
     out[2] = h->geom.x_lo; out[3] = h->slab ? h->geom.x_hi : h->c.gx; out[4] = h->ncap;
+    out[5] = h->n_recuts; out[6] = h->rebalance_every; out[7] = 0;
     return SPH_OK;
 }
 

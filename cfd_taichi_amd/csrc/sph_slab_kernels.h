@@ -22,6 +22,31 @@ __device__ __forceinline__ void write_record(float4 *__restrict__ buf, int slot,
     buf[2 * (size_t)slot + 1] = make_float4(v.y, v.z, warm, __int_as_float(id));
 }
 
+// Re-balancing: owned particles per cell column.  Sorted order makes a block's particles share a few columns, so
+// the block counts in LDS first and flushes only the touched columns.
+__global__ __launch_bounds__(kBlock) void k_column_histogram(Consts c, const float4 *__restrict__ P, const int *__restrict__ id,
+                                                              int *__restrict__ hist)
+{
+    constexpr int kLocal = 2048;
+    __shared__ int local[kLocal];
+    const bool use_lds = c.gx <= kLocal;
+    if (use_lds) {
+        for (int x = threadIdx.x; x < c.gx; x += kBlock) local[x] = 0;
+        __syncthreads();
+    }
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s < c.n && id[s] >= 0) {
+        int cx = (int)floorf(P[s].x / c.h);
+        cx = cx < 0 ? 0 : (cx >= c.gx ? c.gx - 1 : cx);
+        atomicAdd(use_lds ? &local[cx] : &hist[cx], 1);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int x = threadIdx.x; x < c.gx; x += kBlock)
+            if (local[x]) atomicAdd(&hist[x], local[x]);
+    }
+}
+
 // (1) previous ghosts die; owned particles that left the slab are packed for the neighbour and die here.
 __global__ __launch_bounds__(kBlock) void k_classify_migrate(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                              const float *__restrict__ warm, const int *__restrict__ id,

@@ -31,6 +31,9 @@ SCENES = {
     # reference config/dfsph_config_backup.json geometry (N = 5879)
     "dfsph_small": lambda: _scene("dfsph", 1e-3, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
     "wcsph_small": lambda: _scene("wcsph", 2.5e-4, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    # a low, long box with the column in one corner: the mass runs along x within a few hundred steps (slab re-balancing)
+    "dfsph_dam_x": lambda: _scene("dfsph", 1e-3, [2.0, 1.0, 0.6], [0.5, 0.6, 0.4], start_pos=(0.05, 0.05, 0.1)),
+    "wcsph_dam_x": lambda: _scene("wcsph", 2.5e-4, [2.0, 1.0, 0.6], [0.5, 0.6, 0.4], start_pos=(0.05, 0.05, 0.1)),
     # a tiny column resting on the floor next to a wall: exercises wall neighbours from step 1
     "wcsph_tiny_wall": lambda: _scene("wcsph", 2.5e-4, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
     "dfsph_tiny_wall": lambda: _scene("dfsph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),

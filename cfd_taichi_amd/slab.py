@@ -86,7 +86,7 @@ class TorchComm:
 
     def allreduce(self, values, op):
         torch, dist = self.torch, self.dist
-        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        t = torch.tensor(values, dtype=torch.float64).to(self.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX, group=self.group)
         return t.cpu().tolist()
 
@@ -124,10 +124,11 @@ class TorchComm:
 class SlabSimulation:
     """One rank's share of a sharded simulation: a slab handle plus its transport."""
 
-    def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, **native_opts):
+    def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, rebalance_every=0,
+                 **native_opts):
         self.rank, self.world = rank, world
         cfg = nat.config_from_dict(config, solver_name=solver_name, device=device, slab_rank=rank, slab_count=world,
-                                   slab_capacity=slab_capacity, **native_opts)
+                                   slab_capacity=slab_capacity, slab_rebalance_every=rebalance_every, **native_opts)
         self.solver = "wcsph" if cfg.solver == nat.SOLVER_WCSPH else "dfsph"
         self.sim = nat.Simulation(cfg)
         self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes)

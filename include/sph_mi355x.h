@@ -56,7 +56,8 @@ typedef struct SphConfig {
     int32_t slab_rank;          /* multi-GPU x-slab rank, 0 for single GPU */
     int32_t slab_count;         /* number of slabs (world size), 0 or 1 for single GPU */
     int32_t slab_capacity;      /* particles (owned + ghosts) a slab handle can hold; 0 = default (1.75 N / slab_count + 256k) */
-    int32_t reserved[6];
+    int32_t slab_rebalance_every; /* re-cut the slabs from the current particle distribution every M steps; 0 = static cuts */
+    int32_t reserved[5];
 } SphConfig;
 
 typedef struct SphSizes {
@@ -210,8 +211,12 @@ int sph_set_comm(SphHandle *h, const SphComm *comm);
 /* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the equal-count slabs of the
  * scene's initial lattice, counts[k] = particles slab k owns at t = 0 */
 int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);
-/* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity */
-int sph_slab_info(SphHandle *h, int32_t *out5);
+/* host-only: the re-balancing rule.  new_cuts = equal-count cuts of `column_histogram` (grid_x counts), clamped so that every slab
+ * keeps >= 2 columns and old_cuts[k-1] < new_cuts[k] < old_cuts[k+1] (a particle's new owner is its rank or a direct neighbour) */
+int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts);
+/* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity,
+ * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = 0 */
+int sph_slab_info(SphHandle *h, int32_t *out8);
 /* local (device-order) access for slab handles: all resident particles, owned and ghost; ids < 0 mark ghosts (~id) */
 int sph_download_local(SphHandle *h, int field, float *host, size_t n_floats);
 int sph_download_ids(SphHandle *h, int32_t *host, size_t n);

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--scene", required=True)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--rebalance", type=int, default=0)
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import torch
@@ -34,14 +35,17 @@ def main():
     from cfd_taichi_amd import scenes
     from cfd_taichi_amd.slab import SlabSimulation
     cfg = scenes.get(args.scene)
-    sim = SlabSimulation(cfg, rank, world, device=device)
+    sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance)
     dfsph = sim.solver == "dfsph"
     stats = []
+    owned_max = 0
     for _ in range(args.steps):
         st = sim.step(1)
+        owned_max = max(owned_max, sim.sim.slab_info()["owned"])
         if dfsph:
             stats.append([st.n_div, st.n_dens, st.n_div_evals, float(st.div_first_err), float(st.div_err), float(st.dens_err), float(st.dt)])
     info = sim.sim.slab_info()
+    info["owned_max"] = owned_max
     infos = [None] * world if rank == 0 else None
     dist.gather_object(info, infos, dst=0)
     pos = sim.gather(nat.F_POS)

@@ -80,4 +80,39 @@ def test_slab_planner_partitions_the_lattice():
         assert sum(counts) == 1000000
         assert max(counts) <= 1.25 * 1000000 / world      # cell-column granularity: 10k particles per column
     with pytest.raises(nat.SphError):
-        nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_small")), 8)    # 14 columns of fluid cannot feed 8 slabs
+        nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_small")), 9)    # 16 cell columns cannot hold 9 slabs of >= 2 columns
+    cuts, counts = nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_dam_x")), 3)   # fluid narrower than 3 equal-count slabs: widths clamp
+    assert cuts == [0, 3, 5, 21] and sum(counts) == 960 and min(counts) > 0
+
+
+def test_replan_rule_properties():
+    """sph_replan_slabs (host-only): equal-count cuts of a column histogram, never narrower than 2 columns, and every cut
+    stays strictly between its old neighbours so that migration only ever talks to the adjacent slab."""
+    rng = np.random.default_rng(5)
+    gx = 41
+    for nslab in (2, 3, 4, 8):
+        old = [round(k * gx / nslab) for k in range(nslab + 1)]
+        for trial in range(50):
+            hist = np.zeros(gx, dtype=np.int64)
+            lo = int(rng.integers(0, gx - 4))
+            hi = int(rng.integers(lo + 3, gx))
+            hist[lo:hi] = rng.integers(1, 2000, hi - lo)
+            new = nat.replan_slabs(hist, old)
+            assert new[0] == 0 and new[-1] == gx
+            for k in range(nslab):
+                assert new[k + 1] >= new[k] + 2
+            for k in range(1, nslab):
+                assert old[k - 1] < new[k] < old[k + 1]
+            old = new
+    # a fixed distribution is reached after a few re-plans and then stays put (idempotence)
+    hist = np.zeros(gx, dtype=np.int64)
+    hist[20:36] = 1000
+    cuts = [0, 2, 4, 6, gx]
+    for _ in range(40):
+        cuts = nat.replan_slabs(hist, cuts)
+    assert cuts == nat.replan_slabs(hist, cuts)
+    pre = np.concatenate([[0], np.cumsum(hist)])
+    counts = [int(pre[cuts[k + 1]] - pre[cuts[k]]) for k in range(4)]
+    assert counts == [4000, 4000, 4000, 4000], (cuts, counts)
+    with pytest.raises(nat.SphError):
+        nat.replan_slabs(hist, [0, 1, gx])

@@ -19,11 +19,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_slabs(tmp_path, scene, world, steps):
-    out = tmp_path / ("slab_%s_%d.json" % (scene, world))
+def run_slabs(tmp_path, scene, world, steps, rebalance=0):
+    out = tmp_path / ("slab_%s_%d_%d.json" % (scene, world, rebalance))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "slab_worker.py"), "--scene", scene, "--steps", str(steps),
-           "--backend", "gloo", "--out", str(out)]
+           "--backend", "gloo", "--rebalance", str(rebalance), "--out", str(out)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -40,3 +40,20 @@ def test_slabs_match_single_gpu(tmp_path, scene, world, steps):
     assert sum(s["owned"] for s in r["slabs"]) == r["n"]
     assert all(s["ghosts"] > 0 for s in r["slabs"])
     assert r["comm"]["exchange_buffers"] > 0 and r["comm"]["allreduce"] > 0
+
+
+@pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 350, 2), ("wcsph_dam_x", 2, 2000, 1)])
+def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_recuts):
+    """cuts re-chosen every M steps.  The dam runs along x, the cuts follow it, the result stays bit-identical
+    and the largest slab stays smaller than with static cuts."""
+    r = run_slabs(tmp_path, scene, world, steps, rebalance=10)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], r
+    assert r["stats_equal"], (r["stats_last"], r["ref_stats_last"])
+    assert sum(s["owned"] for s in r["slabs"]) == r["n"]
+    assert all(s["recuts"] == r["slabs"][0]["recuts"] for s in r["slabs"]) and r["slabs"][0]["recuts"] >= min_recuts, r["slabs"]
+    for a, b in zip(r["slabs"][:-1], r["slabs"][1:]):
+        assert a["x_hi"] == b["x_lo"]
+    static = run_slabs(tmp_path, scene, world, steps, rebalance=0)
+    assert static["pos_equal"]
+    spread = lambda res: max(s["owned"] for s in res["slabs"]) - min(s["owned"] for s in res["slabs"])   # noqa: E731
+    assert spread(r) <= spread(static), (r["slabs"], static["slabs"])
