@@ -29,7 +29,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 # algorithmic bytes per particle per launch
+# pcisph / iisph sweeps, same accounting (own state read + own results written, neighbour data counted once per particle):
+#   pcisph_predict_rho: PP 16 + PB in/out 32 + rho_predict 4 = 52; pcisph_press_force: PB 16 + V 16 + EF 16 + rho 4 + PF 16 + PP 16 = 84
+#   iisph_d_ij: PB 16 + rho 4 + DIJ 16 = 36; iisph_update_p: PB in/out 32 + DII 16 + DIJ 16 + rho/rho_adv/a_ii 12 = 76
 ALGO_BYTES = {
+    "pcisph_ext_force": 96, "pcisph_predict_rho": 52, "pcisph_press_force": 84, "pcisph_integrate": 96,
+    "iisph_advect": 64, "iisph_rho_adv": 76, "iisph_d_ij": 36, "iisph_update_p": 76, "iisph_integrate": 116,
     "dfsph_density_alpha": 24, "dfsph_warm_start": 48, "dfsph_div_residual": 32, "dfsph_div_correct": 56,
     "dfsph_ext_force": 40, "dfsph_dens_residual": 32, "dfsph_dens_correct": 48, "dfsph_integrate": 48,
     "wcsph_density": 16, "wcsph_force": 52, "hash_count": 16, "order_gather": 64, "build_nl": 0,
@@ -68,7 +73,15 @@ def cpu_baseline(scene_name, solver_kind):
     cores = host_cores()
     cfg = scenes.get(scene_name)
     o = orc.Oracle(cfg, num_threads=cores)
-    if solver_kind == "dfsph":
+    if solver_kind in ("pcisph", "iisph"):
+        step = o.step_pcisph if solver_kind == "pcisph" else o.step_iisph
+        step(1)
+        timed = 2
+        t0 = time.perf_counter()
+        step(timed)
+        dt = time.perf_counter() - t0
+        sample = "steps 2-3 of %s (N=%d, %d pressure iterations in the last step) after 1 untimed step" % (scene_name, o.N, o.last_stats.n_dens)
+    elif solver_kind == "dfsph":
         o.step_dfsph(1, 100)                 # step 1 from rest is atypical (zero divergence residual): untimed
         timed = 2
         t0 = time.perf_counter()
@@ -200,6 +213,12 @@ def main():
                     sim.rigid_step()          # main.py:169-171
                 if stats is not None:
                     stats.append((st.n_div, st.n_dens, st.n_div_evals))
+        elif solver_kind in ("pcisph", "iisph"):
+            step = sim.step_pcisph if solver_kind == "pcisph" else sim.step_iisph
+            for _ in range(nsteps):
+                st = step(1)
+                if stats is not None:
+                    stats.append((0, st.n_dens, 0))
         else:
             sim.step_wcsph(nsteps)
 
@@ -227,7 +246,7 @@ def main():
     slab_info = sim.slab_info() if world > 1 else None
 
     out = {
-        "metric": "million particle-steps/sec (DFSPH dam-break)" if solver_kind == "dfsph" else "million particle-steps/sec (WCSPH dam-break)",
+        "metric": "million particle-steps/sec (%s dam-break)" % solver_kind.upper(),
         "value": value, "unit": "Mparticle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -241,9 +260,13 @@ def main():
     if stats:
         nd = [s[0] for s in stats]; ns = [s[1] for s in stats]; ne = [s[2] for s in stats]
         out["config"].update({"n_div_mean": sum(nd) / len(nd), "n_dens_mean": sum(ns) / len(ns), "n_div_evals_mean": sum(ne) / len(ne)})
-        algo_step = 272 + 88 * (sum(nd) / len(nd)) + 80 * (sum(ns) / len(ns))
-        out["config"]["algorithmic_bytes_per_particle_step"] = algo_step
-        out["step_hbm_frac_algorithmic"] = algo_step * n_total * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world)
+        if solver_kind == "dfsph":
+            algo_step = 272 + 88 * (sum(nd) / len(nd)) + 80 * (sum(ns) / len(ns))
+            out["config"]["algorithmic_bytes_per_particle_step"] = algo_step
+            out["step_hbm_frac_algorithmic"] = algo_step * n_total * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world)
+        else:
+            out["config"].pop("n_div_mean"); out["config"].pop("n_div_evals_mean")
+            out["config"]["pressure_iterations_mean"] = out["config"].pop("n_dens_mean")
 
     # ---- roofline leg: HIP-event timing of every kernel, replaying the SAME steps (warm-up + timed) on a
     # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----

@@ -36,7 +36,7 @@ class ParticleSystem:
         self.box_min = np.asarray(scene["box_min"], dtype=np.float64)
         self.rigid_particles_num = 0
         name = config["solver"].get("name")
-        self._solver_kind = name if name in ("wcsph", "dfsph") else ("dfsph" if self._rigid_input else "wcsph")
+        self._solver_kind = name if name in nat.SOLVER_IDS else ("dfsph" if self._rigid_input else "wcsph")
         self._sim = None
         self._make_sim(self._solver_kind)
         self.particle_num = self._sim.n_fluid                            # :85

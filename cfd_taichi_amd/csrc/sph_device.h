@@ -60,6 +60,9 @@ struct DevScalars {
     int div_active, div_it, div_evals, dens_active;
     int dens_d7_active, dens_it, dens_cap, dens_capped;
     float div_err, div_past, div_first, dens_avg;
+    // pcisph / iisph pressure loops reuse dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds:
+    float res_prev;
+    int res_have_prev, res_diverged, pad2;
 };
 
 enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3 };

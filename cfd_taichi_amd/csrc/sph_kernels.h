@@ -904,6 +904,12 @@ __global__ __launch_bounds__(kBlock) void k_unsort_scalar(int n, const float *__
     if (s >= n) return;
     dst[id[s]] = src[s];
 }
+__global__ __launch_bounds__(kBlock) void k_unsort_w(int n, const float4 *__restrict__ src, const int *__restrict__ id, float *__restrict__ dst)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= n) return;
+    dst[id[s]] = src[s].w;
+}
 __global__ __launch_bounds__(kBlock) void k_unsort_count(int n, const int *__restrict__ cnt, const int *__restrict__ id, float *__restrict__ dst)
 {
     int s = blockIdx.x * kBlock + threadIdx.x;

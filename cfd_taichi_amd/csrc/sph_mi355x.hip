@@ -17,6 +17,7 @@
 
 #include "sph_kernels.h"
 #include "sph_slab_kernels.h"
+#include "sph_pressure_kernels.h"
 #include "sph_rigid_kernels.h"
 
 using namespace sph;
@@ -26,12 +27,15 @@ namespace {
 enum KernelId {
     K_HASH = 0, K_SCAN, K_SCATTER, K_ORDER_GATHER, K_BUILD_NL, K_W_DENSITY, K_W_FORCE, K_D_DENSITY_ALPHA,
     K_D_WARM, K_D_DIV_RESIDUAL, K_D_DIV_CORRECT, K_D_EXT, K_D_DENS_RESIDUAL, K_D_DENS_CORRECT, K_D_INTEGRATE,
-    K_FINALIZE, K_TRANSFER, K_SLAB, K_RIGID, K_COUNT
+    K_FINALIZE, K_TRANSFER, K_SLAB, K_RIGID, K_P_EXT, K_P_PREDICT_RHO, K_P_PRESS, K_P_INTEGRATE, K_I_ADVECT, K_I_RHO_ADV, K_I_DIJ,
+    K_I_UPDATE_P, K_I_INTEGRATE, K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "hash_count", "scan", "scatter", "order_gather", "build_nl", "wcsph_density", "wcsph_force", "dfsph_density_alpha",
     "dfsph_warm_start", "dfsph_div_residual", "dfsph_div_correct", "dfsph_ext_force", "dfsph_dens_residual",
-    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange", "rigid"};
+    "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange", "rigid",
+    "pcisph_ext_force", "pcisph_predict_rho", "pcisph_press_force", "pcisph_integrate", "iisph_advect", "iisph_rho_adv", "iisph_d_ij",
+    "iisph_update_p", "iisph_integrate"};
 
 thread_local std::string g_create_error;
 
@@ -59,7 +63,11 @@ struct SphHandle {
     int *id[2] = {nullptr, nullptr};
     int pcur = 0, vcur = 0, vacur = 0, wcur = 0, icur = 0;
 
-    float *rho = nullptr, *aux = nullptr /* pressure | alpha */, *drho = nullptr, *rho_adv = nullptr;
+    float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr;
+    float4 *X[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pcisph: EF, PF, PP, PB0, PB1; iisph: DII, DIJ, f_press, PB0, PB1
+    int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
+    float pci_delta = 0.f, pci_beta = 0.f;   // pcisph_solver.py:23-24, :47
+    int pci_max_index = -1, pci_max_count = -1;
     int *cnt = nullptr;
     uint32_t *nl = nullptr, *nlb = nullptr;
     int *cell_of = nullptr, *rank = nullptr, *slot_src = nullptr;
@@ -320,7 +328,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.tens_c = (float)(-t_k / m * m);
     c.neg_m = (float)(-m);
     c.dt_cfl_num = (float)(0.4 * r * 2);
-    const float clamp_off = cf.solver == SPH_SOLVER_WCSPH ? c.d : (float)r;   // wcsph_solver.py:57 vs dfsph_solver.py:244
+    const float clamp_off = cf.solver == SPH_SOLVER_WCSPH ? c.d : (float)r;   // wcsph_solver.py:57 vs dfsph_solver.py:244, pcisph_solver.py:82, iisph_solver.py:201
     for (int a = 0; a < 3; ++a) {
         c.clamp_lo[a] = (float)cf.box_min[a] + clamp_off;
         c.clamp_hi[a] = (float)cf.box_max[a] - clamp_off;
@@ -466,6 +474,11 @@ int build_scene(SphHandle *h, HostScene &sc)
     return SPH_OK;
 }
 
+inline bool is_dfsph(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH; }
+inline bool is_pressure_solver(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH; }
+// solvers with a per-particle scalar that must follow the particle through the sort: dfsph warm_start_k, iisph p_past
+inline bool carries_scalar(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH || h->cfg.solver == SPH_SOLVER_IISPH; }
+
 template <class T>
 int dalloc(SphHandle *h, T **p, size_t count)
 {
@@ -489,6 +502,11 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemsetAsync(h->VA[k], 0, sizeof(float4) * n, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->warm[k], 0, sizeof(float) * n, h->stream));
     }
+    if (is_pressure_solver(h))
+        for (int k = 0; k < 5; ++k) {
+            if ((rc = dalloc(h, &h->X[k], n))) return rc;
+            HIP_TRY(h, hipMemsetAsync(h->X[k], 0, sizeof(float4) * n, h->stream));
+        }
     if ((rc = dalloc(h, &h->rho, n))) return rc;
     if ((rc = dalloc(h, &h->aux, n))) return rc;
     if ((rc = dalloc(h, &h->drho, n))) return rc;
@@ -1044,6 +1062,8 @@ int stage_sort_and_lists(SphHandle *h)
     const dim3 b(kBlock);
     const size_t ncell = (size_t)c.C + 2;       // cells, "outside the grid" bucket C, end
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    const bool carry = carries_scalar(h);
+    (void)dfsph;
     {
         ProfScope ps(h, K_HASH);
         HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * ncell, s));
@@ -1070,10 +1090,10 @@ int stage_sort_and_lists(SphHandle *h)
     {
         ProfScope ps(h, K_ORDER_GATHER);
         hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
-                           dfsph ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
+                           carry ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
                            h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
-        if (dfsph) h->wcur ^= 1;
+        if (carry) h->wcur ^= 1;
     }
     if (h->slab) {
         HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * (size_t)c.n, s));
@@ -1422,15 +1442,229 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     return (h->slab || h->host_loops) ? step_dfsph_host_loops(h, st) : step_dfsph_device_loops(h, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// PCISPH / IISPH (SURVEY.md section 8f "next": the solvers coupling_demo.json and breaking_dam_30k.json name)
+// ---------------------------------------------------------------------------------------------
+void launch_pressure_finalize(SphHandle *h, int mode)
+{
+    ProfScope ps(h, K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode);
+}
+
+// pcisph_solver.step :252-259
+int step_pcisph_once(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    memset(st, 0, sizeof(*st));
+    h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
+    if ((rc = stage_density(h))) return rc;                 // compute_all_rho :239; P = (pos, rho)
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(c.n), b(kBlock);
+    const float dt = h->dt_wcsph;                           // delta_time never changes in pcisph
+    float4 *EF = h->X[0], *PF = h->X[1], *PP = h->X[2], *PB[2] = {h->X[3], h->X[4]};
+    const int cap = 80;                                     // max_iteration :21
+    hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
+    {
+        ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
+        hipLaunchKernelGGL(k_pci_ext, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP);
+    }
+    auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
+        ProfScope ps(h, K_P_PREDICT_RHO);
+        hipLaunchKernelGGL(k_pci_predict_rho, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1], PB[(k + 1) & 1],
+                           h->rho_adv, h->psum, h->pcnt, gate);
+    };
+    predict_rho(0, GATE_NONE);                              // :53-56
+    launch_pressure_finalize(h, PFIN_PCI_FIRST);
+    bool first = true;
+    for (int k = 1, chunk = 2; k <= cap; chunk = chunk < 8 ? chunk * 2 : 8) {
+        for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
+            {
+                ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
+                hipLaunchKernelGGL(k_pci_press, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF, h->ds,
+                                   PF, PP, GATE_DENS);
+            }
+            predict_rho(k, GATE_DENS);
+            launch_pressure_finalize(h, PFIN_PCI_LOOP);
+        }
+        if ((rc = read_scalars(h))) return rc;
+        if (first) {
+            if ((rc = check_overflow_all(h))) return rc;
+            first = false;
+        }
+        if (!h->ds_host->dens_active) break;
+    }
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->dens_err = h->ds_host->dens_avg;
+    st->dt = dt;
+    h->pb_final = h->ds_host->dens_it & 1;
+    {
+        ProfScope ps(h, K_P_INTEGRATE);
+        hipLaunchKernelGGL(k_pci_integrate, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], EF, PF, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        h->pcur ^= 1; h->vcur ^= 1;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+// iisph_solver.step :340-347
+int step_iisph_once(SphHandle *h, SphStepStats *st)
+{
+    int rc;
+    memset(st, 0, sizeof(*st));
+    h->simulate_cnt += 1;
+    if ((rc = stage_sort_and_lists(h))) return rc;
+    if ((rc = stage_density(h))) return rc;                 // predict_advection :38; P = (pos, rho)
+    const Consts &c = h->c;
+    hipStream_t s = h->stream;
+    const dim3 g = grid_for(c.n), b(kBlock);
+    const float dt = h->dt_wcsph;
+    float4 *DII = h->X[0], *DIJ = h->X[1], *FP = h->X[2], *PB[2] = {h->X[3], h->X[4]}, *VA = h->VA[0];
+    const int cap = 180;                                    // max_iter_cnt :27
+    hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
+    {
+        ProfScope ps(h, K_I_ADVECT);                        // :43-56
+        hipLaunchKernelGGL(k_ii_advect, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII);
+    }
+    {
+        ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
+        hipLaunchKernelGGL(k_ii_rho_adv, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur], h->rho_adv,
+                           h->aux, PB[0]);
+    }
+    bool first = true;
+    for (int k = 1, chunk = 2; k <= cap; chunk = chunk < 8 ? chunk * 2 : 8) {
+        for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
+            {
+                ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
+                hipLaunchKernelGGL(k_ii_dij, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS);
+            }
+            {
+                ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
+                hipLaunchKernelGGL(k_ii_update_p, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho, h->rho_adv,
+                                   h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS);
+            }
+            launch_pressure_finalize(h, PFIN_II_LOOP);
+        }
+        if ((rc = read_scalars(h))) return rc;
+        if (first) {
+            if ((rc = check_overflow_all(h))) return rc;
+            first = false;
+        }
+        if (!h->ds_host->dens_active) break;
+    }
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->n_div = h->ds_host->res_diverged;                   // 1: the loop left on "Iteration trend to divergence" (:97-99)
+    st->dens_err = h->ds_host->dens_avg;
+    st->dt = dt;
+    h->pb_final = h->ds_host->dens_it & 1;
+    {
+        ProfScope ps(h, K_I_INTEGRATE);
+        hipLaunchKernelGGL(k_ii_integrate, g, b, 0, s, c, dt, h->P[h->pcur], VA, DII, DIJ, PB[h->pb_final], h->P[1 - h->pcur], h->V[1 - h->vcur],
+                           FP, h->warm[h->wcur]);
+        h->pcur ^= 1; h->vcur ^= 1;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+// host copy of solver_base.cubic_kernel_derivative (:90-103), same f32 operations as the device's grad_w
+void grad_w_host(const Consts &c, float rx, float ry, float rz, float out[3])
+{
+    const float r_norm = sqrtf((rx * rx + ry * ry) + rz * rz);
+    const float q = r_norm / c.h;
+    out[0] = out[1] = out[2] = 0.f;
+    float sc;
+    if (1e-5f < q && q <= 0.5f) sc = c.kg6 * (3.0f * (q * q) - 2.0f * q);
+    else if (0.5f < q && q <= 1.0f) { const float t = 1.0f - q; sc = c.neg_kg6 * (t * t); }
+    else return;
+    const float den = c.h * r_norm;
+    out[0] = sc * rx / den; out[1] = sc * ry / den; out[2] = sc * rz / den;
+}
+
+// pcisph_solver.__init__ :23-26 + pre_compute :28-47: beta, the fullest neighbourhood of the initial lattice, delta
+int pcisph_precompute(SphHandle *h, const HostScene &sc)
+{
+    int rc;
+    const Consts &c = h->c;
+    const int N = h->N;
+    const double r = h->cfg.particle_radius;
+    const double m = 1000 * (r * r * r) * 8;
+    const double dtf = (double)h->dt_wcsph;                            // self.delta_time[None] read back as a Python float
+    const double beta = dtf * dtf * m * m * 2 / (double)(1000 * 1000); // :23 (Python f64, left to right)
+    h->pci_beta = (float)beta;
+    // get_max_neighbor_particle_index (ParticleSystem.py:410-422): counts from the device lists, then the single-thread
+    // reading of the atomic_max idiom -- the last particle whose count ties the running maximum
+    if ((rc = stage_sort_and_lists(h))) return rc;
+    if ((rc = read_scalars(h))) return rc;
+    if ((rc = check_overflow(h))) return rc;
+    std::vector<float> counts((size_t)N);
+    hipLaunchKernelGGL(k_unsort_count, grid_for(N), dim3(kBlock), 0, h->stream, N, h->cnt, h->id[h->icur], h->staging);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(counts.data(), h->staging, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int max_count = -1, max_index = -1;
+    for (int i = 0; i < N; ++i) {
+        const int cnt = (int)counts[i];
+        const int old = max_count;
+        if (cnt > max_count) max_count = cnt;
+        if (old == cnt) max_index = i;
+    }
+    h->pci_max_index = max_index; h->pci_max_count = max_count;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
+    if (max_index >= 0) {
+        // for_all_neighbor(max_index) on the host: 27 cells, dx outermost, ascending particle id inside a cell
+        const float *pos = sc.fluid_pos.data();
+        auto cell = [&](const float *p, int cc[3]) { for (int a = 0; a < 3; ++a) cc[a] = (int)floorf(p[a] / c.h); };
+        int ci[3];
+        cell(pos + 3 * (size_t)max_index, ci);
+        std::vector<int> bucket[27];
+        for (int j = 0; j < N; ++j) {
+            int cj[3];
+            cell(pos + 3 * (size_t)j, cj);
+            const int dx = cj[0] - ci[0], dy = cj[1] - ci[1], dz = cj[2] - ci[2];
+            if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
+            if (cj[0] < 0 || cj[0] >= c.gx || cj[1] < 0 || cj[1] >= c.gy || cj[2] < 0 || cj[2] >= c.gz) continue;
+            bucket[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)].push_back(j);
+        }
+        const float *pi = pos + 3 * (size_t)max_index;
+        for (int bk = 0; bk < 27; ++bk)
+            for (int j : bucket[bk]) {
+                if (j == max_index) continue;
+                const float x = pi[0] - pos[3 * (size_t)j], y = pi[1] - pos[3 * (size_t)j + 1], z = pi[2] - pos[3 * (size_t)j + 2];
+                if (sqrtf((x * x + y * y) + z * z) > c.h) continue;
+                float gw[3];
+                grad_w_host(c, x, y, z, gw);
+                sx += gw[0]; sy += gw[1]; sz += gw[2];                 // compute_sum :179-183
+                sq += (gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2]; // compute_square_sum :185-190
+            }
+    }
+    h->pci_delta = 1.0f / ((((sx * sx + sy * sy) + sz * sz) + sq) * h->pci_beta);   // :47
+    return SPH_OK;
+}
+
 int field_floats(SphHandle *h, int species, int field, size_t *count, bool *vec)
 {
     *vec = false;
     if (species == SPH_SPECIES_FLUID) {
         switch (field) {
-        case SPH_F_POS: case SPH_F_VEL: case SPH_F_ACC: case SPH_F_VEL_ADV:
+        case SPH_F_POS: case SPH_F_VEL: case SPH_F_ACC: case SPH_F_VEL_ADV: case SPH_F_PRESS_FORCE: case SPH_F_POS_PREDICT: case SPH_F_D_II:
+        case SPH_F_D_IJ:
             *vec = true; *count = 3 * (size_t)h->N; return SPH_OK;
         case SPH_F_RHO: case SPH_F_PRESSURE: case SPH_F_ALPHA: case SPH_F_WARM_K: case SPH_F_RHO_ADV: case SPH_F_RHO_DER:
-        case SPH_F_NBR_COUNT:
+        case SPH_F_NBR_COUNT: case SPH_F_PRESS_ITER: case SPH_F_A_II:
             *count = (size_t)h->N; return SPH_OK;
         default: break;
         }
@@ -1458,8 +1692,10 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
 {
     if (!cfg || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->solver != SPH_SOLVER_WCSPH && cfg->solver != SPH_SOLVER_DFSPH)
+    if (cfg->solver < SPH_SOLVER_WCSPH || cfg->solver > SPH_SOLVER_IISPH)
         return fail(nullptr, SPH_E_INVALID, "unknown solver %d", cfg->solver);
+    if (cfg->slab_count > 1 && (cfg->solver == SPH_SOLVER_PCISPH || cfg->solver == SPH_SOLVER_IISPH))
+        return fail(nullptr, SPH_E_INVALID, "pcisph / iisph run on a single GPU (the slab decomposition covers wcsph and dfsph)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -1477,6 +1713,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
         HostScene sc;
         if ((rc = build_scene(h, sc))) break;
         if ((rc = alloc_device(h, sc))) break;
+        if (h->cfg.solver == SPH_SOLVER_PCISPH && (rc = pcisph_precompute(h, sc))) break;
         h->wall_pos_host = sc.wall_pos;
         h->wall_vol_host = sc.wall_vol;
     } while (0);
@@ -1527,6 +1764,7 @@ void sph_destroy(SphHandle *h)
         (void)hipFree(h->P[k]); (void)hipFree(h->V[k]); (void)hipFree(h->VA[k]); (void)hipFree(h->warm[k]); (void)hipFree(h->id[k]);
     }
     (void)hipFree(h->rho); (void)hipFree(h->aux); (void)hipFree(h->drho); (void)hipFree(h->rho_adv); (void)hipFree(h->cnt);
+    for (int k = 0; k < 5; ++k) (void)hipFree(h->X[k]);
     (void)hipFree(h->nl); (void)hipFree(h->nlb); (void)hipFree(h->cell_of); (void)hipFree(h->rank); (void)hipFree(h->slot_src);
     (void)hipFree(h->cell_count); (void)hipFree(h->cell_start); (void)hipFree(h->tile_sums); (void)hipFree(h->WP);
     (void)hipFree(h->wcell_start); (void)hipFree(h->psum); (void)hipFree(h->pcnt); (void)hipFree(h->pmax); (void)hipFree(h->ds);
@@ -1612,6 +1850,7 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
     }
     if (h->slab) return fail(h, SPH_E_STATE, "slab handle: use sph_download_local + sph_download_ids (device order, owned and ghost particles)");
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    const bool pcisph = h->cfg.solver == SPH_SOLVER_PCISPH, iisph = h->cfg.solver == SPH_SOLVER_IISPH;
     hipStream_t s = h->stream;
     const dim3 g = grid_for(h->N), b(kBlock);
     const int *id = h->id[h->icur];
@@ -1621,14 +1860,30 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
         case SPH_F_POS: hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->P[h->pcur], id, h->staging); break;
         case SPH_F_VEL: hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->V[h->vcur], id, h->staging); break;
         case SPH_F_ACC:
-            if (dfsph) return fail(h, SPH_E_STATE, "acc is a wcsph field (dfsph never fills it, dfsph_solver.py:418-421)");
+            if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "acc is a wcsph field (the other solvers never fill it, dfsph_solver.py:418-421)");
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break;
+        case SPH_F_PRESS_ITER:
+            if (!is_pressure_solver(h)) return fail(h, SPH_E_STATE, "press_iter / p_iter is a pcisph / iisph field");
+            hipLaunchKernelGGL(k_unsort_w, g, b, 0, s, h->N, h->X[3 + h->pb_final], id, h->staging); break;
+        case SPH_F_PRESS_FORCE:
+            if (!is_pressure_solver(h)) return fail(h, SPH_E_STATE, "press_force / f_press is a pcisph / iisph field");
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[pcisph ? 1 : 2], id, h->staging); break;
+        case SPH_F_POS_PREDICT:
+            if (!pcisph) return fail(h, SPH_E_STATE, "pos_predict is a pcisph field");
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[2], id, h->staging); break;
+        case SPH_F_D_II: case SPH_F_D_IJ:
+            if (!iisph) return fail(h, SPH_E_STATE, "d_ii / d_ij are iisph fields");
+            hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[field == SPH_F_D_II ? 0 : 1], id, h->staging); break;
+        case SPH_F_A_II:
+            if (!iisph) return fail(h, SPH_E_STATE, "a_ii is an iisph field");
+            hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->aux, id, h->staging); break;
         case SPH_F_VEL_ADV:
-            if (!dfsph) return fail(h, SPH_E_STATE, "vel_adv is a dfsph field");
+            if (iisph) { hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break; }   // iisph v_adv
+            if (!dfsph) return fail(h, SPH_E_STATE, "vel_adv is a dfsph / iisph field");
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->VA[0], id, h->staging); break;
         case SPH_F_RHO: hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->rho, id, h->staging); break;
         case SPH_F_PRESSURE:
-            if (dfsph) return fail(h, SPH_E_STATE, "pressure is a wcsph field");
+            if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "pressure is a wcsph field");
             hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->aux, id, h->staging); break;
         case SPH_F_ALPHA:
             if (!dfsph) return fail(h, SPH_E_STATE, "alpha is a dfsph field");
@@ -1798,7 +2053,7 @@ int sph_compute_alpha(SphHandle *h)
 int sph_step_wcsph(SphHandle *h, int nsteps)
 {
     if (!h) return SPH_E_INVALID;
-    if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "handle was created for dfsph");
+    if (h->cfg.solver != SPH_SOLVER_WCSPH) return fail(h, SPH_E_STATE, "handle was not created for wcsph");
     HIP_TRY(h, hipSetDevice(h->device));
     int k = 0;
     // The WCSPH step is a fixed launch sequence with no host decision in it, so two steps (after which the ping-pong
@@ -1841,7 +2096,7 @@ int sph_step_wcsph(SphHandle *h, int nsteps)
 int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last)
 {
     if (!h) return SPH_E_INVALID;
-    if (h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "handle was created for wcsph");
+    if (h->cfg.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_STATE, "handle was not created for dfsph");
     HIP_TRY(h, hipSetDevice(h->device));
     SphStepStats st;
     memset(&st, 0, sizeof(st));
@@ -1853,17 +2108,51 @@ int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last)
     return SPH_OK;
 }
 
+int sph_step_pcisph(SphHandle *h, int nsteps, SphStepStats *last)
+{
+    if (!h) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_PCISPH) return fail(h, SPH_E_STATE, "handle was not created for pcisph");
+    HIP_TRY(h, hipSetDevice(h->device));
+    SphStepStats st;
+    memset(&st, 0, sizeof(st));
+    for (int k = 0; k < nsteps; ++k) {
+        int rc = step_pcisph_once(h, &st);
+        if (rc) return rc;
+    }
+    if (last) *last = st;
+    return SPH_OK;
+}
+
+int sph_step_iisph(SphHandle *h, int nsteps, SphStepStats *last)
+{
+    if (!h) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_IISPH) return fail(h, SPH_E_STATE, "handle was not created for iisph");
+    HIP_TRY(h, hipSetDevice(h->device));
+    SphStepStats st;
+    memset(&st, 0, sizeof(st));
+    for (int k = 0; k < nsteps; ++k) {
+        int rc = step_iisph_once(h, &st);
+        if (rc) return rc;
+    }
+    if (last) *last = st;
+    return SPH_OK;
+}
+
 int sph_get_scalar(SphHandle *h, int which, double *out)
 {
     if (!h || !out) return SPH_E_INVALID;
     switch (which) {
     case SPH_S_DELTA_TIME:
-        if (h->cfg.solver == SPH_SOLVER_WCSPH) { *out = (double)h->dt_wcsph; return SPH_OK; }
+        if (h->cfg.solver != SPH_SOLVER_DFSPH) { *out = (double)h->dt_wcsph; return SPH_OK; }   // only dfsph adapts delta_time
         else { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->dt; return SPH_OK; }
     case SPH_S_SIMULATE_CNT: *out = (double)h->simulate_cnt; return SPH_OK;
     case SPH_S_PARTICLE_M: *out = (double)h->c.m; return SPH_OK;
     case SPH_S_SUPPORT_RADIUS: *out = (double)h->c.h; return SPH_OK;
     case SPH_S_GRAPH_LAUNCHES: *out = (double)h->graph_launches; return SPH_OK;
+    case SPH_S_PCISPH_DELTA: *out = (double)h->pci_delta; return SPH_OK;
+    case SPH_S_PCISPH_BETA: *out = (double)h->pci_beta; return SPH_OK;
+    case SPH_S_PCISPH_MAX_INDEX: *out = (double)h->pci_max_index; return SPH_OK;
+    case SPH_S_PCISPH_MAX_COUNT: *out = (double)h->pci_max_count; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {

@@ -1,0 +1,509 @@
+// sph_pressure_kernels.h -- PCISPH (pcisph_solver.py) and IISPH (iisph_solver.py) sweeps on the same cell-sorted
+// arrays, wave-tiled neighbour lists and sweep skeleton as the WCSPH / DFSPH kernels (sph_kernels.h).
+//
+// Both solvers iterate a pressure field with the positions frozen, so the lists built once per step serve every
+// iteration.  The reference drives the iteration from Python (pcisph_solver.py:49-71, iisph_solver.py:85-108); here
+// k_finalize_pressure evaluates the loop condition on the device and later sweeps of a finished loop exit at
+// their first instruction (same control scheme as DFSPH).
+//
+// Buffer roles (float4, sorted order):
+//   P  = (pos, rho)            written by k_density<false>        static through the step
+//   PB[2] = (pos, pressure)    press_iter (PCISPH) / p_iter (IISPH); ping-pong: a sweep reads the pressures of its
+//                              neighbours from one and writes its own new pressure to the other
+//   PP = (pos_predict, -)      PCISPH            DII = (d_ii, -), DIJ = (d_ij, -)   IISPH
+//   EF = (ext_force, -)  PF = (press_force, -)   PCISPH;   VA = (v_adv, -)   IISPH
+#pragma once
+#include "sph_kernels.h"
+
+namespace sph {
+
+// a / d for a compile-time style constant d with rd = RN(1/d): Markstein's sequence, correctly rounded like `/`
+// (same argument as div_by_h; d = 1e6 has a significand that is not all ones)
+__device__ __forceinline__ float div_const(float a, float d, float rd)
+{
+#ifdef SPH_GENERIC_DIV
+    return a / d;
+#endif
+    float q0 = a * rd;
+    float e = __builtin_fmaf(-q0, d, a);
+    return __builtin_fmaf(e, rd, q0);
+}
+
+template <class Body>
+__device__ __forceinline__ void for_nbrs_ps(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
+                                            const float *__restrict__ S, Body body)
+{
+    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = jn;
+        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
+        const float s0 = S[jj.x], s1 = S[jj.y], s2 = S[jj.z], s3 = S[jj.w];
+        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        body(a0, s0);
+        if (kk + 1 < cnt) body(a1, s1);
+        if (kk + 2 < cnt) body(a2, s2);
+        if (kk + 3 < cnt) body(a3, s3);
+    }
+}
+template <class Body>
+__device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
+                                           const float4 *__restrict__ B, const float4 *__restrict__ C, Body body)
+{
+    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = jn;
+        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
+        const float4 b0 = B[jj.x], b1 = B[jj.y], b2 = B[jj.z], b3 = B[jj.w];
+        const float4 c0 = C[jj.x], c1 = C[jj.y], c2 = C[jj.z], c3 = C[jj.w];
+        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        body(a0, b0, c0);
+        if (kk + 1 < cnt) body(a1, b1, c1);
+        if (kk + 2 < cnt) body(a2, b2, c2);
+        if (kk + 3 < cnt) body(a3, b3, c3);
+    }
+}
+
+// predicted / integrated positions against the clamp walls      pcisph_solver.py:79-89, 234-244; iisph_solver.py:198-207
+__device__ __forceinline__ void clamp_walls(const Consts &c, float pos[3], float vel[3])
+{
+    if (c.boundary_handle) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (pos[a] <= c.clamp_lo[a]) { pos[a] = c.clamp_lo[a]; vel[a] *= -0.5f; }
+        if (pos[a] >= c.clamp_hi[a]) { pos[a] = c.clamp_hi[a]; vel[a] *= -0.5f; }
+    }
+}
+
+// ---- loop control ---------------------------------------------------------------------------------------------
+// mean of the block partials + the reference's while-condition, evaluated on the device (f64 compares like the Python
+// host code).  PCI_FIRST: pcisph_solver.py:56 (the evaluation before the loop); PCI_LOOP: :58-70; II_LOOP:
+// iisph_solver.py:89-100.  Iteration counter, residual and the "open" flag live in DevScalars (dens_* fields).
+enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
+
+__global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                              DevScalars *__restrict__ ds, int mode)
+{
+    if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
+    __shared__ double s_sum[kBlock];
+    __shared__ long long s_cnt[kBlock];
+    double t = 0.0; long long n = 0;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+    s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
+    const float res = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // pcisph :136-137, iisph :119-120
+    const int cap = ds->dens_cap;
+    if (mode == PFIN_PCI_FIRST) {
+        ds->dens_avg = res; ds->dens_it = 0; ds->dens_capped = 0; ds->res_diverged = 0;
+        ds->dens_active = cap > 0 ? 1 : 0;                                          // iter_cnt (0) < min_iteration (1)
+    } else if (mode == PFIN_PCI_LOOP) {
+        const int it = ds->dens_it + 1;                                             // :70
+        ds->dens_it = it; ds->dens_avg = res;
+        const int active = (((double)res > 1000 * 0.1 * 0.01 || it < 1) && it < cap) ? 1 : 0;   // :58
+        if (it >= cap) ds->dens_capped = 1;
+        ds->dens_active = active;
+    } else {
+        const int l = ds->dens_it + 1;                                              // iisph :94
+        ds->dens_it = l; ds->dens_avg = res;
+        int active;
+        if (ds->res_have_prev && (double)res - (double)ds->res_prev > 0) {          // :97-99 "Iteration trend to divergence"
+            ds->res_diverged = 1;
+            active = 0;
+        } else {
+            ds->res_prev = res; ds->res_have_prev = 1;                              // :100
+            active = (((double)res > 0.1 * 1000 * 0.01 || l < 1) && l < cap) ? 1 : 0;   // :88-89
+        }
+        if (l >= cap) ds->dens_capped = 1;
+        ds->dens_active = active;
+    }
+}
+
+__global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
+{
+    ds->dens_active = 1; ds->dens_it = 0; ds->dens_cap = cap; ds->dens_capped = 0; ds->dens_avg = 0.f;
+    ds->res_prev = 0.f; ds->res_have_prev = 0; ds->res_diverged = 0;
+}
+
+// ======================================================================================
+// PCISPH
+// ======================================================================================
+// compute_ext_force (:237-244: tension, viscosity, gravity) + reset() (:247-250) + the first predict_vel_pos (:73-89)
+//   reads P = (pos, rho), V = (vel, -)
+__global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
+                                                    float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
+                                                    float4 *__restrict__ PP)
+{
+    const uint32_t *nlb = nullptr;
+    SPH_SWEEP_PROLOGUE
+    (void)kb; (void)nlbp;
+    const float4 vi = V[ii];
+    const float rho_i = pi.w;
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        tx += st * dx; ty += st * dy; tz += st * dz;
+        float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
+        float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
+        if (shear < 0.f) {
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float q2 = r * r;
+            float nu = c.visc_num / (rho_i + pj.w);          // :187
+            float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
+            float sv = c.neg_m * pi_;                        // :189
+            wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+        }
+    });
+    if (!live) return;
+    float ten[3] = {tx * c.m, ty * c.m, tz * c.m};           // :209
+    float vis[3] = {wx * c.m, wy * c.m, wz * c.m};           // :175
+    float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
+    float pos[3] = {pi.x, pi.y, pi.z};
+    float v[3] = {vi.x, vi.y, vi.z};
+    float ext[3], vp[3], pp[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = (g[a] + ten[a]) + vis[a];                   // pcisph_solver.py:243
+        vp[a] = v[a] + dt * (ext[a] + 0.0f) / c.m;           // :76 with press_force = 0 after reset()
+        pp[a] = pos[a] + dt * vp[a];                         // :77
+    }
+    clamp_walls(c, pp, vp);
+    EF[i] = make_float4(ext[0], ext[1], ext[2], 0.f);
+    PF[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    PB0[i] = make_float4(pi.x, pi.y, pi.z, 0.f);             // press_iter = 0
+    PP[i] = make_float4(pp[0], pp[1], pp[2], 0.f);
+}
+
+// predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
+//   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
+__global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delta, const float4 *__restrict__ P,
+                                                            const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                            const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                            const DevScalars *__restrict__ ds, const float4 *__restrict__ PBin,
+                                                            float4 *__restrict__ PBout, float *__restrict__ rho_predict,
+                                                            double *__restrict__ psum, int *__restrict__ pcnt, int gate)
+{
+    if (gate_closed(ds, gate)) return;
+    SPH_SWEEP_PROLOGUE
+    float rp = 0.f;
+    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;           // :155-156
+    });
+    float rb = 0.f;
+    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        rb += cubic_w(c, norm3(dx, dy, dz)) * pj.w;          // :167-168
+    });
+    float val = 0.f;
+    int flag = 0;
+    if (live) {
+        const float rho_p = c.boundary_handle ? rp + rb * c.rho0 : rp;   // :100 / :102
+        const float err = rho_p - c.rho0;                    // :103
+        rho_predict[i] = rho_p;
+        const float4 pb = PBin[i];
+        float pr = pb.w + err * delta;                       // :107
+        pr = rmax(0.0f, pr);                                 // :108
+        PBout[i] = make_float4(pb.x, pb.y, pb.z, pr);
+        val = rmax(err, 0.0f);                               // :132
+        flag = val > 0.0f;
+    }
+    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+}
+
+// update_press_force (:111-124, :192-224) + predict_vel_pos (:73-89).   P here is PB = (pos, press_iter)
+__global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ WP,
+                                                      const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
+                                                      const int *__restrict__ cnt, const float *__restrict__ rho,
+                                                      const float4 *__restrict__ V, const float4 *__restrict__ EF,
+                                                      const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
+                                                      float4 *__restrict__ PP, int gate)
+{
+    if (gate_closed(ds, gate)) return;
+    SPH_SWEEP_PROLOGUE
+    const float p_i = pi.w;
+    constexpr float kRho0Sq = 1000000.0f;                    // self.rho_0 ** 2 (Python int)
+    constexpr float kRcpRho0Sq = 1.0f / 1000000.0f;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float ps = p_i + pj.w;
+        fx += div_const(ps * g.x, kRho0Sq, kRcpRho0Sq) * c.m * c.m;   // :199
+        fy += div_const(ps * g.y, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
+        fz += div_const(ps * g.z, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
+    });
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    if (c.boundary_handle) {
+        const float rho_i = rho[ii];
+        const float rho_i_2 = rho_i * rho_i;                 // :221
+        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+            float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            float r = norm3(dx, dy, dz);
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float s = pj.w * p_i / rho_i_2;                  // :223
+            bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
+        });
+    }
+    if (!live) return;
+    float pf[3];
+    if (c.boundary_handle) {
+        pf[0] = -fx + bx * c.rho0 * c.m; pf[1] = -fy + by * c.rho0 * c.m; pf[2] = -fz + bz * c.rho0 * c.m;   // :120
+    } else {
+        pf[0] = -fx; pf[1] = -fy; pf[2] = -fz;               // :122
+    }
+    const float4 vi = V[i], e = EF[i];
+    float ext[3] = {e.x, e.y, e.z};
+    float v[3] = {vi.x, vi.y, vi.z};
+    float pos[3] = {pi.x, pi.y, pi.z};
+    float vp[3], pp[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        vp[a] = v[a] + dt * (ext[a] + pf[a]) / c.m;          // :76
+        pp[a] = pos[a] + dt * vp[a];                         // :77
+    }
+    clamp_walls(c, pp, vp);
+    PF[i] = make_float4(pf[0], pf[1], pf[2], 0.f);
+    PP[i] = make_float4(pp[0], pp[1], pp[2], 0.f);
+}
+
+// integration :226-245
+__global__ __launch_bounds__(kBlock) void k_pci_integrate(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                          const float4 *__restrict__ EF, const float4 *__restrict__ PF,
+                                                          float4 *__restrict__ Pn, float4 *__restrict__ Vn)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 p = P[i], vi = V[i], e = EF[i], f = PF[i];
+    float pos[3] = {p.x, p.y, p.z};
+    float vel[3] = {vi.x, vi.y, vi.z};
+    float ext[3] = {e.x, e.y, e.z}, pf[3] = {f.x, f.y, f.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        vel[a] = vel[a] + dt * (ext[a] + pf[a]) / c.m;       // :229-230
+        vel[a] *= 0.9999f;                                   // :231
+        pos[a] = pos[a] + dt * vel[a];                       // :232
+    }
+    clamp_walls(c, pos, vel);
+    Pn[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
+    Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
+}
+
+// ======================================================================================
+// IISPH
+// ======================================================================================
+// predict_advection, first half (:43-56): tension, viscosity, f_adv, v_adv, d_ii.   P = (pos, rho), V = (vel, -)
+__global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                      float4 *__restrict__ VA, float4 *__restrict__ DII)
+{
+    SPH_SWEEP_PROLOGUE
+    const float4 vi = V[ii];
+    const float rho_i = pi.w;
+    const float s_f = c.neg_m / (rho_i * rho_i);             // compute_d_ii :280 (same value for every fluid neighbour)
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    float ex = 0.f, ey = 0.f, ez = 0.f;
+    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        ex += s_f * g.x; ey += s_f * g.y; ez += s_f * g.z;
+        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        tx += st * dx; ty += st * dy; tz += st * dz;
+        float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
+        float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
+        if (shear < 0.f) {
+            float q2 = r * r;
+            float nu = c.visc_num / (rho_i + pj.w);          // :187
+            float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
+            float sv = c.neg_m * pi_;                        // :189
+            wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+        }
+    });
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    if (c.boundary_handle) {
+        const float den = rho_i * rho_i;
+        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+            float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            float r = norm3(dx, dy, dz);
+            F3 g = grad_w(c, dx, dy, dz, r);
+            float s = -pj.w / den;                           // compute_boundary_d_ii :292
+            bx += s * g.x; by += s * g.y; bz += s * g.z;
+        });
+    }
+    if (!live) return;
+    float ten[3] = {tx * c.m, ty * c.m, tz * c.m};
+    float vis[3] = {wx * c.m, wy * c.m, wz * c.m};
+    float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
+    float v[3] = {vi.x, vi.y, vi.z};
+    float va[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float f = (g[a] + ten[a]) + vis[a];                  // iisph_solver.py:46
+        va[a] = v[a] + dt * f / c.m;                         // :48
+    }
+    float d[3] = {ex, ey, ez}, b[3] = {bx, by, bz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (c.boundary_handle) d[a] = (d[a] + b[a] * c.rho0) * dt * dt;   // :54
+        else d[a] = d[a] * dt * dt;                                        // :56
+    }
+    VA[i] = make_float4(va[0], va[1], va[2], 0.f);
+    DII[i] = make_float4(d[0], d[1], d[2], 0.f);
+}
+
+// predict_advection, second half (:58-82): rho_adv, p_iter = 0.5 p_past, a_ii.   P = (pos, rho), V = VA = (v_adv, -)
+__global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                       const float4 *__restrict__ DII, const float *__restrict__ p_past,
+                                                       float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0)
+{
+    SPH_SWEEP_PROLOGUE
+    const float4 vi = V[ii], di = DII[ii];
+    const float rho_i = pi.w;
+    const float cji = -dt * dt * c.m / (rho_i * rho_i);      // scalar prefix of d_ji, compute_a_ii :302-303
+    float ra = 0.f, aii = 0.f;
+    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        ra += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);        // compute_rho_adv :332
+        float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;   // d_ii[i] - d_ji; gradW(-q) = -gradW(q)
+        aii += c.m * dot3(ex, ey, ez, g.x, g.y, g.z);                                  // compute_a_ii :304
+    });
+    float rb = 0.f, ab = 0.f;
+    if (c.boundary_handle) {
+        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+            float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            float r = norm3(dx, dy, dz);
+            F3 g = grad_w(c, dx, dy, dz, r);
+            rb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                        // compute_rho_adv_boundary :349
+            float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;
+            ab += pj.w * dot3(ex, ey, ez, g.x, g.y, g.z);                              // compute_a_ii_boundary :322
+        });
+    }
+    if (!live) return;
+    if (c.boundary_handle) {
+        rho_adv[i] = (ra + rb * c.rho0) * dt + rho_i;        // :64
+        a_ii[i] = aii + ab * c.rho0;                         // :75
+    } else {
+        rho_adv[i] = ra * dt + rho_i;                        // :67
+        a_ii[i] = aii;                                       // :77
+    }
+    PB0[i] = make_float4(pi.x, pi.y, pi.z, 0.5f * p_past[i]);   // :68
+}
+
+// compute_all_d_ij (:130-135, :324-327).   P here is PB = (pos, p_iter)
+__global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
+                                                   const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
+                                                   const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate)
+{
+    if (gate_closed(ds, gate)) return;
+    const uint32_t *nlb = nullptr;
+    SPH_SWEEP_PROLOGUE
+    (void)kb; (void)nlbp;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for_nbrs_ps(nlp, kf, P, rho, [&](const float4 pj, const float rho_j) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        const float a = c.neg_m * pj.w;                      // - m * p_iter[j]
+        const Recip den = recip_prepare(rho_j * rho_j);
+        sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
+    });
+    if (!live) return;
+    DIJ[i] = make_float4(sx * dt * dt, sy * dt * dt, sz * dt * dt, 0.f);   // :135
+}
+
+// update_p (:137-157) + compute_residual partials (:110-121).   P = PBin = (pos, p_iter); writes PBout = (pos, new p_iter)
+__global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ DII,
+                                                        const float4 *__restrict__ DIJ, const float4 *__restrict__ WP,
+                                                        const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
+                                                        const int *__restrict__ cnt, const float *__restrict__ rho,
+                                                        const float *__restrict__ rho_adv, const float *__restrict__ a_ii,
+                                                        const DevScalars *__restrict__ ds, float4 *__restrict__ PBout,
+                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate)
+{
+    if (gate_closed(ds, gate)) return;
+    SPH_SWEEP_PROLOGUE
+    const float p_i = pi.w;
+    const float rho_i = rho[ii];
+    const float cji = -dt * dt * c.m / (rho_i * rho_i);      // :252-253
+    const float4 a = DIJ[ii];
+    float sum = 0.f;
+    for_nbrs_3(nlp, kf, P, DII, DIJ, [&](const float4 pj, const float4 dj, const float4 ej) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        float r = norm3(dx, dy, dz);
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float jx = cji * -g.x * p_i, jy = cji * -g.y * p_i, jz = cji * -g.z * p_i;     // d_ji
+        float tx = a.x - dj.x * pj.w - (ej.x - jx);
+        float ty = a.y - dj.y * pj.w - (ej.y - jy);
+        float tz = a.z - dj.z * pj.w - (ej.z - jz);
+        sum += c.m * dot3(tx, ty, tz, g.x, g.y, g.z);        // sum_factor :254
+    });
+    float bsum = 0.f;
+    if (c.boundary_handle) {
+        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+            float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+            float r = norm3(dx, dy, dz);
+            F3 g = grad_w(c, dx, dy, dz, r);
+            bsum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor_boundary :240
+        });
+    }
+    float val = 0.f;
+    int flag = 0;
+    if (live) {
+        const float r_sum = c.boundary_handle ? sum + bsum : sum;        // :145 / :147
+        const float aii = a_ii[i], radv = rho_adv[i];
+        float p_new;
+        if (fabsf(aii) > 1e-7f) p_new = 0.5f * p_i + 0.5f * ((c.rho0 - radv) - r_sum) / aii;   // :150-151 (omega = 0.5)
+        else p_new = 0.0f;
+        const float p = rmax(p_new, 0.0f);                   // :156
+        PBout[i] = make_float4(pi.x, pi.y, pi.z, p);
+        flag = p > 0.0f;                                     // :115
+        val = ((aii * p + r_sum) + radv) - 1000.0f;          // :116
+    }
+    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+}
+
+// intergation (:189-210) with compute_all_press_force (:172-176)
+__global__ __launch_bounds__(kBlock) void k_ii_integrate(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ VA,
+                                                         const float4 *__restrict__ DII, const float4 *__restrict__ DIJ,
+                                                         const float4 *__restrict__ PB, float4 *__restrict__ Pn, float4 *__restrict__ Vn,
+                                                         float4 *__restrict__ FP, float *__restrict__ p_past)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n) return;
+    const float4 p = P[i], va = VA[i], di = DII[i], dj = DIJ[i];
+    const float p_it = PB[i].w;
+    float pos[3] = {p.x, p.y, p.z};
+    float v[3] = {va.x, va.y, va.z};
+    float dii[3] = {di.x, di.y, di.z}, dij[3] = {dj.x, dj.y, dj.z};
+    float vel[3], fp[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        fp[a] = (dij[a] + dii[a] * p_it) * c.m / (dt * dt);  // :176
+        vel[a] = v[a] + dt * fp[a] / c.m;                    // :193
+        vel[a] *= 0.9999f;                                   // :194
+        pos[a] = pos[a] + dt * vel[a];                       // :195
+    }
+    clamp_walls(c, pos, vel);
+    Pn[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
+    Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
+    FP[i] = make_float4(fp[0], fp[1], fp[2], 0.f);
+    p_past[i] = p_it;                                        // :209-210
+}
+
+}  // namespace sph

@@ -43,6 +43,12 @@ SCENES = {
     "wcsph_250k": lambda: _scene("wcsph", 2.5e-4, [10.0, 6.0, 2.7], [2.5, 5.0, 2.5]),
     "dfsph_1m": lambda: _scene("dfsph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
     "dfsph_10m": lambda: _scene("dfsph", 1e-3, [40.0, 15.0, 10.2], [10.0, 12.5, 10.0]),
+    # the solvers the reference's own configs name.  breaking_dam_30k.json:12 says iisph (dt 0.001 there);
+    # coupling_demo.json:16 says pcisph
+    "breaking_dam_30k_iisph": lambda: _scene("iisph", 1e-3, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
+    "breaking_dam_30k_pcisph": lambda: _scene("pcisph", 1e-3, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
+    "iisph_1m": lambda: _scene("iisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
+    "pcisph_1m": lambda: _scene("pcisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
 }
 
 

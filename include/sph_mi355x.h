@@ -34,6 +34,8 @@ extern "C" {
 
 #define SPH_SOLVER_WCSPH 0
 #define SPH_SOLVER_DFSPH 1
+#define SPH_SOLVER_PCISPH 2   /* pcisph_solver.py (single GPU, no rigid body yet) */
+#define SPH_SOLVER_IISPH 3    /* iisph_solver.py  (single GPU, no rigid body yet) */
 
 /* config/X.json of the reference, flattened (utils.py:3-11 reads it,
  * ParticleSystem.py:31-103 and solver_base.py:7-39 consume it).  Doubles carry the Python
@@ -118,6 +120,12 @@ typedef struct SphRigid {
 #define SPH_F_RHO_DER 8    /* dfsph solver.rho_derivative */
 #define SPH_F_VEL_ADV 9    /* dfsph solver.vel_adv */
 #define SPH_F_NBR_COUNT 14 /* ps.get_neighbour_count(i), as float */
+#define SPH_F_PRESS_ITER 16  /* pcisph solver.press_iter / iisph solver.p_iter after the last step */
+#define SPH_F_PRESS_FORCE 17 /* pcisph solver.press_force / iisph solver.f_press */
+#define SPH_F_POS_PREDICT 18 /* pcisph solver.pos_predict */
+#define SPH_F_D_II 19        /* iisph solver.d_ii */
+#define SPH_F_A_II 20        /* iisph solver.a_ii */
+#define SPH_F_D_IJ 21        /* iisph solver.d_ij */
 #define SPH_F_WALL_POS 32  /* boundary_particles.pos    (species WALL) */
 #define SPH_F_WALL_VOL 33  /* boundary_particles.volume (species WALL) */
 #define SPH_F_RIGID_POS 48    /* rigid_particles.pos    (species RIGID) */
@@ -133,6 +141,10 @@ typedef struct SphRigid {
 #define SPH_S_SUPPORT_RADIUS 3 /* ps.support_radius */
 #define SPH_S_PS_DELTA_TIME 4  /* ps.delta_time[None] */
 #define SPH_S_GRAPH_LAUNCHES 5 /* diagnostics: hipGraph replays issued by sph_step_wcsph (each replays two steps) */
+#define SPH_S_PCISPH_DELTA 6   /* pcisph solver.delta[None]         pcisph_solver.py:47 */
+#define SPH_S_PCISPH_BETA 7    /* pcisph solver.beta                :23 */
+#define SPH_S_PCISPH_MAX_INDEX 8 /* ps.get_max_neighbor_particle_index()  ParticleSystem.py:410-422 (single-thread reading) */
+#define SPH_S_PCISPH_MAX_COUNT 9
 #define SPH_S_RIGID_CENTROID 10   /* +0,1,2: ps.rigid_centriod[None] */
 #define SPH_S_RIGID_OMEGA 13      /* +0,1,2: rigid_solver.omega[None] */
 #define SPH_S_RIGID_VEL 16        /* +0,1,2: rigid_particles.vel (uniform over the body) */
@@ -165,6 +177,12 @@ int sph_step_wcsph(SphHandle *h, int nsteps);
 /* replaces dfsph_solver.step() x nsteps   dfsph_solver.py:440-445; `last` (may be NULL) gets the
  * last step's statistics */
 int sph_step_dfsph(SphHandle *h, int nsteps, SphStepStats *last);
+/* replaces pcisph_solver.step() x nsteps  pcisph_solver.py:252-259.  last->n_dens = iter_cnt and last->dens_err = rho_err_avg as
+ * printed at :71; last->capped = 1 when max_iteration (80) ended the loop */
+int sph_step_pcisph(SphHandle *h, int nsteps, SphStepStats *last);
+/* replaces iisph_solver.step() x nsteps   iisph_solver.py:340-347.  last->n_dens = l and last->dens_err = residual as printed at :102;
+ * last->n_div = 1 when the loop left on "Iteration trend to divergence" (:97-99); last->capped = 1 at max_iter_cnt (180) */
+int sph_step_iisph(SphHandle *h, int nsteps, SphStepStats *last);
 /* stages of the step, for parity tests against the oracle's stages:
  * ps.reset_grid()+update_grid() (+ neighbour-list build), solver.compute_all_rho(), dfsph compute_all_alpha() */
 int sph_build_neighbors(SphHandle *h);

@@ -13,9 +13,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER = range(9)
 F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_NBR_COUNT, F_FORCE_EXT = range(9, 16)
+F_PRESS_ITER, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_A_II, F_D_IJ = range(16, 22)
 F_WALL_POS, F_WALL_VOL = 32, 33
 F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
-_VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT}
+_VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT,
+               F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ}
 _RIGID_FIELDS = {F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS}
 _WALL_FIELDS = {F_WALL_POS, F_WALL_VOL}
 
@@ -94,6 +96,8 @@ def _lib(precision):
             getattr(lib, name).restype = None
         lib.orc_step_wcsph.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.orc_step_dfsph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
+        lib.orc_step_pcisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
+        lib.orc_step_iisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
         lib.orc_cubic_kernel.restype = ctypes.c_float
         lib.orc_cubic_kernel.argtypes = [ctypes.c_float, ctypes.c_float]
         lib.orc_cubic_kernel_derivative.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
@@ -117,7 +121,7 @@ def config_from_dict(config, solver=None, num_threads=1):
     c.boundary_handle = 1 if sol.get("boundary_handle", True) else 0
     c.fs_couple = 1 if sol.get("fs_couple", True) else 0
     name = solver or sol["name"]
-    c.solver = {"wcsph": 0, "dfsph": 1}[name]
+    c.solver = {"wcsph": 0, "dfsph": 1, "pcisph": 2, "iisph": 3}[name]
     c.num_threads = int(num_threads)
     return c
 
@@ -211,6 +215,26 @@ class Oracle:
 
     def step_wcsph(self, nsteps=1):
         self._lib.orc_step_wcsph(self._h, nsteps)
+
+    def step_pcisph(self, nsteps=1):
+        """pcisph_solver.step; last_stats.n_dens = pressure iterations, dens_err = rho_err_avg.  Returns 1 at max_iteration."""
+        rc = self._lib.orc_step_pcisph(self._h, nsteps, ctypes.byref(self.last_stats))
+        assert rc >= 0, "oracle not created with solver pcisph"
+        return rc
+
+    def step_iisph(self, nsteps=1):
+        """iisph_solver.step; last_stats.n_dens = l, dens_err = residual, n_div = 1 if the loop left on 'trend to divergence'."""
+        rc = self._lib.orc_step_iisph(self._h, nsteps, ctypes.byref(self.last_stats))
+        assert rc >= 0, "oracle not created with solver iisph"
+        return rc
+
+    @property
+    def pcisph_delta(self):
+        return self._lib.orc_get_scalar(self._h, 5)
+
+    @property
+    def pcisph_max_index(self):
+        return int(self._lib.orc_get_scalar(self._h, 7)), int(self._lib.orc_get_scalar(self._h, 8))
 
     def step_dfsph(self, nsteps=1, max_dens_iter=0):
         """Returns 1 if the (non-reference) density-iteration cap was hit."""

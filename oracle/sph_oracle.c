@@ -75,6 +75,11 @@ struct Orc {
     real *alpha, *rho_adv, *rho_der, *vel_adv, *vel_adv_delta, *force_ext, *warm_k;
     int *nbr_cnt;
     long lost;
+    /* PCISPH (pcisph_solver.py:8-26) and IISPH (iisph_solver.py:10-29) fields */
+    real *pos_predict, *vel_predict, *press_force, *rho_err, *press_iter;   /* press_iter doubles as IISPH p_iter, press_force as f_press */
+    real *d_ii, *d_ij, *a_ii, *p_past, *p_new, *r_sum;
+    real pci_delta, pci_beta;
+    int pci_max_index, pci_max_count;
     /* rigid body (config 5): particles sampled from the mesh, ParticleSystem.py:41-64 */
     int Nv;                /* mesh vertices */
     int exist_rigid, active_rigid;
@@ -399,6 +404,10 @@ static void compute_all_boundary_volume(Orc *o)
     }
 }
 
+static void pcisph_init(Orc *o);
+static void iisph_init(Orc *o);
+void orc_compute_nbr_count(Orc *o);
+
 Orc *orc_create(const OrcConfig *cfg)
 {
     Orc *o = (Orc *)calloc(1, sizeof(Orc));
@@ -448,12 +457,20 @@ Orc *orc_create(const OrcConfig *cfg)
     ALLOC(o->vel_adv, real, 3 * N); ALLOC(o->vel_adv_delta, real, 3 * N);
     ALLOC(o->force_ext, real, 3 * N); ALLOC(o->warm_k, real, N);
     ALLOC(o->nbr_cnt, int, N);
+    if (c->solver >= 2) {
+        ALLOC(o->pos_predict, real, 3 * N); ALLOC(o->vel_predict, real, 3 * N); ALLOC(o->press_force, real, 3 * N);
+        ALLOC(o->rho_err, real, N); ALLOC(o->press_iter, real, N);
+        ALLOC(o->d_ii, real, 3 * N); ALLOC(o->d_ij, real, 3 * N); ALLOC(o->a_ii, real, N);
+        ALLOC(o->p_past, real, N); ALLOC(o->p_new, real, N); ALLOC(o->r_sum, real, N);
+    }
 #undef ALLOC
     init_particle_pos(o);                                       /* ParticleSystem.py:119 */
     /* init_particles_data                                         :225-247 */
     build_lists(o, o->Nb, o->bpos, o->bcell3, o->bcstart, o->bcitems);   /* :237-238 */
     orc_build_grid(o);                                                   /* :240-241 */
     compute_all_boundary_volume(o);                                      /* :243 */
+    if (c->solver == 2) pcisph_init(o);                                  /* pcisph_solver.__init__ */
+    if (c->solver == 3) iisph_init(o);                                   /* iisph_solver.__init__ */
     return o;
 }
 
@@ -466,6 +483,8 @@ void orc_destroy(Orc *o)
     free(o->rho); free(o->pressure); free(o->pgrad); free(o->bacc); free(o->visc); free(o->tens);
     free(o->alpha); free(o->rho_adv); free(o->rho_der); free(o->vel_adv); free(o->vel_adv_delta);
     free(o->force_ext); free(o->warm_k); free(o->nbr_cnt);
+    free(o->pos_predict); free(o->vel_predict); free(o->press_force); free(o->rho_err); free(o->press_iter);
+    free(o->d_ii); free(o->d_ij); free(o->a_ii); free(o->p_past); free(o->p_new); free(o->r_sum);
     free(o->rpos); free(o->rvol); free(o->rmass); free(o->rforce); free(o->rvert); free(o->rcell3);
     free(o);
 }
@@ -495,6 +514,12 @@ static real *field_ptr(Orc *o, int field, long *count, int *is_int)
     case ORC_F_PGRAD: *count = 3L * o->N; return o->pgrad;
     case ORC_F_BACC: *count = 3L * o->N; return o->bacc;
     case ORC_F_FORCE_EXT: *count = 3L * o->N; return o->force_ext;
+    case ORC_F_PRESS_ITER: *count = o->press_iter ? o->N : -1; return o->press_iter;
+    case ORC_F_PRESS_FORCE: *count = o->press_force ? 3L * o->N : -1; return o->press_force;
+    case ORC_F_POS_PREDICT: *count = o->pos_predict ? 3L * o->N : -1; return o->pos_predict;
+    case ORC_F_D_II: *count = o->d_ii ? 3L * o->N : -1; return o->d_ii;
+    case ORC_F_A_II: *count = o->a_ii ? o->N : -1; return o->a_ii;
+    case ORC_F_D_IJ: *count = o->d_ij ? 3L * o->N : -1; return o->d_ij;
     case ORC_F_WALL_POS: *count = 3L * o->Nb; return o->bpos;
     case ORC_F_WALL_VOL: *count = o->Nb; return o->bvol;
     case ORC_F_NBR_COUNT: *count = o->N; *is_int = 1; return NULL;
@@ -534,6 +559,10 @@ double orc_get_scalar(const Orc *o, int which)
     case 2: return (double)o->m;
     case 3: return (double)o->h;
     case 4: return (double)o->lost;
+    case 5: return (double)o->pci_delta;
+    case 6: return (double)o->pci_beta;
+    case 7: return (double)o->pci_max_index;
+    case 8: return (double)o->pci_max_count;
     case 10: case 11: case 12: return (double)o->centroid[which - 10];
     case 13: case 14: case 15: return (double)o->rs_omega[which - 13];
     case 16: case 17: case 18: return (double)o->r_vel[which - 16];
@@ -1446,6 +1475,459 @@ int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last)
             st.dens_err = (float)(rho_avg - o->rho0);
         }
         compute_all_position(o);
+        st.dt = (float)o->dt;
+        if (last) *last = st;
+    }
+    return capped;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * PCISPH                                                                  pcisph_solver.py
+ * press_iter / press_force / rho_err / pos_predict as in the reference; ext_force lives in force_ext.
+ * The neighbour SET always comes from the current positions (for_all_neighbor tests particle_j.pos,
+ * ParticleSystem.py:462-466); only the kernel argument uses the predicted positions (:155, :167).
+ * ------------------------------------------------------------------------------------- */
+static void clamp_bounds(const Orc *o, real lo[3], real hi[3])
+{
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = R(o->cfg.box_min[a]) + R(o->cfg.particle_radius);
+        hi[a] = R(o->cfg.box_max[a]) - R(o->cfg.particle_radius);
+    }
+}
+
+/* __init__ :8-26 and pre_compute :28-47 */
+static void pcisph_init(Orc *o)
+{
+    const OrcConfig *c = &o->cfg;
+    double r = c->particle_radius;
+    double m = 1000 * (r * r * r) * 8;
+    double dtf = (double)o->dt;                                        /* self.delta_time[None]: the f32 field read back as a Python float */
+    double beta = dtf * dtf * m * m * 2 / (double)(1000 * 1000);       /* :23, Python f64, left to right */
+    o->pci_beta = R(beta);
+    for (int i = 0; i < o->N; ++i) {                                   /* :13 */
+        o->force_ext[3 * i] = o->gravity * R(0); o->force_ext[3 * i + 1] = o->gravity * R(-1); o->force_ext[3 * i + 2] = o->gravity * R(0);
+    }
+    /* get_max_neighbor_particle_index, ParticleSystem.py:410-422, in single-thread order: atomic_max returns the OLD maximum,
+     * so max_index is the last particle whose count ties the running maximum */
+    orc_compute_nbr_count(o);
+    int max_count = -1, max_index = -1;
+    for (int i = 0; i < o->N; ++i) {
+        int cnt = o->nbr_cnt[i];
+        int old = max_count;
+        if (cnt > max_count) max_count = cnt;
+        if (old == cnt) max_index = i;
+    }
+    o->pci_max_index = max_index; o->pci_max_count = max_count;
+    real sx = 0, sy = 0, sz = 0, sq = 0;                               /* pre_compute_delta :41-47 */
+    if (max_index >= 0) {
+        const int i = max_index;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);           /* compute_sum :179-183 */
+            sx += gw[0]; sy += gw[1]; sz += gw[2];
+        });
+        FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);           /* compute_square_sum :185-190 */
+            sq += (gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2];
+        });
+    }
+    o->pci_delta = R(1) / ((((sx * sx + sy * sy) + sz * sz) + sq) * o->pci_beta);   /* :47 */
+}
+
+/* predict_vel_pos :73-89 */
+static void pci_predict_vel_pos(Orc *o)
+{
+    real lo[3], hi[3];
+    clamp_bounds(o, lo, hi);
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            int k = 3 * i + a;
+            o->vel_predict[k] = o->vel[k] + o->dt * (o->force_ext[k] + o->press_force[k]) / o->m;   /* :76 */
+            o->pos_predict[k] = o->pos[k] + o->dt * o->vel_predict[k];                              /* :77 */
+        }
+        if (!o->cfg.boundary_handle)
+            for (int a = 0; a < 3; ++a) {                                                           /* :79-89 */
+                int k = 3 * i + a;
+                if (o->pos_predict[k] <= lo[a]) { o->pos_predict[k] = lo[a]; o->vel_predict[k] *= R(-0.5); }
+                if (o->pos_predict[k] >= hi[a]) { o->pos_predict[k] = hi[a]; o->vel_predict[k] *= R(-0.5); }
+            }
+    }
+}
+
+/* predict_rho :91-103 */
+static void pci_predict_rho(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        const real *pp = o->pos_predict + 3 * i;
+        real rho_predict = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            (void)xij; (void)yij; (void)zij;
+            if (jm_ != 0) continue;                                     /* rigid neighbours: not restated for pcisph */
+            real x = pp[0] - o->pos_predict[3 * j], y = pp[1] - o->pos_predict[3 * j + 1], z = pp[2] - o->pos_predict[3 * j + 2];
+            real q = r_sqrt((x * x + y * y) + z * z);                   /* :155 */
+            rho_predict += cubic_kernel(q, o->h) * o->m;                /* :156 */
+        });
+        if (o->cfg.boundary_handle) {
+            real rho_boundary = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                (void)xij; (void)yij; (void)zij;
+                real x = pp[0] - o->bpos[3 * j], y = pp[1] - o->bpos[3 * j + 1], z = pp[2] - o->bpos[3 * j + 2];
+                real q = r_sqrt((x * x + y * y) + z * z);               /* :167 */
+                rho_boundary += cubic_kernel(q, o->h) * o->bvol[j];     /* :168 */
+            });
+            o->rho_adv[i] = rho_predict + rho_boundary * o->rho0;       /* :100  (rho_predict field kept in rho_adv) */
+        } else {
+            o->rho_adv[i] = rho_predict;
+        }
+        o->rho_err[i] = o->rho_adv[i] - o->rho0;                        /* :103 */
+    }
+}
+
+/* compute_residual :126-138 (mean accumulated in f64: the reference's f32 atomic order is unspecified) */
+static real pci_compute_residual(Orc *o)
+{
+    double sum = 0; long cnt = 0;
+    for (int i = 0; i < o->N; ++i) {
+        real err = r_max(o->rho_err[i], R(0.0));
+        if (err > 0) { sum += (double)err; cnt += 1; }
+    }
+    return cnt > 0 ? R(sum / (double)cnt) : R(0);
+}
+
+/* iter_press :105-109 */
+static void pci_iter_press(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        o->press_iter[i] += o->rho_err[i] * o->pci_delta;
+        o->press_iter[i] = r_max(R(0.0), o->press_iter[i]);
+    }
+}
+
+/* update_press_force :111-124 */
+static void pci_update_press_force(Orc *o)
+{
+    const real rho0_sq = R(1000 * 1000);                                /* self.rho_0 ** 2, Python int */
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real fx = 0, fy = 0, fz = 0;
+        const real p_i = o->press_iter[i];
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real ps = p_i + o->press_iter[j];
+            fx += ps * gw[0] / rho0_sq * o->m * o->m;                   /* :199 */
+            fy += ps * gw[1] / rho0_sq * o->m * o->m;
+            fz += ps * gw[2] / rho0_sq * o->m * o->m;
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            const real rho_i = o->rho[i];
+            const real rho_i_2 = rho_i * rho_i;                         /* :221 */
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = o->bvol[j] * p_i / rho_i_2;                    /* :223 */
+                bx -= s * gw[0]; by -= s * gw[1]; bz -= s * gw[2];
+            });
+            o->press_force[3 * i] = -fx + bx * o->rho0 * o->m;          /* :120 */
+            o->press_force[3 * i + 1] = -fy + by * o->rho0 * o->m;
+            o->press_force[3 * i + 2] = -fz + bz * o->rho0 * o->m;
+        } else {
+            o->press_force[3 * i] = -fx; o->press_force[3 * i + 1] = -fy; o->press_force[3 * i + 2] = -fz;   /* :122 */
+        }
+    }
+}
+
+/* integration :226-245 */
+static void pci_integration(Orc *o)
+{
+    real lo[3], hi[3];
+    clamp_bounds(o, lo, hi);
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            int k = 3 * i + a;
+            o->vel[k] = o->vel[k] + o->dt * (o->force_ext[k] + o->press_force[k]) / o->m;   /* :229-230 */
+            o->vel[k] *= R(0.9999);                                                         /* :231 */
+            o->pos[k] = o->pos[k] + o->dt * o->vel[k];                                      /* :232 */
+        }
+        if (!o->cfg.boundary_handle)
+            for (int a = 0; a < 3; ++a) {
+                int k = 3 * i + a;
+                if (o->pos[k] <= lo[a]) { o->pos[k] = lo[a]; o->vel[k] *= R(-0.5); }
+                if (o->pos[k] >= hi[a]) { o->pos[k] = hi[a]; o->vel[k] *= R(-0.5); }
+            }
+    }
+}
+
+/* pcisph_solver.step :252-259 */
+int orc_step_pcisph(Orc *o, int nsteps, OrcStepStats *last)
+{
+    if (o->cfg.solver != 2) return -1;
+    int capped = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        OrcStepStats st;
+        memset(&st, 0, sizeof(st));
+        o->simulate_cnt += 1;                                          /* solver_base.py:137 */
+        orc_build_grid(o);                                             /* :139-141 */
+        memset(o->press_iter, 0, sizeof(real) * (size_t)o->N);         /* reset() :247-250 */
+        memset(o->press_force, 0, sizeof(real) * 3 * (size_t)o->N);
+        orc_compute_rho(o);                                            /* compute_ext_force :237-244 */
+        solve_all_tension(o);
+        solve_all_viscosity(o);
+        {
+            const real g[3] = { o->gravity * R(0), o->gravity * R(-1), o->gravity * R(0) };
+            PARFOR
+            for (int i = 0; i < o->N; ++i)
+                for (int a = 0; a < 3; ++a)
+                    o->force_ext[3 * i + a] = (g[a] + o->tens[3 * i + a]) + o->visc[3 * i + a];   /* :243 */
+        }
+        int iter_cnt = 0;                                              /* iteration() :49-71 */
+        pci_predict_vel_pos(o);
+        pci_predict_rho(o);
+        real rho_err_avg = pci_compute_residual(o);
+        while (((double)rho_err_avg > 1000 * 0.1 * 0.01 || iter_cnt < 1) && iter_cnt < 80) {   /* :58 (host f64) */
+            pci_iter_press(o);
+            pci_update_press_force(o);
+            pci_predict_vel_pos(o);
+            pci_predict_rho(o);
+            rho_err_avg = pci_compute_residual(o);
+            iter_cnt += 1;
+        }
+        if (iter_cnt >= 80) capped = 1;
+        st.n_dens = iter_cnt;
+        st.dens_err = (float)rho_err_avg;
+        pci_integration(o);
+        st.dt = (float)o->dt;
+        if (last) *last = st;
+    }
+    return capped;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * IISPH                                                                    iisph_solver.py
+ * v_adv -> vel_adv, f_adv -> force_ext, p_iter -> press_iter, f_press -> press_force.
+ * cubic_kernel_derivative(-q) == -cubic_kernel_derivative(q) bit for bit (the norm is even, s*(-x) == -(s*x)).
+ * ------------------------------------------------------------------------------------- */
+static void iisph_init(Orc *o)
+{
+    for (int i = 0; i < o->N; ++i) {                                   /* :18: gravity * (0,-1,0) * m */
+        o->force_ext[3 * i] = o->gravity * R(0.0) * o->m; o->force_ext[3 * i + 1] = o->gravity * R(-1.0) * o->m; o->force_ext[3 * i + 2] = o->gravity * R(0.0) * o->m;
+    }
+}
+
+/* predict_advection :36-82 */
+static void iisph_predict_advection(Orc *o)
+{
+    orc_compute_rho(o);                                                /* :38 */
+    solve_all_tension(o);                                              /* :43 */
+    solve_all_viscosity(o);                                            /* :44 */
+    const real g[3] = { o->gravity * R(0), o->gravity * R(-1), o->gravity * R(0) };
+    PARFOR
+    for (int i = 0; i < o->N; ++i)
+        for (int a = 0; a < 3; ++a)
+            o->force_ext[3 * i + a] = (g[a] + o->tens[3 * i + a]) + o->visc[3 * i + a];       /* :46 */
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {                                                          /* :47-56 */
+        for (int a = 0; a < 3; ++a)
+            o->vel_adv[3 * i + a] = o->vel[3 * i + a] + o->dt * o->force_ext[3 * i + a] / o->m;   /* :48 */
+        const real rho_i = o->rho[i];
+        real dx = 0, dy = 0, dz = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real s = -o->m / (rho_i * rho_i);                           /* compute_d_ii :280 */
+            dx += s * gw[0]; dy += s * gw[1]; dz += s * gw[2];
+        });
+        if (o->cfg.boundary_handle) {
+            real bx = 0, by = 0, bz = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real s = -o->bvol[j] / (rho_i * rho_i);                 /* compute_boundary_d_ii :292 */
+                bx += s * gw[0]; by += s * gw[1]; bz += s * gw[2];
+            });
+            o->d_ii[3 * i] = (dx + bx * o->rho0) * o->dt * o->dt;       /* :54 */
+            o->d_ii[3 * i + 1] = (dy + by * o->rho0) * o->dt * o->dt;
+            o->d_ii[3 * i + 2] = (dz + bz * o->rho0) * o->dt * o->dt;
+        } else {
+            o->d_ii[3 * i] = dx * o->dt * o->dt; o->d_ii[3 * i + 1] = dy * o->dt * o->dt; o->d_ii[3 * i + 2] = dz * o->dt * o->dt;   /* :56 */
+        }
+    }
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {                                                          /* :58-82 */
+        const real rho_i = o->rho[i];
+        const real vx = o->vel_adv[3 * i], vy = o->vel_adv[3 * i + 1], vz = o->vel_adv[3 * i + 2];
+        const real dix = o->d_ii[3 * i], diy = o->d_ii[3 * i + 1], diz = o->d_ii[3 * i + 2];
+        const real cji = -o->dt * o->dt * o->m / (rho_i * rho_i);       /* scalar prefix of d_ji :302-303 */
+        real ra = 0, aii = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real ux = vx - o->vel_adv[3 * j], uy = vy - o->vel_adv[3 * j + 1], uz = vz - o->vel_adv[3 * j + 2];
+            ra += o->m * ((ux * gw[0] + uy * gw[1]) + uz * gw[2]);      /* compute_rho_adv :332 */
+        });
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real ex = dix - cji * -gw[0], ey = diy - cji * -gw[1], ez = diz - cji * -gw[2];
+            aii += o->m * ((ex * gw[0] + ey * gw[1]) + ez * gw[2]);     /* compute_a_ii :304 */
+        });
+        if (o->cfg.boundary_handle) {
+            real rb = 0, ab = 0;
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                rb += o->bvol[j] * ((vx * gw[0] + vy * gw[1]) + vz * gw[2]);                  /* :349 */
+            });
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                real ex = dix - cji * -gw[0], ey = diy - cji * -gw[1], ez = diz - cji * -gw[2];
+                ab += o->bvol[j] * ((ex * gw[0] + ey * gw[1]) + ez * gw[2]);                  /* compute_a_ii_boundary :322 */
+            });
+            o->rho_adv[i] = (ra + rb * o->rho0) * o->dt + rho_i;        /* :64 */
+            o->a_ii[i] = aii + ab * o->rho0;                            /* :75 */
+        } else {
+            o->rho_adv[i] = ra * o->dt + rho_i;                         /* :67 */
+            o->a_ii[i] = aii;
+        }
+        o->press_iter[i] = R(0.5) * o->p_past[i];                       /* :68 */
+    }
+}
+
+/* compute_all_d_ij :130-135 */
+static void iisph_compute_all_d_ij(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real dx = 0, dy = 0, dz = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            real a = -o->m * o->press_iter[j];
+            real den = o->rho[j] * o->rho[j];
+            dx += a * gw[0] / den; dy += a * gw[1] / den; dz += a * gw[2] / den;   /* compute_d_ij :327 */
+        });
+        o->d_ij[3 * i] = dx * o->dt * o->dt; o->d_ij[3 * i + 1] = dy * o->dt * o->dt; o->d_ij[3 * i + 2] = dz * o->dt * o->dt;   /* :135 */
+    }
+}
+
+/* update_p :137-157 */
+static void iisph_update_p(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        const real rho_i = o->rho[i];
+        const real p_i = o->press_iter[i];
+        const real cji = -o->dt * o->dt * o->m / (rho_i * rho_i);       /* :252-253 */
+        const real ax = o->d_ij[3 * i], ay = o->d_ij[3 * i + 1], az = o->d_ij[3 * i + 2];
+        real sum = 0, bsum = 0;
+        FOR_FLUID_NEIGHBORS(o, i, {
+            if (jm_ != 0) continue;
+            real gw[3];
+            cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            const real p_j = o->press_iter[j];
+            real djx = cji * -gw[0] * p_i, djy = cji * -gw[1] * p_i, djz = cji * -gw[2] * p_i;   /* d_ji */
+            real tx = ax - o->d_ii[3 * j] * p_j - (o->d_ij[3 * j] - djx);
+            real ty = ay - o->d_ii[3 * j + 1] * p_j - (o->d_ij[3 * j + 1] - djy);
+            real tz = az - o->d_ii[3 * j + 2] * p_j - (o->d_ij[3 * j + 2] - djz);
+            sum += o->m * ((tx * gw[0] + ty * gw[1]) + tz * gw[2]);     /* sum_factor :254 */
+        });
+        if (o->cfg.boundary_handle) {
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                real gw[3];
+                cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                bsum += ((ax * gw[0] + ay * gw[1]) + az * gw[2]) * o->bvol[j] * o->rho0;   /* sum_factor_boundary :240 */
+            });
+            o->r_sum[i] = sum + bsum;                                   /* :145 */
+        } else {
+            o->r_sum[i] = sum;
+        }
+    }
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {                                    /* :148-153 */
+        if (r_abs(o->a_ii[i]) > R(1e-7))
+            o->p_new[i] = R(0.5) * o->press_iter[i] + R(0.5) * ((o->rho0 - o->rho_adv[i]) - o->r_sum[i]) / o->a_ii[i];
+        else
+            o->p_new[i] = R(0.0);
+    }
+    PARFOR
+    for (int i = 0; i < o->N; ++i) o->press_iter[i] = r_max(o->p_new[i], R(0.0));   /* :155-156 */
+}
+
+/* compute_residual :110-121 */
+static real iisph_compute_residual(Orc *o)
+{
+    double sum = 0; long cnt = 0;
+    for (int i = 0; i < o->N; ++i)
+        if (o->press_iter[i] > 0) {
+            sum += (double)(((o->a_ii[i] * o->press_iter[i] + o->r_sum[i]) + o->rho_adv[i]) - R(1000));   /* :116 */
+            cnt += 1;
+        }
+    return cnt > 0 ? R(sum / (double)cnt) : R(0);
+}
+
+/* intergation :189-210 with compute_all_press_force :172-185 inlined */
+static void iisph_integration(Orc *o)
+{
+    real lo[3], hi[3];
+    clamp_bounds(o, lo, hi);
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            int k = 3 * i + a;
+            o->press_force[k] = (o->d_ij[k] + o->d_ii[k] * o->press_iter[i]) * o->m / (o->dt * o->dt);   /* :176 */
+            o->vel[k] = o->vel_adv[k] + o->dt * o->press_force[k] / o->m;                                /* :193 */
+            o->vel[k] *= R(0.9999);                                                                      /* :194 */
+            o->pos[k] = o->pos[k] + o->dt * o->vel[k];                                                   /* :195 */
+        }
+        if (!o->cfg.boundary_handle)
+            for (int a = 0; a < 3; ++a) {                                                                /* :198-207 */
+                int k = 3 * i + a;
+                if (o->pos[k] <= lo[a]) { o->pos[k] = lo[a]; o->vel[k] *= R(-0.5); }
+                if (o->pos[k] >= hi[a]) { o->pos[k] = hi[a]; o->vel[k] *= R(-0.5); }
+            }
+        o->p_past[i] = o->press_iter[i];                                                                 /* :209-210 */
+    }
+}
+
+/* iisph_solver.step :340-347 */
+int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last)
+{
+    if (o->cfg.solver != 3) return -1;
+    int capped = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        OrcStepStats st;
+        memset(&st, 0, sizeof(st));
+        o->simulate_cnt += 1;                                          /* solver_base.py:137; reset() is a no-op :31-33 */
+        orc_build_grid(o);
+        iisph_predict_advection(o);
+        int l = 0;                                                     /* pressure_solve :85-108 */
+        double residual = INFINITY, prev = 0;
+        int have_prev = 0;
+        const double err = 0.1 * 1000 * 0.01;                          /* :88 */
+        while ((residual > err || l < 1) && l < 180) {
+            iisph_compute_all_d_ij(o);
+            iisph_update_p(o);
+            l += 1;
+            residual = (double)iisph_compute_residual(o);
+            if (have_prev && residual - prev > 0) { st.n_div = 1; break; }   /* "Iteration trend to divergence" :97-99 */
+            prev = residual; have_prev = 1;
+        }
+        if (l >= 180) capped = 1;
+        st.n_dens = l;
+        st.dens_err = (float)residual;
+        iisph_integration(o);
         st.dt = (float)o->dt;
         if (last) *last = st;
     }

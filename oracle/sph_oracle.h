@@ -3,7 +3,7 @@
  *
  * This is a plain-C restatement of the arithmetic in the reference
  * (Jukgei/CFD_Taichi @ 2024_08_07): ParticleSystem.py, solver_base.py,
- * wcsph_solver.py, dfsph_solver.py.  It is NOT Taichi and NOT the reference itself.
+ * wcsph_solver.py, dfsph_solver.py, pcisph_solver.py, iisph_solver.py, rigid_solver.py.  It is NOT Taichi and NOT the reference itself.
  *
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this
  * path, and its runtime (taichi==1.6.0) is not installed in this image (plain
@@ -35,7 +35,7 @@ typedef struct OrcConfig {
     double water_size[3];
     int boundary_handle; /* 1 = Akinci wall particles (default), 0 = clamp walls */
     int fs_couple;       /* unused until rigid coupling is restated */
-    int solver;          /* 0 = wcsph, 1 = dfsph */
+    int solver;          /* 0 = wcsph, 1 = dfsph, 2 = pcisph, 3 = iisph */
     int num_threads;     /* OpenMP threads for the sweeps; results do not depend on it */
 } OrcConfig;
 
@@ -55,6 +55,9 @@ enum {
     ORC_F_ALPHA = 5, ORC_F_WARM_K = 6, ORC_F_RHO_ADV = 7, ORC_F_RHO_DER = 8,
     ORC_F_VEL_ADV = 9, ORC_F_VISCOSITY = 10, ORC_F_TENSION = 11, ORC_F_PGRAD = 12,
     ORC_F_BACC = 13, ORC_F_NBR_COUNT = 14, ORC_F_FORCE_EXT = 15,
+    ORC_F_PRESS_ITER = 16,   /* pcisph press_iter / iisph p_iter */
+    ORC_F_PRESS_FORCE = 17,  /* pcisph press_force / iisph f_press */
+    ORC_F_POS_PREDICT = 18, ORC_F_D_II = 19, ORC_F_A_II = 20, ORC_F_D_IJ = 21,
     ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33,
     ORC_F_RIGID_POS = 48, ORC_F_RIGID_VOL = 49, ORC_F_RIGID_FORCE = 50, ORC_F_RIGID_MASS = 51, ORC_F_RIGID_VERT = 52
 };
@@ -80,7 +83,7 @@ void orc_sizes(const Orc *o, int *out7);
 /* copies the whole field as float (3 floats per particle for vectors); returns element count or -1 */
 long orc_get(Orc *o, int field, float *out);
 long orc_set(Orc *o, int field, const float *in);
-double orc_get_scalar(const Orc *o, int which); /* 0 dt, 1 simulate_cnt, 2 particle_m, 3 h */
+double orc_get_scalar(const Orc *o, int which); /* 0 dt, 1 simulate_cnt, 2 particle_m, 3 h, 4 lost, 5 pcisph delta, 6 pcisph beta, 7/8 pcisph max-neighbour index/count */
 
 void orc_build_grid(Orc *o);               /* reset_grid + update_grid */
 void orc_compute_rho(Orc *o);              /* solver_base.compute_all_rho */
@@ -89,6 +92,9 @@ void orc_compute_nbr_count(Orc *o);        /* get_neighbour_count for all i -> O
 int orc_step_wcsph(Orc *o, int nsteps);
 /* max_dens_iter <= 0 means "no cap" like the reference */
 int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last);
+/* pcisph_solver.step / iisph_solver.step: last->n_dens = pressure iterations, last->dens_err = the printed residual */
+int orc_step_pcisph(Orc *o, int nsteps, OrcStepStats *last);
+int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last);
 
 /* scalar kernels, for the known-answer tests */
 float orc_cubic_kernel(float r, float h);

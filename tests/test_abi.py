@@ -66,7 +66,7 @@ def test_no_gpu_is_a_loud_error():
 def test_out_of_scope_solver_rejected():
     cfg = scenes.get("wcsph_tiny_wall")
     cfg["solver"]["name"] = "pbf"
-    with pytest.raises(ValueError):
+    with pytest.raises(NotImplementedError):
         _native.config_from_dict(cfg)
 
 
