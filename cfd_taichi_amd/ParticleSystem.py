@@ -82,8 +82,6 @@ class ParticleSystem:
     # ---- native handle management -------------------------------------------------------------
     def _make_sim(self, kind):
         cfg = nat.config_from_dict(self.config, solver_name=kind, **self._native_opts)
-        if self._rigid_input is not None and kind != "dfsph":
-            raise NotImplementedError("rigid-fluid coupling is built for the dfsph solver (BASELINE config 5) only")
         self._sim = nat.Simulation(cfg, rigid=self._rigid_input)
         self._solver_kind = kind
 

@@ -584,16 +584,35 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     }
 }
 
+// viscosity against a rigid neighbour (solver_base.py:190-201), shared by the ext-force sweeps: the body velocity is uniform,
+// and rho[particle_j.index] reads the FLUID density at the rigid particle's local index (quirk, :198-199)
+__device__ __forceinline__ void rigid_viscosity(const Consts &c, const RigidView &rv, const float4 vi, float rho_i, const float4 pj, uint32_t j,
+                                                float dx, float dy, float dz, float r, float &wx, float &wy, float &wz)
+{
+    float vx = vi.x - rv.vel[0], vy = vi.y - rv.vel[1], vz = vi.z - rv.vel[2];
+    float shear = dot3(vx, vy, vz, dx, dy, dz);
+    const int jl = rv.rid[j & ~kRigidTag];
+    if (shear < 0.f && jl < rv.n_fluid) {
+        F3 g = grad_w(c, dx, dy, dz, r);
+        float q2 = r * r;
+        float nu = c.visc_num / (rho_i + rv.rho_orig[jl]);
+        float pi_ = -nu * shear / (q2 + c.visc_eps_h2);
+        float sv = -1000.0f * pj.w * pi_;                               // :201
+        wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
+    }
+}
+
 // ======================================================================================
 // W2: WCSPH pressure gradient + wall pressure + viscosity + tension + kinematic phase
 //     wcsph_solver.py:70-129, solver_base.py:170-217, wcsph_solver.py:40-63
 //   reads P = (pos, rho), V = (vel, p/rho^2); writes the next state Pn = (pos', .), Vn = (vel', .), acc
 // ======================================================================================
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                         const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                         const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                         const float *__restrict__ pressure, float4 *__restrict__ Pn,
-                                                        float4 *__restrict__ Vn, float4 *__restrict__ acc_out)
+                                                        float4 *__restrict__ Vn, float4 *__restrict__ acc_out, RigidView rv)
 {
     SPH_SWEEP_PROLOGUE
     const float4 vi = V[ii];
@@ -602,10 +621,17 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
     float gx = 0.f, gy = 0.f, gz = 0.f;                      // pressure gradient
     float wx = 0.f, wy = 0.f, wz = 0.f;                      // viscosity
     float tx = 0.f, ty = 0.f, tz = 0.f;                      // tension
-    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+    const float p_own = (RIGID || c.boundary_handle) ? (live ? pressure[ii] : 0.f) : 0.f;
+    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            const float sr = -pj.w * p_own / (rho_i * rho_i);               // wcsph_solver.py:125
+            gx += sr * g.x * c.rho0; gy += sr * g.y * c.rho0; gz += sr * g.z * c.rho0;
+            rigid_viscosity(c, rv, vi, rho_i, pj, j, dx, dy, dz, r, wx, wy, wz);
+            return;
+        }
         float s = c.m * (a_i + vj.w);                        // wcsph_solver.py:116
         gx -= s * g.x; gy -= s * g.y; gz -= s * g.z;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
@@ -622,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
     });
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (c.boundary_handle) {
-        const float p_i = live ? pressure[ii] : 0.f;
+        const float p_i = p_own;
         const float rho_i_2 = rho_i * rho_i;
         for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

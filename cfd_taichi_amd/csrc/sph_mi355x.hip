@@ -68,6 +68,7 @@ struct SphHandle {
     int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
     float pci_delta = 0.f, pci_beta = 0.f;   // pcisph_solver.py:23-24, :47
     int pci_max_index = -1, pci_max_count = -1;
+    std::vector<float> pci_fluid_pos, rigid_pos_host;   // initial lattice / placed rigid samples, for pre_compute's 27-cell walk on the host
     int *cnt = nullptr;
     uint32_t *nl = nullptr, *nlb = nullptr;
     int *cell_of = nullptr, *rank = nullptr, *slot_src = nullptr;
@@ -864,6 +865,7 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     const float I[9] = {Ixx, Ixy, Ixz, Ixy, Iyy, Iyz, Ixz, Iyz, Izz};
     inverse3h(I, h->inertia_inv);                                                       // :291
     h->rs_dt = (float)h->cfg.delta_time;                                                // rigid_solver.py:13
+    h->rigid_pos_host = rpos;
     // device buffers
     int rc;
     const size_t nr = (size_t)Nr;
@@ -1156,9 +1158,14 @@ int stage_density(SphHandle *h)
                                (const int *)nullptr, (float *)nullptr);
     } else {
         ProfScope ps(h, K_W_DENSITY);
-        hipLaunchKernelGGL((k_density<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                           (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
-                           (const int *)nullptr, (float *)nullptr);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL((k_density<false, true>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                               (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view(h),
+                               h->id[h->icur], h->rho_orig);
+        else
+            hipLaunchKernelGGL((k_density<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                               (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
+                               (const int *)nullptr, (float *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1170,6 +1177,15 @@ int stage_density(SphHandle *h)
     return SPH_OK;
 }
 
+// force of the fluid on the body for wcsph (S = pressure) / pcisph / iisph (PB.w = press_iter / p_iter); see k_rigid_force_p
+template <int MODE>
+void launch_rigid_force_p(SphHandle *h, const float4 *P, const float4 *PB, int gate)
+{
+    ProfScope ps(h, K_RIGID);
+    hipLaunchKernelGGL(k_rigid_force_p<MODE>, grid_for(h->Nr), dim3(kBlock), 0, h->stream, h->c, h->Nr, h->RPs, h->rid, P, h->cell_start, h->rho,
+                       h->aux, PB, h->ds, h->rforce, gate);
+}
+
 int step_wcsph_once(SphHandle *h)
 {
     int rc;
@@ -1177,10 +1193,15 @@ int step_wcsph_once(SphHandle *h)
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     if ((rc = stage_density(h))) return rc;                 // wcsph_solver.py:34-35
     const Consts &c = h->c;
+    if (rigid_coupled(h)) launch_rigid_force_p<RF_WCSPH>(h, h->P[h->pcur], nullptr, GATE_NONE);   // wcsph_solver.py:127, positions of this step
     {
         ProfScope ps(h, K_W_FORCE);                          // wcsph_solver.py:36-38 + kinematic_phase :40-63
-        hipLaunchKernelGGL(k_wcsph_force, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
-                           h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0]);
+        if (rigid_coupled(h))
+            hipLaunchKernelGGL(k_wcsph_force<true>, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
+                               h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], rigid_view(h));
+        else
+            hipLaunchKernelGGL(k_wcsph_force<false>, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
+                               h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], RigidView());
         h->pcur ^= 1; h->vcur ^= 1;
     }
     HIP_TRY(h, hipGetLastError());
@@ -1463,17 +1484,24 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     hipStream_t s = h->stream;
     const dim3 g = grid_for(c.n), b(kBlock);
     const float dt = h->dt_wcsph;                           // delta_time never changes in pcisph
+    const bool rg = rigid_coupled(h);
+    const RigidView rv = rg ? rigid_view(h) : RigidView();
     float4 *EF = h->X[0], *PF = h->X[1], *PP = h->X[2], *PB[2] = {h->X[3], h->X[4]};
     const int cap = 80;                                     // max_iteration :21
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
-        hipLaunchKernelGGL(k_pci_ext, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP);
+        if (rg) hipLaunchKernelGGL(k_pci_ext<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
+        else hipLaunchKernelGGL(k_pci_ext<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
     }
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
-        hipLaunchKernelGGL(k_pci_predict_rho, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1], PB[(k + 1) & 1],
-                           h->rho_adv, h->psum, h->pcnt, gate);
+        if (rg)
+            hipLaunchKernelGGL(k_pci_predict_rho<true>, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
+                               PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv);
+        else
+            hipLaunchKernelGGL(k_pci_predict_rho<false>, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
+                               PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
     launch_pressure_finalize(h, PFIN_PCI_FIRST);
@@ -1482,9 +1510,14 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
-                hipLaunchKernelGGL(k_pci_press, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF, h->ds,
-                                   PF, PP, GATE_DENS);
+                if (rg)
+                    hipLaunchKernelGGL(k_pci_press<true>, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF,
+                                       h->ds, PF, PP, GATE_DENS, rv);
+                else
+                    hipLaunchKernelGGL(k_pci_press<false>, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF,
+                                       h->ds, PF, PP, GATE_DENS, rv);
             }
+            if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
             predict_rho(k, GATE_DENS);
             launch_pressure_finalize(h, PFIN_PCI_LOOP);
         }
@@ -1526,29 +1559,41 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     hipStream_t s = h->stream;
     const dim3 g = grid_for(c.n), b(kBlock);
     const float dt = h->dt_wcsph;
+    const bool rg = rigid_coupled(h);
+    const RigidView rv = rg ? rigid_view(h) : RigidView();
     float4 *DII = h->X[0], *DIJ = h->X[1], *FP = h->X[2], *PB[2] = {h->X[3], h->X[4]}, *VA = h->VA[0];
     const int cap = 180;                                    // max_iter_cnt :27
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_I_ADVECT);                        // :43-56
-        hipLaunchKernelGGL(k_ii_advect, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII);
+        if (rg) hipLaunchKernelGGL(k_ii_advect<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
+        else hipLaunchKernelGGL(k_ii_advect<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
     }
     {
         ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
-        hipLaunchKernelGGL(k_ii_rho_adv, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur], h->rho_adv,
-                           h->aux, PB[0]);
+        if (rg)
+            hipLaunchKernelGGL(k_ii_rho_adv<true>, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur],
+                               h->rho_adv, h->aux, PB[0], rv);
+        else
+            hipLaunchKernelGGL(k_ii_rho_adv<false>, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur],
+                               h->rho_adv, h->aux, PB[0], rv);
     }
     bool first = true;
     for (int k = 1, chunk = 2; k <= cap; chunk = chunk < 8 ? chunk * 2 : 8) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
-                hipLaunchKernelGGL(k_ii_dij, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS);
+                if (rg) hipLaunchKernelGGL(k_ii_dij<true>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
+                else hipLaunchKernelGGL(k_ii_dij<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
             }
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
-                hipLaunchKernelGGL(k_ii_update_p, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho, h->rho_adv,
-                                   h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS);
+                if (rg)
+                    hipLaunchKernelGGL(k_ii_update_p<true>, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho,
+                                       h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv);
+                else
+                    hipLaunchKernelGGL(k_ii_update_p<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho,
+                                       h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv);
             }
             launch_pressure_finalize(h, PFIN_II_LOOP);
         }
@@ -1568,6 +1613,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     st->dens_err = h->ds_host->dens_avg;
     st->dt = dt;
     h->pb_final = h->ds_host->dens_it & 1;
+    if (rg) launch_rigid_force_p<RF_IISPH>(h, h->P[h->pcur], PB[h->pb_final], GATE_NONE);   // compute_all_press_force :172-179
     {
         ProfScope ps(h, K_I_INTEGRATE);
         hipLaunchKernelGGL(k_ii_integrate, g, b, 0, s, c, dt, h->P[h->pcur], VA, DII, DIJ, PB[h->pb_final], h->P[1 - h->pcur], h->V[1 - h->vcur],
@@ -1595,7 +1641,7 @@ void grad_w_host(const Consts &c, float rx, float ry, float rz, float out[3])
 }
 
 // pcisph_solver.__init__ :23-26 + pre_compute :28-47: beta, the fullest neighbourhood of the initial lattice, delta
-int pcisph_precompute(SphHandle *h, const HostScene &sc)
+int pcisph_precompute(SphHandle *h)
 {
     int rc;
     const Consts &c = h->c;
@@ -1611,7 +1657,10 @@ int pcisph_precompute(SphHandle *h, const HostScene &sc)
     if ((rc = read_scalars(h))) return rc;
     if ((rc = check_overflow(h))) return rc;
     std::vector<float> counts((size_t)N);
-    hipLaunchKernelGGL(k_unsort_count, grid_for(N), dim3(kBlock), 0, h->stream, N, h->cnt, h->id[h->icur], h->staging);
+    if (rigid_coupled(h))   // get_neighbour_count with its rigid-entry quirk (ParticleSystem.py:436-444)
+        hipLaunchKernelGGL(k_unsort_scalar_int, grid_for(N), dim3(kBlock), 0, h->stream, N, h->ncount, h->id[h->icur], h->staging);
+    else
+        hipLaunchKernelGGL(k_unsort_count, grid_for(N), dim3(kBlock), 0, h->stream, N, h->cnt, h->id[h->icur], h->staging);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(counts.data(), h->staging, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1625,8 +1674,8 @@ int pcisph_precompute(SphHandle *h, const HostScene &sc)
     h->pci_max_index = max_index; h->pci_max_count = max_count;
     float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
     if (max_index >= 0) {
-        // for_all_neighbor(max_index) on the host: 27 cells, dx outermost, ascending particle id inside a cell
-        const float *pos = sc.fluid_pos.data();
+        // for_all_neighbor(max_index) on the host: 27 cells, dx outermost; inside a cell ascending fluid ids, then the rigid entries
+        const float *pos = h->pci_fluid_pos.data();
         auto cell = [&](const float *p, int cc[3]) { for (int a = 0; a < 3; ++a) cc[a] = (int)floorf(p[a] / c.h); };
         int ci[3];
         cell(pos + 3 * (size_t)max_index, ci);
@@ -1639,17 +1688,29 @@ int pcisph_precompute(SphHandle *h, const HostScene &sc)
             if (cj[0] < 0 || cj[0] >= c.gx || cj[1] < 0 || cj[1] >= c.gy || cj[2] < 0 || cj[2] >= c.gz) continue;
             bucket[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)].push_back(j);
         }
-        const float *pi = pos + 3 * (size_t)max_index;
-        for (int bk = 0; bk < 27; ++bk)
-            for (int j : bucket[bk]) {
-                if (j == max_index) continue;
-                const float x = pi[0] - pos[3 * (size_t)j], y = pi[1] - pos[3 * (size_t)j + 1], z = pi[2] - pos[3 * (size_t)j + 2];
-                if (sqrtf((x * x + y * y) + z * z) > c.h) continue;
-                float gw[3];
-                grad_w_host(c, x, y, z, gw);
-                sx += gw[0]; sy += gw[1]; sz += gw[2];                 // compute_sum :179-183
-                sq += (gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2]; // compute_square_sum :185-190
+        std::vector<int> rbucket[27];
+        if (rigid_coupled(h))
+            for (int j = 0; j < h->Nr; ++j) {
+                int cj[3];
+                cell(h->rigid_pos_host.data() + 3 * (size_t)j, cj);
+                const int dx = cj[0] - ci[0], dy = cj[1] - ci[1], dz = cj[2] - ci[2];
+                if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) continue;
+                rbucket[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)].push_back(j);
             }
+        const float *pi = pos + 3 * (size_t)max_index;
+        auto add = [&](const float *pj) {
+            const float x = pi[0] - pj[0], y = pi[1] - pj[1], z = pi[2] - pj[2];
+            if (sqrtf((x * x + y * y) + z * z) > c.h) return;
+            float gw[3];
+            grad_w_host(c, x, y, z, gw);
+            sx += gw[0]; sy += gw[1]; sz += gw[2];                 // compute_sum :179-183 (any material)
+            sq += (gw[0] * gw[0] + gw[1] * gw[1]) + gw[2] * gw[2]; // compute_square_sum :185-190
+        };
+        for (int bk = 0; bk < 27; ++bk) {
+            for (int j : bucket[bk])
+                if (j != max_index) add(pos + 3 * (size_t)j);
+            for (int j : rbucket[bk]) add(h->rigid_pos_host.data() + 3 * (size_t)j);
+        }
     }
     h->pci_delta = 1.0f / ((((sx * sx + sy * sy) + sz * sz) + sq) * h->pci_beta);   // :47
     return SPH_OK;
@@ -1713,7 +1774,10 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
         HostScene sc;
         if ((rc = build_scene(h, sc))) break;
         if ((rc = alloc_device(h, sc))) break;
-        if (h->cfg.solver == SPH_SOLVER_PCISPH && (rc = pcisph_precompute(h, sc))) break;
+        if (h->cfg.solver == SPH_SOLVER_PCISPH) {
+            h->pci_fluid_pos = sc.fluid_pos;
+            if ((rc = pcisph_precompute(h))) break;
+        }
         h->wall_pos_host = sc.wall_pos;
         h->wall_vol_host = sc.wall_vol;
     } while (0);
@@ -1729,13 +1793,13 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
 int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out)
 {
     if (!cfg || !rigid || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
-    if (cfg->solver != SPH_SOLVER_DFSPH) return fail(nullptr, SPH_E_INVALID, "rigid coupling is built for dfsph (BASELINE config 5) only");
     if (cfg->slab_count > 1) return fail(nullptr, SPH_E_INVALID, "rigid coupling is not available on slab handles");
     if (rigid->n_particles <= 0 || !rigid->points) return fail(nullptr, SPH_E_INVALID, "rigid body has no sample points");
     int rc = sph_create(cfg, out);
     if (rc) return rc;
     SphHandle *h = *out;
     rc = build_rigid(h, rigid);
+    if (!rc && h->cfg.solver == SPH_SOLVER_PCISPH) rc = pcisph_precompute(h);   // the solver is constructed after the ParticleSystem: the grid holds the body
     if (rc) {
         g_create_error = h->err;
         sph_destroy(h);
@@ -2059,7 +2123,7 @@ int sph_step_wcsph(SphHandle *h, int nsteps)
     // The WCSPH step is a fixed launch sequence with no host decision in it, so two steps (after which the ping-pong
     // buffers are back in the same roles) are captured once into a hipGraph and replayed: at 30k particles the step is
     // launch-bound and replay halves it.  Eager launches remain for odd remainders, profiling and slab handles.
-    if (h->graphs_enabled && !h->profiling && !h->slab && nsteps >= 2) {
+    if (h->graphs_enabled && !h->profiling && !h->slab && !h->rigid && nsteps >= 2) {
         while (nsteps - k >= 2) {
             const int key = h->pcur | (h->vcur << 1) | (h->icur << 2);
             if (!h->wcsph_graph[key]) {

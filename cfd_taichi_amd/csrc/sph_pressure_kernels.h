@@ -29,37 +29,53 @@ __device__ __forceinline__ float div_const(float a, float d, float rd)
     return __builtin_fmaf(e, rd, q0);
 }
 
-template <class Body>
+// fluid-list walkers; with RIGID the list may hold tagged rigid entries (bit 31): their position comes from rv.RP and the
+// other operands are undefined.  body(..., j): j & kRigidTag marks a rigid neighbour.
+template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_ps(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
-                                            const float *__restrict__ S, Body body)
+                                            const float *__restrict__ S, const RigidView &rv, Body body)
 {
     uint4 jn = *reinterpret_cast<const uint4 *>(base);
     for (int kk = 0; kk < cnt; kk += 4) {
         const uint4 jj = jn;
-        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
-        const float s0 = S[jj.x], s1 = S[jj.y], s2 = S[jj.z], s3 = S[jj.w];
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4]; float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = j[u] & ~kRigidTag;
+            a[u] = rg ? rv.RP[idx] : A[idx];
+            sc[u] = S[rg ? 0u : idx];
+        }
         jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
-        body(a0, s0);
-        if (kk + 1 < cnt) body(a1, s1);
-        if (kk + 2 < cnt) body(a2, s2);
-        if (kk + 3 < cnt) body(a3, s3);
+        body(a[0], sc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], sc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], sc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
     }
 }
-template <class Body>
+template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
-                                           const float4 *__restrict__ B, const float4 *__restrict__ C, Body body)
+                                           const float4 *__restrict__ B, const float4 *__restrict__ C, const RigidView &rv, Body body)
 {
     uint4 jn = *reinterpret_cast<const uint4 *>(base);
     for (int kk = 0; kk < cnt; kk += 4) {
         const uint4 jj = jn;
-        const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
-        const float4 b0 = B[jj.x], b1 = B[jj.y], b2 = B[jj.z], b3 = B[jj.w];
-        const float4 c0 = C[jj.x], c1 = C[jj.y], c2 = C[jj.z], c3 = C[jj.w];
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4], b[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = j[u] & ~kRigidTag;
+            a[u] = rg ? rv.RP[idx] : A[idx];
+            b[u] = B[rg ? 0u : idx];
+            cc[u] = C[rg ? 0u : idx];
+        }
         jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
-        body(a0, b0, c0);
-        if (kk + 1 < cnt) body(a1, b1, c1);
-        if (kk + 2 < cnt) body(a2, b2, c2);
-        if (kk + 3 < cnt) body(a3, b3, c3);
+        body(a[0], b[0], cc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], cc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], cc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], cc[3], j[3]);
     }
 }
 
@@ -134,10 +150,11 @@ __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 // ======================================================================================
 // compute_ext_force (:237-244: tension, viscosity, gravity) + reset() (:247-250) + the first predict_vel_pos (:73-89)
 //   reads P = (pos, rho), V = (vel, -)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                     float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
-                                                    float4 *__restrict__ PP)
+                                                    float4 *__restrict__ PP, RigidView rv)
 {
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
@@ -146,9 +163,10 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
     const float rho_i = pi.w;
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
-    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
+        if (RIGID && (j & kRigidTag)) { rigid_viscosity(c, rv, vi, rho_i, pj, j, dx, dy, dz, r, wx, wy, wz); return; }
         float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
@@ -184,19 +202,21 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
 
 // predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
 //   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delta, const float4 *__restrict__ P,
                                                             const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                             const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                             const DevScalars *__restrict__ ds, const float4 *__restrict__ PBin,
                                                             float4 *__restrict__ PBout, float *__restrict__ rho_predict,
-                                                            double *__restrict__ psum, int *__restrict__ pcnt, int gate)
+                                                            double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv)
 {
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
     float rp = 0.f;
-    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
-        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;           // :155-156
+    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
+        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;   // rigid entries: the body where it is now (:159-161)
+        if (RIGID && (j & kRigidTag)) rp += cubic_w(c, norm3(dx, dy, dz)) * pj.w * c.rho0;
+        else rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;      // :155-156
     });
     float rb = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -220,12 +240,13 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
 }
 
 // update_press_force (:111-124, :192-224) + predict_vel_pos (:73-89).   P here is PB = (pos, press_iter)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                       const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
                                                       const float4 *__restrict__ V, const float4 *__restrict__ EF,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
-                                                      float4 *__restrict__ PP, int gate)
+                                                      float4 *__restrict__ PP, int gate, RigidView rv)
 {
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
@@ -233,10 +254,17 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
     constexpr float kRho0Sq = 1000000.0f;                    // self.rho_0 ** 2 (Python int)
     constexpr float kRcpRho0Sq = 1.0f / 1000000.0f;
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+    const float rho_own = (RIGID || c.boundary_handle) ? rho[ii] : 1.0f;
+    const Recip rden = recip_prepare(rho_own * rho_own);     // rho_i ** 2, the divisor of every rigid term (:208)
+    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            const float a = pj.w * c.rho0 * p_i;                                  // :208
+            fx += div_shared(a * g.x, rden) * c.m; fy += div_shared(a * g.y, rden) * c.m; fz += div_shared(a * g.z, rden) * c.m;   // :210
+            return;
+        }
         float ps = p_i + pj.w;
         fx += div_const(ps * g.x, kRho0Sq, kRcpRho0Sq) * c.m * c.m;   // :199
         fy += div_const(ps * g.y, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
@@ -244,8 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
     });
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (c.boundary_handle) {
-        const float rho_i = rho[ii];
-        const float rho_i_2 = rho_i * rho_i;                 // :221
+        const float rho_i_2 = rho_own * rho_own;             // :221
         for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
@@ -302,10 +329,11 @@ __global__ __launch_bounds__(kBlock) void k_pci_integrate(Consts c, float dt, co
 // IISPH
 // ======================================================================================
 // predict_advection, first half (:43-56): tension, viscosity, f_adv, v_adv, d_ii.   P = (pos, rho), V = (vel, -)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
-                                                      float4 *__restrict__ VA, float4 *__restrict__ DII)
+                                                      float4 *__restrict__ VA, float4 *__restrict__ DII, RigidView rv)
 {
     SPH_SWEEP_PROLOGUE
     const float4 vi = V[ii];
@@ -314,10 +342,16 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
     float ex = 0.f, ey = 0.f, ez = 0.f;
-    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            const float sr = -pj.w * c.rho0 / (rho_i * rho_i);             // compute_d_ii :286
+            ex += sr * g.x; ey += sr * g.y; ez += sr * g.z;
+            rigid_viscosity(c, rv, vi, rho_i, pj, j, dx, dy, dz, r, wx, wy, wz);
+            return;
+        }
         ex += s_f * g.x; ey += s_f * g.y; ez += s_f * g.z;
         float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
@@ -364,23 +398,31 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
 }
 
 // predict_advection, second half (:58-82): rho_adv, p_iter = 0.5 p_past, a_ii.   P = (pos, rho), V = VA = (v_adv, -)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                        const float4 *__restrict__ DII, const float *__restrict__ p_past,
-                                                       float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0)
+                                                       float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0,
+                                                       RigidView rv)
 {
     SPH_SWEEP_PROLOGUE
     const float4 vi = V[ii], di = DII[ii];
     const float rho_i = pi.w;
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // scalar prefix of d_ji, compute_a_ii :302-303
     float ra = 0.f, aii = 0.f;
-    for_nbrs_pv(nlp, kf, P, V, [&](const float4 pj, const float4 vj) {
+    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
-        ra += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);        // compute_rho_adv :332
         float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;   // d_ii[i] - d_ji; gradW(-q) = -gradW(q)
+        if (RIGID && (j & kRigidTag)) {
+            const F3 w = rigid_velocity(rv, pj, dt, true);                             // compute_rho_adv :337-339
+            ra += pj.w * dot3(vi.x - w.x, vi.y - w.y, vi.z - w.z, g.x, g.y, g.z) * c.rho0;   // :342
+            aii += pj.w * dot3(ex, ey, ez, g.x, g.y, g.z) * c.rho0;                    // compute_a_ii :312
+            return;
+        }
+        ra += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);        // compute_rho_adv :332
         aii += c.m * dot3(ex, ey, ez, g.x, g.y, g.z);                                  // compute_a_ii :304
     });
     float rb = 0.f, ab = 0.f;
@@ -406,16 +448,18 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
 }
 
 // compute_all_d_ij (:130-135, :324-327).   P here is PB = (pos, p_iter)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
-                                                   const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate)
+                                                   const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv)
 {
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
     (void)kb; (void)nlbp;
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for_nbrs_ps(nlp, kf, P, rho, [&](const float4 pj, const float rho_j) {
+    for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, [&](const float4 pj, const float rho_j, const uint32_t j) {
+        if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -428,13 +472,14 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
 }
 
 // update_p (:137-157) + compute_residual partials (:110-121).   P = PBin = (pos, p_iter); writes PBout = (pos, new p_iter)
+template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ DII,
                                                         const float4 *__restrict__ DIJ, const float4 *__restrict__ WP,
                                                         const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                         const int *__restrict__ cnt, const float *__restrict__ rho,
                                                         const float *__restrict__ rho_adv, const float *__restrict__ a_ii,
                                                         const DevScalars *__restrict__ ds, float4 *__restrict__ PBout,
-                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate)
+                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv)
 {
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
@@ -443,10 +488,14 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // :252-253
     const float4 a = DIJ[ii];
     float sum = 0.f;
-    for_nbrs_3(nlp, kf, P, DII, DIJ, [&](const float4 pj, const float4 dj, const float4 ej) {
+    for_nbrs_3<RIGID>(nlp, kf, P, DII, DIJ, rv, [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            sum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor :261
+            return;
+        }
         float jx = cji * -g.x * p_i, jy = cji * -g.y * p_i, jz = cji * -g.z * p_i;     // d_ji
         float tx = a.x - dj.x * pj.w - (ej.x - jx);
         float ty = a.y - dj.y * pj.w - (ej.y - jy);
@@ -504,6 +553,59 @@ __global__ __launch_bounds__(kBlock) void k_ii_integrate(Consts c, float dt, con
     Vn[i] = make_float4(vel[0], vel[1], vel[2], 0.f);
     FP[i] = make_float4(fp[0], fp[1], fp[2], 0.f);
     p_past[i] = p_it;                                        // :209-210
+}
+
+// Force of the fluid on the rigid sample particles for wcsph / pcisph / iisph, gathered per rigid particle over its fluid
+// neighbours in cell-walk order like k_rigid_force (dfsph): no atomics, same serialisation as the oracle.
+//   RF_WCSPH  wcsph_solver.py:125-127   force += -ret * m,  ret = -V_j p_i / rho_i^2 * gradW * rho_0        (S = pressure[])
+//   RF_PCISPH pcisph_solver.py:208-210  force += ret * m,   ret = V_j rho_0 press_iter_i * gradW / rho_i^2   (PB.w, every iteration)
+//   RF_IISPH  iisph_solver.py:166-167   force += f * m,     f = V_j rho_0 / rho_i^2 * gradW * p_iter_i       (PB.w)
+enum { RF_WCSPH = 0, RF_PCISPH = 2, RF_IISPH = 3 };
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_rigid_force_p(Consts c, int nr, const float4 *__restrict__ RP, const int *__restrict__ rid,
+                                                          const float4 *__restrict__ P, const int *__restrict__ cell_start,
+                                                          const float *__restrict__ rho, const float *__restrict__ S,
+                                                          const float4 *__restrict__ PB, const DevScalars *__restrict__ ds,
+                                                          float *__restrict__ force, int gate)
+{
+    if (gate_closed(ds, gate)) return;
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= nr) return;
+    const float4 pr = RP[r];
+    int cx, cy, cz;
+    cell_id_of(c, pr.x, pr.y, pr.z, cx, cy, cz);
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
+                if (x < 0 || y < 0 || z < 0) continue;
+                int cid = x + y * c.sy + z * c.sz;
+                for (int i = cell_start[cid]; i < cell_start[cid + 1]; ++i) {
+                    const float4 pi = P[i];
+                    float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
+                    float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (r2 > c.r2_cut) continue;
+                    F3 g = grad_w(c, ddx, ddy, ddz, sqrtf(r2));
+                    const float rho_i = rho[i];
+                    if (MODE == RF_WCSPH) {
+                        const float s = -pr.w * S[i] / (rho_i * rho_i);                              // :125
+                        fx += -(s * g.x * c.rho0) * c.m; fy += -(s * g.y * c.rho0) * c.m; fz += -(s * g.z * c.rho0) * c.m;   // :127
+                    } else if (MODE == RF_PCISPH) {
+                        const float a = pr.w * c.rho0 * PB[i].w;                                     // :208
+                        const float den = rho_i * rho_i;
+                        fx += a * g.x / den * c.m; fy += a * g.y / den * c.m; fz += a * g.z / den * c.m;   // :209
+                    } else {
+                        const float s = pr.w * c.rho0 / (rho_i * rho_i);                             // :166
+                        const float p = PB[i].w;
+                        fx += s * g.x * p * c.m; fy += s * g.y * p * c.m; fz += s * g.z * p * c.m;   // :167
+                    }
+                }
+            }
+    const int o = rid[r];
+    force[3 * o] += fx; force[3 * o + 1] += fy; force[3 * o + 2] += fz;
 }
 
 }  // namespace sph

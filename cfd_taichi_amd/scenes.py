@@ -43,9 +43,9 @@ SCENES = {
     "wcsph_250k": lambda: _scene("wcsph", 2.5e-4, [10.0, 6.0, 2.7], [2.5, 5.0, 2.5]),
     "dfsph_1m": lambda: _scene("dfsph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
     "dfsph_10m": lambda: _scene("dfsph", 1e-3, [40.0, 15.0, 10.2], [10.0, 12.5, 10.0]),
-    # the solvers the reference's own configs name.  breaking_dam_30k.json:12 says iisph (dt 0.001 there);
+    # the solvers the reference's own configs name.  breaking_dam_30k.json:12 says iisph (delta_time 0.00025 there);
     # coupling_demo.json:16 says pcisph
-    "breaking_dam_30k_iisph": lambda: _scene("iisph", 1e-3, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
+    "breaking_dam_30k_iisph": lambda: _scene("iisph", 2.5e-4, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
     "breaking_dam_30k_pcisph": lambda: _scene("pcisph", 1e-3, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
     "iisph_1m": lambda: _scene("iisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
     "pcisph_1m": lambda: _scene("pcisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
@@ -71,6 +71,16 @@ SCENES.update({
     # reference config/coupling_demo.json geometry with the solver switched to dfsph (BASELINE config 5 is its x3.3 scale-up)
     "coupling_demo_dfsph": lambda: _with_solid(_scene("dfsph", 1e-4, [5.0, 7.0, 2.5], [1.5, 2.0, 2.3]),
                                                _CUBE, 1.0, [2.5, 0.9, 0.7], [0.0, 0.0, 90.0], 5000),
+    # the reference's four shipped solid configs, geometry and solver as shipped (the mesh is this package's copy of the cube1 geometry):
+    # config/coupling_demo.json, dam_flush_cube.json (pcisph), experiment1_config.json (iisph), experiment2_config.json (wcsph)
+    "coupling_demo": lambda: _with_solid(_scene("pcisph", 1e-4, [5.0, 7.0, 2.5], [1.5, 2.0, 2.3]),
+                                         _CUBE, 1.0, [2.5, 0.9, 0.7], [0.0, 0.0, 90.0], 5000),
+    "dam_flush_cube": lambda: _with_solid(_scene("pcisph", 1e-4, [5.0, 3.0, 1.5], [1.8, 2.8, 1.4]),
+                                          _CUBE, 1.0, [3.0, 0.0, 0.2], [0.0, 0.0, 0.0], 2000),
+    "experiment1": lambda: _with_solid(_scene("iisph", 2.5e-4, [2.5, 2.4, 1.5], [1.0, 2.0, 1.4]),
+                                       _CUBE, 0.6, [1.8, 0.0, 0.7], [0.0, 0.0, 0.0], 200),
+    "experiment2": lambda: _with_solid(_scene("wcsph", 2.5e-4, [2.5, 2.4, 1.5], [1.0, 2.0, 1.4]),
+                                       _CUBE, 0.6, [1.7, 0.6, 0.7], [0.0, 0.0, 90.0], 1000),
     "dfsph_rigid_2m": lambda: _with_solid(_scene("dfsph", 1e-3, [16.0, 12.0, 8.0], [5.0, 6.6, 7.6]),
                                           _CUBE, 3.3, [8.25, 2.97, 2.31], [0.0, 0.0, 90.0], 5000),
 })

@@ -630,9 +630,13 @@ static inline void rigid_predicted_velocity(const Orc *o, int jl, int with_alpha
     for (int a = 0; a < 3; ++a) out[a] = (o->r_vel[a] + o->r_acc[a] * o->dt) + vo[a];
 }
 
-/* dfsph_solver.py:212  rigid_particles[j].force += ret * particle_m, accumulated per rigid particle over its fluid
- * neighbours in cell-walk order (the reference uses atomics in thread order: any serialisation is valid) */
-static void rigid_accumulate_force(Orc *o)
+/* Force of the fluid on the rigid sample particles, accumulated per rigid particle over its fluid neighbours in cell-walk
+ * order (the reference uses atomics in thread order from inside the fluid sweeps: any serialisation is valid).
+ *   mode 0 wcsph   wcsph_solver.py:125-127   force += -ret * m,  ret = -V_j p_i / rho_i^2 * gradW * rho_0
+ *   mode 1 dfsph   dfsph_solver.py:204-212   force += ret * m,   ret = V_j rho_0 k_i / rho_i * gradW
+ *   mode 2 pcisph  pcisph_solver.py:208-210  force += ret * m,   ret = V_j rho_0 press_iter_i * gradW / rho_i^2   (every iteration)
+ *   mode 3 iisph   iisph_solver.py:166-167   force += force * m, force = V_j rho_0 / rho_i^2 * gradW * p_iter_i */
+static void rigid_accumulate_force_mode(Orc *o, int mode)
 {
     PARFOR
     for (int r = 0; r < o->Nr; ++r) {
@@ -650,16 +654,32 @@ static void rigid_accumulate_force(Orc *o)
                         if (i >= o->N) continue;                       /* fluid particles exert the force */
                         real xij = o->pos[3 * i] - pr[0], yij = o->pos[3 * i + 1] - pr[1], zij = o->pos[3 * i + 2] - pr[2];
                         if (r_sqrt((xij * xij + yij * yij) + zij * zij) > o->h) continue;
-                        real k_i = (o->rho_adv[i] - o->rho0) * o->alpha[i] / o->dt2;             /* :208 */
                         real gw[3];
                         cubic_kernel_derivative(xij, yij, zij, o->h, gw);
-                        real s = o->rvol[r] * o->rho0 * k_i / o->rho[i];                         /* :211 */
-                        fx += s * gw[0] * o->m; fy += s * gw[1] * o->m; fz += s * gw[2] * o->m;   /* :212 */
+                        if (mode == 1) {
+                            real k_i = (o->rho_adv[i] - o->rho0) * o->alpha[i] / o->dt2;             /* :208 */
+                            real s = o->rvol[r] * o->rho0 * k_i / o->rho[i];                         /* :211 */
+                            fx += s * gw[0] * o->m; fy += s * gw[1] * o->m; fz += s * gw[2] * o->m;   /* :212 */
+                        } else if (mode == 0) {
+                            real rho_i_2 = o->rho[i] * o->rho[i];
+                            real s = -o->rvol[r] * o->pressure[i] / rho_i_2;                         /* wcsph :125 */
+                            fx += -(s * gw[0] * o->rho0) * o->m; fy += -(s * gw[1] * o->rho0) * o->m; fz += -(s * gw[2] * o->rho0) * o->m;   /* :127 */
+                        } else if (mode == 2) {
+                            real a = o->rvol[r] * o->rho0 * o->press_iter[i];                        /* pcisph :208 */
+                            real den = o->rho[i] * o->rho[i];
+                            fx += a * gw[0] / den * o->m; fy += a * gw[1] / den * o->m; fz += a * gw[2] / den * o->m;   /* :209 */
+                        } else {
+                            real s = o->rvol[r] * o->rho0 / (o->rho[i] * o->rho[i]);                  /* iisph :166 */
+                            fx += s * gw[0] * o->press_iter[i] * o->m; fy += s * gw[1] * o->press_iter[i] * o->m;
+                            fz += s * gw[2] * o->press_iter[i] * o->m;                               /* :167 */
+                        }
                     }
                 }
         o->rforce[3 * r] += fx; o->rforce[3 * r + 1] += fy; o->rforce[3 * r + 2] += fz;
     }
 }
+static void rigid_accumulate_force(Orc *o) { rigid_accumulate_force_mode(o, 1); }
+static inline int rigid_coupled(const Orc *o) { return o->exist_rigid && o->active_rigid && o->cfg.fs_couple; }
 
 /* init_rigid_particles_pos + init_rigid_particles_data          ParticleSystem.py:198-223, 249-295 */
 static void init_rigid(Orc *o, const OrcRigid *rg)
@@ -736,7 +756,7 @@ static void init_rigid_data(Orc *o)
 
 Orc *orc_create_rigid(const OrcConfig *cfg, const OrcRigid *rg)
 {
-    if (cfg->solver != 1 || !rg || rg->n_particles <= 0) return NULL;   /* the rigid branches are restated for dfsph only */
+    if (!rg || rg->n_particles <= 0) return NULL;
     Orc *o = orc_create(cfg);
     o->exist_rigid = 1;
     o->active_rigid = rg->active ? 1 : 0;
@@ -753,6 +773,7 @@ Orc *orc_create_rigid(const OrcConfig *cfg, const OrcRigid *rg)
     orc_build_grid(o);                                                  /* :240-241 (now with the rigid particles) */
     init_rigid_data(o);                                                 /* :247 */
     o->rs_dt = R(cfg->delta_time);                                      /* rigid_solver.py:13 */
+    if (cfg->solver == 2) pcisph_init(o);                               /* the solver is constructed after the ParticleSystem: the grid holds the body */
     return o;
 }
 
@@ -987,9 +1008,17 @@ static void solve_all_pressure_gradient(Orc *o)
         const real rho_i_2 = rho_i * rho_i;                             /* :109 */
         const real p_i = o->pressure[i];
         FOR_FLUID_NEIGHBORS(o, i, {
+            real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real sr = -o->rvol[jl] * p_i / rho_i_2;             /* :125 */
+                    rx += sr * gw[0] * o->rho0; ry += sr * gw[1] * o->rho0; rz += sr * gw[2] * o->rho0;
+                }
+                continue;
+            }
             real p_j = o->pressure[j];
             real rho_j = o->rho[j];
-            real gw[3];
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real s = o->m * (p_i / rho_i_2 + p_j / (rho_j * rho_j));    /* :116 */
             rx -= s * gw[0]; ry -= s * gw[1]; rz -= s * gw[2];
@@ -1054,6 +1083,7 @@ int orc_step_wcsph(Orc *o, int nsteps)
         PARFOR
         for (int i = 0; i < o->N; ++i) o->pressure[i] = tait_pressure(o->rho[i]);   /* :66-68 */
         solve_all_pressure_gradient(o);                                /* :36 */
+        if (rigid_coupled(o)) rigid_accumulate_force_mode(o, 0);       /* :127 */
         solve_all_viscosity(o);                                        /* :37 */
         solve_all_tension(o);                                          /* :38 */
         wcsph_kinematic_phase(o);                                      /* :30 */
@@ -1565,7 +1595,14 @@ static void pci_predict_rho(Orc *o)
         real rho_predict = 0;
         FOR_FLUID_NEIGHBORS(o, i, {
             (void)xij; (void)yij; (void)zij;
-            if (jm_ != 0) continue;                                     /* rigid neighbours: not restated for pcisph */
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {                                 /* :157-161: predicted fluid position against the body where it is */
+                    real x = pp[0] - o->rpos[3 * jl], y = pp[1] - o->rpos[3 * jl + 1], z = pp[2] - o->rpos[3 * jl + 2];
+                    real q = r_sqrt((x * x + y * y) + z * z);
+                    rho_predict += cubic_kernel(q, o->h) * o->rvol[jl] * o->rho0;
+                }
+                continue;
+            }
             real x = pp[0] - o->pos_predict[3 * j], y = pp[1] - o->pos_predict[3 * j + 1], z = pp[2] - o->pos_predict[3 * j + 2];
             real q = r_sqrt((x * x + y * y) + z * z);                   /* :155 */
             rho_predict += cubic_kernel(q, o->h) * o->m;                /* :156 */
@@ -1616,8 +1653,16 @@ static void pci_update_press_force(Orc *o)
         real fx = 0, fy = 0, fz = 0;
         const real p_i = o->press_iter[i];
         FOR_FLUID_NEIGHBORS(o, i, {
-            if (jm_ != 0) continue;
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {                                 /* :200-211 */
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real a = o->rvol[jl] * o->rho0 * p_i;
+                    real den = o->rho[i] * o->rho[i];
+                    fx += a * gw[0] / den * o->m; fy += a * gw[1] / den * o->m; fz += a * gw[2] / den * o->m;
+                }
+                continue;
+            }
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real ps = p_i + o->press_iter[j];
             fx += ps * gw[0] / rho0_sq * o->m * o->m;                   /* :199 */
@@ -1694,6 +1739,7 @@ int orc_step_pcisph(Orc *o, int nsteps, OrcStepStats *last)
         while (((double)rho_err_avg > 1000 * 0.1 * 0.01 || iter_cnt < 1) && iter_cnt < 80) {   /* :58 (host f64) */
             pci_iter_press(o);
             pci_update_press_force(o);
+            if (rigid_coupled(o)) rigid_accumulate_force_mode(o, 2);   /* :209, once per iteration: the reset at :60 is commented out */
             pci_predict_vel_pos(o);
             pci_predict_rho(o);
             rho_err_avg = pci_compute_residual(o);
@@ -1739,8 +1785,15 @@ static void iisph_predict_advection(Orc *o)
         const real rho_i = o->rho[i];
         real dx = 0, dy = 0, dz = 0;
         FOR_FLUID_NEIGHBORS(o, i, {
-            if (jm_ != 0) continue;
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real sr = -o->rvol[jl] * o->rho0 / (rho_i * rho_i);  /* compute_d_ii :286 */
+                    dx += sr * gw[0]; dy += sr * gw[1]; dz += sr * gw[2];
+                }
+                continue;
+            }
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real s = -o->m / (rho_i * rho_i);                           /* compute_d_ii :280 */
             dx += s * gw[0]; dy += s * gw[1]; dz += s * gw[2];
@@ -1768,17 +1821,29 @@ static void iisph_predict_advection(Orc *o)
         const real cji = -o->dt * o->dt * o->m / (rho_i * rho_i);       /* scalar prefix of d_ji :302-303 */
         real ra = 0, aii = 0;
         FOR_FLUID_NEIGHBORS(o, i, {
-            if (jm_ != 0) continue;
             real gw[3];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) {                                 /* compute_rho_adv :333-342 */
+                    cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+                    real vj[3];
+                    rigid_predicted_velocity(o, jl, 1, vj);
+                    real ux = vx - vj[0], uy = vy - vj[1], uz = vz - vj[2];
+                    ra += o->rvol[jl] * ((ux * gw[0] + uy * gw[1]) + uz * gw[2]) * o->rho0;
+                }
+                continue;
+            }
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real ux = vx - o->vel_adv[3 * j], uy = vy - o->vel_adv[3 * j + 1], uz = vz - o->vel_adv[3 * j + 2];
             ra += o->m * ((ux * gw[0] + uy * gw[1]) + uz * gw[2]);      /* compute_rho_adv :332 */
         });
         FOR_FLUID_NEIGHBORS(o, i, {
-            if (jm_ != 0) continue;
             real gw[3];
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
             real ex = dix - cji * -gw[0], ey = diy - cji * -gw[1], ez = diz - cji * -gw[2];
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) aii += o->rvol[jl] * ((ex * gw[0] + ey * gw[1]) + ez * gw[2]) * o->rho0;   /* compute_a_ii :305-312 */
+                continue;
+            }
             aii += o->m * ((ex * gw[0] + ey * gw[1]) + ez * gw[2]);     /* compute_a_ii :304 */
         });
         if (o->cfg.boundary_handle) {
@@ -1833,9 +1898,12 @@ static void iisph_update_p(Orc *o)
         const real ax = o->d_ij[3 * i], ay = o->d_ij[3 * i + 1], az = o->d_ij[3 * i + 2];
         real sum = 0, bsum = 0;
         FOR_FLUID_NEIGHBORS(o, i, {
-            if (jm_ != 0) continue;
             real gw[3];
             cubic_kernel_derivative(xij, yij, zij, o->h, gw);
+            if (jm_ != 0) {
+                if (o->cfg.fs_couple) sum += ((ax * gw[0] + ay * gw[1]) + az * gw[2]) * o->rvol[jl] * o->rho0;   /* sum_factor :256-261 */
+                continue;
+            }
             const real p_j = o->press_iter[j];
             real djx = cji * -gw[0] * p_i, djy = cji * -gw[1] * p_i, djz = cji * -gw[2] * p_i;   /* d_ji */
             real tx = ax - o->d_ii[3 * j] * p_j - (o->d_ij[3 * j] - djx);
@@ -1927,6 +1995,7 @@ int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last)
         if (l >= 180) capped = 1;
         st.n_dens = l;
         st.dens_err = (float)residual;
+        if (rigid_coupled(o)) rigid_accumulate_force_mode(o, 3);       /* compute_all_press_force :172-179, before the positions move */
         iisph_integration(o);
         st.dt = (float)o->dt;
         if (last) *last = st;
