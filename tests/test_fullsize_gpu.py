@@ -99,3 +99,38 @@ def test_neighbour_pairs_against_kdtree_250k():
     hi = tree.query_ball_point(pos, 0.1 * (1 + 1e-5), return_length=True) - 1
     assert np.all(cnt >= lo) and np.all(cnt <= hi)
     sim.close()
+
+
+@pytest.mark.parametrize("scene,solver", [("pcisph_1m", "pcisph"), ("iisph_1m", "iisph")])
+def test_pressure_solvers_1m_first_steps_bit_exact_and_reproducible(scene, solver):
+    """PCISPH / IISPH on the 1 M dam break: two steps against the oracle bit for bit (state, iteration counts, residuals), then 20 more
+    steps twice -- the second run reproduces the first exactly and the state stays finite inside the box."""
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=cores())
+    g_step = sim.step_pcisph if solver == "pcisph" else sim.step_iisph
+    o_step = o.step_pcisph if solver == "pcisph" else o.step_iisph
+    if solver == "pcisph":
+        assert np.float32(sim.scalar(nat.S_PCISPH_DELTA)) == np.float32(o.pcisph_delta)
+    for _ in range(2):
+        st = g_step(1)
+        o_step(1)
+        assert (st.n_dens, st.dens_err) == (o.last_stats.n_dens, o.last_stats.dens_err)
+    assert np.array_equal(sim.download(nat.F_POS), o.get(orc.F_POS))
+    assert np.array_equal(sim.download(nat.F_VEL), o.get(orc.F_VEL))
+    assert np.array_equal(sim.download(nat.F_PRESS_ITER), o.get(orc.F_PRESS_ITER))
+    o.close()
+    runs = []
+    for k in range(2):
+        if k:
+            sim = nat.Simulation(nat.config_from_dict(cfg))
+            g_step = sim.step_pcisph if solver == "pcisph" else sim.step_iisph
+            g_step(2)
+        stats = [g_step(1) for _ in range(20)]
+        assert all(s.lost == 0 and s.capped == 0 for s in stats)
+        pos, vel = sim.download(nat.F_POS), sim.download(nat.F_VEL)
+        assert np.isfinite(pos).all() and np.isfinite(vel).all()
+        assert pos.min() >= 0.0 and np.all(pos.max(0) <= np.asarray(cfg["scene"]["box_max"], dtype=np.float32))
+        runs.append((pos, vel, [(s.n_dens, s.dens_err) for s in stats]))
+        sim.close()
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
