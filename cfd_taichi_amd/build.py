@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsph_mi355x.so")
 SOURCES = ["sph_mi355x.hip"]
-HEADERS = ["sph_device.h", "sph_kernels.h", os.path.join("..", "..", "include", "sph_mi355x.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "sph_mi355x.h")]
 
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -52,17 +52,32 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
 
 // `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost take no part in
 // the sort; the sorted arrays simply end after the live particles.
+// The arrays arrive in last step's cell order, so consecutive lanes mostly share a cell: a run of equal cells inside a wave
+// takes ONE atomic (its head lane adds the run length, every lane gets head's base + its offset in the run).  `rank` is only
+// a slot allocator -- k_order_gather establishes the canonical order inside a cell -- so any assignment is fine.
 __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, const int *__restrict__ dead,
                                                        int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count)
 {
-    int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= c.n) return;
-    if (dead && dead[s]) { cell_of[s] = -1; return; }
-    float4 p = P[s];
-    int cx, cy, cz;
-    int id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
-    cell_of[s] = id;
-    rank[s] = atomicAdd(&cell_count[id], 1);
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int id = -1;                                            // -1: no particle in this lane (past the end, or a dead slot)
+    if (s < c.n && !(dead && dead[s])) {
+        float4 p = P[s];
+        int cx, cy, cz;
+        id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+    }
+    if (s < c.n) cell_of[s] = id;
+    const int prev = __shfl_up(id, 1, 64);
+    const bool head = lane == 0 || prev != id;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // heads at lanes <= lane
+    const int start = 63 - __clzll(upto);                   // head lane of this lane's run (upto != 0: lane 0 is always a head)
+    const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int end = after ? lane + 1 + (__ffsll((long long)after) - 1) : 64;                  // one past the run's last lane
+    int base = 0;
+    if (head && id >= 0) base = atomicAdd(&cell_count[id], end - lane);
+    base = __shfl(base, start, 64);
+    if (id >= 0) rank[s] = base + (lane - start);
 }
 
 // exclusive scan, three launches: per-tile scan, scan of tile sums, add-back
@@ -241,18 +256,40 @@ __device__ __forceinline__ void for_fluid_nbrs(const uint32_t *__restrict__ base
 // (ParticleSystem.py:447-469, 337-366), done once per step because positions are frozen
 // between the grid rebuild and the integrator.
 // ======================================================================================
-// Appends one index to a lane's list; a full group of four is written with one 16-byte store.
-__device__ __forceinline__ void nl_push(uint32_t j, uint4 &g, int &k, uint32_t *__restrict__ base, int kcap)
+// Per-build maxima of the list lengths (health counters + the overflow flag).  Every wave used to issue two atomicMax on the
+// same two words: ~31 k same-address atomics at 1 M particles, serialised at ~12 ns each = 370 of the kernel's 470 us (measured by
+// removing everything else).  A relaxed device-scope load first: the stored maximum only grows during the kernel, so a wave whose
+// value does not exceed what it reads has nothing to add; only the few waves that raise the maximum touch it atomically.
+__device__ __forceinline__ void note_list_lengths(const Consts &c, int kf, int kb, DevScalars *__restrict__ ds)
 {
-    const int s = k & 3;
-    if (s == 0) g.x = j; else if (s == 1) g.y = j; else if (s == 2) g.z = j; else g.w = j;
-    if (s == 3 && k < kcap) *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = g;
-    ++k;
+    const int mf = wave_max(kf), mb = wave_max(kb);
+    if ((threadIdx.x & 63) == 0) {
+        if (mf > __hip_atomic_load(&ds->max_nbrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ds->max_nbrs, mf);
+        if (mb > __hip_atomic_load(&ds->max_wall_nbrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ds->max_wall_nbrs, mb);
+        if (mf > c.kmax || mb > c.kbmax) atomicOr(&ds->overflow, 1);
+    }
 }
-__device__ __forceinline__ void nl_flush(const uint4 &g, int k, uint32_t *__restrict__ base, int kcap)
-{
-    if ((k & 3) != 0 && k < kcap) *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = g;   // tail slots: stale but valid indices
-}
+
+// List append through an LDS staging row per lane (transposed: slot s of thread t at [s * kBlock + t], conflict-free): no
+// register shuffling on (k & 3), one 16-byte store per completed group of four.
+struct NlWriter {
+    uint32_t *stage;        // this thread's column of the block's staging area
+    uint32_t *base;
+    int k, kcap;
+    __device__ __forceinline__ void push(uint32_t j)
+    {
+        const int s = k & 3;
+        stage[s * kBlock] = j;
+        if (s == 3 && k < kcap)
+            *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], j);
+        ++k;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        if ((k & 3) != 0 && k < kcap)   // tail slots: stale but valid indices
+            *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
+    }
+};
 
 template <bool RIGID>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
@@ -261,18 +298,20 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
                                                      RigidView rv, int *__restrict__ ncount)
 {
+    __shared__ uint32_t s_stage[2][4 * kBlock];
     int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
     if (i == 0) ds->lost = cell_start[c.C + 1] - cell_start[c.C];   // size of the "outside the grid" bucket
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s_stage[0][q * kBlock + threadIdx.x] = 0; s_stage[1][q * kBlock + threadIdx.x] = 0; }
     if (i < c.n && id[i] < 0) {
         cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
     } else if (i < c.n) {
-        float4 pi = P[i];
+        const float4 pi = P[i];
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
-        uint32_t *fbase = nl + nl_index(i, 0, c.kmax);
-        uint32_t *wbase = nlb + nl_index(i, 0, c.kbmax);
-        uint4 gf = make_uint4(0, 0, 0, 0), gw = make_uint4(0, 0, 0, 0);
+        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kmax), 0, c.kmax};
+        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbmax), 0, c.kbmax};
         int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
         const int my_id = RIGID ? id[i] : 0;
         for (int dx = -1; dx <= 1; ++dx)
@@ -282,21 +321,24 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
                     if (x < 0 || y < 0 || z < 0) continue;
                     int cid = x + y * c.sy + z * c.sz;
-                    int a = cell_start[cid], b = cell_start[cid + 1];
-                    // candidates four at a time: the loads are independent, only the accept/push order is sequential
+                    const int a = cell_start[cid], b = cell_start[cid + 1];
+                    // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
                     for (int j0 = a; j0 < b; j0 += 4) {
-                        float4 pc[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) pc[u] = P[j0 + u < b ? j0 + u : a];
+                        unsigned m = 0;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int j = j0 + u;
-                            if (j >= b || j == i) continue;                  // :461
-                            float ddx = pi.x - pc[u].x, ddy = pi.y - pc[u].y, ddz = pi.z - pc[u].z;
+                            const float4 pc = P[j < b ? j : a];
+                            float ddx = pi.x - pc.x, ddy = pi.y - pc.y, ddz = pi.z - pc.z;
                             float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                            if (r2 > c.r2_cut) continue;                     // :466  (norm > h)
-                            nl_push((uint32_t)j, gf, kf, fbase, c.kmax);
-                            if (RIGID) ++nq;
+                            const bool hit = (j < b) & (j != i) & !(r2 > c.r2_cut);   // :461, :466 (norm > h)
+                            m |= (hit ? 1u : 0u) << u;
+                        }
+                        if (RIGID) nq += __popc(m);
+                        while (m) {
+                            const int u = __ffs(m) - 1;
+                            m &= m - 1;
+                            wf.push((uint32_t)(j0 + u));
                         }
                     }
                     if (RIGID) {
@@ -306,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                             const float4 pj = rv.RP[j];
                             float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                             float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                            if (!(r2 > c.r2_cut)) nl_push((uint32_t)j | kRigidTag, gf, kf, fbase, c.kmax);
+                            if (!(r2 > c.r2_cut)) wf.push((uint32_t)j | kRigidTag);
                             // get_neighbour_count (:436-444): skips when particle_j.index == i (the rigid particle's LOCAL index) and
                             // measures the distance to fluid_particles.pos[particle_j.index]
                             const int jl = rv.rid[j];
@@ -319,28 +361,33 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         }
                     }
                     if (c.boundary_handle) {
-                        int wa = wcell_start[cid], wb = wcell_start[cid + 1];
-                        for (int j = wa; j < wb; ++j) {
-                            float4 pj = WP[j];
-                            float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
-                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                            if (r2 > c.r2_cut) continue;                 // :364
-                            nl_push((uint32_t)j, gw, kb, wbase, c.kbmax);
+                        const int wa = wcell_start[cid], wb = wcell_start[cid + 1];
+                        for (int j0 = wa; j0 < wb; j0 += 4) {
+                            unsigned m = 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = j0 + u;
+                                const float4 pj = WP[j < wb ? j : wa];
+                                float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                                float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                                m |= (((j < wb) & !(r2 > c.r2_cut)) ? 1u : 0u) << u;   // :364
+                            }
+                            while (m) {
+                                const int u = __ffs(m) - 1;
+                                m &= m - 1;
+                                ww.push((uint32_t)(j0 + u));
+                            }
                         }
                     }
                 }
-        nl_flush(gf, kf, fbase, c.kmax);
-        nl_flush(gw, kb, wbase, c.kbmax);
+        wf.flush();
+        ww.flush();
+        kf = wf.k; kb = ww.k;
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
         cnt[i] = kfc | (kbc << 16);
         if (RIGID) ncount[i] = nq;
     }
-    int mf = wave_max(kf), mb = wave_max(kb);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&ds->max_nbrs, mf);
-        atomicMax(&ds->max_wall_nbrs, mb);
-        if (mf > c.kmax || mb > c.kbmax) atomicOr(&ds->overflow, 1);
-    }
+    note_list_lengths(c, kf, kb, ds);
 }
 
 // ======================================================================================

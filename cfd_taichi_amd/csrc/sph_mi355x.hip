@@ -66,6 +66,7 @@ struct SphHandle {
     float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr;
     float4 *X[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pcisph: EF, PF, PP, PB0, PB1; iisph: DII, DIJ, f_press, PB0, PB1
     int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
+    int last_iters = 2;          // iteration count of the last step's density / pressure loop: size of the next step's first chunk
     float pci_delta = 0.f, pci_beta = 0.f;   // pcisph_solver.py:23-24, :47
     int pci_max_index = -1, pci_max_count = -1;
     std::vector<float> pci_fluid_pos, rigid_pos_host;   // initial lattice / placed rigid samples, for pre_compute's 27-cell walk on the host
@@ -1357,31 +1358,17 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     launch_div_residual(h, GATE_NONE);                                               // :398
     launch_finalize(h, FIN_DIV_FIRST);
-    bool first = true;
-    for (int done = 0; done < 15;) {
-        const int chunk = 5;
-        for (int k = 0; k < chunk && done < 15; ++k, ++done) {
-            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
-            launch_div_residual(h, GATE_DIV);                                                 // :408
-            launch_finalize(h, FIN_DIV_LOOP);
-        }
-        if ((rc = read_scalars(h))) return rc;
-        if (first) {
-            if ((rc = check_overflow_all(h))) return rc;     // first read-back of the step: list overflow?
-            first = false;
-        }
-        if (!h->ds_host->div_active) break;
+    // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
+    // and the host does not need the outcome before the density loop's first read-back
+    for (int done = 0; done < 15; ++done) {
+        launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
+        launch_div_residual(h, GATE_DIV);                                                 // :408
+        launch_finalize(h, FIN_DIV_LOOP);
     }
-    st->max_nbrs = h->ds_host->max_nbrs;
-    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
-    st->lost = h->ds_host->lost;
-    st->n_div = h->ds_host->div_it;
-    st->n_div_evals = h->ds_host->div_evals;
-    st->div_first_err = h->ds_host->div_first;
-    st->div_err = h->ds_host->div_err;
     if ((rc = dfsph_ext_and_dt(h))) return rc;
-    // ---- correct_density_error, :221-233 ----
-    for (int chunk = 2;; chunk = chunk < 8 ? chunk * 2 : 8) {
+    // ---- correct_density_error, :221-233: first chunk = last step's iteration count (it changes slowly), then two at a time ----
+    bool first = true;
+    for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
             launch_dens_residual(h, GATE_DENS);                                      // :227
             launch_finalize(h, FIN_DENS);
@@ -1389,8 +1376,20 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
         }
         if ((rc = read_scalars(h))) return rc;
+        if (first) {
+            if ((rc = check_overflow_all(h))) return rc;     // first read-back of the step: list overflow?
+            first = false;
+        }
         if (!h->ds_host->dens_active) break;
     }
+    h->last_iters = h->ds_host->dens_it;
+    st->max_nbrs = h->ds_host->max_nbrs;
+    st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
+    st->lost = h->ds_host->lost;
+    st->n_div = h->ds_host->div_it;
+    st->n_div_evals = h->ds_host->div_evals;
+    st->div_first_err = h->ds_host->div_first;
+    st->div_err = h->ds_host->div_err;
     st->n_dens = h->ds_host->dens_it;
     st->capped = h->ds_host->dens_capped;
     st->dens_err = (float)((double)h->ds_host->dens_avg - 1000.0);
@@ -1506,7 +1505,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     predict_rho(0, GATE_NONE);                              // :53-56
     launch_pressure_finalize(h, PFIN_PCI_FIRST);
     bool first = true;
-    for (int k = 1, chunk = 2; k <= cap; chunk = chunk < 8 ? chunk * 2 : 8) {
+    for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
@@ -1536,6 +1535,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     st->dens_err = h->ds_host->dens_avg;
     st->dt = dt;
     h->pb_final = h->ds_host->dens_it & 1;
+    h->last_iters = h->ds_host->dens_it;
     {
         ProfScope ps(h, K_P_INTEGRATE);
         hipLaunchKernelGGL(k_pci_integrate, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], EF, PF, h->P[1 - h->pcur], h->V[1 - h->vcur]);
@@ -1579,7 +1579,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
                                h->rho_adv, h->aux, PB[0], rv);
     }
     bool first = true;
-    for (int k = 1, chunk = 2; k <= cap; chunk = chunk < 8 ? chunk * 2 : 8) {
+    for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
@@ -1613,6 +1613,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     st->dens_err = h->ds_host->dens_avg;
     st->dt = dt;
     h->pb_final = h->ds_host->dens_it & 1;
+    h->last_iters = h->ds_host->dens_it;
     if (rg) launch_rigid_force_p<RF_IISPH>(h, h->P[h->pcur], PB[h->pb_final], GATE_NONE);   // compute_all_press_force :172-179
     {
         ProfScope ps(h, K_I_INTEGRATE);

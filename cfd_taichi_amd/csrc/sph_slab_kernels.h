@@ -47,30 +47,45 @@ __global__ __launch_bounds__(kBlock) void k_column_histogram(Consts c, const flo
     }
 }
 
+// One atomicAdd per wave instead of one per particle on the same counter (same-address atomics serialise at ~12 ns each:
+// 100 k edge particles would cost over a millisecond): the lanes that want a slot are counted with a ballot, the first of them
+// reserves the block of slots, every lane takes base + its rank among the wanting lanes.
+__device__ __forceinline__ int wave_alloc(int *__restrict__ counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 // (1) previous ghosts die; owned particles that left the slab are packed for the neighbour and die here.
 __global__ __launch_bounds__(kBlock) void k_classify_migrate(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                              const float *__restrict__ warm, const int *__restrict__ id,
                                                              int *__restrict__ dead, float4 *__restrict__ send_left,
                                                              float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
 {
-    int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= c.n) return;
-    int pid = id[s];
-    if (pid < 0) { dead[s] = 1; atomicAdd(&counters[2], 1); return; }
-    float4 p = P[s];
-    int cx = (int)floorf(p.x / c.h);
-    int d = 0;
-    if (g.has_left && cx < g.x_lo) {
-        int slot = atomicAdd(&counters[0], 1);
-        if (slot < cap_records) write_record(send_left, slot, p, V[s], warm ? warm[s] : 0.f, pid);
-        d = 1;
-    } else if (g.has_right && cx >= g.x_hi) {
-        int slot = atomicAdd(&counters[1], 1);
-        if (slot < cap_records) write_record(send_right, slot, p, V[s], warm ? warm[s] : 0.f, pid);
-        d = 1;
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const bool in = s < c.n;
+    const int pid = in ? id[s] : 0;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool go_left = false, go_right = false;
+    if (in && pid >= 0) {
+        p = P[s];
+        const int cx = (int)floorf(p.x / c.h);
+        go_left = g.has_left && cx < g.x_lo;
+        go_right = !go_left && g.has_right && cx >= g.x_hi;
     }
-    dead[s] = d;
-    if (d) atomicAdd(&counters[2], 1);
+    const bool dies = in && (pid < 0 || go_left || go_right);       // last step's ghosts, and owned particles that left the slab
+    const int sl = wave_alloc(&counters[0], go_left);
+    const int sr = wave_alloc(&counters[1], go_right);
+    (void)wave_alloc(&counters[2], dies);
+    if (go_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, pid);
+    if (go_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, pid);
+    if (in) dead[s] = dies ? 1 : 0;
 }
 
 // (2)/(4) received records are appended behind the resident particles
@@ -95,21 +110,23 @@ __global__ __launch_bounds__(kBlock) void k_classify_ghost(Consts c, SlabGeom g,
                                                            const int *__restrict__ dead, float4 *__restrict__ send_left,
                                                            float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
 {
-    int s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= c.n) return;
-    if (dead[s]) return;
-    int pid = id[s];
-    if (pid < 0) return;
-    float4 p = P[s];
-    int cx = (int)floorf(p.x / c.h);
-    if (g.has_left && cx == g.x_lo) {
-        int slot = atomicAdd(&counters[0], 1);
-        if (slot < cap_records) write_record(send_left, slot, p, V[s], warm ? warm[s] : 0.f, pid);
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    bool to_left = false, to_right = false;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pid = 0;
+    if (s < c.n && !dead[s]) {
+        pid = id[s];
+        if (pid >= 0) {
+            p = P[s];
+            const int cx = (int)floorf(p.x / c.h);
+            to_left = g.has_left && cx == g.x_lo;
+            to_right = g.has_right && cx == g.x_hi - 1;
+        }
     }
-    if (g.has_right && cx == g.x_hi - 1) {
-        int slot = atomicAdd(&counters[1], 1);
-        if (slot < cap_records) write_record(send_right, slot, p, V[s], warm ? warm[s] : 0.f, pid);
-    }
+    const int sl = wave_alloc(&counters[0], to_left);
+    const int sr = wave_alloc(&counters[1], to_right);
+    if (to_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, pid);
+    if (to_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, pid);
 }
 
 // Ordered list of the sorted slots that live in cell column `layer_cx`: cells ascending (y, then z), slots
