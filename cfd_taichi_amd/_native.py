@@ -30,7 +30,7 @@ EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
-    "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math",
+    "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_tune_time",
     "sph_set_comm", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
@@ -172,6 +172,7 @@ def load(build_if_missing=True):
     lib.sph_profile_kernel_name.restype = ctypes.c_char_p
     lib.sph_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
+    lib.sph_tune_time.argtypes = [vp, ci, ctypes.c_uint, ci, ctypes.POINTER(ctypes.c_double)]
     lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
     lib.sph_rigid_step.argtypes = [vp]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
@@ -385,6 +386,11 @@ class Simulation:
         return ids[keep], vals[keep]
 
     # ---- profiling (HIP events on the handle's stream) ----
+    def tune_time(self, which, lds_bytes=0, reps=10):
+        out = ctypes.c_double()
+        self._check(self._lib.sph_tune_time(self._h, which, lds_bytes, reps, ctypes.byref(out)))
+        return out.value
+
     def profile_enable(self, on=True):
         self._check(self._lib.sph_profile_enable(self._h, 1 if on else 0))
 

@@ -11,7 +11,10 @@
 
 namespace sph {
 
-constexpr int kBlock = 256;
+#ifndef SPH_KBLOCK
+#define SPH_KBLOCK 256
+#endif
+constexpr int kBlock = SPH_KBLOCK;   // threads per workgroup of every kernel (tuning knob at build time)
 
 // Launch-invariant constants, passed to kernels by value (lands in SGPRs).
 struct Consts {

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *_
 }
 
 // exclusive scan, three launches: per-tile scan, scan of tile sums, add-back
-constexpr int kScanTile = 1024;   // 256 threads x 4
+constexpr int kScanTile = kBlock * 4;   // four entries per thread
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(const int *__restrict__ in, int *__restrict__ out,
                                                        int *__restrict__ tile_sums, int n)
 {

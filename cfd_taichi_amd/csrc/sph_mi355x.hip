@@ -66,6 +66,7 @@ struct SphHandle {
     float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr;
     float4 *X[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pcisph: EF, PF, PP, PB0, PB1; iisph: DII, DIJ, f_press, PB0, PB1
     int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
+    unsigned sweep_lds = 0;      // experiment knob SPH_SWEEP_LDS: dynamic LDS bytes per block on the DFSPH sweeps (caps the waves per CU)
     int last_iters = 2;          // iteration count of the last step's density / pressure loop: size of the next step's first chunk
     float pci_delta = 0.f, pci_beta = 0.f;   // pcisph_solver.py:23-24, :47
     int pci_max_index = -1, pci_max_count = -1;
@@ -1230,11 +1231,11 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+        hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
                            h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h),
                            h->ncount, gate);
     else
-        hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+        hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
                            h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
                            (const int *)nullptr, gate);
 }
@@ -1245,10 +1246,10 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     const Consts &c = h->c;
     ProfScope ps(h, kid);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_correct<MODE, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+        hipLaunchKernelGGL((k_correct<MODE, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
                            h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view(h), gate);
     else
-        hipLaunchKernelGGL((k_correct<MODE, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+        hipLaunchKernelGGL((k_correct<MODE, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
                            h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate);
 }
 
@@ -1257,11 +1258,11 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<true, true>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+        hipLaunchKernelGGL((k_residual<true, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
                            h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount,
                            gate);
     else
-        hipLaunchKernelGGL((k_residual<true, false>), grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+        hipLaunchKernelGGL((k_residual<true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
                            h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
                            (const int *)nullptr, gate);
 }
@@ -1768,6 +1769,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = getenv("SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
+    { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     int rc = SPH_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }
@@ -2264,6 +2266,40 @@ int sph_profile_get(SphHandle *h, int kid, double *total_ms, int64_t *launches)
     drain_profile(h);
     if (total_ms) *total_ms = h->prof_ms[kid];
     if (launches) *launches = h->prof_n[kid];
+    return SPH_OK;
+}
+
+// Tuning aid (not part of the reference's surface): mean duration in microseconds of `reps` back-to-back launches of one DFSPH sweep
+// on the handle's current state with `lds_bytes` of dynamic LDS, bracketed by one HIP event pair.  which: 0 = divergence residual
+// (idempotent), 1 = divergence correction (advances the velocities: use a throw-away handle), 2 = density residual, 3 = sort + list build.
+int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)
+{
+    if (!h || !avg_us || reps < 1) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_DFSPH || h->slab) return fail(h, SPH_E_STATE, "sph_tune_time needs a single-GPU dfsph handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if (!h->nl_valid && (rc = stage_sort_and_lists(h))) return rc;
+    if (!h->density_valid && (rc = stage_density(h))) return rc;
+    const unsigned saved = h->sweep_lds;
+    h->sweep_lds = lds_bytes;
+    hipEvent_t a, b;
+    HIP_TRY(h, hipEventCreate(&a));
+    HIP_TRY(h, hipEventCreate(&b));
+    HIP_TRY(h, hipEventRecord(a, h->stream));
+    for (int k = 0; k < reps; ++k) {
+        if (which == 0) launch_div_residual(h, GATE_NONE);
+        else if (which == 1) launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
+        else if (which == 2) launch_dens_residual(h, GATE_NONE);
+        else if ((rc = stage_sort_and_lists(h))) break;
+    }
+    HIP_TRY(h, hipEventRecord(b, h->stream));
+    HIP_TRY(h, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    h->sweep_lds = saved;
+    if (which == 3) h->density_valid = false;
+    *avg_us = (double)ms * 1000.0 / reps;
     return SPH_OK;
 }
 

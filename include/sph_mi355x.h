@@ -243,6 +243,9 @@ int sph_download_ids(SphHandle *h, int32_t *host, size_t n);
  * compiler flags as the sweeps (op 0: a/b, 1: sqrt(a), 2: cubic_kernel(a, h=b), 3..5:
  * component op-3 of cubic_kernel_derivative((a, b, 0.25*a), h=0.1)).  Used by tests to prove
  * the device's f32 divide/sqrt are correctly rounded like the oracle's. */
+/* tuning aid: mean microseconds of `reps` launches of one dfsph sweep (0 divergence residual, 1 divergence correction, 2 density
+ * residual, 3 sort + list build) with `lds_bytes` of dynamic LDS per block; see tools/tune_sweeps.py */
+int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us);
 int sph_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
 
 #ifdef __cplusplus

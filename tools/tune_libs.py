@@ -1,0 +1,31 @@
+"""Interleaved timing of the DFSPH sweeps for SEVERAL builds of the library inside one process (one clock state):
+    tools/tune_libs.py scene advance_steps name=path[:lds] ...
+Each build gets its own handle on the same scene advanced by the same steps; rounds alternate between the builds."""
+import os
+import random
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfd_taichi_amd import _native as nat, scenes  # noqa: E402
+
+scene, advance = sys.argv[1], int(sys.argv[2])
+sims = {}
+for spec in sys.argv[3:]:
+    name, rest = spec.split("=", 1)
+    path, _, lds = rest.partition(":")
+    nat._lib = None
+    os.environ["SPH_LIB"] = os.path.abspath(path)
+    sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
+    sim.step_dfsph(advance)
+    sim.build_neighbors()
+    sims[name] = (sim, int(lds or 0))
+for which, label in ((0, "div_residual"), (2, "dens_residual"), (1, "div_correct"), (3, "sort+build_nl")):
+    res = {n: [] for n in sims}
+    order = list(sims)
+    for _ in range(int(os.environ.get("TUNE_ROUNDS", "12"))):
+        random.shuffle(order)          # the clock reacts to what ran just before: randomise the order, compare medians
+        for n in order:
+            sim, lds = sims[n]
+            res[n].append(sim.tune_time(which, lds, 10 if which != 3 else 4))
+    print(label, {n: (round(min(t), 1), round(statistics.median(t), 1)) for n, t in res.items()})
