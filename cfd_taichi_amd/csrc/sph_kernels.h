@@ -323,12 +323,15 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     int cid = x + y * c.sy + z * c.sz;
                     const int a = cell_start[cid], b = cell_start[cid + 1];
                     // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
+                    // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
+                    // is harmless: the arrays carry 64 spare elements and the accept mask drops them)
                     for (int j0 = a; j0 < b; j0 += 4) {
                         unsigned m = 0;
+                        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int j = j0 + u;
-                            const float4 pc = P[j < b ? j : a];
+                            const float4 pc = pb[u];
                             float ddx = pi.x - pc.x, ddy = pi.y - pc.y, ddz = pi.z - pc.z;
                             float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                             const bool hit = (j < b) & (j != i) & !(r2 > c.r2_cut);   // :461, :466 (norm > h)
@@ -364,10 +367,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         const int wa = wcell_start[cid], wb = wcell_start[cid + 1];
                         for (int j0 = wa; j0 < wb; j0 += 4) {
                             unsigned m = 0;
+                            const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(WP) + (unsigned)j0 * 16u);
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const int j = j0 + u;
-                                const float4 pj = WP[j < wb ? j : wa];
+                                const float4 pj = pb[u];
                                 float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
                                 float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                                 m |= (((j < wb) & !(r2 > c.r2_cut)) ? 1u : 0u) << u;   // :364

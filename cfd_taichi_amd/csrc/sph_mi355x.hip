@@ -495,7 +495,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     const size_t n = (size_t)c.stride;
     int rc;
     for (int k = 0; k < 2; ++k) {
-        if ((rc = dalloc(h, &h->P[k], n))) return rc;
+        if ((rc = dalloc(h, &h->P[k], n + 64))) return rc;      // k_build_nl reads whole groups of four candidates
         if ((rc = dalloc(h, &h->V[k], n))) return rc;
         if ((rc = dalloc(h, &h->VA[k], n))) return rc;
         if ((rc = dalloc(h, &h->warm[k], n))) return rc;
@@ -533,7 +533,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
     if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
     if ((rc = dalloc(h, &h->tile_sums, (size_t)h->ntiles))) return rc;
-    if ((rc = dalloc(h, &h->WP, (size_t)h->Nb))) return rc;
+    if ((rc = dalloc(h, &h->WP, (size_t)h->Nb + 64))) return rc;
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
     const size_t nblocks_cap = (n + kBlock - 1) / kBlock;
