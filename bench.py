@@ -217,8 +217,14 @@ def main():
             step = sim.step_pcisph if solver_kind == "pcisph" else sim.step_iisph
             for _ in range(nsteps):
                 st = step(1)
+                if has_rigid:
+                    sim.rigid_step()
                 if stats is not None:
                     stats.append((0, st.n_dens, 0))
+        elif has_rigid:
+            for _ in range(nsteps):
+                sim.step_wcsph(1)
+                sim.rigid_step()
         else:
             sim.step_wcsph(nsteps)
 
