@@ -39,8 +39,11 @@ def assert_same(a, b, what):
 
 def test_device_divide_sqrt_are_ieee():
     rng = np.random.default_rng(7)
-    a = np.concatenate([rng.uniform(1e-6, 10, 200000), rng.uniform(1e-30, 1e-20, 1000), [0.0, 1.0, 0.1, 1e-38]]).astype(np.float32)
-    b = np.concatenate([rng.uniform(1e-3, 2000, 200000), rng.uniform(1e-3, 10, 1000), [1.0, 3.0, 0.1, 7.0]]).astype(np.float32)
+    wide = (10.0 ** rng.uniform(-44, 38, 100000)).astype(np.float32)     # denormals to near-overflow
+    edge = np.array([0.0, 1.0, 0.1, 1e-38, 1e-30, 1e30, 9.99e-31, 1.0001e30, 1e-45, 3.4e38], dtype=np.float32)
+    a = np.concatenate([rng.uniform(1e-6, 10, 200000), rng.uniform(1e-30, 1e-20, 1000), wide, edge]).astype(np.float32)
+    b = np.concatenate([rng.uniform(1e-3, 2000, 200000), rng.uniform(1e-3, 10, 1000), rng.uniform(1e-3, 10, len(wide)),
+                        rng.uniform(1.0, 7.0, len(edge))]).astype(np.float32)
     assert_same(nat.selftest_math(0, a, b), (a / b).astype(np.float32), "a/b")
     assert_same(nat.selftest_math(1, a, b), np.sqrt(a).astype(np.float32), "sqrt(a)")
 
