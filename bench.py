@@ -103,16 +103,20 @@ def cpu_baseline(scene_name, solver_kind):
             "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt}
 
 
-def load_traffic(kernel):
+def load_traffic(kernel, key="hbm_bytes_per_launch"):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        return data.get("kernels", {}).get(kernel, {}).get(key)
     except Exception:
         return None
+
+
+# wave64 VALU issue peak: one non-packed f32 instruction per cycle per CU (4 SIMDs x 16 lanes), 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK_GINST = 256 * 2.4
 
 
 def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0):
@@ -298,6 +302,12 @@ def main():
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
                            "note": "gather sweep, not HBM-streaming bound: ~36 L1 line accesses per wave-gather and ~52 f32 VALU instr per pair share the time (PMC, DESIGN.md section 6c)"}
+        insts = load_traffic(dom, "sq_insts_valu_per_launch") if world == 1 and scene_name == "dfsph_1m" else None
+        if insts:
+            # second opinion on the same kernel: the reference's arithmetic needs ~50 f32 instructions per pair for < 1 algorithmic byte,
+            # so the instruction-issue ceiling is reached long before the HBM one (PMC count from profiles/pmc_traffic.json)
+            out["roofline"]["valu"] = {"wave_insts_per_launch": insts, "achieved": insts / avg_s / 1e9, "peak": VALU_PEAK_GINST,
+                                       "unit": "G wave64-inst/s", "frac": insts / avg_s / 1e9 / VALU_PEAK_GINST}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     if has_rigid:

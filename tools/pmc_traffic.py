@@ -2,7 +2,10 @@
 """Turns two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md's
 HBM section prescribes) into profiles/pmc_traffic.json: HBM bytes per launch for every kernel.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write N_particles [out.json]
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write N_particles [out.json] [gpurun_out/pmc_sq]
+
+With a third pass directory (--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES) every kernel also gets its wave-level
+instruction counts per launch: bench.py prices the dominant kernel against the VALU issue peak with them.
 
 Units and gfx950 corrections (MI355X_MICROARCH.md section HBM): the counters are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so the
@@ -50,6 +53,14 @@ def collect(directory, counter):
     return vals
 
 
+def live(vals):
+    """Launches of a gated sweep that exit at their first instruction (the loop had ended) count almost nothing: keep the real ones."""
+    if not vals:
+        return vals
+    top = max(vals)
+    return [v for v in vals if v >= 0.5 * top] if top > 0 else vals
+
+
 def main():
     fetch_dir, write_dir, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     out_path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
@@ -68,14 +79,25 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
-        fr = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [])), 1) * 1024
-        wr = sum(write.get(k, [0])) / max(len(write.get(k, [])), 1) * 1024
+        fl, wl = live(fetch.get(k, [])), live(write.get(k, []))
+        fr = sum(fl) / max(len(fl), 1) * 1024
+        wr = sum(wl) / max(len(wl), 1) * 1024
         kernels[profile_name(k)] = {
             "kernel": k, "launches_sampled": len(fetch.get(k, [])),
             "fetch_bytes_raw_per_launch": fr, "write_bytes_per_launch": wr,
             "hbm_bytes_per_launch": fr * fetch_factor + wr,
             "hbm_bytes_per_particle": (fr * fetch_factor + wr) / n,
         }
+    if len(sys.argv) > 5:
+        sq = {c: collect(sys.argv[5], c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_BUSY_CYCLES")}
+        for k in sorted(sq["SQ_INSTS_VALU"]):
+            if not k.startswith("k_"):
+                continue
+            entry = kernels.setdefault(profile_name(k), {"kernel": k})
+            for c, vals in sq.items():
+                if vals.get(k):
+                    lv = live(vals[k])
+                    entry[c.lower() + "_per_launch"] = sum(lv) / len(lv)
     out = {"n_particles": n, "counter_unit": "KiB", "fetch_correction": fetch_factor, "calibration": calib, "kernels": kernels,
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes)"}
     with open(out_path, "w") as f:
