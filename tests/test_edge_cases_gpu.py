@@ -1,0 +1,65 @@
+"""GPU suite, edge cases (the reference has no tests; these are the degenerate inputs its code paths imply):
+ragged particle counts far below one wave / one workgroup, a single particle, coincident particles (r = 0 takes the q <= 1e-5
+branch of the kernel derivative, solver_base.py:96), and particles resting exactly on a cell face.  All four solvers, against
+the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from cfd_taichi_amd import _native as nat
+from cfd_taichi_amd import scenes
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+SOLVERS = ["wcsph", "dfsph", "pcisph", "iisph"]
+
+
+def tiny_scene(solver, water, start=(0.1, 0.1, 0.1), walls=True):
+    cfg = scenes.get("dfsph_tiny_wall" if walls else "dfsph_tiny_clamp")
+    cfg["solver"]["name"] = solver
+    cfg["solver"]["delta_time"] = 2.5e-4 if solver == "wcsph" else 1e-3
+    cfg["fluid"]["water_size"] = list(water)
+    cfg["fluid"]["start_pos"] = list(start)
+    return cfg
+
+
+def step_both(sim, o, solver, n):
+    for _ in range(n):
+        if solver == "wcsph":
+            sim.step_wcsph(1); o.step_wcsph(1)
+        elif solver == "dfsph":
+            st = sim.step_dfsph(1); o.step_dfsph(1, 100)
+            assert (st.n_div, st.n_dens) == (o.last_stats.n_div, o.last_stats.n_dens)
+        else:
+            st = sim.step(1)
+            (o.step_pcisph if solver == "pcisph" else o.step_iisph)(1)
+            assert st.n_dens == o.last_stats.n_dens
+    for f, of in ((nat.F_POS, orc.F_POS), (nat.F_VEL, orc.F_VEL), (nat.F_RHO, orc.F_RHO)):
+        a, b = sim.download(f), o.get(of)
+        assert np.array_equal(a, b, equal_nan=True), (solver, f, a[:4], b[:4])
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("water", [(0.05, 0.05, 0.05), (0.35, 0.05, 0.05), (0.36, 0.16, 0.16), (0.26, 0.66, 0.06)])
+def test_ragged_particle_counts(solver, water):
+    """N = int(wx/d * wy/d * wz/d) (ParticleSystem.py:85-86): 1, 6, 73 and 82 particles -- below one wave, just above one wave."""
+    cfg = tiny_scene(solver, water, start=(0.05, 0.05, 0.05))
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=2)
+    assert sim.n_fluid == o.N and 1 <= o.N < 128
+    step_both(sim, o, solver, 25)
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_coincident_particles_and_cell_faces(solver):
+    cfg = tiny_scene(solver, (0.3, 0.3, 0.3), start=(0.3, 0.3, 0.3), walls=False)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=2)
+    pos = o.get(orc.F_POS)
+    pos[5] = pos[4]                                     # two particles in the same place: |x_ij| = 0
+    pos[17] = pos[16] + np.float32(1e-7)                # q just above the 1e-5 gate's lower end
+    pos[40] = np.float32([0.4, 0.5, 0.6])               # exactly on cell faces (h = 0.1)
+    o.set(orc.F_POS, pos)
+    sim.upload(nat.F_POS, pos)
+    step_both(sim, o, solver, 15)
+    sim.close(); o.close()
