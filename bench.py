@@ -119,7 +119,7 @@ def load_traffic(kernel, key="hbm_bytes_per_launch"):
 VALU_PEAK_GINST = 256 * 2.4
 
 
-def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0):
+def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0, stream_ordered=None):
     """Single-GPU handle, or this rank's slab of the sharded simulation."""
     cfg = scenes.get(scene_name)
     if world == 1:
@@ -134,7 +134,8 @@ def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, 
     slab.rank, slab.world = rank, world
     slab.solver = cfg["solver"]["name"]
     slab.sim = nat.Simulation(c)
-    slab.comm = TorchComm(rank, world, device=local_rank, capacity_bytes=128 << 20, group=transport_group)
+    slab.comm = TorchComm(rank, world, device=local_rank, capacity_bytes=128 << 20, group=transport_group, stream_ptr=slab.sim.stream_ptr(),
+                          stream_ordered=stream_ordered)
     slab.sim.set_comm(slab.comm.struct)
     slab.n_fluid = slab.sim.n_fluid
     return slab.sim, slab
@@ -171,6 +172,30 @@ def pick_transport(dist, torch, rank, world, local_rank):
     return gloo, "gloo (host staged: RCCL probe failed)"
 
 
+def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance):
+    """The stream-ordered RCCL discipline (no host waits around halo refreshes and residual all-reduces) must give the very bytes the
+    synchronous discipline gives: two steps of the workload in each, SHA-1 of every rank's owned particles, agreement all-reduced."""
+    import hashlib
+    import numpy as np
+    digests = []
+    for ordered in (True, False):
+        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, None, rebalance, stream_ordered=ordered)
+        if ordered and not slab.comm.stream_ordered:
+            sim.close()
+            return False
+        for _ in range(2):
+            (sim.step_dfsph if slab.solver == "dfsph" else sim.step_wcsph)(1)
+        hsh = hashlib.sha1()
+        for f in (nat.F_POS, nat.F_VEL):
+            ids, vals = sim.download_owned(f)
+            hsh.update(np.ascontiguousarray(vals[np.argsort(ids, kind="stable")]).tobytes())
+        digests.append(hsh.hexdigest())
+        sim.close()
+    t = torch.tensor([1 if digests[0] == digests[1] else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,7 +229,15 @@ def main():
     scene_name = args.workload or ("dfsph_1m" if world == 1 else "dfsph_10m")
     cfg = scenes.get(scene_name)
     solver_kind = cfg["solver"]["name"]
-    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance)
+    stream_ordered = None
+    if world > 1 and not rehearsal and transport_group is None:      # RCCL device-to-device transport
+        if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
+            stream_ordered, transport = False, transport + ", synchronous discipline (SPH_SLAB_SYNC=1)"
+        elif verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance):
+            stream_ordered, transport = True, transport + ", stream-ordered (checked against the synchronous discipline on 2 steps: identical bytes)"
+        else:
+            stream_ordered, transport = False, transport + ", synchronous discipline (the stream-ordered check did not reproduce it)"
+    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance, stream_ordered)
     n_total = sim.n_fluid
 
     has_rigid = bool(cfg.get("solid")) and world == 1
@@ -282,7 +315,7 @@ def main():
     # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
     if args.profile_steps > 0:
         sim.close()
-        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance)
+        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance, stream_ordered)
         sim.profile_enable(True)
         nprof = args.warmup + args.steps
         run(nprof)

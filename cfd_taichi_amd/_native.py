@@ -31,7 +31,7 @@ EXPORTS = [
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_tune_time",
-    "sph_set_comm", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
+    "sph_set_comm", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
 
@@ -107,6 +107,7 @@ EXCHANGE_COUNTS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_in
                                       ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
 EXCHANGE_BUFFERS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.c_int32)
+ALLREDUCE_STREAM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32)
 
 
 class SphComm(ctypes.Structure):
@@ -121,7 +122,9 @@ class SphComm(ctypes.Structure):
         ("recv_right", ctypes.c_void_p),
         ("capacity", ctypes.c_size_t),
         ("on_host", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("stream_ordered", ctypes.c_int32),
+        ("allreduce_stream", ALLREDUCE_STREAM_FN),
+        ("reduce_buf", ctypes.c_void_p),
     ]
 
 
@@ -176,6 +179,7 @@ def load(build_if_missing=True):
     lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
     lib.sph_rigid_step.argtypes = [vp]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
+    lib.sph_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -363,6 +367,12 @@ class Simulation:
     def set_comm(self, comm):
         self._comm = comm            # keep the callbacks and buffers alive
         self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
+
+    def stream_ptr(self):
+        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream in stream-ordered transports)."""
+        out = ctypes.c_void_p()
+        self._check(self._lib.sph_get_stream(self._h, ctypes.byref(out)))
+        return out.value or 0
 
     def slab_info(self):
         out = (ctypes.c_int32 * 8)()

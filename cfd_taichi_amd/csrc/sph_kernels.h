@@ -482,22 +482,30 @@ __device__ __forceinline__ void block_partial_max(int blk, float v, float *__res
 // mean = cnt > 0 ? sum / cnt : default   (dfsph_solver.py:148-149, 278-279) after all-reducing (sum, cnt) when sharded.
 enum { FIN_PLAIN = 0, FIN_DIV_FIRST = 1, FIN_DIV_LOOP = 2, FIN_DENS = 3 };
 
+// phase FINP_ALL: reduce and decide in one launch (single GPU).  Sharded runs split it around the all-reduce over the slabs:
+// FINP_REDUCE writes this slab's (sum, count) to red[0..1]; FINP_DECIDE takes the decision from the reduced pair in red.
+enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
+
 __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                          DevScalars *__restrict__ ds, int mode)
+                                                          DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
 {
     if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
-    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0) ds->dens_d7_active = 0; return; }
+    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
-    double t = 0.0; long long n = 0;
-    for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
-    s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+    if (phase != FINP_DECIDE) {
+        double t = 0.0; long long n = 0;
+        for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+        s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
         __syncthreads();
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+            __syncthreads();
+        }
     }
     if (threadIdx.x != 0) return;
+    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
+    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
     ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
     if (mode == FIN_PLAIN) return;
     // the reference's host logic, evaluated where the data is (same f64 compares as the Python host code)
@@ -537,7 +545,8 @@ __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 }
 
 // max |v*| over the block partials                              dfsph_solver.py:100-103
-__global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds)
+__global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds,
+                                                         double *__restrict__ red)
 {
     __shared__ float s_max[kBlock];
     float t = -INFINITY;
@@ -548,13 +557,14 @@ __global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict
         if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) ds->vmax = s_max[0];
+    if (threadIdx.x == 0) { ds->vmax = s_max[0]; if (red) red[0] = (double)s_max[0]; }   // red: this slab's maximum, all-reduced next
 }
 
 // the CFL time step from ds->vmax (global maximum)              dfsph_solver.py:104-119
-__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds)
+__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *__restrict__ red)
 {
-    float max_vel = ds->vmax;
+    float max_vel = red ? (float)red[0] : ds->vmax;        // red: the maximum over all slabs
+    if (red) ds->vmax = max_vel;
     float max_rigid_vel = ds->rigid_vmax;                         // :104-110 (0 without a rigid body)
     max_vel += max_rigid_vel;
     float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112

@@ -100,6 +100,8 @@ struct SphHandle {
     int *edge_list[4] = {nullptr, nullptr, nullptr, nullptr};
     int edge_count[4] = {0, 0, 0, 0};
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
+    double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
+    bool own_red = false, slab_legacy = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
     int *counters = nullptr, *counters_host = nullptr;
@@ -590,6 +592,23 @@ int read_scalars(SphHandle *h)
 // callbacks move the bytes (RCCL send/recv over xGMI in production, gloo in the tests).
 // ---------------------------------------------------------------------------------------------
 int comm_fail(SphHandle *h, const char *what, int rc) { return fail(h, SPH_E_STATE, "comm callback %s failed (%d)", what, rc); }
+inline bool slab_stream_ordered(const SphHandle *h) { return h->slab && !h->comm.on_host && h->comm.stream_ordered; }
+// sharded DFSPH with the device-side loop control of the single-GPU path (needs the transport's in-place all-reduce of reduce_buf)
+inline bool slab_async(const SphHandle *h) { return h->slab && h->comm.allreduce_stream && h->red_dev && !h->slab_legacy; }
+
+// all-reduce red_dev[0..n) over the slabs, ordered on the handle's stream
+int slab_allreduce_stream(SphHandle *h, int n, int op)
+{
+    const SphComm &cm = h->comm;
+    if (cm.on_host) {                                  // host transport: stage through the caller's host buffer
+        HIP_TRY(h, hipMemcpyAsync(cm.reduce_buf, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    int rc = cm.allreduce_stream(cm.user, n, op);
+    if (rc) return comm_fail(h, "allreduce_stream", rc);
+    if (cm.on_host) HIP_TRY(h, hipMemcpyAsync(h->red_dev, cm.reduce_buf, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    return SPH_OK;
+}
 
 int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
 {
@@ -600,8 +619,8 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
         if (sl) HIP_TRY(h, hipMemcpyAsync(cm.send_left, h->dsend[0], sl, hipMemcpyDeviceToHost, h->stream));
         if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
-    int rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);
+    if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
+    int rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);      // stream-ordered transports enqueue behind the pack kernels instead
     if (rc) return comm_fail(h, "exchange_buffers", rc);
     if (cm.on_host) {
         if (rl) HIP_TRY(h, hipMemcpyAsync(h->drecv[0], cm.recv_left, rl, hipMemcpyHostToDevice, h->stream));
@@ -1267,10 +1286,22 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
                            (const int *)nullptr, gate);
 }
 
-void launch_finalize(SphHandle *h, int mode)
+int launch_finalize(SphHandle *h, int mode)
 {
+    if (slab_async(h)) {       // this slab's (sum, count) -> all-reduce over the slabs -> the loop decision, all on the stream
+        {
+            ProfScope ps(h, K_FINALIZE);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev);
+        }
+        int rc = slab_allreduce_stream(h, 2, 0);
+        if (rc) return rc;
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev);
+        return SPH_OK;
+    }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr);
+    return SPH_OK;
 }
 
 void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:212
@@ -1284,7 +1315,7 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
 int reduce_mean_host(SphHandle *h, float dflt, float *mean)
 {
-    launch_finalize(h, FIN_PLAIN);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
     int rc = read_scalars(h);
     if (rc) return rc;
     double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
@@ -1313,21 +1344,26 @@ int dfsph_ext_and_dt(SphHandle *h)
             hipLaunchKernelGGL(k_rigid_vmax, dim3(1), b, 0, s, h->Nr, h->RPos, st, vn, h->ds);
         }
     }
+    const bool async = slab_async(h);
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, h->nblocks, h->ds);
+        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, h->nblocks, h->ds, async ? h->red_dev : (double *)nullptr);
     }
     if (h->slab) {
         if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
-        if ((rc = read_scalars(h))) return rc;
-        double v[1] = {(double)h->ds_host->vmax};
-        if ((rc = h->comm.allreduce(h->comm.user, v, 1, 1))) return comm_fail(h, "allreduce", rc);
-        h->ds_host->vmax = (float)v[0];
-        HIP_TRY(h, hipMemcpyAsync(&h->ds->vmax, &h->ds_host->vmax, sizeof(float), hipMemcpyHostToDevice, s));
+        if (async) {
+            if ((rc = slab_allreduce_stream(h, 1, 1))) return rc;          // max |v*| over all slabs, stays on the device
+        } else {
+            if ((rc = read_scalars(h))) return rc;
+            double v[1] = {(double)h->ds_host->vmax};
+            if ((rc = h->comm.allreduce(h->comm.user, v, 1, 1))) return comm_fail(h, "allreduce", rc);
+            h->ds_host->vmax = (float)v[0];
+            HIP_TRY(h, hipMemcpyAsync(&h->ds->vmax, &h->ds_host->vmax, sizeof(float), hipMemcpyHostToDevice, s));
+        }
     }
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds);   // :112-119
+        hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds, async ? h->red_dev : (const double *)nullptr);   // :112-119
     }
     return SPH_OK;
 }
@@ -1356,15 +1392,24 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
     hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
+    // On a slab handle every sweep whose output the neighbours read is followed by the refresh of that field on the ghosts (enqueued,
+    // not waited for, with a stream-ordered transport); gated sweeps still take part in the exchanges so that all slabs issue the same
+    // sequence of transfers (they re-send unchanged values).
+    auto ghosts_v = [&](float4 *V) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
+    auto ghosts_k = [&]() -> int { return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK; };
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
+    if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
     launch_div_residual(h, GATE_NONE);                                               // :398
-    launch_finalize(h, FIN_DIV_FIRST);
+    if ((rc = ghosts_k())) return rc;
+    if ((rc = launch_finalize(h, FIN_DIV_FIRST))) return rc;
     // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
     // and the host does not need the outcome before the density loop's first read-back
     for (int done = 0; done < 15; ++done) {
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
+        if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         launch_div_residual(h, GATE_DIV);                                                 // :408
-        launch_finalize(h, FIN_DIV_LOOP);
+        if ((rc = ghosts_k())) return rc;
+        if ((rc = launch_finalize(h, FIN_DIV_LOOP))) return rc;
     }
     if ((rc = dfsph_ext_and_dt(h))) return rc;
     // ---- correct_density_error, :221-233: first chunk = last step's iteration count (it changes slowly), then two at a time ----
@@ -1372,9 +1417,11 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
             launch_dens_residual(h, GATE_DENS);                                      // :227
-            launch_finalize(h, FIN_DENS);
+            if ((rc = ghosts_k())) return rc;
+            if ((rc = launch_finalize(h, FIN_DENS))) return rc;
             launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
+            if ((rc = ghosts_v(h->VA[0]))) return rc;
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
@@ -1460,7 +1507,8 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     h->simulate_cnt += 1;                                   // solver_base.py:137
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
     if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
-    return (h->slab || h->host_loops) ? step_dfsph_host_loops(h, st) : step_dfsph_device_loops(h, st);
+    const bool host_loops = h->host_loops || (h->slab && !slab_async(h));
+    return host_loops ? step_dfsph_host_loops(h, st) : step_dfsph_device_loops(h, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1843,6 +1891,7 @@ void sph_destroy(SphHandle *h)
     if (h->rred_host) (void)hipHostFree(h->rred_host);
     for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
     if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
+    if (h->own_red) (void)hipFree(h->red_dev);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
@@ -2030,7 +2079,23 @@ int sph_set_comm(SphHandle *h, const SphComm *comm)
         h->dsend[0] = comm->send_left; h->dsend[1] = comm->send_right;
         h->drecv[0] = comm->recv_left; h->drecv[1] = comm->recv_right;
     }
+    if (h->own_red) { (void)hipFree(h->red_dev); h->own_red = false; }
+    h->red_dev = nullptr;
+    if (comm->allreduce_stream) {
+        if (!comm->reduce_buf) return fail(h, SPH_E_INVALID, "SphComm.allreduce_stream needs reduce_buf");
+        if (comm->on_host) { HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * 4)); h->own_red = true; }
+        else h->red_dev = comm->reduce_buf;
+    }
+    if (comm->stream_ordered && comm->on_host) return fail(h, SPH_E_INVALID, "a stream-ordered transport needs device buffers (on_host = 0)");
+    { const char *e = getenv("SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
     h->comm_set = true;
+    return SPH_OK;
+}
+
+int sph_get_stream(SphHandle *h, void **stream)
+{
+    if (!h || !stream) return SPH_E_INVALID;
+    *stream = (void *)h->stream;
     return SPH_OK;
 }
 

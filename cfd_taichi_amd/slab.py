@@ -10,6 +10,13 @@ the transport:
   * message sizes: one tiny all-gather of (send_left, send_right) counts per particle exchange;
   * residual sums and the CFL maximum: one small all-reduce each.
 
+Two disciplines (include/sph_mi355x.h, SphComm): with `gloo` the library synchronises its stream around every transfer
+and stages through pinned host buffers; with `nccl` the transfers are *stream-ordered* -- `TorchComm` makes the
+library's own HIP stream torch's current stream (`torch.cuda.ExternalStream`) while it issues the RCCL send/recv and
+all-reduce, so they queue up behind the pack kernels and in front of the unpack kernels without the host ever waiting:
+a whole chunk of solver iterations with its halo refreshes and residual all-reduces is in flight at a time.
+`SPH_SLAB_SYNC=1` switches the nccl transport back to the synchronous discipline.
+
     dist.init_process_group("nccl")
     sim = SlabSimulation(config, rank, world, device=local_rank)
     sim.step(10)
@@ -24,7 +31,10 @@ from . import _native as nat
 class TorchComm:
     """SphComm callbacks on top of torch.distributed (backend nccl = RCCL, or gloo)."""
 
-    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None):
+    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None, stream_ptr=0, stream_ordered=None):
+        """stream_ptr: the library handle's hipStream_t (Simulation.stream_ptr()); with the nccl backend and a stream the
+        transport is stream-ordered unless stream_ordered=False / SPH_SLAB_SYNC=1."""
+        import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -37,16 +47,25 @@ class TorchComm:
         self.capacity = int(capacity_bytes)
         self.bufs = {k: torch.empty(self.capacity, dtype=torch.uint8, device=self.device, **kw)
                      for k in ("send_left", "send_right", "recv_left", "recv_right")}
+        self.reduce_t = torch.zeros(4, dtype=torch.float64, device=self.device, **kw)
+        if stream_ordered is None:
+            stream_ordered = os.environ.get("SPH_SLAB_SYNC", "0") != "1"
+        self.stream_ordered = bool(stream_ordered and not self.on_host and stream_ptr)
+        self.stream = torch.cuda.ExternalStream(stream_ptr, device=self.device) if self.stream_ordered else None
         self.error = None
-        self.stats = {"exchange_counts": 0, "exchange_buffers": 0, "allreduce": 0, "bytes_sent": 0}
+        self.stats = {"exchange_counts": 0, "exchange_buffers": 0, "allreduce": 0, "allreduce_stream": 0, "bytes_sent": 0}
         self._cb_counts = nat.EXCHANGE_COUNTS_FN(self._exchange_counts)
         self._cb_buffers = nat.EXCHANGE_BUFFERS_FN(self._exchange_buffers)
         self._cb_allreduce = nat.ALLREDUCE_FN(self._allreduce)
+        self._cb_allreduce_stream = nat.ALLREDUCE_STREAM_FN(self._allreduce_stream)
         self.struct = nat.SphComm()
         self.struct.user = None
         self.struct.exchange_counts = self._cb_counts
         self.struct.exchange_buffers = self._cb_buffers
         self.struct.allreduce = self._cb_allreduce
+        self.struct.allreduce_stream = self._cb_allreduce_stream
+        self.struct.reduce_buf = self.reduce_t.data_ptr()
+        self.struct.stream_ordered = 1 if self.stream_ordered else 0
         for k, t in self.bufs.items():
             setattr(self.struct, k, t.data_ptr())
         self.struct.capacity = self.capacity
@@ -78,11 +97,30 @@ class TorchComm:
             if rr:
                 ops.append(dist.P2POp(dist.irecv, self.bufs["recv_right"][:rr], self.right, self.group))
         if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if not self.on_host:
-                self.torch.cuda.current_stream(self.device).synchronize()   # the library continues on its own stream
+            if self.stream_ordered:
+                # the library's stream is torch's current stream here: RCCL waits for what the library enqueued before this call (the
+                # pack kernels), and req.wait() makes the library's stream -- not the host -- wait for the transfer
+                with self.torch.cuda.stream(self.stream):
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+            else:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                if not self.on_host:
+                    self.torch.cuda.current_stream(self.device).synchronize()   # the library continues on its own stream
         self.stats["bytes_sent"] += sl + sr
+
+    def allreduce_stream(self, n, op):
+        """In-place all-reduce of reduce_t[:n] (the library's (sum, count) pair / CFL maximum)."""
+        dist = self.dist
+        rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        if self.stream_ordered:
+            with self.torch.cuda.stream(self.stream):
+                dist.all_reduce(self.reduce_t[:n], op=rop, group=self.group)      # blocks the library's stream only
+        else:
+            dist.all_reduce(self.reduce_t[:n], op=rop, group=self.group)
+            if not self.on_host:
+                self.torch.cuda.current_stream(self.device).synchronize()
 
     def allreduce(self, values, op):
         torch, dist = self.torch, self.dist
@@ -112,6 +150,12 @@ class TorchComm:
             self.exchange_buffers(sl, sr, rl, rr)
         return self._guard(run)
 
+    def _allreduce_stream(self, user, n, op):
+        def run():
+            self.stats["allreduce_stream"] += 1
+            self.allreduce_stream(n, op)
+        return self._guard(run)
+
     def _allreduce(self, user, values, n, op):
         def run():
             self.stats["allreduce"] += 1
@@ -131,7 +175,7 @@ class SlabSimulation:
                                    slab_capacity=slab_capacity, slab_rebalance_every=rebalance_every, **native_opts)
         self.solver = "wcsph" if cfg.solver == nat.SOLVER_WCSPH else "dfsph"
         self.sim = nat.Simulation(cfg)
-        self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes)
+        self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, stream_ptr=self.sim.stream_ptr())
         self.sim.set_comm(self.comm.struct)
         self.n_fluid = self.sim.n_fluid
 

@@ -210,7 +210,17 @@ int sph_profile_get(SphHandle *h, int kernel_id, double *total_ms, int64_t *laun
  * Buffers: four byte buffers of `capacity` bytes each, owned by the caller (e.g. torch tensors): send/recv x left/right.
  * With on_host = 0 they are device pointers (RCCL over xGMI reads/writes them directly); with on_host = 1 they are host
  * pointers and the library stages through them with hipMemcpy (used by the gloo tests).
- * Callbacks return 0 on success; they are invoked on the calling thread, with the handle's stream idle. */
+ * Callbacks return 0 on success and are invoked on the calling thread.
+ *
+ * Two transport disciplines:
+ *   - synchronous (stream_ordered = 0): the library synchronises its stream before exchange_buffers (the packed data is complete) and
+ *     the callback returns when the receive buffers are filled.  Host transports (on_host = 1) are always of this kind.
+ *   - stream-ordered (stream_ordered = 1, device buffers): the callbacks ENQUEUE the transfer on the handle's own stream
+ *     (sph_get_stream) -- e.g. RCCL send/recv issued with that stream current -- and return at once; the library never blocks the
+ *     host around them, so a whole chunk of solver iterations, halo refreshes and residual all-reduces is in flight at a time.
+ * With allreduce_stream set, DFSPH runs its loops with the device-side control of the single-GPU path: the (sum, count) pair of a
+ * residual is written to reduce_buf, all-reduced in place by allreduce_stream, and a second kernel takes the reference's loop
+ * decision from it -- identical on every slab because all ranks see the same reduced values. */
 typedef struct SphComm {
     void *user;
     /* send my counts to the left / right neighbour and receive theirs (absent neighbour: recv 0) */
@@ -222,10 +232,15 @@ typedef struct SphComm {
     void *send_left, *send_right, *recv_left, *recv_right;
     size_t capacity;
     int32_t on_host;
-    int32_t reserved;
+    int32_t stream_ordered;     /* 1: exchange_buffers / allreduce_stream enqueue on the handle's stream and return (device buffers only) */
+    /* optional: in-place all-reduce of the first n doubles of reduce_buf (op 0 = sum, 1 = max), ordered like exchange_buffers */
+    int (*allreduce_stream)(void *user, int32_t n, int32_t op);
+    double *reduce_buf;         /* >= 4 doubles: device memory with on_host = 0, host memory (the library stages) with on_host = 1 */
 } SphComm;
 
 int sph_set_comm(SphHandle *h, const SphComm *comm);
+/* the handle's HIP stream (a hipStream_t), for stream-ordered transports */
+int sph_get_stream(SphHandle *h, void **stream);
 /* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the equal-count slabs of the
  * scene's initial lattice, counts[k] = particles slab k owns at t = 0 */
 int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);

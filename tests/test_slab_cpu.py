@@ -53,6 +53,13 @@ def _worker(rank, world, port, results):
     ok &= a.value == (9 if rank > 0 else 0) and b.value == (7 if rank < world - 1 else 0)
     vals = (ctypes.c_double * 2)(1.0, float(rank))
     ok &= comm._allreduce(None, vals, 2, 0) == 0 and vals[0] == float(world)
+    # the in-place reduce buffer of the device-side loop control (host transport: the library stages reduce_buf itself)
+    assert not comm.stream_ordered and comm.struct.stream_ordered == 0 and comm.struct.reduce_buf == comm.reduce_t.data_ptr()
+    comm.reduce_t[:2] = torch.tensor([1.5 * (rank + 1), float(rank + 2)], dtype=torch.float64)
+    ok &= comm._allreduce_stream(None, 2, 0) == 0
+    ok &= comm.reduce_t[:2].tolist() == [1.5 * world * (world + 1) / 2, float(sum(r + 2 for r in range(world)))]
+    comm.reduce_t[0] = float(rank)
+    ok &= comm._allreduce_stream(None, 1, 1) == 0 and comm.reduce_t[0].item() == float(world - 1)
     results[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

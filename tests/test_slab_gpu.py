@@ -19,12 +19,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_slabs(tmp_path, scene, world, steps, rebalance=0):
-    out = tmp_path / ("slab_%s_%d_%d.json" % (scene, world, rebalance))
+def run_slabs(tmp_path, scene, world, steps, rebalance=0, legacy=False):
+    out = tmp_path / ("slab_%s_%d_%d_%d.json" % (scene, world, rebalance, legacy))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "slab_worker.py"), "--scene", scene, "--steps", str(steps),
            "--backend", "gloo", "--rebalance", str(rebalance), "--out", str(out)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_SLAB_LEGACY="1" if legacy else "0")
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     return json.loads(out.read_text())
@@ -40,6 +40,15 @@ def test_slabs_match_single_gpu(tmp_path, scene, world, steps):
     assert sum(s["owned"] for s in r["slabs"]) == r["n"]
     assert all(s["ghosts"] > 0 for s in r["slabs"])
     assert r["comm"]["exchange_buffers"] > 0 and r["comm"]["allreduce"] > 0
+    if "dfsph" in scene:      # the loops ran with the device-side control: residuals were reduced in place, not through the host callback
+        assert r["comm"]["allreduce_stream"] >= 3 * steps
+
+
+def test_legacy_host_loops_on_slabs(tmp_path):
+    """SPH_SLAB_LEGACY=1: the host-driven loops (one read-back + host all-reduce per residual) stay available and agree."""
+    r = run_slabs(tmp_path, "dfsph_small", 2, 12, legacy=True)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], r
+    assert r["comm"]["allreduce_stream"] == 0 and r["comm"]["allreduce"] > 12
 
 
 @pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 350, 2), ("wcsph_dam_x", 2, 2000, 1)])
@@ -57,3 +66,12 @@ def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_re
     assert static["pos_equal"]
     spread = lambda res: max(s["owned"] for s in res["slabs"]) - min(s["owned"] for s in res["slabs"])   # noqa: E731
     assert spread(r) <= spread(static), (r["slabs"], static["slabs"])
+
+
+def test_stream_ordered_transport_plumbing_on_rccl():
+    """RCCL itself with one rank (all a 1-GPU box can host): ExternalStream around the library's stream, the in-place all-reduce
+    of the device reduce buffer ordered on it, the synchronous discipline on the same backend (tests/nccl_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(free_port())], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "transport ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
