@@ -141,11 +141,10 @@ def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, 
     return slab.sim, slab
 
 
-def pick_transport(dist, torch, rank, world, local_rank):
+def pick_transport(dist, torch, rank, world, local_rank, gloo):
     """RCCL (nccl backend) device-to-device halo exchange when it works; otherwise the same protocol over a gloo
-    side group with host staging.  Every rank takes the same decision (the probe result is all-reduced)."""
+    side group with host staging.  Every rank takes the same decision (the probe result is all-reduced over `gloo`)."""
     from cfd_taichi_amd.slab import TorchComm
-    gloo = dist.new_group(backend="gloo")
     if os.environ.get("SPH_TRANSPORT", "nccl") == "gloo":
         return gloo, "gloo (host staged, forced by SPH_TRANSPORT)"
     ok = 1
@@ -172,28 +171,42 @@ def pick_transport(dist, torch, rank, world, local_rank):
     return gloo, "gloo (host staged: RCCL probe failed)"
 
 
-def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance):
+def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance, gloo):
     """The stream-ordered RCCL discipline (no host waits around halo refreshes and residual all-reduces) must give the very bytes the
-    synchronous discipline gives: two steps of the workload in each, SHA-1 of every rank's owned particles, agreement all-reduced."""
+    synchronous discipline gives: two steps of the workload in each, SHA-1 of every rank's owned particles.  Agreement -- and any
+    exception on any rank -- is all-reduced over the gloo side group, so every rank takes the same decision."""
     import hashlib
     import numpy as np
+
+    def agreed(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=gloo)
+        return bool(int(t.item()))
+
     digests = []
     for ordered in (True, False):
-        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, None, rebalance, stream_ordered=ordered)
-        if ordered and not slab.comm.stream_ordered:
+        ok, sim = True, None
+        try:
+            sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, None, rebalance, stream_ordered=ordered)
+            ok = slab.comm.stream_ordered == ordered
+            if ok:
+                for _ in range(2):
+                    (sim.step_dfsph if slab.solver == "dfsph" else sim.step_wcsph)(1)
+                hsh = hashlib.sha1()
+                for f in (nat.F_POS, nat.F_VEL):
+                    ids, vals = sim.download_owned(f)
+                    hsh.update(np.ascontiguousarray(vals[np.argsort(ids, kind="stable")]).tobytes())
+                digests.append(hsh.hexdigest())
+        except Exception as e:  # noqa: BLE001
+            print("[bench] rank %d: %s discipline failed in the self-check: %s" % (rank, "stream-ordered" if ordered else "synchronous", e),
+                  file=sys.stderr)
+            ok = False
+        if sim is not None:
             sim.close()
-            return False
-        for _ in range(2):
-            (sim.step_dfsph if slab.solver == "dfsph" else sim.step_wcsph)(1)
-        hsh = hashlib.sha1()
-        for f in (nat.F_POS, nat.F_VEL):
-            ids, vals = sim.download_owned(f)
-            hsh.update(np.ascontiguousarray(vals[np.argsort(ids, kind="stable")]).tobytes())
-        digests.append(hsh.hexdigest())
-        sim.close()
-    t = torch.tensor([1 if digests[0] == digests[1] else 0], dtype=torch.int32, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(int(t.item()))
+        if not agreed(ok):
+            return False, "the %s discipline was not available or failed on some rank" % ("stream-ordered" if ordered else "synchronous")
+    same = agreed(digests[0] == digests[1])
+    return same, "identical bytes" if same else "the two disciplines disagreed"
 
 
 def main():
@@ -215,11 +228,13 @@ def main():
         if rehearsal:
             local_rank = 0
             dist.init_process_group(backend="gloo")
+            side = dist.new_group(backend="gloo")
             transport_group, transport = None, "gloo (rehearsal on one GPU)"
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-            transport_group, transport = pick_transport(dist, torch, rank, world, local_rank)
+            side = dist.new_group(backend="gloo")        # control decisions (probe results) travel over gloo
+            transport_group, transport = pick_transport(dist, torch, rank, world, local_rank, side)
 
     from cfd_taichi_amd import _native as nat
     from cfd_taichi_amd import scenes
@@ -230,13 +245,13 @@ def main():
     cfg = scenes.get(scene_name)
     solver_kind = cfg["solver"]["name"]
     stream_ordered = None
-    if world > 1 and not rehearsal and transport_group is None:      # RCCL device-to-device transport
+    if world > 1 and transport_group is None and (not rehearsal or os.environ.get("SPH_BENCH_VERIFY") == "1"):      # RCCL device-to-device transport
         if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
             stream_ordered, transport = False, transport + ", synchronous discipline (SPH_SLAB_SYNC=1)"
-        elif verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance):
-            stream_ordered, transport = True, transport + ", stream-ordered (checked against the synchronous discipline on 2 steps: identical bytes)"
         else:
-            stream_ordered, transport = False, transport + ", synchronous discipline (the stream-ordered check did not reproduce it)"
+            stream_ordered, why = verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
+            transport += (", stream-ordered (checked against the synchronous discipline on 2 steps: %s)" % why) if stream_ordered else \
+                (", synchronous discipline (self-check: %s)" % why)
     sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance, stream_ordered)
     n_total = sim.n_fluid
 

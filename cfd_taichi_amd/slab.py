@@ -52,6 +52,7 @@ class TorchComm:
             stream_ordered = os.environ.get("SPH_SLAB_SYNC", "0") != "1"
         self.stream_ordered = bool(stream_ordered and not self.on_host and stream_ptr)
         self.stream = torch.cuda.ExternalStream(stream_ptr, device=self.device) if self.stream_ordered else None
+        self._ops_cache = {}
         self.error = None
         self.stats = {"exchange_counts": 0, "exchange_buffers": 0, "allreduce": 0, "allreduce_stream": 0, "bytes_sent": 0}
         self._cb_counts = nat.EXCHANGE_COUNTS_FN(self._exchange_counts)
@@ -83,19 +84,31 @@ class TorchComm:
         recv_right = int(allc[self.right, 0]) if self.right is not None else 0
         return recv_left, recv_right
 
+    def _p2p_ops(self, sl, sr, rl, rr):
+        """The isend / irecv descriptors of one halo message shape (a step uses three or four shapes over and over: cached)."""
+        key = (sl, sr, rl, rr)
+        ops = self._ops_cache.get(key)
+        if ops is None:
+            dist = self.dist
+            ops = []
+            if self.left is not None:
+                if sl:
+                    ops.append(dist.P2POp(dist.isend, self.bufs["send_left"][:sl], self.left, self.group))
+                if rl:
+                    ops.append(dist.P2POp(dist.irecv, self.bufs["recv_left"][:rl], self.left, self.group))
+            if self.right is not None:
+                if sr:
+                    ops.append(dist.P2POp(dist.isend, self.bufs["send_right"][:sr], self.right, self.group))
+                if rr:
+                    ops.append(dist.P2POp(dist.irecv, self.bufs["recv_right"][:rr], self.right, self.group))
+            if len(self._ops_cache) > 64:
+                self._ops_cache.clear()
+            self._ops_cache[key] = ops
+        return ops
+
     def exchange_buffers(self, sl, sr, rl, rr):
         dist = self.dist
-        ops = []
-        if self.left is not None:
-            if sl:
-                ops.append(dist.P2POp(dist.isend, self.bufs["send_left"][:sl], self.left, self.group))
-            if rl:
-                ops.append(dist.P2POp(dist.irecv, self.bufs["recv_left"][:rl], self.left, self.group))
-        if self.right is not None:
-            if sr:
-                ops.append(dist.P2POp(dist.isend, self.bufs["send_right"][:sr], self.right, self.group))
-            if rr:
-                ops.append(dist.P2POp(dist.irecv, self.bufs["recv_right"][:rr], self.right, self.group))
+        ops = self._p2p_ops(sl, sr, rl, rr)
         if ops:
             if self.stream_ordered:
                 # the library's stream is torch's current stream here: RCCL waits for what the library enqueued before this call (the
