@@ -119,7 +119,7 @@ def load_traffic(kernel, key="hbm_bytes_per_launch"):
 VALU_PEAK_GINST = 256 * 2.4
 
 
-def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0, stream_ordered=None):
+def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0, discipline=None):
     """Single-GPU handle, or this rank's slab of the sharded simulation."""
     cfg = scenes.get(scene_name)
     if world == 1:
@@ -134,9 +134,14 @@ def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, 
     slab.rank, slab.world = rank, world
     slab.solver = cfg["solver"]["name"]
     slab.sim = nat.Simulation(c)
-    slab.comm = TorchComm(rank, world, device=local_rank, capacity_bytes=128 << 20, group=transport_group, stream_ptr=slab.sim.stream_ptr(),
-                          stream_ordered=stream_ordered)
-    slab.sim.set_comm(slab.comm.struct)
+    if discipline == "native":          # the library's own RCCL communicator; the id travels over the gloo side group
+        from cfd_taichi_amd.slab import attach_native
+        slab.comm = None
+        attach_native(slab.sim, rank, 128 << 20, transport_group)
+    else:
+        slab.comm = TorchComm(rank, world, device=local_rank, capacity_bytes=128 << 20, group=transport_group, stream_ptr=slab.sim.stream_ptr(),
+                              stream_ordered=None if discipline is None else discipline == "stream")
+        slab.sim.set_comm(slab.comm.struct)
     slab.n_fluid = slab.sim.n_fluid
     return slab.sim, slab
 
@@ -171,10 +176,11 @@ def pick_transport(dist, torch, rank, world, local_rank, gloo):
     return gloo, "gloo (host staged: RCCL probe failed)"
 
 
-def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance, gloo):
-    """The stream-ordered RCCL discipline (no host waits around halo refreshes and residual all-reduces) must give the very bytes the
-    synchronous discipline gives: two steps of the workload in each, SHA-1 of every rank's owned particles.  Agreement -- and any
-    exception on any rank -- is all-reduced over the gloo side group, so every rank takes the same decision."""
+def choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance, gloo):
+    """Which RCCL discipline drives the halo: "native" (the library issues ncclSend / ncclRecv / ncclAllReduce itself on its stream),
+    "stream" (torch.distributed calls ordered on the library's stream) or "sync" (host waits around every transfer).  The faster ones
+    are only used if two steps of the workload give the very bytes the synchronous discipline gives (SHA-1 of every rank's owned
+    particles).  Agreement -- and any exception on any rank -- is all-reduced over the gloo side group: all ranks decide alike."""
     import hashlib
     import numpy as np
 
@@ -183,12 +189,12 @@ def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=gloo)
         return bool(int(t.item()))
 
-    digests = []
-    for ordered in (True, False):
-        ok, sim = True, None
+    def digest(mode):
+        ok, sim, out = True, None, None
         try:
-            sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, None, rebalance, stream_ordered=ordered)
-            ok = slab.comm.stream_ordered == ordered
+            sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, gloo if mode == "native" else None, rebalance, discipline=mode)
+            if mode != "native":
+                ok = slab.comm.stream_ordered == (mode == "stream")
             if ok:
                 for _ in range(2):
                     (sim.step_dfsph if slab.solver == "dfsph" else sim.step_wcsph)(1)
@@ -196,17 +202,23 @@ def verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist
                 for f in (nat.F_POS, nat.F_VEL):
                     ids, vals = sim.download_owned(f)
                     hsh.update(np.ascontiguousarray(vals[np.argsort(ids, kind="stable")]).tobytes())
-                digests.append(hsh.hexdigest())
+                out = hsh.hexdigest()
         except Exception as e:  # noqa: BLE001
-            print("[bench] rank %d: %s discipline failed in the self-check: %s" % (rank, "stream-ordered" if ordered else "synchronous", e),
-                  file=sys.stderr)
+            print("[bench] rank %d: the %s discipline failed in the self-check: %s" % (rank, mode, e), file=sys.stderr)
             ok = False
         if sim is not None:
             sim.close()
-        if not agreed(ok):
-            return False, "the %s discipline was not available or failed on some rank" % ("stream-ordered" if ordered else "synchronous")
-    same = agreed(digests[0] == digests[1])
-    return same, "identical bytes" if same else "the two disciplines disagreed"
+        return out if agreed(ok) else None
+
+    ref = digest("sync")
+    if ref is None:
+        return "sync", "the synchronous discipline itself failed in the self-check on some rank"
+    wanted = [m for m in os.environ.get("SPH_SLAB_DISCIPLINES", "native,stream").split(",") if m in ("native", "stream")]
+    for mode in wanted:
+        d = digest(mode)
+        if agreed(d is not None and d == ref):
+            return mode, "2 steps reproduce the synchronous discipline byte for byte"
+    return "sync", "no faster discipline reproduced it"
 
 
 def main():
@@ -244,15 +256,16 @@ def main():
     scene_name = args.workload or ("dfsph_1m" if world == 1 else "dfsph_10m")
     cfg = scenes.get(scene_name)
     solver_kind = cfg["solver"]["name"]
-    stream_ordered = None
+    discipline = None
     if world > 1 and transport_group is None and (not rehearsal or os.environ.get("SPH_BENCH_VERIFY") == "1"):      # RCCL device-to-device transport
         if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
-            stream_ordered, transport = False, transport + ", synchronous discipline (SPH_SLAB_SYNC=1)"
+            discipline, why = "sync", "forced by SPH_SLAB_SYNC=1"
         else:
-            stream_ordered, why = verify_stream_ordered(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
-            transport += (", stream-ordered (checked against the synchronous discipline on 2 steps: %s)" % why) if stream_ordered else \
-                (", synchronous discipline (self-check: %s)" % why)
-    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance, stream_ordered)
+            discipline, why = choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
+        transport += "; discipline: %s (%s)" % ({"native": "native RCCL calls on the library's stream", "stream": "torch.distributed ordered on the library's stream",
+                                                  "sync": "synchronous"}[discipline], why)
+    group_for = (side if discipline == "native" else transport_group) if world > 1 else None
+    sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, group_for, args.rebalance, discipline)
     n_total = sim.n_fluid
 
     has_rigid = bool(cfg.get("solid")) and world == 1
@@ -314,7 +327,7 @@ def main():
     }
     if slab_info is not None:
         out["config"]["rank0_slab"] = slab_info
-        out["config"]["rank0_comm"] = slab.comm.stats
+        out["config"]["rank0_comm"] = slab.comm.stats if slab.comm is not None else "native transport (no callbacks)"
     if stats:
         nd = [s[0] for s in stats]; ns = [s[1] for s in stats]; ne = [s[2] for s in stats]
         out["config"].update({"n_div_mean": sum(nd) / len(nd), "n_dens_mean": sum(ns) / len(ns), "n_div_evals_mean": sum(ne) / len(ne)})
@@ -330,7 +343,7 @@ def main():
     # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
     if args.profile_steps > 0:
         sim.close()
-        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, args.rebalance, stream_ordered)
+        sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, group_for, args.rebalance, discipline)
         sim.profile_enable(True)
         nprof = args.warmup + args.steps
         run(nprof)

@@ -31,7 +31,7 @@ EXPORTS = [
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_tune_time",
-    "sph_set_comm", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
+    "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
 
@@ -180,6 +180,9 @@ def load(build_if_missing=True):
     lib.sph_rigid_step.argtypes = [vp]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
     lib.sph_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.sph_rccl_unique_id.argtypes = [vp]
+    lib.sph_rccl_attach.argtypes = [vp, vp, ctypes.c_size_t]
+    lib.sph_rccl_selftest.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.c_int32]
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
@@ -233,6 +236,16 @@ def plan_slabs(cfg, slab_count):
     if rc != SPH_OK:
         raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
     return list(cuts), list(counts)
+
+
+def rccl_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (rank 0 calls this and broadcasts them)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(128)
+    rc = lib.sph_rccl_unique_id(buf)
+    if rc != SPH_OK:
+        raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
+    return buf.raw
 
 
 def replan_slabs(column_histogram, old_cuts):
@@ -367,6 +380,16 @@ class Simulation:
     def set_comm(self, comm):
         self._comm = comm            # keep the callbacks and buffers alive
         self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
+
+    def rccl_attach(self, unique_id, capacity_bytes=64 << 20):
+        """Collective over all slabs: the library opens its own RCCL communicator (native transport, no callbacks)."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.sph_rccl_attach(self._h, buf, capacity_bytes))
+
+    def rccl_selftest(self, values, op=0):
+        arr = (ctypes.c_double * len(values))(*values)
+        self._check(self._lib.sph_rccl_selftest(self._h, arr, len(values), op))
+        return list(arr)
 
     def stream_ptr(self):
         """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream in stream-ordered transports)."""

@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "sph_kernels.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: librccl is dlopen'ed when a handle attaches the native transport
 #include "sph_slab_kernels.h"
 #include "sph_pressure_kernels.h"
 #include "sph_rigid_kernels.h"
@@ -101,6 +103,12 @@ struct SphHandle {
     int edge_count[4] = {0, 0, 0, 0};
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
+    // native transport (sph_rccl_attach): the library drives RCCL itself on its stream
+    bool native = false;
+    ncclComm_t nccl = nullptr;
+    int red_cap = 4;              // doubles in red_dev
+    int *cnt_dev = nullptr, *cnt_host = nullptr;     // neighbour count exchange: [send_left, send_right, recv_left, recv_right]
+    double *red_host = nullptr;   // pinned staging for host-side all-reduces
     bool own_red = false, slab_legacy = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -592,13 +600,16 @@ int read_scalars(SphHandle *h)
 // callbacks move the bytes (RCCL send/recv over xGMI in production, gloo in the tests).
 // ---------------------------------------------------------------------------------------------
 int comm_fail(SphHandle *h, const char *what, int rc) { return fail(h, SPH_E_STATE, "comm callback %s failed (%d)", what, rc); }
-inline bool slab_stream_ordered(const SphHandle *h) { return h->slab && !h->comm.on_host && h->comm.stream_ordered; }
+inline bool slab_stream_ordered(const SphHandle *h) { return h->slab && (h->native || (!h->comm.on_host && h->comm.stream_ordered)); }
 // sharded DFSPH with the device-side loop control of the single-GPU path (needs the transport's in-place all-reduce of reduce_buf)
-inline bool slab_async(const SphHandle *h) { return h->slab && h->comm.allreduce_stream && h->red_dev && !h->slab_legacy; }
+inline bool slab_async(const SphHandle *h) { return h->slab && (h->native || h->comm.allreduce_stream) && h->red_dev && !h->slab_legacy; }
+
+int native_allreduce_stream(SphHandle *h, int n, int op);
 
 // all-reduce red_dev[0..n) over the slabs, ordered on the handle's stream
 int slab_allreduce_stream(SphHandle *h, int n, int op)
 {
+    if (h->native) return native_allreduce_stream(h, n, op);
     const SphComm &cm = h->comm;
     if (cm.on_host) {                                  // host transport: stage through the caller's host buffer
         HIP_TRY(h, hipMemcpyAsync(cm.reduce_buf, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
@@ -607,6 +618,127 @@ int slab_allreduce_stream(SphHandle *h, int n, int op)
     int rc = cm.allreduce_stream(cm.user, n, op);
     if (rc) return comm_fail(h, "allreduce_stream", rc);
     if (cm.on_host) HIP_TRY(h, hipMemcpyAsync(h->red_dev, cm.reduce_buf, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// native RCCL transport: ncclSend / ncclRecv to the left and right slab neighbour (one direct xGMI link per pair) and
+// ncclAllReduce of the residual pair, issued by the library on its own stream -- no Python, no host waits.  librccl is
+// dlopen'ed so that the library itself has no link-time dependency on it.
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+    bool ok = false;
+};
+
+RcclApi &rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) { a.why = "librccl.so not found"; return a; }
+#define SPH_RCCL_SYM(field, sym) a.field = (decltype(a.field))dlsym(a.lib, sym); if (!a.field) { a.why = std::string("missing symbol ") + sym; return a; }
+        SPH_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") SPH_RCCL_SYM(CommInitRank, "ncclCommInitRank") SPH_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+        SPH_RCCL_SYM(GroupStart, "ncclGroupStart") SPH_RCCL_SYM(GroupEnd, "ncclGroupEnd") SPH_RCCL_SYM(Send, "ncclSend") SPH_RCCL_SYM(Recv, "ncclRecv")
+        SPH_RCCL_SYM(AllReduce, "ncclAllReduce") SPH_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef SPH_RCCL_SYM
+        a.ok = true;
+        return a;
+    }();
+    return api;
+}
+
+#define NCCL_TRY(h, expr)                                                                                        \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess) return fail(h, SPH_E_HIP, "%s failed: %s", #expr, rccl().GetErrorString(r_));     \
+    } while (0)
+
+// exchange_buffers of the native transport: one group of up to four point-to-point transfers, ordered on the handle's stream
+int native_exchange(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
+{
+    RcclApi &n = rccl();
+    const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
+    if (!((left >= 0 && (sl || rl)) || (right >= 0 && (sr || rr)))) return SPH_OK;
+    NCCL_TRY(h, n.GroupStart());
+    if (left >= 0) {
+        if (sl) NCCL_TRY(h, n.Send(h->dsend[0], sl, ncclChar, left, h->nccl, h->stream));
+        if (rl) NCCL_TRY(h, n.Recv(h->drecv[0], rl, ncclChar, left, h->nccl, h->stream));
+    }
+    if (right >= 0) {
+        if (sr) NCCL_TRY(h, n.Send(h->dsend[1], sr, ncclChar, right, h->nccl, h->stream));
+        if (rr) NCCL_TRY(h, n.Recv(h->drecv[1], rr, ncclChar, right, h->nccl, h->stream));
+    }
+    NCCL_TRY(h, n.GroupEnd());
+    return SPH_OK;
+}
+
+// exchange_counts of the native transport: one int each way with each neighbour, then the host reads the two it received
+int native_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr)
+{
+    RcclApi &n = rccl();
+    const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
+    h->cnt_host[0] = sl; h->cnt_host[1] = sr; h->cnt_host[2] = 0; h->cnt_host[3] = 0;
+    HIP_TRY(h, hipMemcpyAsync(h->cnt_dev, h->cnt_host, sizeof(int) * 4, hipMemcpyHostToDevice, h->stream));
+    if (left >= 0 || right >= 0) {
+        NCCL_TRY(h, n.GroupStart());
+        if (left >= 0) {
+            NCCL_TRY(h, n.Send(h->cnt_dev + 0, 1, ncclInt32, left, h->nccl, h->stream));
+            NCCL_TRY(h, n.Recv(h->cnt_dev + 2, 1, ncclInt32, left, h->nccl, h->stream));
+        }
+        if (right >= 0) {
+            NCCL_TRY(h, n.Send(h->cnt_dev + 1, 1, ncclInt32, right, h->nccl, h->stream));
+            NCCL_TRY(h, n.Recv(h->cnt_dev + 3, 1, ncclInt32, right, h->nccl, h->stream));
+        }
+        NCCL_TRY(h, n.GroupEnd());
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->cnt_host, h->cnt_dev, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *rl = h->cnt_host[2]; *rr = h->cnt_host[3];
+    return SPH_OK;
+}
+
+int native_allreduce_stream(SphHandle *h, int n, int op)
+{
+    NCCL_TRY(h, rccl().AllReduce(h->red_dev, h->red_dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->nccl, h->stream));
+    return SPH_OK;
+}
+
+// neighbour counts / host-side all-reduce through whichever transport the handle has
+int slab_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr)
+{
+    if (h->native) return native_exchange_counts(h, sl, sr, rl, rr);
+    int rc = h->comm.exchange_counts(h->comm.user, sl, sr, rl, rr);
+    return rc ? comm_fail(h, "exchange_counts", rc) : SPH_OK;
+}
+
+int slab_allreduce_host(SphHandle *h, double *v, int n, int op)
+{
+    if (!h->native) {
+        int rc = h->comm.allreduce(h->comm.user, v, n, op);
+        return rc ? comm_fail(h, "allreduce", rc) : SPH_OK;
+    }
+    if (n > h->red_cap) return fail(h, SPH_E_INVALID, "all-reduce of %d doubles exceeds the reduce buffer (%d)", n, h->red_cap);
+    memcpy(h->red_host, v, sizeof(double) * n);
+    HIP_TRY(h, hipMemcpyAsync(h->red_dev, h->red_host, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    int rc = native_allreduce_stream(h, n, op);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->red_host, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(v, h->red_host, sizeof(double) * n);
     return SPH_OK;
 }
 
@@ -620,8 +752,13 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
         if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, h->stream));
     }
     if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
-    int rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);      // stream-ordered transports enqueue behind the pack kernels instead
-    if (rc) return comm_fail(h, "exchange_buffers", rc);
+    int rc;
+    if (h->native) {
+        if ((rc = native_exchange(h, sl, sr, rl, rr))) return rc;
+    } else {
+        rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);      // stream-ordered transports enqueue behind the pack kernels instead
+        if (rc) return comm_fail(h, "exchange_buffers", rc);
+    }
     if (cm.on_host) {
         if (rl) HIP_TRY(h, hipMemcpyAsync(h->drecv[0], cm.recv_left, rl, hipMemcpyHostToDevice, h->stream));
         if (rr) HIP_TRY(h, hipMemcpyAsync(h->drecv[1], cm.recv_right, rr, hipMemcpyHostToDevice, h->stream));
@@ -654,8 +791,8 @@ int slab_rebalance(SphHandle *h)
     HIP_TRY(h, hipStreamSynchronize(s));
     std::vector<double> v((size_t)c.gx);
     for (int x = 0; x < c.gx; ++x) v[x] = (double)h->col_hist_host[x];
-    int rc = h->comm.allreduce(h->comm.user, v.data(), c.gx, 0);
-    if (rc) return comm_fail(h, "allreduce", rc);
+    int rc = slab_allreduce_host(h, v.data(), c.gx, 0);
+    if (rc) return rc;
     std::vector<long long> hist((size_t)c.gx);
     for (int x = 0; x < c.gx; ++x) hist[x] = (long long)v[x];
     std::vector<int> cut;
@@ -691,7 +828,7 @@ int slab_exchange_particles(SphHandle *h)
     const int mL = h->counters_host[0], mR = h->counters_host[1], ndead = h->counters_host[2];
     if (mL > cap_rec || mR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d migrating particles exceed the comm buffer (%d records)", mL, mR, cap_rec);
     int32_t rL = 0, rR = 0;
-    if ((rc = h->comm.exchange_counts(h->comm.user, mL, mR, &rL, &rR))) return comm_fail(h, "exchange_counts", rc);
+    if ((rc = slab_exchange_counts(h, mL, mR, &rL, &rR))) return rc;
     if ((long long)n_prev + rL + rR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by migration", h->ncap);
     if ((rc = slab_xfer(h, 32 * (size_t)mL, 32 * (size_t)mR, 32 * (size_t)rL, 32 * (size_t)rR))) return rc;
     {
@@ -711,7 +848,7 @@ int slab_exchange_particles(SphHandle *h)
     const int gL = h->counters_host[0], gR = h->counters_host[1];
     if (gL > cap_rec || gR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d ghost particles exceed the comm buffer (%d records)", gL, gR, cap_rec);
     int32_t hL = 0, hR = 0;
-    if ((rc = h->comm.exchange_counts(h->comm.user, gL, gR, &hL, &hR))) return comm_fail(h, "exchange_counts", rc);
+    if ((rc = slab_exchange_counts(h, gL, gR, &hL, &hR))) return rc;
     if ((long long)n_in + hL + hR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by ghosts", h->ncap);
     if ((rc = slab_xfer(h, 32 * (size_t)gL, 32 * (size_t)gR, 32 * (size_t)hL, 32 * (size_t)hR))) return rc;
     {
@@ -1237,8 +1374,8 @@ int check_overflow_all(SphHandle *h)
     int ovf = h->ds_host->overflow;
     if (h->slab) {
         double v[1] = {(double)ovf};
-        int rc = h->comm.allreduce(h->comm.user, v, 1, 1);
-        if (rc) return comm_fail(h, "allreduce", rc);
+        int rc = slab_allreduce_host(h, v, 1, 1);
+        if (rc) return rc;
         if (v[0] > 0.0 && !ovf) return fail(h, SPH_E_OVERFLOW, "neighbour list overflow on another slab");
     }
     return check_overflow(h);
@@ -1319,7 +1456,7 @@ int reduce_mean_host(SphHandle *h, float dflt, float *mean)
     int rc = read_scalars(h);
     if (rc) return rc;
     double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
-    if (h->slab && (rc = h->comm.allreduce(h->comm.user, v, 2, 0))) return comm_fail(h, "allreduce", rc);
+    if (h->slab && (rc = slab_allreduce_host(h, v, 2, 0))) return rc;
     *mean = v[1] > 0.0 ? (float)(v[0] / v[1]) : dflt;       // dfsph_solver.py:148-149, 278-279
     return SPH_OK;
 }
@@ -1356,7 +1493,7 @@ int dfsph_ext_and_dt(SphHandle *h)
         } else {
             if ((rc = read_scalars(h))) return rc;
             double v[1] = {(double)h->ds_host->vmax};
-            if ((rc = h->comm.allreduce(h->comm.user, v, 1, 1))) return comm_fail(h, "allreduce", rc);
+            if ((rc = slab_allreduce_host(h, v, 1, 1))) return rc;
             h->ds_host->vmax = (float)v[0];
             HIP_TRY(h, hipMemcpyAsync(&h->ds->vmax, &h->ds_host->vmax, sizeof(float), hipMemcpyHostToDevice, s));
         }
@@ -1892,6 +2029,10 @@ void sph_destroy(SphHandle *h)
     for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
     if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
     if (h->own_red) (void)hipFree(h->red_dev);
+    if (h->nccl && rccl().ok) (void)rccl().CommDestroy(h->nccl);
+    if (h->cnt_dev) (void)hipFree(h->cnt_dev);
+    if (h->cnt_host) (void)hipHostFree(h->cnt_host);
+    if (h->red_host) (void)hipHostFree(h->red_host);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
@@ -2059,10 +2200,71 @@ int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t sl
     return SPH_OK;
 }
 
+int sph_rccl_unique_id(void *id128)
+{
+    if (!id128) return SPH_E_INVALID;
+    RcclApi &n = rccl();
+    if (!n.ok) return fail(nullptr, SPH_E_STATE, "RCCL is not available: %s", n.why.c_str());
+    ncclUniqueId id;
+    ncclResult_t r = n.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, SPH_E_HIP, "ncclGetUniqueId failed: %s", n.GetErrorString(r));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return SPH_OK;
+}
+
+int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
+{
+    if (!h || !id128) return SPH_E_INVALID;
+    RcclApi &n = rccl();
+    if (!n.ok) return fail(h, SPH_E_STATE, "RCCL is not available: %s", n.why.c_str());
+    if (h->native) return fail(h, SPH_E_STATE, "the native transport is already attached");
+    if (capacity_bytes < 4096) return fail(h, SPH_E_INVALID, "halo buffers smaller than 4 KiB");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // a single-GPU handle may attach as a communicator of one rank: that is all a 1-GPU box can exercise (tests), it never exchanges
+    const int rank = h->slab ? h->slab_rank : 0, world = h->slab ? h->nslab : 1;
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCL_TRY(h, n.CommInitRank(&h->nccl, world, id, rank));
+    if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(h, hipMalloc(&h->dsend[k], capacity_bytes));
+        HIP_TRY(h, hipMalloc(&h->drecv[k], capacity_bytes));
+    }
+    h->own_dev_comm = true;
+    if (h->own_red) (void)hipFree(h->red_dev);
+    h->red_cap = std::max(1024, h->c.gx + 8);                  // the re-balancing histogram (gx counts) goes through it too
+    HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * (size_t)h->red_cap));
+    h->own_red = true;
+    HIP_TRY(h, hipHostMalloc((void **)&h->red_host, sizeof(double) * (size_t)h->red_cap, hipHostMallocDefault));
+    HIP_TRY(h, hipMalloc((void **)&h->cnt_dev, sizeof(int) * 4));
+    HIP_TRY(h, hipHostMalloc((void **)&h->cnt_host, sizeof(int) * 4, hipHostMallocDefault));
+    memset(&h->comm, 0, sizeof(h->comm));
+    h->comm.capacity = capacity_bytes;
+    h->comm.stream_ordered = 1;
+    { const char *e = getenv("SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
+    h->native = true;
+    h->comm_set = true;
+    return SPH_OK;
+}
+
+int sph_rccl_selftest(SphHandle *h, double *inout, int32_t n, int32_t op)
+{
+    if (!h || !inout || n < 1) return SPH_E_INVALID;
+    if (!h->native) return fail(h, SPH_E_STATE, "attach the native transport first (sph_rccl_attach)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = slab_allreduce_host(h, inout, n, op);       // H2D, ncclAllReduce on the handle's stream, D2H
+    if (rc) return rc;
+    int32_t rl = -1, rr = -1;
+    if ((rc = native_exchange_counts(h, 11, 22, &rl, &rr))) return rc;
+    if (!h->slab && (rl != 0 || rr != 0)) return fail(h, SPH_E_STATE, "a one-rank communicator has no neighbours");
+    return native_exchange(h, 0, 0, 0, 0);
+}
+
 int sph_set_comm(SphHandle *h, const SphComm *comm)
 {
     if (!h || !comm) return SPH_E_INVALID;
     if (!h->slab) return fail(h, SPH_E_STATE, "sph_set_comm needs a handle created with slab_count > 1");
+    if (h->native) return fail(h, SPH_E_STATE, "the native RCCL transport is attached to this handle");
     if (!comm->exchange_counts || !comm->exchange_buffers || !comm->allreduce) return fail(h, SPH_E_INVALID, "SphComm callbacks must all be set");
     if (!comm->send_left || !comm->send_right || !comm->recv_left || !comm->recv_right || comm->capacity < 4096)
         return fail(h, SPH_E_INVALID, "SphComm buffers missing or smaller than 4 KiB");

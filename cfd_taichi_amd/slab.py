@@ -178,18 +178,33 @@ class TorchComm:
         return self._guard(run)
 
 
+def attach_native(sim, rank, capacity_bytes=64 << 20, group=None):
+    """Native transport: rank 0's ncclGetUniqueId travels over the existing torch.distributed group, then every rank's library
+    opens the communicator itself (collective) and drives ncclSend / ncclRecv / ncclAllReduce on its own stream."""
+    import torch.distributed as dist
+    box = [nat.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    sim.rccl_attach(box[0], capacity_bytes)
+
+
 class SlabSimulation:
     """One rank's share of a sharded simulation: a slab handle plus its transport."""
 
     def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, rebalance_every=0,
-                 **native_opts):
+                 transport="torch", group=None, **native_opts):
+        """transport: "torch" (TorchComm callbacks: RCCL through torch.distributed, or gloo) or "native" (the library opens its
+        own RCCL communicator and issues the transfers itself; one GPU per rank required)."""
         self.rank, self.world = rank, world
         cfg = nat.config_from_dict(config, solver_name=solver_name, device=device, slab_rank=rank, slab_count=world,
                                    slab_capacity=slab_capacity, slab_rebalance_every=rebalance_every, **native_opts)
         self.solver = "wcsph" if cfg.solver == nat.SOLVER_WCSPH else "dfsph"
         self.sim = nat.Simulation(cfg)
-        self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, stream_ptr=self.sim.stream_ptr())
-        self.sim.set_comm(self.comm.struct)
+        if transport == "native":
+            self.comm = None
+            attach_native(self.sim, rank, capacity_bytes, group)
+        else:
+            self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, group=group, stream_ptr=self.sim.stream_ptr())
+            self.sim.set_comm(self.comm.struct)
         self.n_fluid = self.sim.n_fluid
 
     def step(self, nsteps=1):
@@ -202,7 +217,7 @@ class SlabSimulation:
             self.sim.step_wcsph(nsteps)
             return None
         except nat.SphError:
-            if self.comm.error is not None:
+            if self.comm is not None and self.comm.error is not None:
                 raise self.comm.error
             raise
 
@@ -211,7 +226,7 @@ class SlabSimulation:
 
     def gather(self, field, dst=0):
         """All owned particles of all ranks assembled in original particle order on rank `dst` (else None)."""
-        dist = self.comm.dist
+        import torch.distributed as dist
         ids, vals = self.owned(field)
         parts = [None] * self.world if self.rank == dst else None
         dist.gather_object((ids, vals), parts, dst=dst)

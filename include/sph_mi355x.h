@@ -239,6 +239,14 @@ typedef struct SphComm {
 } SphComm;
 
 int sph_set_comm(SphHandle *h, const SphComm *comm);
+/* Native transport: instead of callbacks, the library itself issues ncclSend / ncclRecv to the left and right slab neighbour and
+ * ncclAllReduce of the residual pair on its own stream (librccl is dlopen'ed).  Rank 0 obtains a 128-byte id with
+ * sph_rccl_unique_id and the application broadcasts it by any means; every rank then calls sph_rccl_attach (collective:
+ * ncclCommInitRank with rank = slab_rank, world = slab_count) instead of sph_set_comm.  sph_rccl_selftest all-reduces n doubles and
+ * runs an empty neighbour exchange (a single-GPU handle attaches as a communicator of one rank for it). */
+int sph_rccl_unique_id(void *id128);
+int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes);
+int sph_rccl_selftest(SphHandle *h, double *inout, int32_t n, int32_t op);
 /* the handle's HIP stream (a hipStream_t), for stream-ordered transports */
 int sph_get_stream(SphHandle *h, void **stream);
 /* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the equal-count slabs of the

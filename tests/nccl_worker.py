@@ -43,6 +43,13 @@ def main():
     assert not sync.stream_ordered and sync.struct.stream_ordered == 0
     sync.reduce_t[0] = 2.0
     assert sync._allreduce_stream(None, 1, 0) == 0 and sync.reduce_t[0].item() == 2.0
+    # the native transport: the library's own communicator of one rank (dlopen'ed librccl, ncclCommInitRank, ncclAllReduce and an
+    # empty neighbour exchange on the handle's stream), then ordinary stepping on the same handle
+    sim.rccl_attach(nat.rccl_unique_id(), 1 << 16)
+    assert sim.rccl_selftest([1.5, -2.0, 4.0], 0) == [1.5, -2.0, 4.0]
+    assert sim.rccl_selftest([1.5, -2.0], 1) == [1.5, -2.0]
+    sim.step_dfsph(2)
+    sim.synchronize()
     sim.close()
     dist.destroy_process_group()
     print("nccl single-rank transport ok")
