@@ -41,6 +41,9 @@ ALGO_BYTES = {
 }
 
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / device-buffer sharing across processes needs dmabuf IPC on this driver
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,7 +264,10 @@ def main():
         if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
             discipline, why = "sync", "forced by SPH_SLAB_SYNC=1"
         else:
-            discipline, why = choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
+            try:
+                discipline, why = choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
+            except Exception as e:  # noqa: BLE001 - never lose the run over the self-check
+                discipline, why = "sync", "the self-check raised %s" % type(e).__name__
         transport += "; discipline: %s (%s)" % ({"native": "native RCCL calls on the library's stream", "stream": "torch.distributed ordered on the library's stream",
                                                   "sync": "synchronous"}[discipline], why)
     group_for = (side if discipline == "native" else transport_group) if world > 1 else None
