@@ -874,15 +874,17 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
     const int nsl = h->edge_count[1], nsr = h->edge_count[2], nrl = h->edge_count[0], nrr = h->edge_count[3];
     {
         ProfScope ps(h, K_SLAB);
-        if (nsl) hipLaunchKernelGGL(k_pack_field, grid_for(nsl), b, 0, s, h->edge_list[1], nsl, mode, P, V, (float *)h->dsend[0]);
-        if (nsr) hipLaunchKernelGGL(k_pack_field, grid_for(nsr), b, 0, s, h->edge_list[2], nsr, mode, P, V, (float *)h->dsend[1]);
+        if (nsl + nsr)
+            hipLaunchKernelGGL(k_pack_field, grid_for(nsl + nsr), b, 0, s, h->edge_list[1], nsl, (float *)h->dsend[0], h->edge_list[2], nsr,
+                               (float *)h->dsend[1], mode, P, V);
     }
     int rc = slab_xfer(h, 4 * fl * nsl, 4 * fl * nsr, 4 * fl * nrl, 4 * fl * nrr);
     if (rc) return rc;
     {
         ProfScope ps(h, K_SLAB);
-        if (nrl) hipLaunchKernelGGL(k_unpack_field, grid_for(nrl), b, 0, s, h->edge_list[0], nrl, mode, (const float *)h->drecv[0], P, V, rho);
-        if (nrr) hipLaunchKernelGGL(k_unpack_field, grid_for(nrr), b, 0, s, h->edge_list[3], nrr, mode, (const float *)h->drecv[1], P, V, rho);
+        if (nrl + nrr)
+            hipLaunchKernelGGL(k_unpack_field, grid_for(nrl + nrr), b, 0, s, h->edge_list[0], nrl, (const float *)h->drecv[0], h->edge_list[3], nrr,
+                               (const float *)h->drecv[1], mode, P, V, rho);
     }
     HIP_TRY(h, hipGetLastError());
     return SPH_OK;

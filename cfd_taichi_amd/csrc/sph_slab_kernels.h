@@ -180,31 +180,40 @@ __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__re
     for (int s = a; s < b; ++s) list[o + (s - a)] = s;
 }
 
-// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats)
-__global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ list, int count, int mode, const float4 *__restrict__ P,
-                                                       const float4 *__restrict__ V, float *__restrict__ out)
+// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats).  One launch serves both sides:
+// threads [0, count_a) work on side a (left), threads [count_a, count_a + count_b) on side b (right).
+__global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ list_a, int count_a, float *__restrict__ out_a,
+                                                       const int *__restrict__ list_b, int count_b, float *__restrict__ out_b, int mode,
+                                                       const float4 *__restrict__ P, const float4 *__restrict__ V)
 {
     int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= count) return;
-    int s = list[r];
+    if (r >= count_a + count_b) return;
+    const bool b = r >= count_a;
+    if (b) r -= count_a;
+    const int s = (b ? list_b : list_a)[r];
+    float *out = b ? out_b : out_a;
     if (mode == 0) out[r] = P[s].w;
     else if (mode == 1) { float4 v = V[s]; out[3 * (size_t)r] = v.x; out[3 * (size_t)r + 1] = v.y; out[3 * (size_t)r + 2] = v.z; }
     else { out[2 * (size_t)r] = P[s].w; out[2 * (size_t)r + 1] = V[s].w; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__ list, int count, int mode, const float *__restrict__ in,
+__global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__ list_a, int count_a, const float *__restrict__ in_a,
+                                                         const int *__restrict__ list_b, int count_b, const float *__restrict__ in_b, int mode,
                                                          float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ rho)
 {
     int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= count) return;
-    int s = list[r];
+    if (r >= count_a + count_b) return;
+    const bool b = r >= count_a;
+    if (b) r -= count_a;
+    const int s = (b ? list_b : list_a)[r];
+    const float *in = b ? in_b : in_a;
     if (mode == 0) P[s].w = in[r];
     else if (mode == 1) { V[s].x = in[3 * (size_t)r]; V[s].y = in[3 * (size_t)r + 1]; V[s].z = in[3 * (size_t)r + 2]; }
     else {
         P[s].w = in[2 * (size_t)r];
-        float b = in[2 * (size_t)r + 1];
-        V[s].w = b;
-        if (rho) rho[s] = b;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
+        float bb = in[2 * (size_t)r + 1];
+        V[s].w = bb;
+        if (rho) rho[s] = bb;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
     }
 }
 
