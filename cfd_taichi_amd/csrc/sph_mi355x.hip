@@ -390,6 +390,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         h->rebalance_every = cf.slab_rebalance_every > 0 ? cf.slab_rebalance_every : 0;
         h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
         h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
+        if (cf.solver == SPH_SOLVER_PCISPH) h->pci_fluid_pos = sc.fluid_pos;   // pre_compute looks at the whole lattice on every slab
         std::vector<float> own_pos; std::vector<int> own_id;
         for (int i = 0; i < N; ++i)
             if (col[i] >= h->geom.x_lo && col[i] < h->geom.x_hi) {
@@ -813,8 +814,7 @@ int slab_exchange_particles(SphHandle *h)
     Consts &c = h->c;
     hipStream_t s = h->stream;
     const dim3 b(kBlock);
-    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
-    float *warm = dfsph ? h->warm[h->wcur] : nullptr;
+    float *warm = carries_scalar(h) ? h->warm[h->wcur] : nullptr;   // dfsph warm_start_k / iisph p_past travel with the particle
     const int cap_rec = (int)std::min<size_t>(h->comm.capacity / 32, 0x7fffffff);
     const int n_prev = c.n;
     HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * 4, s));
@@ -870,7 +870,7 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
 {
     hipStream_t s = h->stream;
     const dim3 b(kBlock);
-    const size_t fl = mode == 0 ? 1 : (mode == 1 ? 3 : 2);
+    const size_t fl = mode == 0 ? 1 : (mode == 1 ? 3 : 2);      // modes 2 and 3: two floats
     const int nsl = h->edge_count[1], nsr = h->edge_count[2], nrl = h->edge_count[0], nrr = h->edge_count[3];
     {
         ProfScope ps(h, K_SLAB);
@@ -1330,7 +1330,8 @@ int stage_density(SphHandle *h)
     }
     HIP_TRY(h, hipGetLastError());
     if (h->slab) {   // ghosts need (k/rho, rho) resp. (rho, p/rho^2) from their owners
-        int rc = slab_exchange_field(h, 2, dfsph ? h->P[1 - h->pcur] : h->P[h->pcur], h->V[h->vcur], dfsph ? h->rho : nullptr);
+        const bool ps = is_pressure_solver(h);            // their sweeps read rho[] of the neighbours: mode 3 fills it from P.w
+        int rc = slab_exchange_field(h, ps ? 3 : 2, dfsph ? h->P[1 - h->pcur] : h->P[h->pcur], h->V[h->vcur], (dfsph || ps) ? h->rho : nullptr);
         if (rc) return rc;
     }
     h->density_valid = true;
@@ -1653,10 +1654,30 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
 // ---------------------------------------------------------------------------------------------
 // PCISPH / IISPH (SURVEY.md section 8f "next": the solvers coupling_demo.json and breaking_dam_30k.json name)
 // ---------------------------------------------------------------------------------------------
-void launch_pressure_finalize(SphHandle *h, int mode)
+int launch_pressure_finalize(SphHandle *h, int mode)
 {
+    if (h->slab) {
+        {
+            ProfScope ps(h, K_FINALIZE);
+            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev);
+        }
+        int rc = slab_allreduce_stream(h, 2, 0);
+        if (rc) return rc;
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev);
+        return SPH_OK;
+    }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode);
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr);
+    return SPH_OK;
+}
+
+// sharded pcisph / iisph need the device-side loop control (an in-place all-reduce on the stream)
+int require_async_slab(SphHandle *h)
+{
+    if (h->slab && !slab_async(h))
+        return fail(h, SPH_E_STATE, "pcisph / iisph on slabs need a transport with allreduce_stream (TorchComm) or the native RCCL transport");
+    return SPH_OK;
 }
 
 // pcisph_solver.step :252-259
@@ -1665,6 +1686,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     int rc;
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = require_async_slab(h))) return rc;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     if ((rc = stage_density(h))) return rc;                 // compute_all_rho :239; P = (pos, rho)
     const Consts &c = h->c;
@@ -1681,6 +1703,10 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         if (rg) hipLaunchKernelGGL(k_pci_ext<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
         else hipLaunchKernelGGL(k_pci_ext<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
     }
+    // sharded: the ghosts' predicted positions / pressures come from their owners after the sweep that produced them
+    auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
+    auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
+    if ((rc = ghosts_xyz(PP))) return rc;
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
         if (rg)
@@ -1691,7 +1717,8 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
                                PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
-    launch_pressure_finalize(h, PFIN_PCI_FIRST);
+    if ((rc = ghosts_w(PB[1]))) return rc;
+    if ((rc = launch_pressure_finalize(h, PFIN_PCI_FIRST))) return rc;
     bool first = true;
     for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
@@ -1705,8 +1732,10 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
                                        h->ds, PF, PP, GATE_DENS, rv);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
+            if ((rc = ghosts_xyz(PP))) return rc;
             predict_rho(k, GATE_DENS);
-            launch_pressure_finalize(h, PFIN_PCI_LOOP);
+            if ((rc = ghosts_w(PB[(k + 1) & 1]))) return rc;
+            if ((rc = launch_pressure_finalize(h, PFIN_PCI_LOOP))) return rc;
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
@@ -1741,6 +1770,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     int rc;
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;
+    if ((rc = require_async_slab(h))) return rc;
     if ((rc = stage_sort_and_lists(h))) return rc;
     if ((rc = stage_density(h))) return rc;                 // predict_advection :38; P = (pos, rho)
     const Consts &c = h->c;
@@ -1757,6 +1787,10 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
         if (rg) hipLaunchKernelGGL(k_ii_advect<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
         else hipLaunchKernelGGL(k_ii_advect<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
     }
+    auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
+    auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
+    if ((rc = ghosts_xyz(VA))) return rc;                   // v_adv and d_ii of the ghosts (their 0.5 p_past travels with the particle)
+    if ((rc = ghosts_xyz(DII))) return rc;
     {
         ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
         if (rg)
@@ -1774,6 +1808,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
                 if (rg) hipLaunchKernelGGL(k_ii_dij<true>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
                 else hipLaunchKernelGGL(k_ii_dij<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
             }
+            if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
                 if (rg)
@@ -1783,7 +1818,8 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
                     hipLaunchKernelGGL(k_ii_update_p<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho,
                                        h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv);
             }
-            launch_pressure_finalize(h, PFIN_II_LOOP);
+            if ((rc = ghosts_w(PB[k & 1]))) return rc;
+            if ((rc = launch_pressure_finalize(h, PFIN_II_LOOP))) return rc;
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
@@ -1842,10 +1878,47 @@ int pcisph_precompute(SphHandle *h)
     h->pci_beta = (float)beta;
     // get_max_neighbor_particle_index (ParticleSystem.py:410-422): counts from the device lists, then the single-thread
     // reading of the atomic_max idiom -- the last particle whose count ties the running maximum
+    std::vector<float> counts((size_t)N);
+    if (h->slab) {
+        // every slab needs the same delta: neighbour counts of the WHOLE initial lattice, on the host (same r2 > r2_cut criterion as
+        // k_build_nl; one-time, O(216 N))
+        const float *pos = h->pci_fluid_pos.data();
+        std::vector<int> cid((size_t)N), start((size_t)c.C + 1, 0), order((size_t)N);
+        for (int i = 0; i < N; ++i) {
+            const int x = (int)floorf(pos[3 * (size_t)i] / c.h), y = (int)floorf(pos[3 * (size_t)i + 1] / c.h), z = (int)floorf(pos[3 * (size_t)i + 2] / c.h);
+            int id = x + y * c.sy + z * c.sz;
+            if (x < 0 || y < 0 || z < 0 || x >= c.gx || y >= c.gy || z >= c.gz) id = -1;
+            cid[i] = id;
+            if (id >= 0) start[(size_t)id + 1]++;
+        }
+        for (int k = 0; k < c.C; ++k) start[(size_t)k + 1] += start[k];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < N; ++i) if (cid[i] >= 0) order[fill[cid[i]]++] = i;
+        for (int i = 0; i < N; ++i) {
+            int cnt = 0;
+            if (cid[i] >= 0) {
+                const int x = cid[i] % c.gx, z = (cid[i] / c.gx) % c.gz, y = cid[i] / (c.gx * c.gz);
+                for (int dx = -1; dx <= 1; ++dx)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dz = -1; dz <= 1; ++dz) {
+                            const int xx = x + dx, yy = y + dy, zz = z + dz;
+                            if (xx < 0 || yy < 0 || zz < 0 || xx >= c.gx || yy >= c.gy || zz >= c.gz) continue;
+                            const int nb = xx + yy * c.sy + zz * c.sz;
+                            for (int e = start[nb]; e < start[(size_t)nb + 1]; ++e) {
+                                const int j = order[e];
+                                if (j == i) continue;
+                                const float ax = pos[3 * (size_t)i] - pos[3 * (size_t)j], ay = pos[3 * (size_t)i + 1] - pos[3 * (size_t)j + 1],
+                                            az = pos[3 * (size_t)i + 2] - pos[3 * (size_t)j + 2];
+                                if (!((ax * ax + ay * ay) + az * az > c.r2_cut)) ++cnt;
+                            }
+                        }
+            }
+            counts[i] = (float)cnt;
+        }
+    } else {
     if ((rc = stage_sort_and_lists(h))) return rc;
     if ((rc = read_scalars(h))) return rc;
     if ((rc = check_overflow(h))) return rc;
-    std::vector<float> counts((size_t)N);
     if (rigid_coupled(h))   // get_neighbour_count with its rigid-entry quirk (ParticleSystem.py:436-444)
         hipLaunchKernelGGL(k_unsort_scalar_int, grid_for(N), dim3(kBlock), 0, h->stream, N, h->ncount, h->id[h->icur], h->staging);
     else
@@ -1853,6 +1926,7 @@ int pcisph_precompute(SphHandle *h)
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(counts.data(), h->staging, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     int max_count = -1, max_index = -1;
     for (int i = 0; i < N; ++i) {
         const int cnt = (int)counts[i];
@@ -1944,8 +2018,6 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     *out = nullptr;
     if (cfg->solver < SPH_SOLVER_WCSPH || cfg->solver > SPH_SOLVER_IISPH)
         return fail(nullptr, SPH_E_INVALID, "unknown solver %d", cfg->solver);
-    if (cfg->slab_count > 1 && (cfg->solver == SPH_SOLVER_PCISPH || cfg->solver == SPH_SOLVER_IISPH))
-        return fail(nullptr, SPH_E_INVALID, "pcisph / iisph run on a single GPU (the slab decomposition covers wcsph and dfsph)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -1965,7 +2037,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
         if ((rc = build_scene(h, sc))) break;
         if ((rc = alloc_device(h, sc))) break;
         if (h->cfg.solver == SPH_SOLVER_PCISPH) {
-            h->pci_fluid_pos = sc.fluid_pos;
+            if (!h->slab) h->pci_fluid_pos = sc.fluid_pos;
             if ((rc = pcisph_precompute(h))) break;
         }
         h->wall_pos_host = sc.wall_pos;

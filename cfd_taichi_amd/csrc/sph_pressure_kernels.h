@@ -96,21 +96,26 @@ __device__ __forceinline__ void clamp_walls(const Consts &c, float pos[3], float
 // iisph_solver.py:89-100.  Iteration counter, residual and the "open" flag live in DevScalars (dens_* fields).
 enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
 
+// phase / red: as k_finalize_mean (FINP_ALL on one GPU; FINP_REDUCE -> all-reduce over the slabs -> FINP_DECIDE when sharded)
 __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                              DevScalars *__restrict__ ds, int mode)
+                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
 {
     if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
-    double t = 0.0; long long n = 0;
-    for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
-    s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+    if (phase != FINP_DECIDE) {
+        double t = 0.0; long long n = 0;
+        for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+        s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
         __syncthreads();
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
+            __syncthreads();
+        }
     }
     if (threadIdx.x != 0) return;
+    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
+    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
     ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
     const float res = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // pcisph :136-137, iisph :119-120
     const int cap = ds->dens_cap;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
         pr = rmax(0.0f, pr);                                 // :108
         PBout[i] = make_float4(pb.x, pb.y, pb.z, pr);
         val = rmax(err, 0.0f);                               // :132
-        flag = val > 0.0f;
+        flag = val > 0.0f && !ghost;                         // ghosts (multi-GPU) are counted by their owner
     }
     block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         else p_new = 0.0f;
         const float p = rmax(p_new, 0.0f);                   // :156
         PBout[i] = make_float4(pi.x, pi.y, pi.z, p);
-        flag = p > 0.0f;                                     // :115
+        flag = p > 0.0f && !ghost;                           // :115; ghosts (multi-GPU) are counted by their owner
         val = ((aii * p + r_sum) + radv) - 1000.0f;          // :116
     }
     block_partial_mean(blk, (double)val, flag, psum, pcnt);

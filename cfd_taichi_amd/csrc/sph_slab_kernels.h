@@ -180,7 +180,8 @@ __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__re
     for (int s = a; s < b; ++s) list[o + (s - a)] = s;
 }
 
-// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats).  One launch serves both sides:
+// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats; rho[] := V.w, dfsph),
+// 3 = (P.w, V.w) with rho[] := P.w (pcisph / iisph: P.w carries rho).  One launch serves both sides:
 // threads [0, count_a) work on side a (left), threads [count_a, count_a + count_b) on side b (right).
 __global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ list_a, int count_a, float *__restrict__ out_a,
                                                        const int *__restrict__ list_b, int count_b, float *__restrict__ out_b, int mode,
@@ -210,10 +211,11 @@ __global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__
     if (mode == 0) P[s].w = in[r];
     else if (mode == 1) { V[s].x = in[3 * (size_t)r]; V[s].y = in[3 * (size_t)r + 1]; V[s].z = in[3 * (size_t)r + 2]; }
     else {
-        P[s].w = in[2 * (size_t)r];
-        float bb = in[2 * (size_t)r + 1];
+        const float aa = in[2 * (size_t)r];
+        const float bb = in[2 * (size_t)r + 1];
+        P[s].w = aa;
         V[s].w = bb;
-        if (rho) rho[s] = bb;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
+        if (rho) rho[s] = mode == 3 ? aa : bb;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
     }
 }
 

@@ -49,6 +49,8 @@ SCENES = {
     "breaking_dam_30k_pcisph": lambda: _scene("pcisph", 1e-3, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
     "iisph_1m": lambda: _scene("iisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
     "pcisph_1m": lambda: _scene("pcisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
+    "dfsph_tiny_wall_pcisph": lambda: _scene("pcisph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
+    "dfsph_tiny_wall_iisph": lambda: _scene("iisph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
 }
 
 

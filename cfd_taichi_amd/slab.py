@@ -197,7 +197,7 @@ class SlabSimulation:
         self.rank, self.world = rank, world
         cfg = nat.config_from_dict(config, solver_name=solver_name, device=device, slab_rank=rank, slab_count=world,
                                    slab_capacity=slab_capacity, slab_rebalance_every=rebalance_every, **native_opts)
-        self.solver = "wcsph" if cfg.solver == nat.SOLVER_WCSPH else "dfsph"
+        self.solver = {v: k for k, v in nat.SOLVER_IDS.items()}[cfg.solver]
         self.sim = nat.Simulation(cfg)
         if transport == "native":
             self.comm = None
@@ -209,13 +209,13 @@ class SlabSimulation:
 
     def step(self, nsteps=1):
         try:
-            if self.solver == "dfsph":
-                st = None
-                for _ in range(nsteps):
-                    st = self.sim.step_dfsph(1)
-                return st
-            self.sim.step_wcsph(nsteps)
-            return None
+            if self.solver == "wcsph":
+                self.sim.step_wcsph(nsteps)
+                return None
+            st = None
+            for _ in range(nsteps):
+                st = self.sim.step(1)
+            return st
         except nat.SphError:
             if self.comm is not None and self.comm.error is not None:
                 raise self.comm.error

@@ -36,7 +36,7 @@ def main():
     from cfd_taichi_amd.slab import SlabSimulation
     cfg = scenes.get(args.scene)
     sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance)
-    dfsph = sim.solver == "dfsph"
+    dfsph = sim.solver != "wcsph"      # every solver but wcsph reports per-step statistics
     stats = []
     owned_max = 0
     for _ in range(args.steps):
@@ -57,7 +57,7 @@ def main():
         ref_stats = []
         for _ in range(args.steps):
             if dfsph:
-                st = ref.step_dfsph(1)
+                st = ref.step(1)
                 ref_stats.append([st.n_div, st.n_dens, st.n_div_evals, float(st.div_first_err), float(st.div_err), float(st.dens_err), float(st.dt)])
             else:
                 ref.step_wcsph(1)
