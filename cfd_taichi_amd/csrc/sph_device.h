@@ -41,6 +41,7 @@ struct Consts {
     int n;             // particles resident in the arrays
     int stride;        // neighbour-list row stride (>= n, multiple of 64)
     int kmax, kbmax;   // neighbour-list rows (fluid, wall)
+    int strict_cells;  // slab handles: a particle with any cell coordinate outside the grid is binned nowhere (see cell_id_of)
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

@@ -47,6 +47,11 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
     cz = (int)floorf(z / c.h);
     int id = cx + cy * c.sy + cz * c.sz;
     if (id < 0 || id >= c.C) id = c.C;   // "lost" bucket (reference prints and skips, :393-395)
+    // The reference guards only the 1-D index: a particle that slipped through a wall keeps a valid index and is binned into a
+    // WRAPPED cell, a box length away from where it is -- a candidate that never passes the distance test there.  On a slab handle
+    // that wrapped cell may be a column this rank shares with a neighbour (ordered edge / ghost lists), so such a particle is binned
+    // nowhere instead: same results (nobody could see it), consistent lists.
+    if (c.strict_cells && (cx < 0 || cx >= c.gx || cy < 0 || cy >= c.gy || cz < 0 || cz >= c.gz)) id = c.C;
     return id;
 }
 

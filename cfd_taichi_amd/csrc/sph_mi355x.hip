@@ -349,6 +349,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.gx = g[0]; c.gy = g[1]; c.gz = g[2]; c.C = (int)C;
     c.sy = g[0] * g[2]; c.sz = g[0];               // :102
     c.boundary_handle = cf.boundary_handle ? 1 : 0;
+    c.strict_cells = cf.slab_count > 1 ? 1 : 0;
     c.n = h->N;                                    // refined below for slab handles
     c.stride = (h->N + 63) / 64 * 64;
     c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
@@ -386,6 +387,12 @@ int build_scene(SphHandle *h, HostScene &sc)
         std::vector<int> col, cut;
         std::string why;
         if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why)) return fail(h, SPH_E_INVALID, "%s", why.c_str());
+        if (const char *e = getenv("SPH_SLAB_CUTS")) {       // debugging aid: comma-separated interior cuts, e.g. "9,18" for three slabs
+            std::vector<int> forced{0};
+            for (const char *q = e; *q;) { forced.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            forced.push_back(c.gx);
+            if ((int)forced.size() == h->nslab + 1) cut = forced;
+        }
         h->cuts = cut;
         h->rebalance_every = cf.slab_rebalance_every > 0 ? cf.slab_rebalance_every : 0;
         h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];

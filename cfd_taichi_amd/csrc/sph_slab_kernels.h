@@ -6,6 +6,7 @@
 // order inside a cell -- and with it every neighbour sum -- is the same on every decomposition.
 #pragma once
 #include "sph_device.h"
+#include "sph_kernels.h"
 
 namespace sph {
 
@@ -118,9 +119,15 @@ __global__ __launch_bounds__(kBlock) void k_classify_ghost(Consts c, SlabGeom g,
         pid = id[s];
         if (pid >= 0) {
             p = P[s];
-            const int cx = (int)floorf(p.x / c.h);
-            to_left = g.has_left && cx == g.x_lo;
-            to_right = g.has_right && cx == g.x_hi - 1;
+            // The ordered edge lists (k_layer_list) enumerate the CELL LISTS of the edge columns, so "is an edge particle" must be
+            // decided by the cell the sort bins the particle into -- the reference's 1-D index (ParticleSystem.py:486-494, guarded only
+            // by 0 <= id <= C at :393): a particle that slipped through a wall in y or z still has a valid 1-D index (it wraps into a
+            // neighbouring row of the same column) and is a member of that cell; one whose index is out of range sits in no cell.
+            int cx, cy, cz;
+            const int cid = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+            const int col = cid < c.C ? cid % c.gx : -1;
+            to_left = g.has_left && col == g.x_lo;
+            to_right = g.has_right && col == g.x_hi - 1;
         }
     }
     const int sl = wave_alloc(&counters[0], to_left);

@@ -1,0 +1,15 @@
+set -o pipefail
+run() { # scene world steps rebalance
+  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $2 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) tests/slab_worker.py --scene $1 --steps $3 --backend gloo --rebalance $4 --out gpurun_out/soak_$1_$2.json > gpurun_out/soak_$1_$2.log 2>&1
+  echo "rc=$? $1 world=$2 steps=$3"; python - <<PY
+import json
+r=json.load(open("gpurun_out/soak_$1_$2.json"))
+print({k:r[k] for k in ("pos_equal","vel_equal","rho_equal","stats_equal","pos_rel_err")}, [(s["owned"],s["x_lo"],s["x_hi"],s["recuts"]) for s in r["slabs"]])
+PY
+}
+export HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2
+run dfsph_dam_x 3 2500 7
+run dfsph_dam_x 4 1500 5
+run wcsph_dam_x 3 8000 11
+run dfsph_tiny_wall_iisph 3 1500 9
+run dfsph_tiny_wall_pcisph 2 800 13
