@@ -63,3 +63,33 @@ def test_coincident_particles_and_cell_faces(solver):
     sim.upload(nat.F_POS, pos)
     step_both(sim, o, solver, 15)
     sim.close(); o.close()
+
+
+@pytest.mark.parametrize("scene,solver,steps", [("dfsph_dam_x", "dfsph", 1500), ("wcsph_dam_x", "wcsph", 5000), ("dfsph_tiny_wall_iisph", "iisph", 800),
+                                                ("dfsph_tiny_wall_pcisph", "pcisph", 500)])
+def test_long_runs_with_wall_leaks_match_oracle(scene, solver, steps):
+    """Hundreds to thousands of steps on small scenes whose single-layer walls leak: particles whose 1-D cell index wraps into a far cell
+    or falls out of range (ParticleSystem.py:393).  The GPU path must stay on the oracle's trajectory bit for bit through all of it."""
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=8)
+    chunk = 100
+    for s0 in range(0, steps, chunk):
+        if solver == "wcsph":
+            sim.step_wcsph(chunk); o.step_wcsph(chunk)
+        else:
+            for _ in range(chunk):
+                st = sim.step(1)
+                if solver == "dfsph":
+                    o.step_dfsph(1, 100)
+                    assert (st.n_div, st.n_dens) == (o.last_stats.n_div, o.last_stats.n_dens), s0
+                else:
+                    (o.step_pcisph if solver == "pcisph" else o.step_iisph)(1)
+                    assert st.n_dens == o.last_stats.n_dens, s0
+        a, b = sim.download(nat.F_POS), o.get(orc.F_POS)
+        assert np.array_equal(a, b, equal_nan=True), (scene, s0 + chunk, int((a != b).sum()))
+    pos = o.get(orc.F_POS)
+    box = np.asarray(cfg["scene"]["box_max"], dtype=np.float32)
+    leaked = int(((pos < 0) | (pos > box)).any(axis=1).sum())
+    print(scene, "particles outside the box at the end:", leaked)
+    sim.close(); o.close()
