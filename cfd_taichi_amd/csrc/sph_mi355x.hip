@@ -623,6 +623,9 @@ int slab_allreduce_stream(SphHandle *h, int n, int op)
         HIP_TRY(h, hipMemcpyAsync(cm.reduce_buf, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    // synchronous discipline on device buffers: the transport works on its own stream, so the pair must be complete before it reads
+    // (it returns only when the reduced values are in place)
+    if (!cm.on_host && !cm.stream_ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));
     int rc = cm.allreduce_stream(cm.user, n, op);
     if (rc) return comm_fail(h, "allreduce_stream", rc);
     if (cm.on_host) HIP_TRY(h, hipMemcpyAsync(h->red_dev, cm.reduce_buf, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
