@@ -1,6 +1,7 @@
 """Headless runner: the reference's frame loop (main.py:95-206) without the GGUI window.
 
     python -m cfd_taichi_amd.run --config config/dfsph_small.json [--solver dfsph] [--until 4.0 | --steps N] [--ply-dir output]
+    torchrun --nproc-per-node 8 -m cfd_taichi_amd.run --config config/dfsph_10m.json --steps 100      # one x-slab per GPU (no rigid body)
 
 Per frame: `iter_cnt` fluid steps, then `iter_cnt` rigid steps if a rigid body is active (main.py:165-171),
 t += iter_cnt * solver.delta_time[None] (:173); stops at t > 4.0 (:205) or after --steps frames.  With --ply-dir (or
@@ -35,6 +36,54 @@ def write_obj(path, vertices, faces):
             f.write("f %d %d %d\n" % tuple(int(k) + 1 for k in t))
 
 
+def main_sharded(args, config):
+    """WORLD_SIZE > 1 (launched by torchrun): one x-slab per rank, native RCCL transport when every rank has its own GPU (else
+    torch.distributed callbacks); rank 0 gathers the positions for the PLY frames."""
+    import torch
+    import torch.distributed as dist
+    from . import _native as nat
+    from .slab import SlabSimulation
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if config.get("solid"):
+        raise SystemExit("rigid bodies are not sharded: run this config on one GPU")
+    own_gpu = torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    device = local if own_gpu else 0
+    if own_gpu:
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo")
+    transport = os.environ.get("SPH_RUN_TRANSPORT", "native" if own_gpu else "torch")
+    sim = SlabSimulation(config, rank, world, device=device, transport=transport, rebalance_every=50)
+    scene_config, solver_config = config["scene"], config["solver"]
+    iter_cnt = solver_config.get("iter_cnt")
+    ply_dir = args.ply_dir or ("./output" if scene_config.get("is_output_ply", False) else None)
+    if ply_dir and rank == 0:
+        os.makedirs(ply_dir, exist_ok=True)
+    rgba = np.tile(np.float32([0.0, 0.26, 0.68, 1.0]), (sim.n_fluid, 1))          # ParticleSystem.py:152
+    frame_time = 1.0 / scene_config.get("output_fps", 60)
+    frame_cnt, ply_cnt, t = 0, 0, 0.0
+    start_time = time.time()
+    while True:
+        sim.step(iter_cnt)
+        frame_cnt += 1
+        t += iter_cnt * sim.sim.scalar(nat.S_DELTA_TIME)
+        if ply_dir and (t / frame_time) > ply_cnt:
+            pos = sim.gather(nat.F_POS)
+            if rank == 0:
+                write_ply_ascii(os.path.join(ply_dir, "output_%06d.ply" % ply_cnt), pos, rgba)
+            ply_cnt += 1
+        if (args.steps and frame_cnt >= args.steps) or t > args.until or frame_cnt > 100000:
+            break
+    if rank == 0:
+        print("slabs: %d, frames: %d, simulated time: %.6f s, PLY frames: %d" % (world, frame_cnt, t, ply_cnt))
+        print("Simulation time: {}".format(time.time() - start_time))
+    sim.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return frame_cnt, t, ply_cnt
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--config", default="./default.json")          # main.py:14
@@ -48,6 +97,8 @@ def main(argv=None):
     config = utils.read_config(args.config)
     if args.solver:
         config["solver"]["name"] = args.solver
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return main_sharded(args, config)
     scene_config, solver_config = config["scene"], config["solver"]
     print("Simulation Start!")
     start_time = time.time()

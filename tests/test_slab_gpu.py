@@ -97,3 +97,18 @@ def test_stream_ordered_transport_plumbing_on_rccl():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py"), str(free_port())], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "transport ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_headless_runner_on_slabs(tmp_path):
+    """torchrun -m cfd_taichi_amd.run: the frame loop with one x-slab per rank; rank 0 writes the gathered PLY frames."""
+    out = tmp_path / "ply"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), "-m", "cfd_taichi_amd.run", "--config", os.path.join(ROOT, "config", "dfsph_small.json"),
+           "--steps", "20", "--ply-dir", str(out)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", PYTHONPATH=ROOT)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "slabs: 2, frames: 20" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    frames = sorted(os.listdir(out))
+    assert frames and frames[0] == "output_000000.ply"
+    head = open(out / frames[0]).read().split("end_header")[0]
+    assert "element vertex 5879" in head
