@@ -365,11 +365,26 @@ int build_scene(SphHandle *h, HostScene &sc)
         const float xz_num = (float)((cf.water_size[0] / d) * (cf.water_size[2] / d));
         const float radius = (float)r;
         const float sp[3] = {(float)cf.start_pos[0], (float)cf.start_pos[1], (float)cf.start_pos[2]};
+        // The reference forms the lattice coordinates from the particle index in f32, which is exact only below 2^24 particles: beyond
+        // that its own initial condition degenerates (indices collide).  From 2^24 on the same expressions are evaluated in f64 -- the
+        // continuation the formulas intend; below 2^24 the f32 path is kept bit for bit (SPH_LATTICE_F64=1 forces f64 everywhere: a test
+        // checks that both agree there).
+        const char *force64 = getenv("SPH_LATTICE_F64");
+        const int f32_limit = (force64 && force64[0] == '1') ? 0 : (1 << 24);
         for (int i = 0; i < N; ++i) {
-            float fi = (float)i;
-            float x = fmod_py(fi, x_num);
-            float z = fmod_py(floorf(fi / x_num), z_num);
-            int y = (int)(fi / xz_num);
+            float x, z; int y;
+            if (i < f32_limit) {
+                float fi = (float)i;
+                x = fmod_py(fi, x_num);
+                z = fmod_py(floorf(fi / x_num), z_num);
+                y = (int)(fi / xz_num);
+            } else {
+                const double di = (double)i, xn = (double)x_num, zn = (double)z_num;
+                const double row = floor(di / xn);
+                x = (float)(di - xn * floor(di / xn));
+                z = (float)(row - zn * floor(row / zn));
+                y = (int)(di / (double)xz_num);
+            }
             sc.fluid_pos[3 * (size_t)i + 0] = x * radius * 2.0f + sp[0];
             sc.fluid_pos[3 * (size_t)i + 1] = (float)y * radius * 2.0f + sp[1];
             sc.fluid_pos[3 * (size_t)i + 2] = z * radius * 2.0f + sp[2];

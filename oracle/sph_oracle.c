@@ -328,10 +328,18 @@ static void init_particle_pos(Orc *o)
     real radius = R(c->particle_radius);
     real sp[3] = { R(c->start_pos[0]), R(c->start_pos[1]), R(c->start_pos[2]) };
     for (int i = 0; i < o->N; ++i) {
-        real fi = R(i);
-        real x = fmod_py(fi, x_num);                       /* :147 */
-        real z = fmod_py(r_floor(fi / x_num), z_num);      /* :148 */
-        int y = (int)(fi / xz_num);                        /* :149 */
+        real x, z; int y;
+        if (i < (1 << 24) || sizeof(real) == 8) {
+            real fi = R(i);
+            x = fmod_py(fi, x_num);                        /* :147 */
+            z = fmod_py(r_floor(fi / x_num), z_num);       /* :148 */
+            y = (int)(fi / xz_num);                        /* :149 */
+        } else {    /* beyond 2^24 the f32 index is no longer exact and the reference's lattice collapses: continue in f64 (same rule as the library) */
+            double di = (double)i, xn = (double)x_num, zn = (double)z_num, row = floor(di / xn);
+            x = R(di - xn * floor(di / xn));
+            z = R(row - zn * floor(row / zn));
+            y = (int)(di / (double)xz_num);
+        }
         o->pos[3 * i + 0] = x * radius * R(2) + sp[0];     /* :150 */
         o->pos[3 * i + 1] = R(y) * radius * R(2) + sp[1];
         o->pos[3 * i + 2] = z * radius * R(2) + sp[2];

@@ -134,3 +134,18 @@ def test_pressure_solvers_1m_first_steps_bit_exact_and_reproducible(scene, solve
         runs.append((pos, vel, [(s.n_dens, s.dens_err) for s in stats]))
         sim.close()
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1]) and runs[0][2] == runs[1][2]
+
+
+def test_lattice_f64_continuation_agrees_below_2_24(monkeypatch):
+    """Beyond 2^24 particles the reference's f32 index arithmetic (ParticleSystem.py:142-151) can no longer tell particles apart; the
+    library continues the lattice in f64 there.  Forcing the f64 expressions everywhere must reproduce the f32 lattice below 2^24."""
+    cfg = scenes.get("dfsph_1m")
+    a = nat.Simulation(nat.config_from_dict(cfg))
+    pa = a.download(nat.F_POS)
+    a.close()
+    monkeypatch.setenv("SPH_LATTICE_F64", "1")
+    b = nat.Simulation(nat.config_from_dict(cfg))
+    pb = b.download(nat.F_POS)
+    b.close()
+    assert np.array_equal(pa, pb)
+    assert len(np.unique(pa.view([("x", "f4"), ("y", "f4"), ("z", "f4")]))) == len(pa)      # all lattice points distinct
