@@ -3,8 +3,8 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from cfd_taichi_amd import _native as nat, scenes
 cfg = scenes.get("dfsph_10m")
-cfg["scene"]["box_max"] = [70.0, 8.0, 10.2]
-cfg["fluid"]["water_size"] = [62.5, 5.0, 10.0]
+cfg["scene"]["box_max"] = [110.0, 8.0, 20.2]
+cfg["fluid"]["water_size"] = [100.0, 6.25, 20.0]
 t0 = time.time()
 sim = nat.Simulation(nat.config_from_dict(cfg))
 print("N", sim.n_fluid, "Nb", sim.n_wall, "grid", sim.grid, "create s", round(time.time() - t0, 1), flush=True)
