@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scene", required=True)
+    ap.add_argument("--scene", required=True, help="scene name from cfd_taichi_amd.scenes, or a path to a config JSON")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--rebalance", type=int, default=0)
@@ -34,7 +34,7 @@ def main():
     from cfd_taichi_amd import _native as nat
     from cfd_taichi_amd import scenes
     from cfd_taichi_amd.slab import SlabSimulation
-    cfg = scenes.get(args.scene)
+    cfg = json.load(open(args.scene)) if os.path.exists(args.scene) else scenes.get(args.scene)
     sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance)
     dfsph = sim.solver != "wcsph"      # every solver but wcsph reports per-step statistics
     stats = []

@@ -20,7 +20,7 @@ def free_port():
 
 
 def run_slabs(tmp_path, scene, world, steps, rebalance=0, legacy=False):
-    out = tmp_path / ("slab_%s_%d_%d_%d.json" % (scene, world, rebalance, legacy))
+    out = tmp_path / ("slab_%s_%d_%d_%d.json" % (os.path.basename(scene), world, rebalance, legacy))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "slab_worker.py"), "--scene", scene, "--steps", str(steps),
            "--backend", "gloo", "--rebalance", str(rebalance), "--out", str(out)]
@@ -112,3 +112,20 @@ def test_headless_runner_on_slabs(tmp_path):
     assert frames and frames[0] == "output_000000.ply"
     head = open(out / frames[0]).read().split("end_header")[0]
     assert "element vertex 5879" in head
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_scenes_on_slabs(tmp_path, seed):
+    """Seeded random scenes (radius, box, water block, dt, wall model, solver) on 2-4 slabs with re-balancing every 3 steps."""
+    import json as _json
+    import numpy as np
+    from test_fuzz_gpu import random_scene
+    rng = np.random.default_rng(2000 + seed)
+    solver = ["dfsph", "wcsph", "iisph", "pcisph", "dfsph"][seed]
+    cfg = random_scene(rng, solver)
+    cfg["scene"]["box_max"][0] = float(np.round(cfg["scene"]["box_max"][0] + 8 * 4 * cfg["scene"]["particle_radius"], 3))   # room for 4 slabs
+    path = tmp_path / "scene.json"
+    path.write_text(_json.dumps(cfg))
+    world = int(rng.integers(2, 5))
+    r = run_slabs(tmp_path, str(path), world, 60, rebalance=3)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], (cfg, {k: r[k] for k in ("pos_rel_err", "slabs")})
