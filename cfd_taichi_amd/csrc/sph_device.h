@@ -17,6 +17,8 @@ namespace sph {
 constexpr int kBlock = SPH_KBLOCK;   // threads per workgroup of every kernel (tuning knob at build time)
 
 // Launch-invariant constants, passed to kernels by value (lands in SGPRs).
+enum { CELL_ORDER_LINEAR = 0, CELL_ORDER_TILED = 1 };
+
 struct Consts {
     float h;           // support radius = kernel_h = 4r            ParticleSystem.py:82, solver_base.py:17
     float m;           // particle_m                                ParticleSystem.py:83
@@ -41,7 +43,13 @@ struct Consts {
     int n;             // particles resident in the arrays
     int stride;        // neighbour-list row stride (>= n, multiple of 64)
     int kmax, kbmax;   // neighbour-list rows (fluid, wall)
+    int kpitch, kbpitch; // rows between consecutive 64-particle tiles of a list (>= kmax; see build_scene)
     int strict_cells;  // slab handles: a particle with any cell coordinate outside the grid is binned nowhere (see cell_id_of)
+    // Storage order of the cells (see cell_slot() in sph_kernels.h): where cell_start[] keeps each reference cell.
+    int order;            // CELL_ORDER_LINEAR (the reference's 1-D index) or CELL_ORDER_TILED (Morton curve, see cell_slot_xyz)
+    int S;                // slots in cell_start[] (>= C: tiles pad each axis to a multiple of the tile edge); slot S = "outside the grid"
+    int tbits, tnx, tnxz; // tiles of 2^tbits cells per axis; tile strides: tiles along x, tiles along x times tiles along z
+    const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

@@ -55,6 +55,33 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
     return id;
 }
 
+// Where a cell's particles are STORED is a free choice: every consumer reaches a cell through cell_start[slot of the cell] and
+// walks the 27 cells in the reference's (dx, dy, dz) sequence with ascending particle id inside a cell, so the order of every sum
+// is the reference's whatever the storage order.  The reference's own order (x fastest) makes the ~8 cells of a wave a run along
+// x whose neighbourhood is 3 x 3 x 10 = 90 cells.  Stored along the Morton curve of (x, y, z) they are a 2x2x2 block with a
+// 4x4x4 = 64 cell neighbourhood, the 32 cells of a workgroup a 4x4x2 block (144 cells instead of 306) and an XCD's eighth of a
+// launch a compact brick -- that is what the L1/L2 hit rates of the neighbour sweeps see (dfsph 1M: 167 -> 203 Mparticle-steps/s).
+// Two levels keep it arithmetic: cubic tiles of 2^tbits cells per axis, bits interleaved inside a tile, and a small table with
+// the rank of every tile along the Morton curve of the tile coordinates.
+__device__ __forceinline__ int cell_slot_xyz(const Consts &c, int x, int y, int z, int id)
+{
+    if (c.order != CELL_ORDER_TILED) return id;
+    const int b = c.tbits, tile = (x >> b) + (z >> b) * c.tnx + (y >> b) * c.tnxz;
+    int code = 0;
+    for (int k = 0; k < b; ++k)
+        code |= (((x >> k) & 1) | ((y >> k) & 1) << 1 | ((z >> k) & 1) << 2) << (3 * k);
+    return (c.tile_rank[tile] << (3 * b)) | code;
+}
+
+// from a 1-D index as cell_id_of returns it (a wrapped index of a particle outside the box is a valid cell; C = binned nowhere)
+__device__ __forceinline__ int cell_slot(const Consts &c, int id)
+{
+    if (id >= c.C) return c.S;
+    if (c.order != CELL_ORDER_TILED) return id;
+    const int q = id / c.gx;                                // id = x + z*gx + y*gx*gz     ParticleSystem.py:102
+    return cell_slot_xyz(c, id - q * c.gx, q / c.gz, q % c.gz, id);
+}
+
 // `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost take no part in
 // the sort; the sorted arrays simply end after the live particles.
 // The arrays arrive in last step's cell order, so consecutive lanes mostly share a cell: a run of equal cells inside a wave
@@ -69,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *_
     if (s < c.n && !(dead && dead[s])) {
         float4 p = P[s];
         int cx, cy, cz;
-        id = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+        id = cell_slot(c, cell_id_of(c, p.x, p.y, p.z, cx, cy, cz));
     }
     if (s < c.n) cell_of[s] = id;
     const int prev = __shfl_up(id, 1, 64);
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
     int raw = id_in[src];
     int key = raw < 0 ? ~raw : raw;          // ghosts carry ~id; order by the true id
     int r = 0;
-    if (cell < c.C) {
+    if (cell < c.S) {
         for (int e = a; e < b; ++e) {
             int o = id_in[slot_src[e]];
             r += ((o < 0 ? ~o : o) < key) ? 1 : 0;
@@ -229,15 +256,38 @@ __device__ __forceinline__ F3 rigid_velocity(const RigidView &rv, float4 pj, flo
     return o;
 }
 
+// The index stream of a list is the one part of a sweep that always comes from HBM (every row is read once per sweep), at
+// 800-1100 cycles per request; the gathers it feeds mostly hit L2.  Rows are requested SPH_NL_AHEAD groups before they are used.
+#ifndef SPH_NL_AHEAD
+#define SPH_NL_AHEAD 1          // index groups requested ahead of the one being processed
+#endif
+struct NlAhead {
+    uint4 q[SPH_NL_AHEAD];
+    const uint32_t *base;
+    __device__ __forceinline__ explicit NlAhead(const uint32_t *b) : base(b)
+    {
+#pragma unroll
+        for (int d = 0; d < SPH_NL_AHEAD; ++d) q[d] = *reinterpret_cast<const uint4 *>(base + (size_t)d * 256);
+    }
+    __device__ __forceinline__ uint4 front() const { return q[0]; }
+    // drop the front group, request group (kk/4 + SPH_NL_AHEAD)
+    __device__ __forceinline__ void advance(int kk)
+    {
+#pragma unroll
+        for (int d = 0; d + 1 < SPH_NL_AHEAD; ++d) q[d] = q[d + 1];
+        q[SPH_NL_AHEAD - 1] = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + SPH_NL_AHEAD) * 256);
+    }
+};
+
 // fluid-list walkers that understand tagged rigid entries; body(pj, vj, j): j & kRigidTag marks a rigid neighbour,
 // then pj = (x, y, z, V_r) and vj is undefined
 template <bool RIGID, bool WITHV, class Body>
 __device__ __forceinline__ void for_fluid_nbrs(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                                const float4 *__restrict__ B, const RigidView &rv, Body body)
 {
-    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = jn;
+        const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4], b[4];
 #pragma unroll
@@ -248,7 +298,7 @@ __device__ __forceinline__ void for_fluid_nbrs(const uint32_t *__restrict__ base
             if (WITHV) b[u] = B[rg ? 0u : idx];
             else b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        ahead.advance(kk);
         body(a[0], b[0], j[0]);
         if (kk + 1 < cnt) body(a[1], b[1], j[1]);
         if (kk + 2 < cnt) body(a[2], b[2], j[2]);
@@ -306,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     __shared__ uint32_t s_stage[2][4 * kBlock];
     int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
-    if (i == 0) ds->lost = cell_start[c.C + 1] - cell_start[c.C];   // size of the "outside the grid" bucket
+    if (i == 0) ds->lost = cell_start[c.S + 1] - cell_start[c.S];   // size of the "outside the grid" bucket
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s_stage[0][q * kBlock + threadIdx.x] = 0; s_stage[1][q * kBlock + threadIdx.x] = 0; }
     if (i < c.n && id[i] < 0) {
@@ -315,8 +365,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         const float4 pi = P[i];
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
-        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kmax), 0, c.kmax};
-        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbmax), 0, c.kbmax};
+        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kpitch), 0, c.kmax};
+        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbpitch), 0, c.kbmax};
         int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
         const int my_id = RIGID ? id[i] : 0;
         for (int dx = -1; dx <= 1; ++dx)
@@ -325,8 +375,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     int x = cx + dx, y = cy + dy, z = cz + dz;
                     if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
                     if (x < 0 || y < 0 || z < 0) continue;
-                    int cid = x + y * c.sy + z * c.sz;
-                    const int a = cell_start[cid], b = cell_start[cid + 1];
+                    const int cid = x + y * c.sy + z * c.sz;
+                    const int slot = cell_slot_xyz(c, x, y, z, cid);
+                    const int a = cell_start[slot], b = cell_start[slot + 1];
                     // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
                     // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
                     // is harmless: the arrays carry 64 spare elements and the accept mask drops them)
@@ -351,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     }
                     if (RIGID) {
                         // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
-                        const int ra = rv.rcell_start[cid], rb = rv.rcell_start[cid + 1];
+                        const int ra = rv.rcell_start[slot], rb = rv.rcell_start[slot + 1];
                         for (int j = ra; j < rb; ++j) {
                             const float4 pj = rv.RP[j];
                             float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
@@ -412,8 +463,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     const bool ghost = cw < 0;                               \
     (void)ghost;                                             \
     const float4 pi = P[ii];                                 \
-    const uint32_t *nlp = nl + nl_index(ii, 0, c.kmax);      \
-    const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbmax) : nullptr;
+    const uint32_t *nlp = nl + nl_index(ii, 0, c.kpitch);     \
+    const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbpitch) : nullptr;
 
 // Walk of a neighbour list in groups of four: one 16-byte index load, four independent float4
 // gathers in flight, the next group's indices requested before the four bodies run.  Bodies run in
@@ -423,11 +474,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
 template <class Body>
 __device__ __forceinline__ void for_nbrs_p(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A, Body body)
 {
-    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = jn;
+        const uint4 jj = ahead.front();
         const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
-        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        ahead.advance(kk);
         body(a0);
         if (kk + 1 < cnt) body(a1);
         if (kk + 2 < cnt) body(a2);
@@ -438,12 +489,12 @@ template <class Body>
 __device__ __forceinline__ void for_nbrs_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                             const float4 *__restrict__ B, Body body)
 {
-    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = jn;
+        const uint4 jj = ahead.front();
         const float4 a0 = A[jj.x], a1 = A[jj.y], a2 = A[jj.z], a3 = A[jj.w];
         const float4 b0 = B[jj.x], b1 = B[jj.y], b2 = B[jj.z], b3 = B[jj.w];
-        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        ahead.advance(kk);
         body(a0, b0);
         if (kk + 1 < cnt) body(a1, b1);
         if (kk + 2 < cnt) body(a2, b2);

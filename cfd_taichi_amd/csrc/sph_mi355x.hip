@@ -80,6 +80,9 @@ struct SphHandle {
     int ntiles = 0;
     float4 *WP = nullptr;        // wall particles, cell-sorted: (x, y, z, V_b)
     int *wcell_start = nullptr;
+    std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
+    std::vector<char *> arenas;                      // dcommit() allocations
+    int *tile_rank = nullptr;            // Consts.tile_rank
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
     DevScalars *ds = nullptr;    // device
     DevScalars *ds_host = nullptr;   // pinned mirror
@@ -347,6 +350,23 @@ int build_scene(SphHandle *h, HostScene &sc)
         c.clamp_hi[a] = (float)cf.box_max[a] - clamp_off;
     }
     c.gx = g[0]; c.gy = g[1]; c.gz = g[2]; c.C = (int)C;
+    {
+        // Storage order of the cells (cell_slot() in sph_kernels.h).  The Morton curve pays once the particle state no longer sits
+        // in one XCD's L2 (measured, Mparticle-steps/s linear -> Morton: dfsph 1M 167 -> 203, 10M 162 -> 195, 250k 138 -> 148;
+        // iisph 1M 37 -> 48; wcsph 1M 1348 -> 1423, 250k equal); scenes of tens of thousands of particles are launch-bound and
+        // run 5-8% faster in the reference's own order.  SPH_CELL_ORDER=linear|morton forces one, SPH_CELL_TILE=4|8|16 the tile edge.
+        const char *e = getenv("SPH_CELL_ORDER"), *t = getenv("SPH_CELL_TILE");
+        const bool morton = e && !strcmp(e, "morton") ? true : e && !strcmp(e, "linear") ? false : h->N >= (1 << 17);
+        c.order = morton ? CELL_ORDER_TILED : CELL_ORDER_LINEAR;
+        const int edge = t ? atoi(t) : 4;
+        c.tbits = edge >= 16 ? 4 : edge >= 8 ? 3 : 2;
+        const int te = 1 << c.tbits;
+        c.tnx = (c.gx + te - 1) / te;
+        c.tnxz = c.tnx * ((c.gz + te - 1) / te);
+        const long long slots = c.order == CELL_ORDER_TILED ? ((long long)c.tnxz * ((c.gy + te - 1) / te)) << (3 * c.tbits) : C;
+        if (slots + 2 > 0x7fffffffLL) return fail(h, SPH_E_INVALID, "grid of %lld cell slots is too large", slots);
+        c.S = (int)slots;
+    }
     c.sy = g[0] * g[2]; c.sz = g[0];               // :102
     c.boundary_handle = cf.boundary_handle ? 1 : 0;
     c.strict_cells = cf.slab_count > 1 ? 1 : 0;
@@ -354,7 +374,19 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.stride = (h->N + 63) / 64 * 64;
     c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
     c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64) + 3) & ~3;
+    if (cf.boundary_handle == 0) c.kbmax = 4;      // clamp walls: no wall particles, the wall lists stay empty (one row group, never walked)
     if (c.kmax > 0xffff || c.kbmax > 0x7fff) return fail(h, SPH_E_INVALID, "neighbour capacity too large");
+    {
+        // A tile's rows are 1 KiB each, so with kmax = 64 every tile starts 16 KiB after the previous one and, because all waves
+        // walk their lists at about the same pace, the rows in flight at any moment agree in address bits 10-13: the HBM channel
+        // hash then sees a fraction of its inputs and the read latency of a sweep depends on where the allocator put the list
+        // (measured: 833 vs 1090 cycles per request, sweeps 110 vs 145 us for identical handles).  An odd number of row groups
+        // per tile walks the rows of consecutive tiles through all residues.
+        const char *e = getenv("SPH_NL_PITCH_PAD");
+        const int pad = e ? atoi(e) & ~3 : 4;
+        c.kpitch = c.kmax + (((c.kmax >> 2) & 1) ? 0 : pad);
+        c.kbpitch = c.kbmax + (((c.kbmax >> 2) & 1) ? 0 : pad);
+    }
     if ((long long)h->N >= (1LL << 28) || (long long)h->Nb >= (1LL << 28))
         return fail(h, SPH_E_INVALID, "%d fluid / %d wall particles: one handle addresses its particle arrays with 32-bit byte offsets (< 2^28 particles); shard the scene over slabs", h->N, h->Nb);
 
@@ -517,11 +549,61 @@ inline bool is_pressure_solver(const SphHandle *h) { return h->cfg.solver == SPH
 // solvers with a per-particle scalar that must follow the particle through the sort: dfsph warm_start_k, iisph p_past
 inline bool carries_scalar(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH || h->cfg.solver == SPH_SOLVER_IISPH; }
 
+// Device memory of a handle comes from ONE allocation per build phase (fluid state, rigid body): dalloc() records a request,
+// dcommit() sizes the arena, allocates and zeroes it and hands out the pointers.  Identical handles have identical layouts,
+// arrays of 2 MiB and more start on a 2 MiB boundary, and closing a handle is one hipFree per phase.
 template <class T>
 int dalloc(SphHandle *h, T **p, size_t count)
 {
-    HIP_TRY(h, hipMalloc((void **)p, sizeof(T) * (count > 0 ? count : 1)));
+    *p = nullptr;
+    h->plan.push_back({(void **)p, sizeof(T) * (count > 0 ? count : 1)});
     return SPH_OK;
+}
+
+int dcommit(SphHandle *h)
+{
+    const size_t big = (size_t)2 << 20;
+    std::vector<size_t> off(h->plan.size());
+    size_t cur = 0;
+    for (size_t k = 0; k < h->plan.size(); ++k) {
+        const size_t bytes = h->plan[k].second, align = bytes >= big ? big : 256;
+        cur = (cur + align - 1) / align * align;
+        off[k] = cur;
+        cur += bytes;
+    }
+    char *base = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&base, cur > 0 ? cur : 1));
+    h->arenas.push_back(base);
+    for (size_t k = 0; k < h->plan.size(); ++k) *h->plan[k].first = base + off[k];
+    HIP_TRY(h, hipMemsetAsync(base, 0, cur, h->stream));
+    if (getenv("SPH_ALLOC_DEBUG")) fprintf(stderr, "[alloc] handle %p: arena of %zu MiB at %p, %zu arrays\n", (void *)h, cur >> 20, (void *)base, h->plan.size());
+    h->plan.clear();
+    return SPH_OK;
+}
+
+// Consts.tile_rank: position of every tile (index tx + tz*tnx + ty*tnxz) along the Morton curve of (tx, ty, tz)
+std::vector<int> morton_tile_ranks(const Consts &c)
+{
+    auto spread = [](uint64_t v) {          // 21 bits -> every third bit
+        v &= 0x1fffffull;
+        v = (v | v << 32) & 0x1f00000000ffffull;
+        v = (v | v << 16) & 0x1f0000ff0000ffull;
+        v = (v | v << 8) & 0x100f00f00f00f00full;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+        v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    };
+    const int te = 1 << c.tbits, tnx = c.tnx, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
+    std::vector<std::pair<uint64_t, int>> key;
+    key.reserve((size_t)tnx * tnz * tny);
+    for (int ty = 0; ty < tny; ++ty)
+        for (int tz = 0; tz < tnz; ++tz)
+            for (int tx = 0; tx < tnx; ++tx)
+                key.push_back({spread((uint64_t)tx) | spread((uint64_t)ty) << 1 | spread((uint64_t)tz) << 2, tx + tz * c.tnx + ty * c.tnxz});
+    std::sort(key.begin(), key.end());
+    std::vector<int> rank(key.size());
+    for (size_t r = 0; r < key.size(); ++r) rank[(size_t)key[r].second] = (int)r;
+    return rank;
 }
 
 int alloc_device(SphHandle *h, const HostScene &sc)
@@ -529,41 +611,34 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     const Consts &c = h->c;
     const size_t n = (size_t)c.stride;
     int rc;
+    std::vector<int> tile_rank;
+    if (c.order == CELL_ORDER_TILED) {
+        tile_rank = morton_tile_ranks(c);
+        if ((rc = dalloc(h, &h->tile_rank, tile_rank.size()))) return rc;
+    }
     for (int k = 0; k < 2; ++k) {
         if ((rc = dalloc(h, &h->P[k], n + 64))) return rc;      // k_build_nl reads whole groups of four candidates
         if ((rc = dalloc(h, &h->V[k], n))) return rc;
         if ((rc = dalloc(h, &h->VA[k], n))) return rc;
         if ((rc = dalloc(h, &h->warm[k], n))) return rc;
         if ((rc = dalloc(h, &h->id[k], n))) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->P[k], 0, sizeof(float4) * n, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->V[k], 0, sizeof(float4) * n, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->VA[k], 0, sizeof(float4) * n, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->warm[k], 0, sizeof(float) * n, h->stream));
     }
     if (is_pressure_solver(h))
         for (int k = 0; k < 5; ++k) {
             if ((rc = dalloc(h, &h->X[k], n))) return rc;
-            HIP_TRY(h, hipMemsetAsync(h->X[k], 0, sizeof(float4) * n, h->stream));
         }
     if ((rc = dalloc(h, &h->rho, n))) return rc;
     if ((rc = dalloc(h, &h->aux, n))) return rc;
     if ((rc = dalloc(h, &h->drho, n))) return rc;
     if ((rc = dalloc(h, &h->rho_adv, n))) return rc;
     if ((rc = dalloc(h, &h->cnt, n))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->rho, 0, sizeof(float) * n, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->aux, 0, sizeof(float) * n, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->drho, 0, sizeof(float) * n, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->rho_adv, 0, sizeof(float) * n, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->cnt, 0, sizeof(int) * n, h->stream));
     // one spare 64-particle tile at the end: the software-pipelined walks read one row ahead
-    if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kmax))) return rc;
-    if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbmax))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->nl, 0, sizeof(uint32_t) * (n + 64) * (size_t)c.kmax, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->nlb, 0, sizeof(uint32_t) * (n + 64) * (size_t)c.kbmax, h->stream));
+    if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
+    if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbpitch))) return rc;
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
-    const size_t ncell = (size_t)c.C + 2;
+    const size_t ncell = (size_t)c.S + 2;
     h->ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
     if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
     if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
@@ -577,7 +652,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
     if (h->slab) {
         if ((rc = dalloc(h, &h->dead, n))) return rc;
-        HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * n, h->stream));
         for (int k = 0; k < 4; ++k) {
             if ((rc = dalloc(h, &h->edge_off[k], (size_t)c.gy * c.gz + 1))) return rc;
             if ((rc = dalloc(h, &h->edge_list[k], n))) return rc;
@@ -591,6 +665,13 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
     size_t stg = 3 * std::max(n, (size_t)h->Nb);
     if ((rc = dalloc(h, &h->staging, stg))) return rc;
+
+    if ((rc = dcommit(h))) return rc;
+    if (c.order == CELL_ORDER_TILED) {
+        HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->c.tile_rank = h->tile_rank;
+    }
 
     // upload the scene
     std::vector<float4> p4((size_t)h->n_owned);
@@ -1062,29 +1143,28 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->rcell_of, nr))) return rc;
     if ((rc = dalloc(h, &h->rrank, nr))) return rc;
     if ((rc = dalloc(h, &h->rslot, nr))) return rc;
-    if ((rc = dalloc(h, &h->rcell_count, (size_t)c.C + 2))) return rc;
-    if ((rc = dalloc(h, &h->rcell_start, (size_t)c.C + 2))) return rc;
+    if ((rc = dalloc(h, &h->rcell_count, (size_t)c.S + 2))) return rc;
+    if ((rc = dalloc(h, &h->rcell_start, (size_t)c.S + 2))) return rc;
     if ((rc = dalloc(h, &h->rforce, 3 * nr))) return rc;
     if ((rc = dalloc(h, &h->rvert, 3 * (size_t)(Nv > 0 ? Nv : 1)))) return rc;
     if ((rc = dalloc(h, &h->pos_orig, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->rho_orig, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->ncount, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->rred, 1))) return rc;
+    const size_t stg_need = 3 * std::max(nr, (size_t)Nv);
+    if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb))
+        if ((rc = dalloc(h, &h->staging, stg_need))) return rc;      // the fluid arena's staging buffer is too small for this body
+    if ((rc = dcommit(h))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->rred_host, sizeof(RigidReduce), hipHostMallocDefault));
     std::vector<float4> rp4(nr);
     for (int i = 0; i < Nr; ++i) rp4[i] = make_float4(rpos[3 * (size_t)i], rpos[3 * (size_t)i + 1], rpos[3 * (size_t)i + 2], h->rvol_host[i]);
     HIP_TRY(h, hipMemcpyAsync(h->RPos, rp4.data(), sizeof(float4) * nr, hipMemcpyHostToDevice, h->stream));
     if (Nv > 0) HIP_TRY(h, hipMemcpyAsync(h->rvert, rvert.data(), sizeof(float) * 3 * (size_t)Nv, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rforce, 0, sizeof(float) * 3 * nr, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)c.C + 2), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)c.S + 2), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rho_orig, 0, sizeof(float) * (size_t)h->c.stride, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->ncount, 0, sizeof(int) * (size_t)h->c.stride, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    size_t stg_need = 3 * std::max(nr, (size_t)Nv);
-    if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb)) {
-        (void)hipFree(h->staging);
-        if ((rc = dalloc(h, &h->staging, stg_need))) return rc;
-    }
     h->rigid = true;
     return SPH_OK;
 }
@@ -1096,7 +1176,7 @@ int stage_sort_rigid(SphHandle *h)
     cr.n = h->Nr;
     hipStream_t s = h->stream;
     const dim3 g = grid_for(h->Nr), b(kBlock);
-    const size_t ncell = (size_t)cr.C + 2;
+    const size_t ncell = (size_t)cr.S + 2;
     ProfScope ps(h, K_RIGID);
     HIP_TRY(h, hipMemsetAsync(h->rcell_count, 0, sizeof(int) * ncell, s));
     hipLaunchKernelGGL(k_hash_count, g, b, 0, s, cr, h->RPos, (const int *)nullptr, h->rcell_of, h->rrank, h->rcell_count);
@@ -1249,7 +1329,7 @@ int stage_sort_and_lists(SphHandle *h)
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
     const dim3 b(kBlock);
-    const size_t ncell = (size_t)c.C + 2;       // cells, "outside the grid" bucket C, end
+    const size_t ncell = (size_t)c.S + 2;       // cell slots, "outside the grid" bucket S, end
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     const bool carry = carries_scalar(h);
     (void)dfsph;
@@ -2113,21 +2193,8 @@ void sph_destroy(SphHandle *h)
     for (auto &e : h->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : h->ev_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 8; ++k) if (h->wcsph_graph[k]) (void)hipGraphExecDestroy(h->wcsph_graph[k]);
-    for (int k = 0; k < 2; ++k) {
-        (void)hipFree(h->P[k]); (void)hipFree(h->V[k]); (void)hipFree(h->VA[k]); (void)hipFree(h->warm[k]); (void)hipFree(h->id[k]);
-    }
-    (void)hipFree(h->rho); (void)hipFree(h->aux); (void)hipFree(h->drho); (void)hipFree(h->rho_adv); (void)hipFree(h->cnt);
-    for (int k = 0; k < 5; ++k) (void)hipFree(h->X[k]);
-    (void)hipFree(h->nl); (void)hipFree(h->nlb); (void)hipFree(h->cell_of); (void)hipFree(h->rank); (void)hipFree(h->slot_src);
-    (void)hipFree(h->cell_count); (void)hipFree(h->cell_start); (void)hipFree(h->tile_sums); (void)hipFree(h->WP);
-    (void)hipFree(h->wcell_start); (void)hipFree(h->psum); (void)hipFree(h->pcnt); (void)hipFree(h->pmax); (void)hipFree(h->ds);
-    (void)hipFree(h->staging);
-    (void)hipFree(h->dead); (void)hipFree(h->counters);
-    (void)hipFree(h->RPos); (void)hipFree(h->RPs); (void)hipFree(h->rid); (void)hipFree(h->rcell_of); (void)hipFree(h->rrank);
-    (void)hipFree(h->rslot); (void)hipFree(h->rcell_count); (void)hipFree(h->rcell_start); (void)hipFree(h->rforce); (void)hipFree(h->rvert);
-    (void)hipFree(h->pos_orig); (void)hipFree(h->rho_orig); (void)hipFree(h->ncount); (void)hipFree(h->rred);
+    for (char *arena : h->arenas) (void)hipFree(arena);        // every dalloc'd array
     if (h->rred_host) (void)hipHostFree(h->rred_host);
-    for (int k = 0; k < 4; ++k) { (void)hipFree(h->edge_off[k]); (void)hipFree(h->edge_list[k]); }
     if (h->own_dev_comm) { (void)hipFree(h->dsend[0]); (void)hipFree(h->dsend[1]); (void)hipFree(h->drecv[0]); (void)hipFree(h->drecv[1]); }
     if (h->own_red) (void)hipFree(h->red_dev);
     if (h->nccl && rccl().ok) (void)rccl().CommDestroy(h->nccl);

@@ -35,9 +35,9 @@ template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_ps(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                             const float *__restrict__ S, const RigidView &rv, Body body)
 {
-    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = jn;
+        const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4]; float sc[4];
 #pragma unroll
@@ -47,7 +47,7 @@ __device__ __forceinline__ void for_nbrs_ps(const uint32_t *__restrict__ base, i
             a[u] = rg ? rv.RP[idx] : A[idx];
             sc[u] = S[rg ? 0u : idx];
         }
-        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        ahead.advance(kk);
         body(a[0], sc[0], j[0]);
         if (kk + 1 < cnt) body(a[1], sc[1], j[1]);
         if (kk + 2 < cnt) body(a[2], sc[2], j[2]);
@@ -58,9 +58,9 @@ template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                            const float4 *__restrict__ B, const float4 *__restrict__ C, const RigidView &rv, Body body)
 {
-    uint4 jn = *reinterpret_cast<const uint4 *>(base);
+    NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = jn;
+        const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4], b[4], cc[4];
 #pragma unroll
@@ -71,7 +71,7 @@ __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, in
             b[u] = B[rg ? 0u : idx];
             cc[u] = C[rg ? 0u : idx];
         }
-        jn = *reinterpret_cast<const uint4 *>(base + (size_t)((kk >> 2) + 1) * 256);
+        ahead.advance(kk);
         body(a[0], b[0], cc[0], j[0]);
         if (kk + 1 < cnt) body(a[1], b[1], cc[1], j[1]);
         if (kk + 2 < cnt) body(a[2], b[2], cc[2], j[2]);
@@ -587,8 +587,8 @@ __global__ __launch_bounds__(kBlock) void k_rigid_force_p(Consts c, int nr, cons
                 int x = cx + dx, y = cy + dy, z = cz + dz;
                 if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
                 if (x < 0 || y < 0 || z < 0) continue;
-                int cid = x + y * c.sy + z * c.sz;
-                for (int i = cell_start[cid]; i < cell_start[cid + 1]; ++i) {
+                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                for (int i = cell_start[slot]; i < cell_start[slot + 1]; ++i) {
                     const float4 pi = P[i];
                     float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
                     float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;

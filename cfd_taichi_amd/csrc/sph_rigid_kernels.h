@@ -46,8 +46,8 @@ __global__ __launch_bounds__(kBlock) void k_rigid_force(Consts c, int nr, const 
                 int x = cx + dx, y = cy + dy, z = cz + dz;
                 if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
                 if (x < 0 || y < 0 || z < 0) continue;
-                int cid = x + y * c.sy + z * c.sz;
-                for (int i = cell_start[cid]; i < cell_start[cid + 1]; ++i) {
+                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                for (int i = cell_start[slot]; i < cell_start[slot + 1]; ++i) {
                     const float4 pi = P[i];
                     float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
                     float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;

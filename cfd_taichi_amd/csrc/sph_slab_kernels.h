@@ -152,8 +152,8 @@ __global__ __launch_bounds__(kBlock) void k_layer_offsets(Consts c, const int *_
         int v = 0;
         if (k < ncol && layer_cx >= 0 && layer_cx < c.gx) {
             int y = k / c.gz, z = k - y * c.gz;
-            int cid = layer_cx + y * c.sy + z * c.sz;
-            v = cell_start[cid + 1] - cell_start[cid];
+            const int slot = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
+            v = cell_start[slot + 1] - cell_start[slot];
         }
         int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         int inc = v;
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__re
     int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= c.gy * c.gz || layer_cx < 0 || layer_cx >= c.gx) return;
     int y = k / c.gz, z = k - y * c.gz;
-    int cid = layer_cx + y * c.sy + z * c.sz;
-    int a = cell_start[cid], b = cell_start[cid + 1];
+    const int slot = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
+    int a = cell_start[slot], b = cell_start[slot + 1];
     int o = off[k];
     for (int s = a; s < b; ++s) list[o + (s - a)] = s;
 }

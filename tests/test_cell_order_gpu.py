@@ -1,0 +1,107 @@
+"""GPU suite: the storage order of the cells is invisible in the results.
+
+The library keeps the cells of large scenes along a Morton curve (tiles of 4 cells per axis, cell_slot() in
+csrc/sph_kernels.h) and those of small scenes in the reference's 1-D order; every consumer still walks the 27 cells in the
+reference's sequence, so both orders must give the same bits.  The other GPU suites run their small scenes in the linear
+order; here the same kinds of scene (walls, clamp walls, particles that leak out of the box, a rigid body, slabs) are forced
+onto the Morton curve and compared with the linear order and with the oracle."""
+import numpy as np
+import pytest
+
+from cfd_taichi_amd import _native as nat
+from cfd_taichi_amd import mesh, scenes
+from oracle import oracle as orc
+from test_fuzz_gpu import random_scene
+from test_slab_gpu import run_slabs
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = (nat.F_POS, nat.F_VEL, nat.F_RHO)
+
+
+def make(cfg, order, monkeypatch, tile="4", rigid=None):
+    monkeypatch.setenv("SPH_CELL_ORDER", order)
+    monkeypatch.setenv("SPH_CELL_TILE", tile)
+    return nat.Simulation(nat.config_from_dict(cfg), rigid=rigid)
+
+
+@pytest.mark.parametrize("scene,steps", [("wcsph_small", 80), ("dfsph_small", 40), ("dfsph_tiny_wall", 60), ("wcsph_tiny_wall", 120),
+                                         ("dfsph_tiny_wall_pcisph", 40), ("dfsph_tiny_wall_iisph", 800), ("dfsph_dam_x", 1500),
+                                         ("breaking_dam_30k_dfsph", 10)])
+@pytest.mark.parametrize("tile", ["4", "16"])
+def test_morton_and_linear_orders_agree(scene, steps, tile, monkeypatch):
+    cfg = scenes.get(scene)
+    a, b = make(cfg, "morton", monkeypatch, tile), make(cfg, "linear", monkeypatch)
+    lost = 0
+    for s in range(steps):
+        sa, sb = a.step(1), b.step(1)
+        if sa is not None:
+            assert (sa.n_div, sa.n_dens, sa.div_err, sa.dens_err, sa.dt, sa.lost, sa.max_nbrs) == (
+                sb.n_div, sb.n_dens, sb.div_err, sb.dens_err, sb.dt, sb.lost, sb.max_nbrs), (scene, s)
+            lost = max(lost, sa.lost)
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), (scene, f)
+    if steps >= 800:             # the long cases are here for particles that leak through the walls: wrapped cell indices, the "outside" bucket
+        pos = a.download(nat.F_POS)
+        outside = int(((pos < 0) | (pos > np.asarray(cfg["scene"]["box_max"], dtype=np.float32))).any(axis=1).sum())
+        assert outside > 0 or lost > 0, scene
+    a.close(); b.close()
+
+
+def test_morton_device_order_small_scene(monkeypatch):
+    """The sorted arrays follow the Morton curve of the cell coordinates, ascending id inside a cell."""
+    cfg = scenes.get("dfsph_small")
+    sim = make(cfg, "morton", monkeypatch)
+    sim.step_dfsph(20)
+    sim.build_neighbors()
+    ids, lpos = sim.download_local(nat.F_POS)
+    c3 = np.floor(lpos / np.float32(4 * cfg["scene"]["particle_radius"])).astype(np.int64)
+    code = np.zeros(len(c3), dtype=np.int64)
+    for k in range(10):
+        for a in range(3):
+            code |= ((c3[:, a] >> k) & 1) << (3 * k + a)
+    assert np.all(np.diff(code) >= 0) and len(np.unique(code)) > 100
+    same = np.diff(code) == 0
+    assert np.all(np.diff(ids.astype(np.int64))[same] > 0)
+    sim.close()
+
+
+@pytest.mark.parametrize("solver", ["wcsph", "dfsph", "pcisph", "iisph"])
+@pytest.mark.parametrize("seed", range(3))
+def test_random_scene_on_the_morton_curve_matches_oracle(solver, seed, monkeypatch):
+    rng = np.random.default_rng(3000 + seed)
+    cfg = random_scene(rng, solver)
+    sim = make(cfg, "morton", monkeypatch)
+    o = orc.Oracle(cfg, solver=solver, num_threads=4)
+    for s in range(25):
+        sim.step(1)
+        {"wcsph": o.step_wcsph, "pcisph": o.step_pcisph, "iisph": o.step_iisph}.get(solver, lambda n: o.step_dfsph(n, 100))(1)
+    for f, of in ((nat.F_POS, orc.F_POS), (nat.F_VEL, orc.F_VEL), (nat.F_RHO, orc.F_RHO)):
+        assert np.array_equal(sim.download(f), o.get(of), equal_nan=True), (solver, seed, f, cfg)
+    sim.close(); o.close()
+
+
+def test_rigid_coupling_on_the_morton_curve(monkeypatch):
+    cfg = scenes.get("dfsph_rigid_small")
+    rg = mesh.rigid_from_config(cfg)
+    sim = make(cfg, "morton", monkeypatch, rigid=rg)
+    o = orc.Oracle(cfg, num_threads=8, rigid=rg)
+    for s in range(80):
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        assert (st.n_div, st.n_dens, st.div_err, st.dt) == (o.last_stats.n_div, o.last_stats.n_dens, o.last_stats.div_err, o.last_stats.dt), s
+        sim.rigid_step(); o.rigid_step()
+    a, b = sim.rigid_scalars(), o.rigid_scalars()
+    for k in ("centroid", "omega", "vel"):
+        assert np.array_equal(np.float32(a[k]), np.float32(b[k])), k
+    assert np.array_equal(sim.download(nat.F_POS), o.get(orc.F_POS)) and np.array_equal(sim.download(nat.F_VEL), o.get(orc.F_VEL))
+    assert np.array_equal(sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), o.get(orc.F_RIGID_FORCE))
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_small", 3, 25, 0), ("dfsph_dam_x", 3, 500, 7), ("dfsph_tiny_wall_iisph", 2, 200, 9)])
+def test_slabs_on_the_morton_curve(tmp_path, monkeypatch, scene, world, steps, rebalance):
+    """Edge and ghost lists enumerate cell columns in (y, z) order whatever the storage order: slabs still match one GPU."""
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    r = run_slabs(tmp_path, scene, world, steps, rebalance=rebalance)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "slabs")}

@@ -1,5 +1,5 @@
 """Interleaved timing of the DFSPH sweeps for SEVERAL builds of the library inside one process (one clock state):
-    tools/tune_libs.py scene advance_steps name=path[:lds] ...
+    tools/tune_libs.py scene advance_steps name=path[:lds[:ENV=value]] ...      (ENV is set while that handle is created)
 Each build gets its own handle on the same scene advanced by the same steps; rounds alternate between the builds."""
 import os
 import random
@@ -13,10 +13,14 @@ scene, advance = sys.argv[1], int(sys.argv[2])
 sims = {}
 for spec in sys.argv[3:]:
     name, rest = spec.split("=", 1)
-    path, _, lds = rest.partition(":")
+    path, lds, env = (rest.split(":") + ["", ""])[:3]
     nat._lib = None
     os.environ["SPH_LIB"] = os.path.abspath(path)
+    if env:
+        os.environ[env.split("=")[0]] = env.split("=")[1]
     sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
+    if env:
+        del os.environ[env.split("=")[0]]
     sim.step_dfsph(advance)
     sim.build_neighbors()
     sims[name] = (sim, int(lds or 0))
