@@ -63,14 +63,22 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
 // launch a compact brick -- that is what the L1/L2 hit rates of the neighbour sweeps see (dfsph 1M: 167 -> 203 Mparticle-steps/s).
 // Two levels keep it arithmetic: cubic tiles of 2^tbits cells per axis, bits interleaved inside a tile, and a small table with
 // the rank of every tile along the Morton curve of the tile coordinates.
+// one coordinate's share of a slot: its tile term (scaled by the tile stride of the axis) and its interleaved low bits
+struct SlotPart { int tile, code; };
+__device__ __forceinline__ SlotPart slot_part(const Consts &c, int v, int axis, int tile_stride)
+{
+    int code = 0;
+    for (int k = 0; k < c.tbits; ++k) code |= ((v >> k) & 1) << (3 * k + axis);
+    return {(v >> c.tbits) * tile_stride, code};
+}
+__device__ __forceinline__ int slot_of_parts(const Consts &c, SlotPart x, SlotPart y, SlotPart z)
+{
+    return (c.tile_rank[x.tile + y.tile + z.tile] << (3 * c.tbits)) | (x.code | y.code | z.code);
+}
 __device__ __forceinline__ int cell_slot_xyz(const Consts &c, int x, int y, int z, int id)
 {
     if (c.order != CELL_ORDER_TILED) return id;
-    const int b = c.tbits, tile = (x >> b) + (z >> b) * c.tnx + (y >> b) * c.tnxz;
-    int code = 0;
-    for (int k = 0; k < b; ++k)
-        code |= (((x >> k) & 1) | ((y >> k) & 1) << 1 | ((z >> k) & 1) << 2) << (3 * k);
-    return (c.tile_rank[tile] << (3 * b)) | code;
+    return slot_of_parts(c, slot_part(c, x, 0, 1), slot_part(c, y, 1, c.tnxz), slot_part(c, z, 2, c.tnx));
 }
 
 // from a 1-D index as cell_id_of returns it (a wrapped index of a particle outside the box is a valid cell; C = binned nowhere)
@@ -371,14 +379,17 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbpitch), 0, c.kbmax};
         int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
         const int my_id = RIGID ? id[i] : 0;
-        for (int dx = -1; dx <= 1; ++dx)
-            for (int dy = -1; dy <= 1; ++dy)
+        const bool tiled = c.order == CELL_ORDER_TILED;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const SlotPart sx = slot_part(c, cx + dx, 0, 1);           // the slot of a cell, one coordinate per loop level
+            for (int dy = -1; dy <= 1; ++dy) {
+                const SlotPart sy = slot_part(c, cy + dy, 1, c.tnxz);
                 for (int dz = -1; dz <= 1; ++dz) {
                     int x = cx + dx, y = cy + dy, z = cz + dz;
                     if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
                     if (x < 0 || y < 0 || z < 0) continue;
                     const int cid = x + y * c.sy + z * c.sz;
-                    const int slot = cell_slot_xyz(c, x, y, z, cid);
+                    const int slot = tiled ? slot_of_parts(c, sx, sy, slot_part(c, z, 2, c.tnx)) : cid;
                     const int a = cell_start[slot], b = cell_start[slot + 1];
                     // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
                     // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
@@ -442,6 +453,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         }
                     }
                 }
+            }
+        }
         wf.flush();
         ww.flush();
         kf = wf.k; kb = ww.k;
