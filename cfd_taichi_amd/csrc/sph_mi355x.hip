@@ -353,10 +353,10 @@ int build_scene(SphHandle *h, HostScene &sc)
     {
         // Storage order of the cells (cell_slot() in sph_kernels.h).  The Morton curve pays once the particle state no longer sits
         // in one XCD's L2 (measured, Mparticle-steps/s linear -> Morton: dfsph 1M 167 -> 203, 10M 162 -> 195, 250k 138 -> 148;
-        // iisph 1M 37 -> 48; wcsph 1M 1348 -> 1423, 250k equal); scenes of tens of thousands of particles are launch-bound and
+        // iisph 1M 37 -> 48; wcsph 1M 1348 -> 1423, 250k equal or 3% slower); scenes of tens of thousands of particles are launch-bound and
         // run 5-8% faster in the reference's own order.  SPH_CELL_ORDER=linear|morton forces one, SPH_CELL_TILE=4|8|16 the tile edge.
         const char *e = getenv("SPH_CELL_ORDER"), *t = getenv("SPH_CELL_TILE");
-        const bool morton = e && !strcmp(e, "morton") ? true : e && !strcmp(e, "linear") ? false : h->N >= (1 << 17);
+        const bool morton = e && !strcmp(e, "morton") ? true : e && !strcmp(e, "linear") ? false : h->N >= (cf.solver == SPH_SOLVER_WCSPH ? 1 << 19 : 1 << 17);
         c.order = morton ? CELL_ORDER_TILED : CELL_ORDER_LINEAR;
         const int edge = t ? atoi(t) : 4;
         c.tbits = edge >= 16 ? 4 : edge >= 8 ? 3 : 2;
