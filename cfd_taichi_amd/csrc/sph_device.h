@@ -50,6 +50,7 @@ struct Consts {
     int S;                // slots in cell_start[] (>= C: tiles pad each axis to a multiple of the tile edge); slot S = "outside the grid"
     int tbits, tnx, tnxz; // tiles of 2^tbits cells per axis; tile strides: tiles along x, tiles along x times tiles along z
     const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
+    int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

@@ -356,19 +356,102 @@ struct NlWriter {
     }
 };
 
-template <bool RIGID>
+// ---- LDS staging of a workgroup's neighbourhood (large scenes on the Morton curve) ----------------------------------------
+// The sweeps are bound by L1 tag look-ups: a 64-lane gather of P[j] touches ~44 cache lines (TCP_TOTAL_CACHE_ACCESSES / wave
+// read), one look-up per cycle and CU -- 54 M look-ups = 88 us of a 104 us residual sweep at 1 M particles.  On the Morton curve
+// the particles a 256-particle workgroup can see (all cells around its own cells) are only ~1300 (max ~1800): the list build
+// also writes, per workgroup, the ordered set of those particles (stage_src) and the lists in indices LOCAL to that set; a
+// sweep then copies its operand array through stage_src into LDS once (coalesced: ~150 line look-ups per workgroup instead of
+// ~8000) and gathers from LDS.  A workgroup whose neighbourhood does not fit (sparse regions) keeps global indices: stage_cnt < 0.
+constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
+constexpr int kStageMaxCells = 640;
+// Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
+// workgroups of a residual sweep resident per CU (4 x 39 KiB of the 160 KiB LDS), ~2 % of the workgroups at 1 M particles exceed it.
+__device__ __forceinline__ int stage_hash(int slot) { return (int)(((unsigned)slot * 2654435761u) >> 22); }
+__device__ __forceinline__ int stage_lookup(const int *key, const int *base, int slot)
+{
+    int hq = stage_hash(slot);
+    while (key[hq] != slot) hq = (hq + 1) & (kStageHash - 1);
+    return base[hq];
+}
+
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
-                                                     RigidView rv, int *__restrict__ ncount)
+                                                     RigidView rv, int *__restrict__ ncount, uint32_t *__restrict__ stage_src,
+                                                     int *__restrict__ stage_cnt)
 {
     __shared__ uint32_t s_stage[2][4 * kBlock];
-    int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
+    __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_ncell, s_ok;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    int i = blk * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
     if (i == 0) ds->lost = cell_start[c.S + 1] - cell_start[c.S];   // size of the "outside the grid" bucket
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s_stage[0][q * kBlock + threadIdx.x] = 0; s_stage[1][q * kBlock + threadIdx.x] = 0; }
+    if (STAGED) {
+        // (1) the set of cell slots around the cells of this workgroup's own particles
+        for (int q = threadIdx.x; q < kStageHash; q += kBlock) s_key[q] = -1;
+        if (threadIdx.x == 0) { s_ncell = 0; s_ok = 1; }
+        __syncthreads();
+        if (i < c.n && id[i] >= 0) {
+            const float4 pi = P[i];
+            int cx, cy, cz, px, py, pz;
+            const int home = cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+            bool head = threadIdx.x == 0 || id[i - 1] < 0;
+            if (!head) { const float4 pp = P[i - 1]; head = cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz) != home; }
+            if (head)
+                for (int dx = -1; dx <= 1; ++dx)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dz = -1; dz <= 1; ++dz) {
+                            const int x = cx + dx, y = cy + dy, z = cz + dz;
+                            if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
+                            const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                            int hq = stage_hash(slot);
+                            for (int probe = 0; probe < kStageHash; ++probe) {
+                                const int was = atomicCAS(&s_key[hq], -1, slot);
+                                if (was == slot) break;
+                                if (was == -1) { if (atomicAdd(&s_ncell, 1) >= kStageMaxCells) s_ok = 0; break; }
+                                if (s_ok == 0) break;
+                                hq = (hq + 1) & (kStageHash - 1);
+                            }
+                        }
+        }
+        __syncthreads();
+        // (2) local base of every cell of the set (table order), the ordered source list, the verdict
+        int own[kStageHash / kBlock], run = 0;
+        const bool ok = s_ok != 0;
+#pragma unroll
+        for (int q = 0; q < kStageHash / kBlock; ++q) {
+            const int key = ok ? s_key[threadIdx.x * (kStageHash / kBlock) + q] : -1;
+            own[q] = key >= 0 ? cell_start[key + 1] - cell_start[key] : 0;
+            run += own[q];
+        }
+        int inc = run;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();
+        int before = inc - run, total = 0;
+        for (int k = 0; k < kBlock / 64; ++k) { if (k < w) before += s_wsum[k]; total += s_wsum[k]; }
+        const bool staged = ok && total <= c.stage_cap;
+#pragma unroll
+        for (int q = 0; q < kStageHash / kBlock; ++q) {
+            const int e = threadIdx.x * (kStageHash / kBlock) + q;
+            s_base[e] = before;
+            if (staged && own[q] > 0) {
+                const int a = cell_start[s_key[e]];
+                for (int r = 0; r < own[q]; ++r) stage_src[(size_t)blk * c.stage_cap + before + r] = (uint32_t)(a + r);
+            }
+            before += own[q];
+        }
+        if (threadIdx.x == 0) { stage_cnt[blk] = staged ? total : -1; s_ok = staged ? 1 : 0; }
+        __syncthreads();
+    }
+    const bool staged = STAGED && s_ok != 0;
     if (i < c.n && id[i] < 0) {
         cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
     } else if (i < c.n) {
@@ -391,6 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     const int cid = x + y * c.sy + z * c.sz;
                     const int slot = tiled ? slot_of_parts(c, sx, sy, slot_part(c, z, 2, c.tnx)) : cid;
                     const int a = cell_start[slot], b = cell_start[slot + 1];
+                    const int lbase = staged ? stage_lookup(s_key, s_base, slot) - a : 0;      // local index = lbase + j
                     // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
                     // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
                     // is harmless: the arrays carry 64 spare elements and the accept mask drops them)
@@ -410,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                         while (m) {
                             const int u = __ffs(m) - 1;
                             m &= m - 1;
-                            wf.push((uint32_t)(j0 + u));
+                            wf.push((uint32_t)(lbase + j0 + u));       // staged workgroups keep LOCAL indices
                         }
                     }
                     if (RIGID) {
@@ -652,19 +736,102 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
 //   WCSPH: writes Pout = (pos, rho), Vout = (vel, p/rho^2), rho[], pressure[]
 //   DFSPH: writes Pout = (pos, (warm_k/dt)/rho) for the warm start, Vout = (vel, rho), rho[], alpha[]
 // ======================================================================================
-template <bool DFSPH, bool RIGID>
+// the workgroup's operand array through stage_src into LDS (see the staging plan in k_build_nl); returns false when this
+// workgroup keeps global indices.  Uniform per workgroup; every thread of the workgroup must call it.
+__device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
+                                              const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_cnt[blk];
+    if (nst < 0) return false;
+    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+    for (int e = threadIdx.x; e < nst; e += kBlock) s_A[e] = A[src[e]];
+    __syncthreads();
+    return true;
+}
+
+// two-operand variant: A staged in LDS, the global index of every staged element next to it (B is gathered from HBM/L2 through it)
+__device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__restrict__ s_A, uint32_t *__restrict__ s_src,
+                                                  const float4 *__restrict__ A, const uint32_t *__restrict__ stage_src,
+                                                  const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_cnt[blk];
+    if (nst < 0) return false;
+    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+    for (int e = threadIdx.x; e < nst; e += kBlock) { const uint32_t j = src[e]; s_src[e] = j; s_A[e] = A[j]; }
+    __syncthreads();
+    return true;
+}
+template <class Body>
+__device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                   const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { b[u] = B[s_src[j[u]]]; a[u] = s_A[j[u]]; }
+        ahead.advance(kk);
+        body(a[0], b[0], 0u);
+        if (kk + 1 < cnt) body(a[1], b[1], 0u);
+        if (kk + 2 < cnt) body(a[2], b[2], 0u);
+        if (kk + 3 < cnt) body(a[3], b[3], 0u);
+    }
+}
+
+// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle
+__device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
+                                                 const float4 *__restrict__ A, const float4 *__restrict__ B,
+                                                 const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_cnt[blk];
+    if (nst < 0) return false;
+    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+    for (int e = threadIdx.x; e < nst; e += kBlock) {
+        const uint32_t j = src[e];
+        const float4 a = A[j], b = B[j];
+        s_A[e] = make_float4(a.x, a.y, a.z, b.x);
+        s_B[e] = make_float2(b.y, b.z);
+    }
+    __syncthreads();
+    return true;
+}
+template <class Body>
+__device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                    const float2 *__restrict__ s_B, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4]; float2 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = s_A[j[u]]; b[u] = s_B[j[u]]; }
+        ahead.advance(kk);
+        body(make_float4(a[0].x, a[0].y, a[0].z, 0.f), make_float4(a[0].w, b[0].x, b[0].y, 0.f), 0u);
+        if (kk + 1 < cnt) body(make_float4(a[1].x, a[1].y, a[1].z, 0.f), make_float4(a[1].w, b[1].x, b[1].y, 0.f), 0u);
+        if (kk + 2 < cnt) body(make_float4(a[2].x, a[2].y, a[2].z, 0.f), make_float4(a[2].w, b[2].x, b[2].y, 0.f), 0u);
+        if (kk + 3 < cnt) body(make_float4(a[3].x, a[3].y, a[3].z, 0.f), make_float4(a[3].w, b[3].x, b[3].y, 0.f), 0u);
+    }
+}
+
+template <bool DFSPH, bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                     const float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     float *__restrict__ rho_out, float *__restrict__ aux_out,
                                                     float4 *__restrict__ Pout, float4 *Vout, RigidView rv,
-                                                    const int *__restrict__ id, float *__restrict__ rho_orig)
+                                                    const int *__restrict__ id, float *__restrict__ rho_orig,
+                                                    const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
+    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     float rho = 0.001f;                                      // solver_base.py:44
     float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
-    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         const bool rg = RIGID && (j & kRigidTag);
@@ -677,7 +844,9 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             sx += rx; sy += ry; sz += rz;
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
-    });
+    };
+    if (staged) for_fluid_nbrs<false, false>(nlp, kf, s_operand, nullptr, rv, pair);
+    else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -827,16 +996,19 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
 // ======================================================================================
 enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
 
-template <int MODE, bool RIGID>
+template <int MODE, bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
-                                                    const float4 *Vin, float4 *Vout, RigidView rv, int gate)
+                                                    const float4 *Vin, float4 *Vout, RigidView rv, int gate,
+                                                    const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     SPH_SWEEP_PROLOGUE
+    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     const float dt = ds->dt;
     const float rho_i = rho[ii];
     float k_i;
@@ -845,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
     const float kr_i = k_i / rho_i;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -859,7 +1031,9 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                 ax += s * g.x; ay += s * g.y; az += s * g.z;
             }
         }
-    });
+    };
+    if (staged) for_fluid_nbrs<false, false>(nlp, kf, s_operand, nullptr, rv, pair);
+    else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -890,23 +1064,27 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
 //   D6 (dfsph_solver.py:124-176): rho*_i = max(rho_i + dt (same sums with v*), rho0)
 // Writes Pout.w = k/rho for the correction sweep that follows and the block partials of the mean.
 // ======================================================================================
-template <bool DENS, bool RIGID>
+template <bool DENS, bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                      const float *__restrict__ rho, const float *__restrict__ alpha,
                                                      const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
-                                                     RigidView rv, const int *__restrict__ ncount, int gate)
+                                                     RigidView rv, const int *__restrict__ ncount, int gate,
+                                                     const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
+    float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_pv(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     float acc = 0.f;
     const int nq = RIGID ? (live ? ncount[ii] : 0) : kf;                          // ps.get_neighbour_count(i)
     const bool skip = !DENS && nq < 20;                                           // :258-261
     const float dt_r = RIGID ? ds->dt : 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -916,7 +1094,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         } else {
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);          // :287 / :162
         }
-    });
+    };
+    if (staged) for_staged_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float accb = 0.f;
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -952,20 +1132,24 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
 // D5: tension + viscosity + external force + v* and max |v*|
 //     solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
 // ======================================================================================
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
-                                                      float *__restrict__ pmax, RigidView rv)
+                                                      float *__restrict__ pmax, RigidView rv,
+                                                      const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
     (void)kb; (void)nlbp;
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);      // (vel, rho) needs 16 B: gathered from memory
+    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = vi.w;
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         if (RIGID && (j & kRigidTag)) {
@@ -996,7 +1180,9 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             float sv = c.neg_m * pi_;                        // :189
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
-    });
+    };
+    if (staged) for_staged_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float vn = -INFINITY;
     if (live) {
         const float dt = ds->dt;

@@ -83,6 +83,9 @@ struct SphHandle {
     std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
+    bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
+    uint32_t *stage_src = nullptr;
+    int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
     DevScalars *ds = nullptr;    // device
     DevScalars *ds_host = nullptr;   // pinned mirror
@@ -635,6 +638,16 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     // one spare 64-particle tile at the end: the software-pipelined walks read one row ahead
     if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbpitch))) return rc;
+    {
+        // LDS staging of the gather operands (plan in k_build_nl): DFSPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
+        const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
+        h->staged = c.order == CELL_ORDER_TILED && is_dfsph(h) && !(e && atoi(e) == 0);
+        h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
+        if (h->staged) {
+            if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap))) return rc;
+            if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
+        }
+    }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
@@ -1381,13 +1394,24 @@ int stage_sort_and_lists(SphHandle *h)
         // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
         HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
         if (rigid_coupled(h))
-            hipLaunchKernelGGL(k_build_nl<true>, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
-                               h->nlb, h->cnt, h->ds, rigid_view(h), h->ncount);
+            hipLaunchKernelGGL((k_build_nl<true, false>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
+                               h->nlb, h->cnt, h->ds, rigid_view(h), h->ncount, (uint32_t *)nullptr, (int *)nullptr);
+        else if (h->staged)
+            hipLaunchKernelGGL((k_build_nl<false, true>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
+                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr, h->stage_src, h->stage_cnt);
         else
-            hipLaunchKernelGGL(k_build_nl<false>, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
-                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr);
+            hipLaunchKernelGGL((k_build_nl<false, false>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
+                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr, (uint32_t *)nullptr, (int *)nullptr);
     }
     HIP_TRY(h, hipGetLastError());
+    if (h->staged && getenv("SPH_STAGE_DEBUG")) {
+        std::vector<int> sc((size_t)h->nblocks);
+        HIP_TRY(h, hipMemcpyAsync(sc.data(), h->stage_cnt, sizeof(int) * sc.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        long long tot = 0; int bad = 0, mx = 0;
+        for (int v : sc) { if (v < 0) ++bad; else { tot += v; mx = std::max(mx, v); } }
+        fprintf(stderr, "[stage] %d workgroups, %d unstaged, mean %.0f max %d staged particles\n", h->nblocks, bad, sc.size() > (size_t)bad ? (double)tot / (sc.size() - bad) : 0.0, mx);
+    }
     h->nl_valid = true;
     h->density_valid = false;
     return SPH_OK;
@@ -1416,23 +1440,27 @@ int stage_density(SphHandle *h)
         // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
         if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_density<true, true>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+            hipLaunchKernelGGL((k_density<true, true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
                                h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view(h),
-                               h->id[h->icur], h->rho_orig);
+                               h->id[h->icur], h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
+        else if (h->staged)
+            hipLaunchKernelGGL((k_density<true, false, true>), g, b, (size_t)c.stage_cap * sizeof(float4), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+                               h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], RigidView(),
+                               (const int *)nullptr, (float *)nullptr, h->stage_src, h->stage_cnt);
         else
-            hipLaunchKernelGGL((k_density<true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+            hipLaunchKernelGGL((k_density<true, false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
                                h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], RigidView(),
-                               (const int *)nullptr, (float *)nullptr);
+                               (const int *)nullptr, (float *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
     } else {
         ProfScope ps(h, K_W_DENSITY);
         if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_density<false, true>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+            hipLaunchKernelGGL((k_density<false, true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
                                (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view(h),
-                               h->id[h->icur], h->rho_orig);
+                               h->id[h->icur], h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
         else
-            hipLaunchKernelGGL((k_density<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+            hipLaunchKernelGGL((k_density<false, false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
                                (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
-                               (const int *)nullptr, (float *)nullptr);
+                               (const int *)nullptr, (float *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1497,13 +1525,17 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<false, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+        hipLaunchKernelGGL((k_residual<false, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
                            h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h),
-                           h->ncount, gate);
-    else
-        hipLaunchKernelGGL((k_residual<false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+                           h->ncount, gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    else if (h->staged)
+        hipLaunchKernelGGL((k_residual<false, false, true>), grid_for(c.n), dim3(kBlock), ((size_t)c.stage_cap * (sizeof(float4) + sizeof(float2))), h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
                            h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate);
+                           (const int *)nullptr, gate, h->stage_src, h->stage_cnt);
+    else
+        hipLaunchKernelGGL((k_residual<false, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
+                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                           (const int *)nullptr, gate, (const uint32_t *)nullptr, (const int *)nullptr);
 }
 
 template <int MODE>
@@ -1512,11 +1544,14 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     const Consts &c = h->c;
     ProfScope ps(h, kid);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_correct<MODE, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
-                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view(h), gate);
+        hipLaunchKernelGGL((k_correct<MODE, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view(h), gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    else if (h->staged)
+        hipLaunchKernelGGL((k_correct<MODE, false, true>), grid_for(c.n), dim3(kBlock), (size_t)c.stage_cap * sizeof(float4), h->stream, c, h->P[1 - h->pcur], h->WP,
+                           h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate, h->stage_src, h->stage_cnt);
     else
-        hipLaunchKernelGGL((k_correct<MODE, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
-                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate);
+        hipLaunchKernelGGL((k_correct<MODE, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
+                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate, (const uint32_t *)nullptr, (const int *)nullptr);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -1524,13 +1559,17 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<true, true>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+        hipLaunchKernelGGL((k_residual<true, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
                            h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount,
-                           gate);
-    else
-        hipLaunchKernelGGL((k_residual<true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+                           gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    else if (h->staged)
+        hipLaunchKernelGGL((k_residual<true, false, true>), grid_for(c.n), dim3(kBlock), ((size_t)c.stage_cap * (sizeof(float4) + sizeof(float2))), h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
                            h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate);
+                           (const int *)nullptr, gate, h->stage_src, h->stage_cnt);
+    else
+        hipLaunchKernelGGL((k_residual<true, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
+                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
+                           (const int *)nullptr, gate, (const uint32_t *)nullptr, (const int *)nullptr);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -1581,9 +1620,12 @@ int dfsph_ext_and_dt(SphHandle *h)
     {
         ProfScope ps(h, K_D_EXT);
         if (rigid_coupled(h))
-            hipLaunchKernelGGL(k_dfsph_ext<true>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, rigid_view(h));
+            hipLaunchKernelGGL((k_dfsph_ext<true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, rigid_view(h), (const uint32_t *)nullptr, (const int *)nullptr);
+        else if (h->staged)
+            hipLaunchKernelGGL((k_dfsph_ext<false, true>), g, b, (size_t)c.stage_cap * (sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt,
+                               h->ds, h->VA[0], h->pmax, RigidView(), h->stage_src, h->stage_cnt);
         else
-            hipLaunchKernelGGL(k_dfsph_ext<false>, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, RigidView());
+            hipLaunchKernelGGL((k_dfsph_ext<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, RigidView(), (const uint32_t *)nullptr, (const int *)nullptr);
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
             for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];

@@ -4,7 +4,12 @@ The library keeps the cells of large scenes along a Morton curve (tiles of 4 cel
 csrc/sph_kernels.h) and those of small scenes in the reference's 1-D order; every consumer still walks the 27 cells in the
 reference's sequence, so both orders must give the same bits.  The other GPU suites run their small scenes in the linear
 order; here the same kinds of scene (walls, clamp walls, particles that leak out of the box, a rigid body, slabs) are forced
-onto the Morton curve and compared with the linear order and with the oracle."""
+onto the Morton curve and compared with the linear order and with the oracle.
+
+On the curve the DFSPH sweeps also stage their gather operands in LDS (the list build writes, per workgroup, the set of particles it
+can see and the neighbour lists in indices local to that set; workgroups whose set exceeds the capacity keep global indices).  That is
+on by default, so every Morton case here runs it; the staging tests below compare it with SPH_STAGE=0 and with capacities small
+enough that staged and unstaged workgroups mix."""
 import numpy as np
 import pytest
 
@@ -105,3 +110,21 @@ def test_slabs_on_the_morton_curve(tmp_path, monkeypatch, scene, world, steps, r
     monkeypatch.setenv("SPH_CELL_ORDER", "morton")
     r = run_slabs(tmp_path, scene, world, steps, rebalance=rebalance)
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "slabs")}
+
+
+@pytest.mark.parametrize("scene,steps", [("dfsph_small", 40), ("dfsph_tiny_wall", 60), ("dfsph_dam_x", 300), ("breaking_dam_30k_dfsph", 12)])
+@pytest.mark.parametrize("cap", ["1664", "700", "300", "64"])
+def test_lds_staging_is_invisible(scene, steps, cap, monkeypatch):
+    """Same bits with the operands staged in LDS, at several capacities (64: almost every workgroup falls back to global indices)."""
+    cfg = scenes.get(scene)
+    monkeypatch.setenv("SPH_STAGE", "1")
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    a = make(cfg, "morton", monkeypatch)
+    monkeypatch.setenv("SPH_STAGE", "0")
+    b = make(cfg, "morton", monkeypatch)
+    for s_ in range(steps):
+        sa, sb = a.step(1), b.step(1)
+        assert (sa.n_div, sa.n_dens, sa.div_err, sa.dens_err, sa.dt, sa.max_nbrs) == (sb.n_div, sb.n_dens, sb.div_err, sb.dens_err, sb.dt, sb.max_nbrs), (scene, s_)
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), (scene, cap, f)
+    a.close(); b.close()
