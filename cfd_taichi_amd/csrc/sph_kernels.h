@@ -761,9 +761,32 @@ __device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__res
     __syncthreads();
     return true;
 }
-template <class Body>
+// staged walkers: fluid entries are LOCAL indices into the staged arrays, tagged rigid entries stay global (rv.RP)
+template <bool RIGID, class Body>
+__device__ __forceinline__ void for_staged_nbrs(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A, const RigidView &rv,
+                                                Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            a[u] = rg ? rv.RP[j[u] & ~kRigidTag] : s_A[RIGID ? (j[u] & ~kRigidTag) : j[u]];
+        }
+        ahead.advance(kk);
+        const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+        body(a[0], none, j[0]);
+        if (kk + 1 < cnt) body(a[1], none, j[1]);
+        if (kk + 2 < cnt) body(a[2], none, j[2]);
+        if (kk + 3 < cnt) body(a[3], none, j[3]);
+    }
+}
+template <bool RIGID, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
-                                                   const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, Body body)
+                                                   const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, const RigidView &rv, Body body)
 {
     NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
@@ -771,12 +794,17 @@ __device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ 
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { b[u] = B[s_src[j[u]]]; a[u] = s_A[j[u]]; }
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            b[u] = B[rg ? 0u : s_src[idx]];
+            a[u] = rg ? rv.RP[idx] : s_A[idx];
+        }
         ahead.advance(kk);
-        body(a[0], b[0], 0u);
-        if (kk + 1 < cnt) body(a[1], b[1], 0u);
-        if (kk + 2 < cnt) body(a[2], b[2], 0u);
-        if (kk + 3 < cnt) body(a[3], b[3], 0u);
+        body(a[0], b[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], j[3]);
     }
 }
 
@@ -797,22 +825,33 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
     __syncthreads();
     return true;
 }
-template <class Body>
+template <bool RIGID, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
-                                                    const float2 *__restrict__ s_B, Body body)
+                                                    const float2 *__restrict__ s_B, const RigidView &rv, Body body)
 {
     NlAhead ahead(base);
     for (int kk = 0; kk < cnt; kk += 4) {
         const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
-        float4 a[4]; float2 b[4];
+        float4 a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = s_A[j[u]]; b[u] = s_B[j[u]]; }
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            if (rg) {
+                a[u] = rv.RP[idx];                                   // (x, y, z, V_r); the velocity operand is undefined for rigid entries
+                b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float4 pa = s_A[idx]; const float2 pb = s_B[idx];
+                a[u] = make_float4(pa.x, pa.y, pa.z, 0.f);
+                b[u] = make_float4(pa.w, pb.x, pb.y, 0.f);
+            }
+        }
         ahead.advance(kk);
-        body(make_float4(a[0].x, a[0].y, a[0].z, 0.f), make_float4(a[0].w, b[0].x, b[0].y, 0.f), 0u);
-        if (kk + 1 < cnt) body(make_float4(a[1].x, a[1].y, a[1].z, 0.f), make_float4(a[1].w, b[1].x, b[1].y, 0.f), 0u);
-        if (kk + 2 < cnt) body(make_float4(a[2].x, a[2].y, a[2].z, 0.f), make_float4(a[2].w, b[2].x, b[2].y, 0.f), 0u);
-        if (kk + 3 < cnt) body(make_float4(a[3].x, a[3].y, a[3].z, 0.f), make_float4(a[3].w, b[3].x, b[3].y, 0.f), 0u);
+        body(a[0], b[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], j[3]);
     }
 }
 
@@ -845,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
     };
-    if (staged) for_fluid_nbrs<false, false>(nlp, kf, s_operand, nullptr, rv, pair);
+    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
@@ -1032,7 +1071,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             }
         }
     };
-    if (staged) for_fluid_nbrs<false, false>(nlp, kf, s_operand, nullptr, rv, pair);
+    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -1095,7 +1134,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);          // :287 / :162
         }
     };
-    if (staged) for_staged_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair);
+    if (staged) for_staged_nbrs_pv2<RIGID>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float accb = 0.f;
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
@@ -1181,7 +1220,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
     };
-    if (staged) for_staged_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
+    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float vn = -INFINITY;
     if (live) {

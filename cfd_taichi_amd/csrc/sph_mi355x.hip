@@ -547,6 +547,25 @@ int build_scene(SphHandle *h, HostScene &sc)
     return SPH_OK;
 }
 
+// kernel<T0, RIGID, STAGED> / kernel<RIGID, STAGED> chosen at run time (rigid coupling active, LDS staging on)
+#define SPH_LAUNCH_RS(K, T0, rg, st, g, b, lds, s, ...)                                              \
+    do {                                                                                             \
+        if ((rg) && (st)) hipLaunchKernelGGL((K<T0, true, true>), g, b, lds, s, __VA_ARGS__);        \
+        else if (rg) hipLaunchKernelGGL((K<T0, true, false>), g, b, lds, s, __VA_ARGS__);            \
+        else if (st) hipLaunchKernelGGL((K<T0, false, true>), g, b, lds, s, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((K<T0, false, false>), g, b, lds, s, __VA_ARGS__);                   \
+    } while (0)
+#define SPH_LAUNCH_RS0(K, rg, st, g, b, lds, s, ...)                                                 \
+    do {                                                                                             \
+        if ((rg) && (st)) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, __VA_ARGS__);            \
+        else if (rg) hipLaunchKernelGGL((K<true, false>), g, b, lds, s, __VA_ARGS__);                \
+        else if (st) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, __VA_ARGS__);                \
+        else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, __VA_ARGS__);                       \
+    } while (0)
+// dynamic LDS of a staged sweep: bytes per staged particle x capacity (else the occupancy-experiment knob)
+inline size_t sweep_lds(const SphHandle *h, size_t bytes_per_staged) { return h->staged ? (size_t)h->c.stage_cap * bytes_per_staged : (size_t)h->sweep_lds; }
+inline RigidView rigid_view_or_none(const SphHandle *h);
+
 inline bool is_dfsph(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH; }
 inline bool is_pressure_solver(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH; }
 // solvers with a per-particle scalar that must follow the particle through the sort: dfsph warm_start_k, iisph p_past
@@ -1061,6 +1080,7 @@ RigidView rigid_view(const SphHandle *h)
 }
 
 inline bool rigid_coupled(const SphHandle *h) { return h->rigid && h->rigid_active && h->cfg.fs_couple; }
+inline RigidView rigid_view_or_none(const SphHandle *h) { return rigid_coupled(h) ? rigid_view(h) : RigidView(); }
 
 // init_rigid_particles_pos + init_rigid_particles_data (ParticleSystem.py:198-223, 249-295), once, on the host
 int build_rigid(SphHandle *h, const SphRigid *rg)
@@ -1393,15 +1413,8 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_BUILD_NL);
         // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
         HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_build_nl<true, false>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
-                               h->nlb, h->cnt, h->ds, rigid_view(h), h->ncount, (uint32_t *)nullptr, (int *)nullptr);
-        else if (h->staged)
-            hipLaunchKernelGGL((k_build_nl<false, true>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
-                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr, h->stage_src, h->stage_cnt);
-        else
-            hipLaunchKernelGGL((k_build_nl<false, false>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl,
-                               h->nlb, h->cnt, h->ds, RigidView(), (int *)nullptr, (uint32_t *)nullptr, (int *)nullptr);
+        SPH_LAUNCH_RS0(k_build_nl, rigid_coupled(h), h->staged, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur],
+                       h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt);
     }
     HIP_TRY(h, hipGetLastError());
     if (h->staged && getenv("SPH_STAGE_DEBUG")) {
@@ -1439,28 +1452,14 @@ int stage_density(SphHandle *h)
         // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
         // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_density<true, true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view(h),
-                               h->id[h->icur], h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
-        else if (h->staged)
-            hipLaunchKernelGGL((k_density<true, false, true>), g, b, (size_t)c.stage_cap * sizeof(float4), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
-                               h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], RigidView(),
-                               (const int *)nullptr, (float *)nullptr, h->stage_src, h->stage_cnt);
-        else
-            hipLaunchKernelGGL((k_density<true, false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], RigidView(),
-                               (const int *)nullptr, (float *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
+        SPH_LAUNCH_RS(k_density, true, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+                      h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
+                      h->rho_orig, h->stage_src, h->stage_cnt);
     } else {
         ProfScope ps(h, K_W_DENSITY);
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_density<false, true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view(h),
-                               h->id[h->icur], h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
-        else
-            hipLaunchKernelGGL((k_density<false, false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                               (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], RigidView(),
-                               (const int *)nullptr, (float *)nullptr, (const uint32_t *)nullptr, (const int *)nullptr);
+        SPH_LAUNCH_RS(k_density, false, rigid_coupled(h), false, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                      (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
+                      h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1524,18 +1523,9 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
-    if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<false, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
-                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h),
-                           h->ncount, gate, (const uint32_t *)nullptr, (const int *)nullptr);
-    else if (h->staged)
-        hipLaunchKernelGGL((k_residual<false, false, true>), grid_for(c.n), dim3(kBlock), ((size_t)c.stage_cap * (sizeof(float4) + sizeof(float2))), h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
-                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate, h->stage_src, h->stage_cnt);
-    else
-        hipLaunchKernelGGL((k_residual<false, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->V[h->vcur], h->WP,
-                           h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    SPH_LAUNCH_RS(k_residual, false, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+                  h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt);
 }
 
 template <int MODE>
@@ -1543,33 +1533,17 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
-    if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_correct<MODE, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
-                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view(h), gate, (const uint32_t *)nullptr, (const int *)nullptr);
-    else if (h->staged)
-        hipLaunchKernelGGL((k_correct<MODE, false, true>), grid_for(c.n), dim3(kBlock), (size_t)c.stage_cap * sizeof(float4), h->stream, c, h->P[1 - h->pcur], h->WP,
-                           h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate, h->stage_src, h->stage_cnt);
-    else
-        hipLaunchKernelGGL((k_correct<MODE, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[1 - h->pcur], h->WP, h->nl, h->nlb,
-                           h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, RigidView(), gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    SPH_LAUNCH_RS(k_correct, MODE, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[1 - h->pcur], h->WP,
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
-    if (rigid_coupled(h))
-        hipLaunchKernelGGL((k_residual<true, true, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
-                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, rigid_view(h), h->ncount,
-                           gate, (const uint32_t *)nullptr, (const int *)nullptr);
-    else if (h->staged)
-        hipLaunchKernelGGL((k_residual<true, false, true>), grid_for(c.n), dim3(kBlock), ((size_t)c.stage_cap * (sizeof(float4) + sizeof(float2))), h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
-                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate, h->stage_src, h->stage_cnt);
-    else
-        hipLaunchKernelGGL((k_residual<true, false, false>), grid_for(c.n), dim3(kBlock), h->sweep_lds, h->stream, c, h->P[h->pcur], h->VA[0], h->WP, h->nl,
-                           h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt, RigidView(),
-                           (const int *)nullptr, gate, (const uint32_t *)nullptr, (const int *)nullptr);
+    SPH_LAUNCH_RS(k_residual, true, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+                  h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -1619,13 +1593,8 @@ int dfsph_ext_and_dt(SphHandle *h)
     int rc;
     {
         ProfScope ps(h, K_D_EXT);
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL((k_dfsph_ext<true, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, rigid_view(h), (const uint32_t *)nullptr, (const int *)nullptr);
-        else if (h->staged)
-            hipLaunchKernelGGL((k_dfsph_ext<false, true>), g, b, (size_t)c.stage_cap * (sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt,
-                               h->ds, h->VA[0], h->pmax, RigidView(), h->stage_src, h->stage_cnt);
-        else
-            hipLaunchKernelGGL((k_dfsph_ext<false, false>), g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds, h->VA[0], h->pmax, RigidView(), (const uint32_t *)nullptr, (const int *)nullptr);
+        SPH_LAUNCH_RS0(k_dfsph_ext, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
+                       h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt);
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
             for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];

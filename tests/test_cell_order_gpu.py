@@ -128,3 +128,25 @@ def test_lds_staging_is_invisible(scene, steps, cap, monkeypatch):
     for f in FIELDS:
         assert np.array_equal(a.download(f), b.download(f), equal_nan=True), (scene, cap, f)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("cap", ["1664", "200"])
+def test_lds_staging_with_a_rigid_body(cap, monkeypatch):
+    """Tagged rigid entries stay global inside staged lists; the coupled run equals the unstaged one, body included."""
+    cfg = scenes.get("dfsph_rigid_small")
+    rg = mesh.rigid_from_config(cfg)
+    monkeypatch.setenv("SPH_STAGE", "1")
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    a = make(cfg, "morton", monkeypatch, rigid=rg)
+    monkeypatch.setenv("SPH_STAGE", "0")
+    b = make(cfg, "morton", monkeypatch, rigid=rg)
+    for s_ in range(100):
+        sa, sb = a.step_dfsph(1), b.step_dfsph(1)
+        assert (sa.n_div, sa.n_dens, sa.div_err, sa.dens_err, sa.dt) == (sb.n_div, sb.n_dens, sb.div_err, sb.dens_err, sb.dt), s_
+        a.rigid_step(); b.rigid_step()
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), f
+    ra, rb = a.rigid_scalars(), b.rigid_scalars()
+    for k in ("centroid", "omega", "vel"):
+        assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), k
+    a.close(); b.close()
