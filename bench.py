@@ -368,7 +368,7 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom) if world == 1 and scene_name == "dfsph_1m" else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
-                           "note": "gather sweep, not HBM-streaming bound: ~36 L1 line accesses per wave-gather and ~52 f32 VALU instr per pair share the time (PMC, DESIGN.md section 6c)"}
+                           "note": "neighbour sweep, bound by f32 instruction issue, not by HBM: ~52 VALU instructions per pair (the reference's IEEE sqrt and divides) for < 1 algorithmic byte; see roofline.valu and DESIGN.md section 6c"}
         insts = load_traffic(dom, "sq_insts_valu_per_launch") if world == 1 and scene_name == "dfsph_1m" else None
         if insts:
             # second opinion on the same kernel: the reference's arithmetic needs ~50 f32 instructions per pair for < 1 algorithmic byte,
