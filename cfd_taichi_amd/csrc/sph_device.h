@@ -176,7 +176,22 @@ __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float 
 
 // ti.max(a, b) as the oracle restates it: a > b ? a : b (keeps the sign-of-zero behaviour identical)
 __device__ __forceinline__ float rmax(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+// RN(sqrt(x)) for 0 <= x < 2^63 in 11 instructions (hipcc's generic correctly rounded expansion: 16 + hazard nops, for its range
+// and class handling).  Scaling by 2^64 is exact, lifts denormal inputs into v_sqrt_f32's domain and cannot overflow below 2^63;
+// the hardware root is within 1 ulp, so the exact residuals x - y'*y of the two neighbours y' = y -+ 1 ulp (one fma each) decide
+// the rounding -- the same correction step the generic expansion uses; unscaling by 2^-32 is exact again.  x = 0 stays 0 (the
+// neighbour below is a NaN pattern whose compare fails).  Squared distances between particles of a scene are far inside the range.
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float xs = x * 0x1p64f;
+    const float y = __builtin_amdgcn_sqrtf(xs);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, xs), rp = __builtin_fmaf(-yp, y, xs);
+    float r = 0.0f >= rm ? ym : y;
+    r = 0.0f < rp ? yp : r;
+    return r * 0x1p-32f;
+}
+__device__ __forceinline__ float norm3(float x, float y, float z) { return sqrt_rn((x * x + y * y) + z * z); }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     return (ax * bx + ay * by) + az * bz;

@@ -1329,6 +1329,7 @@ __global__ void k_selftest(Consts c, int op, const float *__restrict__ a, const 
     if (op == 0) r = x / y;
     else if (op == 1) r = sqrtf(x);
     else if (op == 2) { c.h = y; r = cubic_w(c, x); }
+    else if (op == 6) r = sqrt_rn(x);
     else {
         float dz = 0.25f * x;
         float rn = norm3(x, y, dz);

@@ -48,6 +48,10 @@ def test_device_divide_sqrt_are_ieee():
         quotient = (a / b).astype(np.float32)
     assert_same(nat.selftest_math(0, a, b), quotient, "a/b")
     assert_same(nat.selftest_math(1, a, b), np.sqrt(a).astype(np.float32), "sqrt(a)")
+    # the sweeps' 11-instruction root (sph_device.h sqrt_rn): correctly rounded on [0, 2^63), denormals and perfect squares included
+    s = np.concatenate([a[a < 9e18], (rng.integers(1, 4000, 50000).astype(np.float32) ** 2) * np.float32(2.0) ** rng.integers(-60, 20, 50000).astype(np.float32),
+                        np.float32([0.0, 1e-45, 1.1754944e-38, 1.1754942e-38, 0.01, 0.010000001, 9.2e18])]).astype(np.float32)
+    assert_same(nat.selftest_math(6, s, s), np.sqrt(s).astype(np.float32), "sqrt_rn(s)")
 
 
 def test_device_kernel_functions_match_oracle():
