@@ -174,6 +174,38 @@ __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float 
     return o;
 }
 
+// The same two functions for a pair taken from a neighbour list and evaluated at the positions the list was built from: list
+// membership is |x_ij| <= h exactly (r2_cut), so q = RN(r/h) <= 1 unless it is NaN, and NaN fails `1e-5 < q` as well: the gradient
+// needs two compares instead of four.  (PCISPH / IISPH sweeps at PREDICTED positions must use the general forms.)
+__device__ __forceinline__ float cubic_w_in(const Consts &c, float r)
+{
+    float q = div_by_h(c, r);
+    float q2 = q * q;
+    float q3 = q2 * q;
+    float w1 = c.kw * (6.0f * (q3 - q2) + 1.0f);
+    float t = 1.0f - q;
+    float w2 = 2.0f * c.kw * (t * (t * t));
+    return q <= 0.5f ? w1 : (q <= 1.0f ? w2 : 0.0f);      // 0 <= q holds; the upper compare stays for q = NaN (a particle that blew up
+                                                          // passes the reference's `norm > h` skip and must contribute 0, solver_base.py:84-87)
+}
+__device__ __forceinline__ F3 grad_w_in(const Consts &c, float dx, float dy, float dz, float r_norm)
+{
+    float q = div_by_h(c, r_norm);
+    float q2 = q * q;
+    float s1 = c.kg6 * (3.0f * q2 - 2.0f * q);
+    float t = 1.0f - q;
+    float s2 = c.neg_kg6 * (t * t);
+    float s = q <= 0.5f ? s1 : s2;
+    const Recip den = recip_prepare(c.h * r_norm);
+    float ox = div_shared(s * dx, den), oy = div_shared(s * dy, den), oz = div_shared(s * dz, den);
+    const bool in = 1e-5f < q;                            // :97 (q <= 1 holds for every list member)
+    F3 o;
+    o.x = in ? ox : 0.0f;
+    o.y = in ? oy : 0.0f;
+    o.z = in ? oz : 0.0f;
+    return o;
+}
+
 // ti.max(a, b) as the oracle restates it: a > b ? a : b (keeps the sign-of-zero behaviour identical)
 __device__ __forceinline__ float rmax(float a, float b) { return a > b ? a : b; }
 // RN(sqrt(x)) for 0 <= x < 2^63 in 11 instructions (hipcc's generic correctly rounded expansion: 16 + hazard nops, for its range

@@ -874,10 +874,10 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         const bool rg = RIGID && (j & kRigidTag);
-        if (rg) rho += pj.w * cubic_w(c, r) * c.rho0;        // solver_base.py:65  (V_j * W * rho_0)
-        else rho += c.m * cubic_w(c, r);                     // solver_base.py:62
+        if (rg) rho += pj.w * cubic_w_in(c, r) * c.rho0;        // solver_base.py:65  (V_j * W * rho_0)
+        else rho += c.m * cubic_w_in(c, r);                     // solver_base.py:62
         if (DFSPH) {
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             const float cm = rg ? pj.w * c.rho0 : c.m;       // dfsph_solver.py:62,75 / :58,70
             float rx = cm * g.x, ry = cm * g.y, rz = cm * g.z;
             sx += rx; sy += ry; sz += rz;
@@ -890,9 +890,9 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        rho_b += pj.w * cubic_w(c, r);                       // solver_base.py:70-71
+        rho_b += pj.w * cubic_w_in(c, r);                       // solver_base.py:70-71
         if (DFSPH) {
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             float cc = pj.w * c.rho0;                        // dfsph_solver.py:82,88
             float rx = cc * g.x, ry = cc * g.y, rz = cc * g.z;
             bx += rx; by += ry; bz += rz;
@@ -933,7 +933,7 @@ __device__ __forceinline__ void rigid_viscosity(const Consts &c, const RigidView
     float shear = dot3(vx, vy, vz, dx, dy, dz);
     const int jl = rv.rid[j & ~kRigidTag];
     if (shear < 0.f && jl < rv.n_fluid) {
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         float q2 = r * r;
         float nu = c.visc_num / (rho_i + rv.rho_orig[jl]);
         float pi_ = -nu * shear / (q2 + c.visc_eps_h2);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
     for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const float sr = -pj.w * p_own / (rho_i * rho_i);               // wcsph_solver.py:125
             gx += sr * g.x * c.rho0; gy += sr * g.y * c.rho0; gz += sr * g.z * c.rho0;
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
             float sv = c.neg_m * pi_;                        // :189
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
-        float st = c.tens_c * cubic_w(c, r);                 // :216
+        float st = c.tens_c * cubic_w_in(c, r);                 // :216
         tx += st * dx; ty += st * dy; tz += st * dz;
     });
     float bx = 0.f, by = 0.f, bz = 0.f;
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
         for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             float s = pj.w * p_i / rho_i_2;                  // wcsph_solver.py:99
             bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
         });
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             float s = pj.w * c.rho0 * k_i / rho_i;                                // :345 / :377 / :211  (no 1e-5 gate)
             ax += s * g.x; ay += s * g.y; az += s * g.z;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219
         bx += s * g.x; by += s * g.y; bz += s * g.z;
     });
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const F3 w = rigid_velocity(rv, pj, dt_r, DENS);                      // :292-293 / :168-169
             acc += pj.w * c.rho0 * dot3(vi.x - w.x, vi.y - w.y, vi.z - w.z, g.x, g.y, g.z);   // :294 / :170
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
     });
     float val = 0.f;
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             float shear = dot3(vx, vy, vz, dx, dy, dz);
             const int jl = rv.rid[j & ~kRigidTag];
             if (shear < 0.f && jl < rv.n_fluid) {
-                F3 g = grad_w(c, dx, dy, dz, r);
+                F3 g = grad_w_in(c, dx, dy, dz, r);
                 float q2 = r * r;
                 float nu = c.visc_num / (rho_i + rv.rho_orig[jl]);
                 float pi_ = -nu * shear / (q2 + c.visc_eps_h2);
@@ -1207,12 +1207,12 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             }
             return;
         }
-        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        float st = c.tens_c * cubic_w_in(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
         float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
         if (shear < 0.f) {
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             float q2 = r * r;
             float nu = c.visc_num / (rho_i + vj.w);          // :187
             float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
