@@ -35,48 +35,26 @@ template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_ps(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                             const float *__restrict__ S, const RigidView &rv, Body body)
 {
-    NlAhead ahead(base);
-    for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = ahead.front();
-        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
-        float4 a[4]; float sc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool rg = RIGID && (j[u] & kRigidTag);
-            const uint32_t idx = j[u] & ~kRigidTag;
-            a[u] = rg ? rv.RP[idx] : A[idx];
-            sc[u] = S[rg ? 0u : idx];
-        }
-        ahead.advance(kk);
-        body(a[0], sc[0], j[0]);
-        if (kk + 1 < cnt) body(a[1], sc[1], j[1]);
-        if (kk + 2 < cnt) body(a[2], sc[2], j[2]);
-        if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
-    }
+    struct Op { float4 a; float s; };
+    walk_list<Op>(base, cnt, [&](uint32_t j, Op &o) {
+        const bool rg = RIGID && (j & kRigidTag);
+        const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+        o.a = rg ? rv.RP[idx] : A[idx];
+        o.s = S[rg ? 0u : idx];
+    }, [&](const Op &o, uint32_t j) { body(o.a, o.s, j); });
 }
 template <bool RIGID, class Body>
 __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ A,
                                            const float4 *__restrict__ B, const float4 *__restrict__ C, const RigidView &rv, Body body)
 {
-    NlAhead ahead(base);
-    for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = ahead.front();
-        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
-        float4 a[4], b[4], cc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool rg = RIGID && (j[u] & kRigidTag);
-            const uint32_t idx = j[u] & ~kRigidTag;
-            a[u] = rg ? rv.RP[idx] : A[idx];
-            b[u] = B[rg ? 0u : idx];
-            cc[u] = C[rg ? 0u : idx];
-        }
-        ahead.advance(kk);
-        body(a[0], b[0], cc[0], j[0]);
-        if (kk + 1 < cnt) body(a[1], b[1], cc[1], j[1]);
-        if (kk + 2 < cnt) body(a[2], b[2], cc[2], j[2]);
-        if (kk + 3 < cnt) body(a[3], b[3], cc[3], j[3]);
-    }
+    struct Op { float4 a, b, c; };
+    walk_list<Op>(base, cnt, [&](uint32_t j, Op &o) {
+        const bool rg = RIGID && (j & kRigidTag);
+        const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+        o.a = rg ? rv.RP[idx] : A[idx];
+        o.b = B[rg ? 0u : idx];
+        o.c = C[rg ? 0u : idx];
+    }, [&](const Op &o, uint32_t j) { body(o.a, o.b, o.c, j); });
 }
 
 // predicted / integrated positions against the clamp walls      pcisph_solver.py:79-89, 234-244; iisph_solver.py:198-207
