@@ -67,6 +67,8 @@ __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, flo
 struct SlotPart { int tile, code; };
 __device__ __forceinline__ SlotPart slot_part(const Consts &c, int v, int axis, int tile_stride)
 {
+    if (c.tbits == 2)                                       // the default tile edge, without the loop
+        return {(v >> 2) * tile_stride, ((v & 1) | (v & 2) << 2) << axis};
     int code = 0;
     for (int k = 0; k < c.tbits; ++k) code |= ((v >> k) & 1) << (3 * k + axis);
     return {(v >> c.tbits) * tile_stride, code};
@@ -359,6 +361,26 @@ __device__ __forceinline__ void note_list_lengths(const Consts &c, int kf, int k
     }
 }
 
+// accept mask of four consecutive candidates: bit u set <=> !(|x_i - x_u|^2 > r2_cut), the distance formed as (dx*dx + dy*dy) + dz*dz.
+// (x, y) travel as one register pair straight from the 16-byte load, so the subtraction and the squares are one packed instruction each
+// and nothing has to be shuffled (left to itself the compiler pairs ACROSS candidates and spends 14 moves per batch on it).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned near_mask4(f32x2 pi_xy, float pi_z, const float4 *__restrict__ pb, float r2_cut)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float4 pc = pb[u];
+        const f32x2 c_xy = {pc.x, pc.y};
+        const f32x2 d = pi_xy - c_xy;
+        const f32x2 sq = d * d;
+        const float dz = pi_z - pc.z;
+        const float r2 = (sq.x + sq.y) + dz * dz;
+        m |= (!(r2 > r2_cut) ? 1u : 0u) << u;
+    }
+    return m;
+}
+
 // List append through an LDS staging row per lane (transposed: slot s of thread t at [s * kBlock + t], conflict-free): no
 // register shuffling on (k & 3), one 16-byte store per completed group of four.
 struct NlWriter {
@@ -480,6 +502,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
     } else if (i < c.n) {
         const float4 pi = P[i];
+        const f32x2 pi_xy = {pi.x, pi.y};
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
         NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kpitch), 0, c.kmax};
@@ -488,9 +511,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         const int my_id = RIGID ? id[i] : 0;
         const bool tiled = c.order == CELL_ORDER_TILED;
         for (int dx = -1; dx <= 1; ++dx) {
-            const SlotPart sx = slot_part(c, cx + dx, 0, 1);           // the slot of a cell, one coordinate per loop level
+            const SlotPart sx = tiled ? slot_part(c, cx + dx, 0, 1) : SlotPart{0, 0};   // the slot of a cell, one coordinate per loop level
             for (int dy = -1; dy <= 1; ++dy) {
-                const SlotPart sy = slot_part(c, cy + dy, 1, c.tnxz);
+                const SlotPart sy = tiled ? slot_part(c, cy + dy, 1, c.tnxz) : SlotPart{0, 0};
                 for (int dz = -1; dz <= 1; ++dz) {
                     int x = cx + dx, y = cy + dy, z = cz + dz;
                     if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
@@ -503,17 +526,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
                     // is harmless: the arrays carry 64 spare elements and the accept mask drops them)
                     for (int j0 = a; j0 < b; j0 += 4) {
-                        unsigned m = 0;
                         const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int j = j0 + u;
-                            const float4 pc = pb[u];
-                            float ddx = pi.x - pc.x, ddy = pi.y - pc.y, ddz = pi.z - pc.z;
-                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                            const bool hit = (j < b) & (j != i) & !(r2 > c.r2_cut);   // :461, :466 (norm > h)
-                            m |= (hit ? 1u : 0u) << u;
-                        }
+                        unsigned m = near_mask4(pi_xy, pi.z, pb, c.r2_cut);                          // :466 (norm > h)
+                        m &= (b - j0 >= 4 ? 15u : (1u << (b - j0)) - 1u);                            // candidates of this cell only
+                        const unsigned self = (unsigned)(i - j0);                                    // :461 (j != i)
+                        if (self < 4u) m &= ~(1u << self);
                         if (RIGID) nq += __popc(m);
                         while (m) {
                             const int u = __ffs(m) - 1;
@@ -543,16 +560,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     if (c.boundary_handle) {
                         const int wa = wcell_start[cid], wb = wcell_start[cid + 1];
                         for (int j0 = wa; j0 < wb; j0 += 4) {
-                            unsigned m = 0;
                             const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(WP) + (unsigned)j0 * 16u);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int j = j0 + u;
-                                const float4 pj = pb[u];
-                                float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
-                                float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                                m |= (((j < wb) & !(r2 > c.r2_cut)) ? 1u : 0u) << u;   // :364
-                            }
+                            unsigned m = near_mask4(pi_xy, pi.z, pb, c.r2_cut);                      // :364
+                            m &= (wb - j0 >= 4 ? 15u : (1u << (wb - j0)) - 1u);
                             while (m) {
                                 const int u = __ffs(m) - 1;
                                 m &= m - 1;
