@@ -76,7 +76,12 @@ struct DevScalars {
     // pcisph / iisph pressure loops reuse dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds:
     float res_prev;
     int res_have_prev, res_diverged, pad2;
+    // Per-build maxima of the list lengths, sharded: workgroup w raises shard w % kNoteShards, the host takes the maximum over the
+    // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
+    // list build: same-address traffic serialises even when it is only loads.)
+    int nbr_shard[64], wall_shard[64];
 };
+constexpr int kNoteShards = 64;
 
 enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3 };
 __device__ __forceinline__ bool gate_closed(const DevScalars *ds, int gate)

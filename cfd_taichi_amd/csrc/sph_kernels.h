@@ -98,9 +98,12 @@ __device__ __forceinline__ int cell_slot(const Consts &c, int id)
 // takes ONE atomic (its head lane adds the run length, every lane gets head's base + its offset in the run).  `rank` is only
 // a slot allocator -- k_order_gather establishes the canonical order inside a cell -- so any assignment is fine.
 __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, const int *__restrict__ dead,
-                                                       int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count)
+                                                       int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count,
+                                                       DevScalars *__restrict__ ds)
 {
     const int s = blockIdx.x * kBlock + threadIdx.x;
+    // the per-build maxima of the list lengths start at zero (instead of a memset launch before the list build)
+    if (ds && blockIdx.x == 0 && threadIdx.x < 2 * kNoteShards) ds->nbr_shard[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63;
     int id = -1;                                            // -1: no particle in this lane (past the end, or a dead slot)
     if (s < c.n && !(dead && dead[s])) {
@@ -124,14 +127,18 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *_
 
 // exclusive scan, three launches: per-tile scan, scan of tile sums, add-back
 constexpr int kScanTile = kBlock * 4;   // four entries per thread
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(const int *__restrict__ in, int *__restrict__ out,
+// `in` (the cell histogram) is zeroed as it is read: the next step's k_hash_count finds it clean without a memset launch
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(int *__restrict__ in, int *__restrict__ out,
                                                        int *__restrict__ tile_sums, int n)
 {
     __shared__ int wsum[kBlock / 64];
     int base = blockIdx.x * kScanTile + threadIdx.x * 4;
     int v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? in[base + k] : 0;
+    for (int k = 0; k < 4; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        if (base + k < n) in[base + k] = 0;
+    }
     int tsum = v[0] + v[1] + v[2] + v[3];
     // inclusive wave scan of tsum
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -355,8 +362,9 @@ __device__ __forceinline__ void note_list_lengths(const Consts &c, int kf, int k
 {
     const int mf = wave_max(kf), mb = wave_max(kb);
     if ((threadIdx.x & 63) == 0) {
-        if (mf > __hip_atomic_load(&ds->max_nbrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ds->max_nbrs, mf);
-        if (mb > __hip_atomic_load(&ds->max_wall_nbrs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ds->max_wall_nbrs, mb);
+        int *nf = &ds->nbr_shard[blockIdx.x & (kNoteShards - 1)], *nw = &ds->wall_shard[blockIdx.x & (kNoteShards - 1)];
+        if (mf > __hip_atomic_load(nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nf, mf);
+        if (mb > __hip_atomic_load(nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(nw, mb);
         if (mf > c.kmax || mb > c.kbmax) atomicOr(&ds->overflow, 1);
     }
 }

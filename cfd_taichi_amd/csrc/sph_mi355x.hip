@@ -730,6 +730,10 @@ int read_scalars(SphHandle *h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->ds_host, h->ds, sizeof(DevScalars), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < kNoteShards; ++k) {      // the sharded per-build maxima of the list lengths (note_list_lengths)
+        h->ds_host->max_nbrs = std::max(h->ds_host->max_nbrs, h->ds_host->nbr_shard[k]);
+        h->ds_host->max_wall_nbrs = std::max(h->ds_host->max_wall_nbrs, h->ds_host->wall_shard[k]);
+    }
     return SPH_OK;
 }
 
@@ -1212,7 +1216,7 @@ int stage_sort_rigid(SphHandle *h)
     const size_t ncell = (size_t)cr.S + 2;
     ProfScope ps(h, K_RIGID);
     HIP_TRY(h, hipMemsetAsync(h->rcell_count, 0, sizeof(int) * ncell, s));
-    hipLaunchKernelGGL(k_hash_count, g, b, 0, s, cr, h->RPos, (const int *)nullptr, h->rcell_of, h->rrank, h->rcell_count);
+    hipLaunchKernelGGL(k_hash_count, g, b, 0, s, cr, h->RPos, (const int *)nullptr, h->rcell_of, h->rrank, h->rcell_count, (DevScalars *)nullptr);
     hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->rcell_count, h->rcell_start, h->tile_sums, (int)ncell);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles);
     hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->rcell_start, h->tile_sums, (int)ncell);
@@ -1368,9 +1372,9 @@ int stage_sort_and_lists(SphHandle *h)
     (void)dfsph;
     {
         ProfScope ps(h, K_HASH);
-        HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * ncell, s));
+        // cell_count is clean: the arena starts zeroed and k_scan_tiles zeroes the histogram as it consumes it
         hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->slab ? h->dead : (const int *)nullptr, h->cell_of, h->rank,
-                           h->cell_count);
+                           h->cell_count, h->ds);
     }
     {
         ProfScope ps(h, K_SCAN);
@@ -1411,8 +1415,7 @@ int stage_sort_and_lists(SphHandle *h)
     if (rigid_coupled(h) && (rc = stage_sort_rigid(h))) return rc;
     {
         ProfScope ps(h, K_BUILD_NL);
-        // zero the per-build maxima; `overflow` stays sticky until check_overflow reports it
-        HIP_TRY(h, hipMemsetAsync(&h->ds->max_nbrs, 0, sizeof(int) * 2, s));
+        // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
         SPH_LAUNCH_RS0(k_build_nl, rigid_coupled(h), h->staged, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur],
                        h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt);
     }
