@@ -422,11 +422,17 @@ constexpr int kStageMaxCells = 640;
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
 // workgroups of a residual sweep resident per CU (4 x 39 KiB of the 160 KiB LDS), ~2 % of the workgroups at 1 M particles exceed it.
 __device__ __forceinline__ int stage_hash(int slot) { return (int)(((unsigned)slot * 2654435761u) >> 22); }
-__device__ __forceinline__ int stage_lookup(const int *key, const int *base, int slot)
+// every cell a particle walks was inserted by the head of its run (see the plan); the probe is bounded all the same, a miss would
+// otherwise hang the GPU: it raises the overflow flag (bit 1) instead and the step reports SPH_E_OVERFLOW
+__device__ __forceinline__ int stage_lookup(const int *key, const int *base, int slot, DevScalars *__restrict__ ds)
 {
     int hq = stage_hash(slot);
-    while (key[hq] != slot) hq = (hq + 1) & (kStageHash - 1);
-    return base[hq];
+    for (int probe = 0; probe < kStageHash; ++probe) {
+        if (key[hq] == slot) return base[hq];
+        hq = (hq + 1) & (kStageHash - 1);
+    }
+    atomicOr(&ds->overflow, 2);
+    return 0;
 }
 
 template <bool RIGID, bool STAGED>
@@ -453,9 +459,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         if (i < c.n && id[i] >= 0) {
             const float4 pi = P[i];
             int cx, cy, cz, px, py, pz;
-            const int home = cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+            cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+            // the first particle of every run of equal cell COORDINATES inserts the neighbourhood: particles that left the box share a
+            // (wrapped or "outside") cell index with particles whose coordinates, and hence neighbour cells, differ
             bool head = threadIdx.x == 0 || id[i - 1] < 0;
-            if (!head) { const float4 pp = P[i - 1]; head = cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz) != home; }
+            if (!head) { const float4 pp = P[i - 1]; cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz); head = px != cx || py != cy || pz != cz; }
             if (head)
                 for (int dx = -1; dx <= 1; ++dx)
                     for (int dy = -1; dy <= 1; ++dy)
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     const int cid = x + y * c.sy + z * c.sz;
                     const int slot = tiled ? slot_of_parts(c, sx, sy, slot_part(c, z, 2, c.tnx)) : cid;
                     const int a = cell_start[slot], b = cell_start[slot + 1];
-                    const int lbase = staged ? stage_lookup(s_key, s_base, slot) - a : 0;      // local index = lbase + j
+                    const int lbase = staged ? stage_lookup(s_key, s_base, slot, ds) - a : 0;      // local index = lbase + j
                     // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
                     // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
                     // is harmless: the arrays carry 64 spare elements and the accept mask drops them)

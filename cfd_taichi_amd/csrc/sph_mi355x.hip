@@ -658,9 +658,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbpitch))) return rc;
     {
-        // LDS staging of the gather operands (plan in k_build_nl): DFSPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
+        // LDS staging of the gather operands (plan in k_build_nl): DFSPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
         const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
-        h->staged = c.order == CELL_ORDER_TILED && is_dfsph(h) && !(e && atoi(e) == 0);
+        h->staged = c.order == CELL_ORDER_TILED && (is_dfsph(h) || h->cfg.solver == SPH_SOLVER_IISPH) && !(e && atoi(e) == 0);
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap))) return rc;
@@ -1438,6 +1438,8 @@ int check_overflow(SphHandle *h)
     // ds_host must be fresh
     if (h->ds_host->overflow) {
         (void)hipMemsetAsync(&h->ds->overflow, 0, sizeof(int), h->stream);
+        if (h->ds_host->overflow & 2)
+            return fail(h, SPH_E_OVERFLOW, "internal: a cell was missing from a workgroup's staging plan (run with SPH_STAGE=0 and report)");
         return fail(h, SPH_E_OVERFLOW, "neighbour list overflow: %d fluid / %d wall neighbours, capacity %d / %d (raise max_neighbors)",
                     h->ds_host->max_nbrs, h->ds_host->max_wall_nbrs, h->c.kmax, h->c.kbmax);
     }
@@ -1460,9 +1462,9 @@ int stage_density(SphHandle *h)
                       h->rho_orig, h->stage_src, h->stage_cnt);
     } else {
         ProfScope ps(h, K_W_DENSITY);
-        SPH_LAUNCH_RS(k_density, false, rigid_coupled(h), false, g, b, 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                      (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, (const uint32_t *)nullptr, (const int *)nullptr);
+        SPH_LAUNCH_RS(k_density, false, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+                      h->cnt, (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
+                      h->rho_orig, h->stage_src, h->stage_cnt);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1905,8 +1907,8 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_I_ADVECT);                        // :43-56
-        if (rg) hipLaunchKernelGGL(k_ii_advect<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
-        else hipLaunchKernelGGL(k_ii_advect<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, VA, DII, rv);
+        SPH_LAUNCH_RS0(k_ii_advect, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+                       h->cnt, VA, DII, rv, h->stage_src, h->stage_cnt);
     }
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
     auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
@@ -1914,30 +1916,22 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     if ((rc = ghosts_xyz(DII))) return rc;
     {
         ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
-        if (rg)
-            hipLaunchKernelGGL(k_ii_rho_adv<true>, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur],
-                               h->rho_adv, h->aux, PB[0], rv);
-        else
-            hipLaunchKernelGGL(k_ii_rho_adv<false>, g, b, 0, s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt, DII, h->warm[h->wcur],
-                               h->rho_adv, h->aux, PB[0], rv);
+        SPH_LAUNCH_RS0(k_ii_rho_adv, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
+                       DII, h->warm[h->wcur], h->rho_adv, h->aux, PB[0], rv, h->stage_src, h->stage_cnt);
     }
     bool first = true;
     for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
-                if (rg) hipLaunchKernelGGL(k_ii_dij<true>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
-                else hipLaunchKernelGGL(k_ii_dij<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds, DIJ, GATE_DENS, rv);
+                SPH_LAUNCH_RS0(k_ii_dij, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
+                               DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
-                if (rg)
-                    hipLaunchKernelGGL(k_ii_update_p<true>, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho,
-                                       h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv);
-                else
-                    hipLaunchKernelGGL(k_ii_update_p<false>, g, b, 0, s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl, h->nlb, h->cnt, h->rho,
-                                       h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv);
+                SPH_LAUNCH_RS0(k_ii_update_p, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
+                               h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_w(PB[k & 1]))) return rc;
             if ((rc = launch_pressure_finalize(h, PFIN_II_LOOP))) return rc;

@@ -57,6 +57,58 @@ __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, in
     }, [&](const Op &o, uint32_t j) { body(o.a, o.b, o.c, j); });
 }
 
+// staged forms (LDS staging plan of k_build_nl, IISPH on the Morton curve): the first operand comes from LDS, the others are
+// gathered from memory through the staged source index
+template <bool RIGID, class Body>
+__device__ __forceinline__ void for_staged_nbrs_ps(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                   const uint32_t *__restrict__ s_src, const float *__restrict__ S, const RigidView &rv, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4]; float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            sc[u] = S[rg ? 0u : s_src[idx]];
+            a[u] = rg ? rv.RP[idx] : s_A[idx];
+        }
+        ahead.advance(kk);
+        body(a[0], sc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], sc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], sc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
+    }
+}
+template <bool RIGID, class Body>
+__device__ __forceinline__ void for_staged_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                  const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, const float4 *__restrict__ C,
+                                                  const RigidView &rv, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4], b[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            const uint32_t src = rg ? 0u : s_src[idx];
+            b[u] = B[src];
+            cc[u] = C[src];
+            a[u] = rg ? rv.RP[idx] : s_A[idx];
+        }
+        ahead.advance(kk);
+        body(a[0], b[0], cc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], cc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], cc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], cc[3], j[3]);
+    }
+}
+
 // predicted / integrated positions against the clamp walls      pcisph_solver.py:79-89, 234-244; iisph_solver.py:198-207
 __device__ __forceinline__ void clamp_walls(const Consts &c, float pos[3], float vel[3])
 {
@@ -312,20 +364,24 @@ __global__ __launch_bounds__(kBlock) void k_pci_integrate(Consts c, float dt, co
 // IISPH
 // ======================================================================================
 // predict_advection, first half (:43-56): tension, viscosity, f_adv, v_adv, d_ii.   P = (pos, rho), V = (vel, -)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
-                                                      float4 *__restrict__ VA, float4 *__restrict__ DII, RigidView rv)
+                                                      float4 *__restrict__ VA, float4 *__restrict__ DII, RigidView rv,
+                                                      const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = pi.w;
     const float s_f = c.neg_m / (rho_i * rho_i);             // compute_d_ii :280 (same value for every fluid neighbour)
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
     float ex = 0.f, ey = 0.f, ez = 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -347,7 +403,9 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
             float sv = c.neg_m * pi_;                        // :189
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
-    });
+    };
+    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (c.boundary_handle) {
         const float den = rho_i * rho_i;
@@ -381,20 +439,23 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
 }
 
 // predict_advection, second half (:58-82): rho_adv, p_iter = 0.5 p_past, a_ii.   P = (pos, rho), V = VA = (v_adv, -)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                        const float4 *__restrict__ DII, const float *__restrict__ p_past,
                                                        float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0,
-                                                       RigidView rv)
+                                                       RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
+    float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_pv(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
     const float4 vi = V[ii], di = DII[ii];
     const float rho_i = pi.w;
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // scalar prefix of d_ji, compute_a_ii :302-303
     float ra = 0.f, aii = 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -407,7 +468,9 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
         }
         ra += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);        // compute_rho_adv :332
         aii += c.m * dot3(ex, ey, ez, g.x, g.y, g.z);                                  // compute_a_ii :304
-    });
+    };
+    if (staged) for_staged_nbrs_pv2<RIGID>(nlp, kf, s_operand, s_v2, rv, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float rb = 0.f, ab = 0.f;
     if (c.boundary_handle) {
         for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -431,17 +494,21 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
 }
 
 // compute_all_d_ij (:130-135, :324-327).   P here is PB = (pos, p_iter)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
-                                                   const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv)
+                                                   const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv,
+                                                   const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
     (void)kb; (void)nlbp;
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, [&](const float4 pj, const float rho_j, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float rho_j, const uint32_t j) {
         if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -449,29 +516,35 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
         const float a = c.neg_m * pj.w;                      // - m * p_iter[j]
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
-    });
+    };
+    if (staged) for_staged_nbrs_ps<RIGID>(nlp, kf, s_operand, s_src, rho, rv, pair);
+    else for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, pair);
     if (!live) return;
     DIJ[i] = make_float4(sx * dt * dt, sy * dt * dt, sz * dt * dt, 0.f);   // :135
 }
 
 // update_p (:137-157) + compute_residual partials (:110-121).   P = PBin = (pos, p_iter); writes PBout = (pos, new p_iter)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ DII,
                                                         const float4 *__restrict__ DIJ, const float4 *__restrict__ WP,
                                                         const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                         const int *__restrict__ cnt, const float *__restrict__ rho,
                                                         const float *__restrict__ rho_adv, const float *__restrict__ a_ii,
                                                         const DevScalars *__restrict__ ds, float4 *__restrict__ PBout,
-                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv)
+                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
+                                                        const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float p_i = pi.w;
     const float rho_i = rho[ii];
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // :252-253
     const float4 a = DIJ[ii];
     float sum = 0.f;
-    for_nbrs_3<RIGID>(nlp, kf, P, DII, DIJ, rv, [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -484,7 +557,9 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         float ty = a.y - dj.y * pj.w - (ej.y - jy);
         float tz = a.z - dj.z * pj.w - (ej.z - jz);
         sum += c.m * dot3(tx, ty, tz, g.x, g.y, g.z);        // sum_factor :254
-    });
+    };
+    if (staged) for_staged_nbrs_3<RIGID>(nlp, kf, s_operand, s_src, DII, DIJ, rv, pair);
+    else for_nbrs_3<RIGID>(nlp, kf, P, DII, DIJ, rv, pair);
     float bsum = 0.f;
     if (c.boundary_handle) {
         for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
