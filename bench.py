@@ -69,6 +69,9 @@ def host_cores():
     return cores
 
 
+CPU_BASELINE_SECONDS = 10.0     # bounded sample of the same workload on the host cores
+
+
 def cpu_baseline(scene_name, solver_kind):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
     from cfd_taichi_amd import scenes
@@ -76,30 +79,30 @@ def cpu_baseline(scene_name, solver_kind):
     cores = host_cores()
     cfg = scenes.get(scene_name)
     o = orc.Oracle(cfg, num_threads=cores)
-    if solver_kind in ("pcisph", "iisph"):
-        step = o.step_pcisph if solver_kind == "pcisph" else o.step_iisph
-        step(1)
-        timed = 2
-        t0 = time.perf_counter()
-        step(timed)
-        dt = time.perf_counter() - t0
-        sample = "steps 2-3 of %s (N=%d, %d pressure iterations in the last step) after 1 untimed step" % (scene_name, o.N, o.last_stats.n_dens)
+    # one untimed step (from rest the first step is atypical: zero divergence residual), then whole steps until ~10 s of CPU work
+    if solver_kind == "pcisph":
+        one = lambda: o.step_pcisph(1)
+    elif solver_kind == "iisph":
+        one = lambda: o.step_iisph(1)
     elif solver_kind == "dfsph":
-        o.step_dfsph(1, 100)                 # step 1 from rest is atypical (zero divergence residual): untimed
-        timed = 2
-        t0 = time.perf_counter()
-        for _ in range(timed):
-            o.step_dfsph(1, 100)
-        dt = time.perf_counter() - t0
-        sample = "steps 2-3 of %s (N=%d, n_div=%d, n_dens=%d) after 1 untimed step" % (
-            scene_name, o.N, o.last_stats.n_div, o.last_stats.n_dens)
+        one = lambda: o.step_dfsph(1, 100)
     else:
-        o.step_wcsph(1)
-        timed = 3
-        t0 = time.perf_counter()
-        o.step_wcsph(timed)
+        one = lambda: o.step_wcsph(1)
+    one()
+    timed, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        timed += 1
         dt = time.perf_counter() - t0
-        sample = "steps 2-4 of %s (N=%d) after 1 untimed step" % (scene_name, o.N)
+        if dt >= CPU_BASELINE_SECONDS or timed >= 2000:
+            break
+    if solver_kind == "dfsph":
+        detail = ", n_div=%d, n_dens=%d in the last step" % (o.last_stats.n_div, o.last_stats.n_dens)
+    elif solver_kind in ("pcisph", "iisph"):
+        detail = ", %d pressure iterations in the last step" % o.last_stats.n_dens
+    else:
+        detail = ""
+    sample = "steps 2-%d of %s (N=%d%s) after 1 untimed step" % (timed + 1, scene_name, o.N, detail)
     value = o.N * timed / dt / 1e6
     o.close()
     return {"value": value, "unit": "Mparticle-steps/s", "cores": cores, "kind": "port",
