@@ -184,3 +184,20 @@ def test_lds_staging_with_particles_outside_the_box(solver, monkeypatch):
         assert np.array_equal(a.download(f), b.download(f), equal_nan=True), f
     assert lost > 0
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_scenes_on_slabs_on_the_morton_curve(tmp_path, monkeypatch, seed):
+    """The seeded random scenes of test_slab_gpu (radius, box, water block, dt, wall model, solver) on 2-4 slabs, with the cells on the
+    Morton curve and the DFSPH / IISPH sweeps staged, re-balanced every 3 steps."""
+    import json as _json
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    rng = np.random.default_rng(2100 + seed)
+    solver = ["dfsph", "iisph", "dfsph"][seed]
+    cfg = random_scene(rng, solver)
+    cfg["scene"]["box_max"][0] = float(np.round(cfg["scene"]["box_max"][0] + 8 * 4 * cfg["scene"]["particle_radius"], 3))   # room for 4 slabs
+    path = tmp_path / "scene.json"
+    path.write_text(_json.dumps(cfg))
+    world = int(rng.integers(2, 5))
+    r = run_slabs(tmp_path, str(path), world, 60, rebalance=3)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], (cfg, {k: r[k] for k in ("pos_rel_err", "slabs")})
