@@ -128,6 +128,8 @@ struct SphHandle {
     float rigid_rho = 0.f;
     float4 *RPos = nullptr;       // [Nr] rigid particles in their own index order: (x, y, z, V_r)
     float4 *RPs = nullptr;        // [Nr] cell-sorted copy, rebuilt every step
+    uint32_t *rnl = nullptr;             // fluid neighbours of the rigid sample particles (k_build_rnl), rcnt = their number
+    int *rcnt = nullptr;
     int *rid = nullptr, *rcell_of = nullptr, *rrank = nullptr, *rslot = nullptr, *rcell_count = nullptr, *rcell_start = nullptr;
     float *rforce = nullptr;      // [3 Nr] rigid_particles.force
     float *rvert = nullptr;       // [3 Nv] mesh vertices
@@ -1188,6 +1190,8 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->rho_orig, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->ncount, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->rred, 1))) return rc;
+    if ((rc = dalloc(h, &h->rnl, (nr + 64) * (size_t)c.kpitch))) return rc;
+    if ((rc = dalloc(h, &h->rcnt, nr))) return rc;
     const size_t stg_need = 3 * std::max(nr, (size_t)Nv);
     if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb))
         if ((rc = dalloc(h, &h->staging, stg_need))) return rc;      // the fluid arena's staging buffer is too small for this body
@@ -1419,6 +1423,10 @@ int stage_sort_and_lists(SphHandle *h)
         SPH_LAUNCH_RS0(k_build_nl, rigid_coupled(h), h->staged, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur],
                        h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt);
     }
+    if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
+        ProfScope ps(h, K_RIGID);
+        hipLaunchKernelGGL(k_build_rnl, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->P[h->pcur], h->cell_start, h->rnl, h->rcnt, h->ds);
+    }
     HIP_TRY(h, hipGetLastError());
     if (h->staged && getenv("SPH_STAGE_DEBUG")) {
         std::vector<int> sc((size_t)h->nblocks);
@@ -1482,7 +1490,7 @@ template <int MODE>
 void launch_rigid_force_p(SphHandle *h, const float4 *P, const float4 *PB, int gate)
 {
     ProfScope ps(h, K_RIGID);
-    hipLaunchKernelGGL(k_rigid_force_p<MODE>, grid_for(h->Nr), dim3(kBlock), 0, h->stream, h->c, h->Nr, h->RPs, h->rid, P, h->cell_start, h->rho,
+    hipLaunchKernelGGL(k_rigid_force_p<MODE>, grid_for(h->Nr), dim3(kBlock), 0, h->stream, h->c, h->Nr, h->RPs, h->rid, P, h->rnl, h->rcnt, h->rho,
                        h->aux, PB, h->ds, h->rforce, gate);
 }
 
@@ -1573,7 +1581,7 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_RIGID);
-    hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), dim3(kBlock), 0, h->stream, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->cell_start, h->rho,
+    hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), dim3(kBlock), 0, h->stream, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->rnl, h->rcnt, h->rho,
                        h->rho_adv, h->aux, h->ds, h->rforce, gate);
 }
 

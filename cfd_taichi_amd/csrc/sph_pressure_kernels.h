@@ -622,46 +622,39 @@ enum { RF_WCSPH = 0, RF_PCISPH = 2, RF_IISPH = 3 };
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_rigid_force_p(Consts c, int nr, const float4 *__restrict__ RP, const int *__restrict__ rid,
-                                                          const float4 *__restrict__ P, const int *__restrict__ cell_start,
-                                                          const float *__restrict__ rho, const float *__restrict__ S,
-                                                          const float4 *__restrict__ PB, const DevScalars *__restrict__ ds,
-                                                          float *__restrict__ force, int gate)
+                                                          const float4 *__restrict__ P, const uint32_t *__restrict__ rnl,
+                                                          const int *__restrict__ rcnt, const float *__restrict__ rho,
+                                                          const float *__restrict__ S, const float4 *__restrict__ PB,
+                                                          const DevScalars *__restrict__ ds, float *__restrict__ force, int gate)
 {
     if (gate_closed(ds, gate)) return;
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= nr) return;
     const float4 pr = RP[r];
-    int cx, cy, cz;
-    cell_id_of(c, pr.x, pr.y, pr.z, cx, cy, cz);
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dz = -1; dz <= 1; ++dz) {
-                int x = cx + dx, y = cy + dy, z = cz + dz;
-                if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
-                if (x < 0 || y < 0 || z < 0) continue;
-                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
-                for (int i = cell_start[slot]; i < cell_start[slot + 1]; ++i) {
-                    const float4 pi = P[i];
-                    float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
-                    float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                    if (r2 > c.r2_cut) continue;
-                    F3 g = grad_w(c, ddx, ddy, ddz, sqrtf(r2));
-                    const float rho_i = rho[i];
-                    if (MODE == RF_WCSPH) {
-                        const float s = -pr.w * S[i] / (rho_i * rho_i);                              // :125
-                        fx += -(s * g.x * c.rho0) * c.m; fy += -(s * g.y * c.rho0) * c.m; fz += -(s * g.z * c.rho0) * c.m;   // :127
-                    } else if (MODE == RF_PCISPH) {
-                        const float a = pr.w * c.rho0 * PB[i].w;                                     // :208
-                        const float den = rho_i * rho_i;
-                        fx += a * g.x / den * c.m; fy += a * g.y / den * c.m; fz += a * g.z / den * c.m;   // :209
-                    } else {
-                        const float s = pr.w * c.rho0 / (rho_i * rho_i);                             // :166
-                        const float p = PB[i].w;
-                        fx += s * g.x * p * c.m; fy += s * g.y * p * c.m; fz += s * g.z * p * c.m;   // :167
-                    }
-                }
-            }
+    struct Op { float4 p; float rho, s; };
+    walk_list<Op>(rnl + nl_index(r, 0, c.kpitch), rcnt[r], [&](uint32_t i, Op &o) {      // k_build_rnl (sph_rigid_kernels.h)
+        o.p = P[i]; o.rho = rho[i];
+        o.s = MODE == RF_WCSPH ? S[i] : PB[i].w;
+    }, [&](const Op &o, uint32_t) {
+        const float4 pi = o.p;
+        float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
+        float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+        F3 g = grad_w(c, ddx, ddy, ddz, sqrtf(r2));
+        const float rho_i = o.rho;
+        if (MODE == RF_WCSPH) {
+            const float s = -pr.w * o.s / (rho_i * rho_i);                               // :125
+            fx += -(s * g.x * c.rho0) * c.m; fy += -(s * g.y * c.rho0) * c.m; fz += -(s * g.z * c.rho0) * c.m;   // :127
+        } else if (MODE == RF_PCISPH) {
+            const float a = pr.w * c.rho0 * o.s;                                         // :208
+            const float den = rho_i * rho_i;
+            fx += a * g.x / den * c.m; fy += a * g.y / den * c.m; fz += a * g.z / den * c.m;   // :209
+        } else {
+            const float s = pr.w * c.rho0 / (rho_i * rho_i);                             // :166
+            const float p = o.s;
+            fx += s * g.x * p * c.m; fy += s * g.y * p * c.m; fz += s * g.z * p * c.m;   // :167
+        }
+    });
     const int o = rid[r];
     force[3 * o] += fx; force[3 * o + 1] += fy; force[3 * o + 2] += fz;
 }

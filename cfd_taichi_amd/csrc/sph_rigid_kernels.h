@@ -24,41 +24,75 @@ __global__ __launch_bounds__(kBlock) void k_rigid_order(int nr, const int *__res
     rid[a + r] = src;
 }
 
+// Fluid neighbours of every rigid sample particle, once per step (fluid and body are frozen between the grid rebuild and the
+// integrators): the reference's walk order -- cells dx-outermost, ascending fluid index inside a cell (for_all_neighbor,
+// ParticleSystem.py:447-469) -- in the wave-tiled layout of the fluid lists.  The force kernels below run once per solver
+// iteration (100 times per step at config 5) and used to repeat the 27-cell walk every time.
+__global__ __launch_bounds__(kBlock) void k_build_rnl(Consts c, int nr, const float4 *__restrict__ RP, const float4 *__restrict__ P,
+                                                      const int *__restrict__ cell_start, uint32_t *__restrict__ rnl, int *__restrict__ rcnt,
+                                                      DevScalars *__restrict__ ds)
+{
+    __shared__ uint32_t s_stage[4 * kBlock];
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_stage[q * kBlock + threadIdx.x] = 0;
+    if (r >= nr) return;
+    const float4 pr = RP[r];
+    const f32x2 pr_xy = {pr.x, pr.y};
+    int cx, cy, cz;
+    cell_id_of(c, pr.x, pr.y, pr.z, cx, cy, cz);
+    NlWriter w{&s_stage[threadIdx.x], rnl + nl_index(r, 0, c.kpitch), 0, c.kmax};
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
+                if (x < 0 || y < 0 || z < 0) continue;
+                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                const int a = cell_start[slot], b = cell_start[slot + 1];
+                for (int j0 = a; j0 < b; j0 += 4) {
+                    const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);
+                    unsigned m = near_mask4(pr_xy, pr.z, pb, c.r2_cut);        // (x_i - x_r)^2 == (x_r - x_i)^2 term by term
+                    m &= (b - j0 >= 4 ? 15u : (1u << (b - j0)) - 1u);
+                    while (m) {
+                        const int u = __ffs(m) - 1;
+                        m &= m - 1;
+                        w.push((uint32_t)(j0 + u));
+                    }
+                }
+            }
+    w.flush();
+    rcnt[r] = w.k < c.kmax ? w.k : c.kmax;
+    if (w.k > c.kmax) atomicOr(&ds->overflow, 1);
+}
+
 // rigid_particles[j].force += ret * particle_m (dfsph_solver.py:204-212), gathered per rigid particle over its fluid
-// neighbours in cell-walk order: no atomics, and the same serialisation as the oracle.
+// neighbours in list (= cell-walk) order: no atomics, and the same serialisation as the oracle.
 __global__ __launch_bounds__(kBlock) void k_rigid_force(Consts c, int nr, const float4 *__restrict__ RP, const int *__restrict__ rid,
-                                                        const float4 *__restrict__ P, const int *__restrict__ cell_start,
-                                                        const float *__restrict__ rho, const float *__restrict__ rho_adv,
-                                                        const float *__restrict__ alpha, const DevScalars *__restrict__ ds,
-                                                        float *__restrict__ force, int gate)
+                                                        const float4 *__restrict__ P, const uint32_t *__restrict__ rnl,
+                                                        const int *__restrict__ rcnt, const float *__restrict__ rho,
+                                                        const float *__restrict__ rho_adv, const float *__restrict__ alpha,
+                                                        const DevScalars *__restrict__ ds, float *__restrict__ force, int gate)
 {
     if (gate_closed(ds, gate)) return;
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= nr) return;
     const float4 pr = RP[r];
     const float dt2 = ds->dt2;
-    int cx, cy, cz;
-    cell_id_of(c, pr.x, pr.y, pr.z, cx, cy, cz);
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    for (int dx = -1; dx <= 1; ++dx)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dz = -1; dz <= 1; ++dz) {
-                int x = cx + dx, y = cy + dy, z = cz + dz;
-                if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
-                if (x < 0 || y < 0 || z < 0) continue;
-                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
-                for (int i = cell_start[slot]; i < cell_start[slot + 1]; ++i) {
-                    const float4 pi = P[i];
-                    float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
-                    float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                    if (r2 > c.r2_cut) continue;
-                    float rn = sqrtf(r2);
-                    float k_i = (rho_adv[i] - c.rho0) * alpha[i] / dt2;             // :208
-                    F3 g = grad_w(c, ddx, ddy, ddz, rn);
-                    float s = pr.w * c.rho0 * k_i / rho[i];                         // :211
-                    fx += s * g.x * c.m; fy += s * g.y * c.m; fz += s * g.z * c.m;  // :212
-                }
-            }
+    struct Op { float4 p; float rho, rho_adv, alpha; };
+    walk_list<Op>(rnl + nl_index(r, 0, c.kpitch), rcnt[r], [&](uint32_t i, Op &o) {
+        o.p = P[i]; o.rho = rho[i]; o.rho_adv = rho_adv[i]; o.alpha = alpha[i];
+    }, [&](const Op &o, uint32_t) {
+        const float4 pi = o.p;
+        float ddx = pi.x - pr.x, ddy = pi.y - pr.y, ddz = pi.z - pr.z;
+        float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+        float rn = sqrtf(r2);
+        float k_i = (o.rho_adv - c.rho0) * o.alpha / dt2;                           // :208
+        F3 g = grad_w(c, ddx, ddy, ddz, rn);
+        float s = pr.w * c.rho0 * k_i / o.rho;                                      // :211
+        fx += s * g.x * c.m; fy += s * g.y * c.m; fz += s * g.z * c.m;              // :212
+    });
     const int o = rid[r];
     force[3 * o] += fx; force[3 * o + 1] += fy; force[3 * o + 2] += fz;
 }
