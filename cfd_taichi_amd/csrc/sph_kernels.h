@@ -674,8 +674,18 @@ __global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restri
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
     if (phase != FINP_DECIDE) {
+        // thread t adds the partials t, t + 256, ... in ascending order (the order is part of the result); eight loads are in flight at a
+        // time, the additions keep their sequence
         double t = 0.0; long long n = 0;
-        for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+        int k = threadIdx.x;
+        for (; k + 7 * kBlock < nblocks; k += 8 * kBlock) {
+            double v[8]; int m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = psum[k + u * kBlock]; m[u] = pcnt[k + u * kBlock]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t += v[u]; n += m[u]; }
+        }
+        for (; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
         s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
         __syncthreads();
         for (int off = kBlock / 2; off > 0; off >>= 1) {

@@ -135,7 +135,15 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__re
     __shared__ long long s_cnt[kBlock];
     if (phase != FINP_DECIDE) {
         double t = 0.0; long long n = 0;
-        for (int k = threadIdx.x; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+        int k = threadIdx.x;                       // same order as k_finalize_mean, eight loads in flight
+        for (; k + 7 * kBlock < nblocks; k += 8 * kBlock) {
+            double v[8]; int m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = psum[k + u * kBlock]; m[u] = pcnt[k + u * kBlock]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t += v[u]; n += m[u]; }
+        }
+        for (; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
         s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
         __syncthreads();
         for (int off = kBlock / 2; off > 0; off >>= 1) {
