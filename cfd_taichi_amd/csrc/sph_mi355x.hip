@@ -660,9 +660,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbpitch))) return rc;
     {
-        // LDS staging of the gather operands (plan in k_build_nl): DFSPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
+        // LDS staging of the gather operands (plan in k_build_nl): DFSPH, PCISPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
         const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
-        h->staged = c.order == CELL_ORDER_TILED && (is_dfsph(h) || h->cfg.solver == SPH_SOLVER_IISPH) && !(e && atoi(e) == 0);
+        h->staged = c.order == CELL_ORDER_TILED && h->cfg.solver != SPH_SOLVER_WCSPH && !(e && atoi(e) == 0);
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap))) return rc;
@@ -1831,8 +1831,8 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
-        if (rg) hipLaunchKernelGGL(k_pci_ext<true>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
-        else hipLaunchKernelGGL(k_pci_ext<false>, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF, PB[0], PP, rv);
+        SPH_LAUNCH_RS0(k_pci_ext, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF,
+                       PB[0], PP, rv, h->stage_src, h->stage_cnt);
     }
     // sharded: the ghosts' predicted positions / pressures come from their owners after the sweep that produced them
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
@@ -1840,12 +1840,8 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     if ((rc = ghosts_xyz(PP))) return rc;
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
-        if (rg)
-            hipLaunchKernelGGL(k_pci_predict_rho<true>, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
-                               PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv);
-        else
-            hipLaunchKernelGGL(k_pci_predict_rho<false>, g, b, 0, s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
-                               PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv);
+        SPH_LAUNCH_RS0(k_pci_predict_rho, rg, h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
+                       PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv, h->stage_src, h->stage_cnt);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
     if ((rc = ghosts_w(PB[1]))) return rc;
@@ -1855,12 +1851,8 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
-                if (rg)
-                    hipLaunchKernelGGL(k_pci_press<true>, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF,
-                                       h->ds, PF, PP, GATE_DENS, rv);
-                else
-                    hipLaunchKernelGGL(k_pci_press<false>, g, b, 0, s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur], EF,
-                                       h->ds, PF, PP, GATE_DENS, rv);
+                SPH_LAUNCH_RS0(k_pci_press, rg, h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
+                               EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
             if ((rc = ghosts_xyz(PP))) return rc;

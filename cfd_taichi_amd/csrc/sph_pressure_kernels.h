@@ -193,20 +193,23 @@ __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 // ======================================================================================
 // compute_ext_force (:237-244: tension, viscosity, gravity) + reset() (:247-250) + the first predict_vel_pos (:73-89)
 //   reads P = (pos, rho), V = (vel, -)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                     float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
-                                                    float4 *__restrict__ PP, RigidView rv)
+                                                    float4 *__restrict__ PP, RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
     (void)kb; (void)nlbp;
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = pi.w;
     float wx = 0.f, wy = 0.f, wz = 0.f;
     float tx = 0.f, ty = 0.f, tz = 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         if (RIGID && (j & kRigidTag)) { rigid_viscosity(c, rv, vi, rho_i, pj, j, dx, dy, dz, r, wx, wy, wz); return; }
@@ -222,7 +225,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
             float sv = c.neg_m * pi_;                        // :189
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
-    });
+    };
+    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     if (!live) return;
     float ten[3] = {tx * c.m, ty * c.m, tz * c.m};           // :209
     float vis[3] = {wx * c.m, wy * c.m, wz * c.m};           // :175
@@ -245,22 +250,27 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
 
 // predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
 //   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delta, const float4 *__restrict__ P,
                                                             const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                             const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                             const DevScalars *__restrict__ ds, const float4 *__restrict__ PBin,
                                                             float4 *__restrict__ PBout, float *__restrict__ rho_predict,
-                                                            double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv)
+                                                            double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
+                                                            const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
+    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     float rp = 0.f;
-    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;   // rigid entries: the body where it is now (:159-161)
         if (RIGID && (j & kRigidTag)) rp += cubic_w(c, norm3(dx, dy, dz)) * pj.w * c.rho0;
         else rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;      // :155-156
-    });
+    };
+    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float rb = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -283,23 +293,25 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
 }
 
 // update_press_force (:111-124, :192-224) + predict_vel_pos (:73-89).   P here is PB = (pos, press_iter)
-template <bool RIGID>
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                       const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
                                                       const float4 *__restrict__ V, const float4 *__restrict__ EF,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
-                                                      float4 *__restrict__ PP, int gate, RigidView rv)
+                                                      float4 *__restrict__ PP, int gate, RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
+    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     const float p_i = pi.w;
     constexpr float kRho0Sq = 1000000.0f;                    // self.rho_0 ** 2 (Python int)
     constexpr float kRcpRho0Sq = 1.0f / 1000000.0f;
     float fx = 0.f, fy = 0.f, fz = 0.f;
     const float rho_own = (RIGID || c.boundary_handle) ? rho[ii] : 1.0f;
     const Recip rden = recip_prepare(rho_own * rho_own);     // rho_i ** 2, the divisor of every rigid term (:208)
-    for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, [&](const float4 pj, const float4, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w(c, dx, dy, dz, r);
@@ -312,7 +324,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
         fx += div_const(ps * g.x, kRho0Sq, kRcpRho0Sq) * c.m * c.m;   // :199
         fy += div_const(ps * g.y, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
         fz += div_const(ps * g.z, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
-    });
+    };
+    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     if (c.boundary_handle) {
         const float rho_i_2 = rho_own * rho_own;             // :221
