@@ -806,10 +806,17 @@ __device__ __forceinline__ void for_staged_nbrs(const uint32_t *__restrict__ bas
         const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4];
+        // a group without a rigid entry anywhere in the wave (nearly all of them: the body touches a thin layer of the fluid) takes the
+        // plain path; the branch is wave-uniform
+        if (RIGID && __any(((j[0] | j[1] | j[2] | j[3]) & kRigidTag) != 0)) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool rg = RIGID && (j[u] & kRigidTag);
-            a[u] = rg ? rv.RP[j[u] & ~kRigidTag] : s_A[RIGID ? (j[u] & ~kRigidTag) : j[u]];
+            for (int u = 0; u < 4; ++u) {
+                const bool rg = (j[u] & kRigidTag) != 0;
+                a[u] = rg ? rv.RP[j[u] & ~kRigidTag] : s_A[j[u] & ~kRigidTag];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = s_A[j[u]];
         }
         ahead.advance(kk);
         const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -869,15 +876,24 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
         const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
         float4 a[4], b[4];
+        if (RIGID && __any(((j[0] | j[1] | j[2] | j[3]) & kRigidTag) != 0)) {      // wave-uniform, rare (see for_staged_nbrs)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool rg = RIGID && (j[u] & kRigidTag);
-            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
-            if (rg) {
-                a[u] = rv.RP[idx];                                   // (x, y, z, V_r); the velocity operand is undefined for rigid entries
-                b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const float4 pa = s_A[idx]; const float2 pb = s_B[idx];
+            for (int u = 0; u < 4; ++u) {
+                const bool rg = (j[u] & kRigidTag) != 0;
+                const uint32_t idx = j[u] & ~kRigidTag;
+                if (rg) {
+                    a[u] = rv.RP[idx];                               // (x, y, z, V_r); the velocity operand is undefined for rigid entries
+                    b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const float4 pa = s_A[idx]; const float2 pb = s_B[idx];
+                    a[u] = make_float4(pa.x, pa.y, pa.z, 0.f);
+                    b[u] = make_float4(pa.w, pb.x, pb.y, 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 pa = s_A[j[u]]; const float2 pb = s_B[j[u]];
                 a[u] = make_float4(pa.x, pa.y, pa.z, 0.f);
                 b[u] = make_float4(pa.w, pb.x, pb.y, 0.f);
             }
