@@ -82,6 +82,41 @@ __device__ __forceinline__ void for_staged_nbrs_ps(const uint32_t *__restrict__ 
         if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
     }
 }
+// first operand and a per-particle scalar both staged (20 B per staged particle)
+__device__ __forceinline__ bool stage_operand_scalar(const Consts &c, float4 *__restrict__ s_A, float *__restrict__ s_S, const float4 *__restrict__ A,
+                                                     const float *__restrict__ S, const uint32_t *__restrict__ stage_src,
+                                                     const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_cnt[blk];
+    if (nst < 0) return false;
+    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+    for (int e = threadIdx.x; e < nst; e += kBlock) { const uint32_t j = src[e]; s_A[e] = A[j]; s_S[e] = S[j]; }
+    __syncthreads();
+    return true;
+}
+template <bool RIGID, class Body>
+__device__ __forceinline__ void for_staged_nbrs_ps2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                    const float *__restrict__ s_S, const RigidView &rv, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4]; float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            sc[u] = s_S[rg ? 0u : idx];
+            a[u] = rg ? rv.RP[idx] : s_A[idx];
+        }
+        ahead.advance(kk);
+        body(a[0], sc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], sc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], sc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
+    }
+}
 template <bool RIGID, class Body>
 __device__ __forceinline__ void for_staged_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                   const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, const float4 *__restrict__ C,
@@ -527,8 +562,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE
     (void)kb; (void)nlbp;
-    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
-    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
+    float *s_rho = reinterpret_cast<float *>(s_operand + c.stage_cap);
+    const bool staged = STAGED && stage_operand_scalar(c, s_operand, s_rho, P, rho, stage_src, stage_cnt, blk);
     float sx = 0.f, sy = 0.f, sz = 0.f;
     auto pair = [&](const float4 pj, const float rho_j, const uint32_t j) {
         if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
@@ -539,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
     };
-    if (staged) for_staged_nbrs_ps<RIGID>(nlp, kf, s_operand, s_src, rho, rv, pair);
+    if (staged) for_staged_nbrs_ps2<RIGID>(nlp, kf, s_operand, s_rho, rv, pair);
     else for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, pair);
     if (!live) return;
     DIJ[i] = make_float4(sx * dt * dt, sy * dt * dt, sz * dt * dt, 0.f);   // :135
