@@ -1930,7 +1930,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
-                SPH_LAUNCH_RS0(k_ii_update_p, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
+                SPH_LAUNCH_RS0(k_ii_update_p, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
                                h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_w(PB[k & 1]))) return rc;

@@ -117,6 +117,35 @@ __device__ __forceinline__ void for_staged_nbrs_ps2(const uint32_t *__restrict__
         if (kk + 3 < cnt) body(a[3], sc[3], j[3]);
     }
 }
+// update_p: positions + p, the source index and the three components of the third operand staged (32 B per staged particle);
+// the second operand is gathered from memory through the source index
+template <bool RIGID, class Body>
+__device__ __forceinline__ void for_staged_nbrs_3e(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                   const uint32_t *__restrict__ s_src, const float *__restrict__ s_cx,
+                                                   const float *__restrict__ s_cy, const float *__restrict__ s_cz,
+                                                   const float4 *__restrict__ B, const RigidView &rv, Body body)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+        float4 a[4], b[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rg = RIGID && (j[u] & kRigidTag);
+            const uint32_t idx = RIGID ? (j[u] & ~kRigidTag) : j[u];
+            const uint32_t li = rg ? 0u : idx;
+            b[u] = B[s_src[li]];
+            cc[u] = make_float4(s_cx[li], s_cy[li], s_cz[li], 0.f);
+            a[u] = rg ? rv.RP[idx] : s_A[idx];
+        }
+        ahead.advance(kk);
+        body(a[0], b[0], cc[0], j[0]);
+        if (kk + 1 < cnt) body(a[1], b[1], cc[1], j[1]);
+        if (kk + 2 < cnt) body(a[2], b[2], cc[2], j[2]);
+        if (kk + 3 < cnt) body(a[3], b[3], cc[3], j[3]);
+    }
+}
 template <bool RIGID, class Body>
 __device__ __forceinline__ void for_staged_nbrs_3(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                   const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, const float4 *__restrict__ C,
@@ -595,7 +624,19 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
-    const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
+    float *s_ex = reinterpret_cast<float *>(s_src + c.stage_cap), *s_ey = s_ex + c.stage_cap, *s_ez = s_ey + c.stage_cap;
+    const int nst = STAGED ? stage_cnt[blk] : -1;
+    const bool staged = nst >= 0;
+    if (staged) {
+        const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+        for (int e = threadIdx.x; e < nst; e += kBlock) {
+            const uint32_t j = src[e];
+            const float4 ev = DIJ[j];
+            s_src[e] = j; s_operand[e] = P[j];
+            s_ex[e] = ev.x; s_ey[e] = ev.y; s_ez[e] = ev.z;
+        }
+        __syncthreads();
+    }
     const float p_i = pi.w;
     const float rho_i = rho[ii];
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // :252-253
@@ -615,7 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         float tz = a.z - dj.z * pj.w - (ej.z - jz);
         sum += c.m * dot3(tx, ty, tz, g.x, g.y, g.z);        // sum_factor :254
     };
-    if (staged) for_staged_nbrs_3<RIGID>(nlp, kf, s_operand, s_src, DII, DIJ, rv, pair);
+    if (staged) for_staged_nbrs_3e<RIGID>(nlp, kf, s_operand, s_src, s_ex, s_ey, s_ez, DII, rv, pair);
     else for_nbrs_3<RIGID>(nlp, kf, P, DII, DIJ, rv, pair);
     float bsum = 0.f;
     if (c.boundary_handle) {
