@@ -30,6 +30,7 @@ struct Consts {
     float neg_kg6;     // -48/(pi h^3) * 6                          solver_base.py:100
     float r2_cut;      // largest f32 t with sqrtf(t) <= h: (|x_ij| > h) <=> (r2 > r2_cut)
     float rh;          // RN(1/h), for the exact division by the constant h
+    float rh_s, h_s;   // rh * 2^-32 and h * 2^32: the same division for a numerator carried with a factor 2^32 (grad_w_scaled)
     float visc_num;    // 2*alpha*h*c_s (f64-folded)                solver_base.py:187
     float visc_eps_h2; // eps*h*h (f64-folded)                      solver_base.py:188
     float tens_c;      // -k/m*m (f64-folded)                       solver_base.py:216
@@ -229,6 +230,43 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r * 0x1p-32f;
 }
 __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrt_rn((x * x + y * y) + z * z); }
+
+// The staged DFSPH sweeps keep the neighbour positions in LDS multiplied by 2^32 (exact), and the particle's own position likewise:
+// the difference vector then carries 2^32, its squared length 2^64 -- exactly what sqrt_rn multiplies in -- and the root 2^32.
+// Scaling by a power of two commutes with every rounding involved (no overflow: |x| < 2^20 m; no underflow: it only moves values away
+// from the denormal range), so the two multiplications of sqrt_rn disappear and nothing else changes:
+//   norm3_scaled(d * 2^32)                     = norm3(d) * 2^32
+//   grad_w_scaled(c, d * 2^32, r * 2^32)       = grad_w_in(c, d, r)         (q = r/h through h * 2^32; numerator and divisor of the
+//                                                                            three divisions both carry 2^32)
+__device__ __forceinline__ float norm3_scaled(float xs, float ys, float zs)
+{
+    const float x = (xs * xs + ys * ys) + zs * zs;                 // |d|^2 * 2^64
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+    float r = 0.0f >= rm ? ym : y;
+    r = 0.0f < rp ? yp : r;
+    return r;
+}
+__device__ __forceinline__ F3 grad_w_scaled(const Consts &c, float dxs, float dys, float dzs, float rs)
+{
+    float q0 = rs * c.rh_s;                                        // div_by_h with both sides scaled
+    float e = __builtin_fmaf(-q0, c.h_s, rs);
+    float q = __builtin_fmaf(e, c.rh_s, q0);
+    float q2 = q * q;
+    float s1 = c.kg6 * (3.0f * q2 - 2.0f * q);
+    float t = 1.0f - q;
+    float s2 = c.neg_kg6 * (t * t);
+    float s = q <= 0.5f ? s1 : s2;
+    const Recip den = recip_prepare(c.h * rs);                     // (h * r) * 2^32
+    float ox = div_shared(s * dxs, den), oy = div_shared(s * dys, den), oz = div_shared(s * dzs, den);
+    const bool in = 1e-5f < q;
+    F3 o;
+    o.x = in ? ox : 0.0f;
+    o.y = in ? oy : 0.0f;
+    o.z = in ? oz : 0.0f;
+    return o;
+}
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     return (ax * bx + ay * by) + az * bz;

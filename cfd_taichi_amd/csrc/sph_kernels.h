@@ -773,13 +773,18 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
 // ======================================================================================
 // the workgroup's operand array through stage_src into LDS (see the staging plan in k_build_nl); returns false when this
 // workgroup keeps global indices.  Uniform per workgroup; every thread of the workgroup must call it.
+// SCALED: the positions are staged multiplied by 2^32 (exact; see norm3_scaled in sph_device.h), .w unchanged
+template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
                                               const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
 {
     const int nst = stage_cnt[blk];
     if (nst < 0) return false;
     const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int e = threadIdx.x; e < nst; e += kBlock) s_A[e] = A[src[e]];
+    for (int e = threadIdx.x; e < nst; e += kBlock) {
+        const float4 a = A[src[e]];
+        s_A[e] = SCALED ? make_float4(a.x * 0x1p32f, a.y * 0x1p32f, a.z * 0x1p32f, a.w) : a;
+    }
     __syncthreads();
     return true;
 }
@@ -797,7 +802,7 @@ __device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__res
     return true;
 }
 // staged walkers: fluid entries are LOCAL indices into the staged arrays, tagged rigid entries stay global (rv.RP)
-template <bool RIGID, class Body>
+template <bool RIGID, bool SCALED = false, class Body>
 __device__ __forceinline__ void for_staged_nbrs(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A, const RigidView &rv,
                                                 Body body)
 {
@@ -812,7 +817,12 @@ __device__ __forceinline__ void for_staged_nbrs(const uint32_t *__restrict__ bas
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool rg = (j[u] & kRigidTag) != 0;
-                a[u] = rg ? rv.RP[j[u] & ~kRigidTag] : s_A[j[u] & ~kRigidTag];
+                if (rg) {
+                    const float4 q = rv.RP[j[u] & ~kRigidTag];
+                    a[u] = SCALED ? make_float4(q.x * 0x1p32f, q.y * 0x1p32f, q.z * 0x1p32f, q.w) : q;
+                } else {
+                    a[u] = s_A[j[u] & ~kRigidTag];
+                }
             }
         } else {
 #pragma unroll
@@ -851,6 +861,7 @@ __device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ 
 }
 
 // both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle
+template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
                                                  const float4 *__restrict__ A, const float4 *__restrict__ B,
                                                  const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
@@ -861,13 +872,13 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
     for (int e = threadIdx.x; e < nst; e += kBlock) {
         const uint32_t j = src[e];
         const float4 a = A[j], b = B[j];
-        s_A[e] = make_float4(a.x, a.y, a.z, b.x);
+        s_A[e] = SCALED ? make_float4(a.x * 0x1p32f, a.y * 0x1p32f, a.z * 0x1p32f, b.x) : make_float4(a.x, a.y, a.z, b.x);
         s_B[e] = make_float2(b.y, b.z);
     }
     __syncthreads();
     return true;
 }
-template <bool RIGID, class Body>
+template <bool RIGID, bool SCALED = false, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                     const float2 *__restrict__ s_B, const RigidView &rv, Body body)
 {
@@ -882,7 +893,8 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
                 const bool rg = (j[u] & kRigidTag) != 0;
                 const uint32_t idx = j[u] & ~kRigidTag;
                 if (rg) {
-                    a[u] = rv.RP[idx];                               // (x, y, z, V_r); the velocity operand is undefined for rigid entries
+                    const float4 q = rv.RP[idx];                     // (x, y, z, V_r); the velocity operand is undefined for rigid entries
+                    a[u] = SCALED ? make_float4(q.x * 0x1p32f, q.y * 0x1p32f, q.z * 0x1p32f, q.w) : q;
                     b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     const float4 pa = s_A[idx]; const float2 pb = s_B[idx];
@@ -1098,7 +1110,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     SPH_SWEEP_PROLOGUE
-    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
+    const bool staged = STAGED && stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk);     // positions * 2^32
     const float dt = ds->dt;
     const float rho_i = rho[ii];
     float k_i;
@@ -1122,7 +1134,24 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             }
         }
     };
-    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    // the same pair with every position carrying 2^32 (staged operands): two multiplications less per pair, same bits
+    const float sx_i = pi.x * 0x1p32f, sy_i = pi.y * 0x1p32f, sz_i = pi.z * 0x1p32f;
+    auto pair_scaled = [&](const float4 pj, const float4, const uint32_t j) {
+        float dx = sx_i - pj.x, dy = sy_i - pj.y, dz = sz_i - pj.z;
+        float r = norm3_scaled(dx, dy, dz);
+        F3 g = grad_w_scaled(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            float s = pj.w * c.rho0 * k_i / rho_i;
+            ax += s * g.x; ay += s * g.y; az += s * g.z;
+        } else {
+            float ks = kr_i + pj.w;
+            if (MODE != CORR_DIV || ks > 1e-5f) {
+                float s = c.m * ks;
+                ax += s * g.x; ay += s * g.y; az += s * g.z;
+            }
+        }
+    };
+    if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -1168,7 +1197,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
-    const bool staged = STAGED && stage_operand_pv(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
+    const bool staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
     const float4 vi = V[ii];
     float acc = 0.f;
     const int nq = RIGID ? (live ? ncount[ii] : 0) : kf;                          // ps.get_neighbour_count(i)
@@ -1185,7 +1214,20 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);          // :287 / :162
         }
     };
-    if (staged) for_staged_nbrs_pv2<RIGID>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair);
+    const float sx_i = pi.x * 0x1p32f, sy_i = pi.y * 0x1p32f, sz_i = pi.z * 0x1p32f;
+    auto pair_scaled = [&](const float4 pj, const float4 vj, const uint32_t j) {      // positions carry 2^32 (see k_correct)
+        float dx = sx_i - pj.x, dy = sy_i - pj.y, dz = sz_i - pj.z;
+        float r = norm3_scaled(dx, dy, dz);
+        F3 g = grad_w_scaled(c, dx, dy, dz, r);
+        if (RIGID && (j & kRigidTag)) {
+            const float4 pu = make_float4(pj.x * 0x1p-32f, pj.y * 0x1p-32f, pj.z * 0x1p-32f, pj.w);
+            const F3 w = rigid_velocity(rv, pu, dt_r, DENS);
+            acc += pj.w * c.rho0 * dot3(vi.x - w.x, vi.y - w.y, vi.z - w.z, g.x, g.y, g.z);
+        } else {
+            acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);
+        }
+    };
+    if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float accb = 0.f;
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {

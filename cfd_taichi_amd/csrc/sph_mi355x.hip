@@ -332,6 +332,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     const float h3 = c.h * (c.h * c.h);            // ti.pow(h, 3) by squaring
     c.kw = 8.0f / (pi_f * h3);                     // solver_base.py:79
     c.rh = 1.0f / c.h;
+    c.rh_s = c.rh * 0x1p-32f; c.h_s = c.h * 0x1p32f;     // exact
     const float kg = 48.0f / (pi_f * h3);          // :95
     c.kg6 = kg * 6.0f;
     c.neg_kg6 = -kg * 6.0f;
