@@ -201,3 +201,34 @@ def test_random_scenes_on_slabs_on_the_morton_curve(tmp_path, monkeypatch, seed)
     world = int(rng.integers(2, 5))
     r = run_slabs(tmp_path, str(path), world, 60, rebalance=3)
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], (cfg, {k: r[k] for k in ("pos_rel_err", "slabs")})
+
+
+@pytest.mark.parametrize("solver,dt,steps", [("wcsph", 2.5e-4, 120), ("pcisph", 2.5e-4, 80), ("iisph", 5e-4, 80)])
+def test_rigid_coupling_of_the_other_solvers_on_the_morton_curve(solver, dt, steps, monkeypatch):
+    """Rigid-coupled WCSPH / PCISPH / IISPH with the cells on the Morton curve (PCISPH and IISPH with staged sweeps, tagged rigid entries
+    inside staged lists, the body's own neighbour lists) against the linear order: fluid and body bit for bit.  The lattice is squeezed
+    towards the body like in test_rigid_gpu.make_solver, so that the pressure coupling acts from the first step."""
+    cfg = scenes.get("dfsph_rigid_small")
+    cfg["solver"]["name"] = solver
+    cfg["solver"]["delta_time"] = dt
+    rg = mesh.rigid_from_config(cfg)
+    a = make(cfg, "morton", monkeypatch, rigid=rg)
+    b = make(cfg, "linear", monkeypatch, rigid=rg)
+    pos = a.download(nat.F_POS)
+    about = np.array([pos[:, 0].max(), pos[:, 1].min(), 0.5 * (pos[:, 2].min() + pos[:, 2].max())], dtype=np.float32)
+    squeezed = (about + (pos - about) * np.float32(0.86)).astype(np.float32)
+    a.upload(nat.F_POS, squeezed); b.upload(nat.F_POS, squeezed)
+    pushed = False
+    for s_ in range(steps):
+        a.step(1); b.step(1)
+        fa, fb = a.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), b.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)
+        assert np.array_equal(fa, fb), (solver, s_)
+        pushed = pushed or float(np.abs(fa).max()) > 0
+        a.rigid_step(); b.rigid_step()
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), (solver, f)
+    ra, rb = a.rigid_scalars(), b.rigid_scalars()
+    for k in ("centroid", "omega", "vel"):
+        assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), (solver, k)
+    assert pushed, "the fluid never pushed the body: coupling not exercised"
+    a.close(); b.close()
