@@ -15,7 +15,7 @@ del os.environ["SPH_STAGE"]
 t0 = time.time()
 for s in range(steps):
     a, b = sims[0].step(1), sims[1].step(1)
-    assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt, a.max_nbrs, a.lost) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt, b.max_nbrs, b.lost), s
+    assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt, a.max_nbrs, a.lost) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt, b.max_nbrs, b.lost), s   # all four solvers fill SphStepStats except wcsph
     if (s + 1) % every == 0 or s + 1 == steps:
         for f in (nat.F_POS, nat.F_VEL):
             assert np.array_equal(sims[0].download(f), sims[1].download(f), equal_nan=True), (s, f)
