@@ -1,9 +1,12 @@
-"""Minimal mesh loading and solid voxelisation for the rigid body of config 5 (replaces the reference's use of
+"""Minimal mesh loading and voxelisation for the rigid body of config 5 (replaces the reference's use of
 trimesh, ParticleSystem.py:42-50, which is not installable here).
 
-PARITY UNPINNED for this file: trimesh's `voxelized(pitch).fill().points` could not be run; the convention chosen is
-voxel centres on the global lattice {k * pitch}, every lattice point inside or on the closed surface (the bounding
-box faces included).  For obj/cube1.STL (box 0.8 x 0.5 x 1.0, pitch 0.05) that is a 17 x 11 x 21 block."""
+PARITY UNPINNED for this file: trimesh's `voxelized(pitch).fill().points` could not be run.  What is restated is trimesh's
+documented default path -- subdivide the surface until every edge is at most pitch/2, occupy voxel round(vertex / pitch) for every
+vertex, fill the enclosed holes of the dense grid (scipy.ndimage.binary_fill_holes), return the voxel centres index * pitch in C
+order of the index -- so voxel centres lie on the global lattice {k * pitch} and may lie up to pitch/2 OUTSIDE the mesh.
+For obj/cube1.STL (box 0.8 x 0.5 x 1.0, pitch 0.05) that is a 17 x 11 x 21 block; at scale 0.6 an 11 x 7 x 13 block (the box ends
+at 0.48, which occupies voxel 10); at scale 3.3 a 54 x 34 x 67 block."""
 import struct
 
 import numpy as np
@@ -43,71 +46,67 @@ def load_mesh(path):
     return uniq[order], rank[inv.reshape(-1)].reshape(-1, 3)
 
 
-def voxelize_filled(vertices, faces, pitch):
-    """Lattice points {k*pitch} inside or on the closed triangle mesh (ray casting along +x, boundary counts as inside)."""
+def _subdivided_voxels(vertices, faces, pitch, max_iter=10):
+    """Voxel indices hit by the vertices of the mesh subdivided until every edge is at most pitch/2 -- trimesh's
+    `voxelize_subdivide(mesh, pitch, max_iter=10, edge_factor=2.0)`: four-way midpoint subdivision of every triangle that still has an
+    edge longer than pitch/2 (`remesh.subdivide_to_size`), then `np.round(vertex / pitch)` (round-half-even) of every vertex."""
     v = np.asarray(vertices, dtype=np.float64)
-    lo = np.round(v.min(0) / pitch).astype(int)
-    hi = np.round(v.max(0) / pitch).astype(int)
-    ks = [np.arange(lo[a], hi[a] + 1) for a in range(3)]
-    gx, gy, gz = np.meshgrid(ks[0] * pitch, ks[1] * pitch, ks[2] * pitch, indexing="ij")
-    pts = np.stack([gx.ravel(), gy.ravel(), gz.ravel()], axis=1)
-    tri = v[np.asarray(faces)]
-    eps = 1e-6 * max(1.0, float(np.abs(v).max()))     # STL coordinates are f32: 0.8 is stored as 0.79999995
-    inside = np.zeros(len(pts), dtype=bool)
-    # on-surface test (distance to any triangle plane within its edges) + parity of +x ray crossings
-    crossings = np.zeros(len(pts), dtype=np.int64)
-    on_surface = np.zeros(len(pts), dtype=bool)
-    for a, b, c in tri:
-        n = np.cross(b - a, c - a)
-        nn = np.linalg.norm(n)
-        if nn == 0:
-            continue
-        # barycentric coordinates of the projection of every point along x onto the triangle's (y,z) shadow
-        d = (b[1] - a[1]) * (c[2] - a[2]) - (c[1] - a[1]) * (b[2] - a[2])
-        if abs(d) > eps:
-            u = ((pts[:, 1] - a[1]) * (c[2] - a[2]) - (c[1] - a[1]) * (pts[:, 2] - a[2])) / d
-            w = ((b[1] - a[1]) * (pts[:, 2] - a[2]) - (pts[:, 1] - a[1]) * (b[2] - a[2])) / d
-            hit = (u >= -1e-9) & (w >= -1e-9) & (u + w <= 1 + 1e-9)
-            xs = a[0] + u * (b[0] - a[0]) + w * (c[0] - a[0])
-            on_surface |= hit & (np.abs(xs - pts[:, 0]) <= eps)
-            # half-open rule on the shadow avoids double counting shared edges
-            hit_strict = (u > 1e-9) & (w > 1e-9) & (u + w < 1 - 1e-9)
-            crossings += (hit_strict & (xs > pts[:, 0] + eps)).astype(np.int64)
-        else:
-            # triangle parallel to the x axis: points lying in its plane and inside it are on the surface
-            dist = np.abs((pts - a) @ n) / nn
-            u_ = np.cross(b - a, pts - a) @ n
-            v_ = np.cross(c - b, pts - b) @ n
-            w_ = np.cross(a - c, pts - c) @ n
-            on_surface |= (dist <= eps) & (u_ >= -eps) & (v_ >= -eps) & (w_ >= -eps)
-    inside = on_surface | (crossings % 2 == 1)
-    # lattice points on the bounding-box shell whose rays graze edges: for closed convex shells (the cube) use the bbox test
-    bb = np.all((pts >= v.min(0) - eps) & (pts <= v.max(0) + eps), axis=1)
-    if _is_axis_aligned_box(v, tri, eps):
-        inside = bb
-    return pts[inside & bb]
+    tri = v[np.asarray(faces, dtype=np.int64)]                     # (n, 3, 3): triangles as coordinates, no index bookkeeping
+    max_edge = pitch / 2.0
+    hits = []
+    for _ in range(max_iter + 1):
+        edge = np.sqrt(((tri[:, [1, 2, 0]] - tri) ** 2).sum(axis=2))
+        too_long = (edge > max_edge).any(axis=1)
+        done = tri[~too_long].reshape(-1, 3)
+        if len(done):
+            hits.append(np.unique(np.round(done / pitch).astype(np.int64), axis=0))
+        if not too_long.any():
+            break
+        t = tri[too_long]
+        a, b, c = t[:, 0], t[:, 1], t[:, 2]
+        ab, bc, ca = (a + b) / 2.0, (b + c) / 2.0, (c + a) / 2.0   # `vertices[edges].mean(axis=1)`
+        tri = np.concatenate([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)])
+    else:
+        raise ValueError("max_iter exceeded: the mesh has edges longer than %g x 2^%d" % (max_edge, max_iter))
+    return np.unique(np.concatenate(hits), axis=0)
 
 
-def _is_axis_aligned_box(v, tri, eps):
-    mn, mx = v.min(0), v.max(0)
-    on_face = np.any((np.abs(v - mn) <= eps) | (np.abs(v - mx) <= eps), axis=1)
-    corners = np.all((np.abs(v - mn) <= eps) | (np.abs(v - mx) <= eps), axis=1)
-    return bool(on_face.all() and corners.all() and len(v) == 8)
+def voxelize(vertices, faces, pitch, fill=True):
+    """Voxel centres of `mesh.voxelized(pitch)[.fill()].points` (ParticleSystem.py:46-50) as trimesh documents the default path:
+    surface voxels = round(subdivided surface vertices / pitch); `fill()` = method 'holes' = scipy.ndimage.binary_fill_holes of the
+    dense occupancy grid (6-connected background); points in C order of the (x, y, z) voxel index, centre = index * pitch + origin.
+    The occupied voxels are NOT clipped to the mesh: a vertex at 0.48 with pitch 0.05 occupies voxel 10 (centre 0.5)."""
+    occ = _subdivided_voxels(vertices, faces, pitch)
+    origin = occ.min(axis=0)
+    shape = occ.max(axis=0) - origin + 1
+    dense = np.zeros(shape, dtype=bool)
+    dense[tuple((occ - origin).T)] = True
+    if fill:
+        from scipy import ndimage
+        dense = ndimage.binary_fill_holes(dense)
+    idx = np.column_stack(np.nonzero(dense))                       # C order: x slowest, z fastest
+    return idx.astype(np.float64) * pitch + origin.astype(np.float64) * pitch
+
+
+def voxelize_filled(vertices, faces, pitch):
+    return voxelize(vertices, faces, pitch, fill=True)
 
 
 def _resolve(path):
+    """A mesh path from a config: as given (absolute, or relative to the working directory), else relative to this package
+    (shipped configs say assets/cube1.stl), else the packaged asset of the same base name (the reference's ./obj/cube1.stl).
+    File names match case-insensitively: coupling_demo.json:27 spells cube1.STL as cube1.stl."""
     import os
-    if os.path.exists(path):
-        return path
-    d, b = os.path.split(path)
-    d = d or "."
-    if os.path.isdir(d):                                   # the reference's configs spell cube1.STL as cube1.stl
-        for name in os.listdir(d):
-            if name.lower() == b.lower():
-                return os.path.join(d, name)
-    packaged = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", b.lower())
-    if os.path.exists(packaged):
-        return packaged
+    here = os.path.dirname(os.path.abspath(__file__))
+    for cand in (path, os.path.join(here, path), os.path.join(here, "assets", os.path.basename(path))):
+        d, b = os.path.split(cand)
+        d = d or "."
+        if os.path.exists(cand):
+            return cand
+        if os.path.isdir(d):
+            for name in os.listdir(d):
+                if name.lower() == b.lower():
+                    return os.path.join(d, name)
     raise FileNotFoundError(path)
 
 
@@ -117,9 +116,7 @@ def rigid_from_config(config):
     solid = config["solid"]
     vertices, faces = load_mesh(_resolve(solid["mesh"]))
     vertices = vertices * float(solid.get("scale", 1))                       # mesh.apply_scale, :43
-    if not solid.get("fill", True):
-        raise NotImplementedError("solid.fill = false (surface-only voxelisation) is not built")
-    points = voxelize_filled(vertices, faces, float(solid["voxel_radius"]) * 2)   # :47
+    points = voxelize(vertices, faces, float(solid["voxel_radius"]) * 2, fill=bool(solid.get("fill", True)))   # :46-50
     return {"points": points.astype(np.float32), "vertices": vertices.astype(np.float32), "faces": faces,
             "rho_0": float(solid["rho_0"]), "pos_offset": [float(v) for v in solid["pos_offset"]],
             "attitude_offset": [float(v) for v in solid["attitude_offset"]], "active": bool(solid.get("active", False))}

@@ -61,7 +61,8 @@ def _with_solid(cfg, mesh, scale, pos_offset, attitude_offset, rho_0, active=Tru
     return cfg
 
 
-_CUBE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "cube1.stl")
+# relative to the package directory (mesh._resolve); the reference's configs say ./obj/cube1.stl relative to its checkout
+_CUBE = "assets/cube1.stl"
 
 SCENES.update({
     # config 5 family: DFSPH + one rigid box (the geometry of the reference's obj/cube1.STL: 0.8 x 0.5 x 1.0)

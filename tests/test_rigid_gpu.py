@@ -168,3 +168,45 @@ def test_shipped_solid_configs_run(scene, solver):
     same(ps.fluid_particles.vel.to_numpy(), o.get(orc.F_VEL), "fluid velocities")
     same(ps.rigid_particles.pos.to_numpy(), o.get(orc.F_RIGID_POS), "rigid positions")
     o.close()
+
+
+@pytest.mark.parametrize("body,fill", [("sphere", True), ("tilted_box", True), ("sphere", False)])
+def test_coupled_steps_non_box_body(body, fill):
+    """Bodies that are not an axis-aligned box, through the general voxeliser (ParticleSystem.py:42-50; `fill` true and false): an
+    icosphere and a box tilted in the mesh frame dropped next to the water column, 100 coupled DFSPH steps against the oracle."""
+    import meshes
+    cfg = scenes.get("dfsph_rigid_small")
+    if body == "sphere":
+        v, f = meshes.icosphere(0.2, level=2, centre=(0.0, 0.0, 0.0))
+        offset = [0.95, 0.3, 0.75]
+    else:
+        v, f = meshes.box((0.4, 0.25, 0.5), rotation=meshes.rot_zyx(0.4, 0.3, -0.5))
+        offset = [0.8, 0.2, 0.5]
+    pts = mesh.voxelize(v, f, 0.05, fill=fill)
+    assert len(pts) > 150 and len(np.unique(np.round(pts / 0.05).astype(int), axis=0)) == len(pts)
+    rg = {"points": pts.astype(np.float32), "vertices": v.astype(np.float32), "faces": f, "rho_0": 800.0, "pos_offset": offset,
+          "attitude_offset": [10.0, 0.0, 25.0], "active": True}
+    sim = nat.Simulation(nat.config_from_dict(cfg), rigid=rg)
+    o = orc.Oracle(cfg, num_threads=8, rigid=rg)
+    assert sim.n_rigid == o.Nr == len(pts)
+    same(sim.download(nat.F_RIGID_VOL, nat.SPECIES_RIGID), o.get(orc.F_RIGID_VOL), "rigid volumes")
+    pushed = False
+    for s in range(100):
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        so = o.last_stats
+        assert (st.n_div, st.n_dens, st.div_err, st.dens_err, st.dt) == (so.n_div, so.n_dens, so.div_err, so.dens_err, so.dt), s
+        fo = o.get(orc.F_RIGID_FORCE)
+        if s % 20 == 0:
+            same(sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), fo, "force on the body before rigid step %d" % s)
+        pushed = pushed or float(np.abs(fo).max()) > 0
+        sim.rigid_step()
+        o.rigid_step()
+        a, b = sim.rigid_scalars(), o.rigid_scalars()
+        for k in ("centroid", "omega", "vel", "inertia_inv"):
+            same(np.float32(a[k]), np.float32(b[k]), "%s after step %d" % (k, s))
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "fluid positions")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "fluid velocities")
+    same(sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_POS), "rigid positions")
+    assert pushed, "the fluid never pushed the body: coupling not exercised"
+    sim.close(); o.close()
