@@ -8,13 +8,20 @@ A "step" is one dfsph_solver.step() (grid rebuild, density/alpha, divergence sol
 forces, adaptive dt, density solve, integration) over the whole particle set, which is resident in
 HBM before the timed region starts.  Rank 0 prints ONE JSON line.
 
+The timed window: `--preroll` untimed steps first (default 50, reported as config.preroll_steps) so that whatever --warmup / --steps
+the caller passes land in the collapsing phase SURVEY.md 8d prescribes (50 warm-up + 200 timed), not in the first steps from rest
+where the density loop runs its minimum of 2 iterations; the pre-roll itself is timed and reported as `early_phase`.
+
 Extra objects on the line:
   roofline      dominant kernel: algorithmic bytes per launch / its mean launch
                 duration, measured live with HIP events on the library's stream (a separate,
-                profiled pass after the timed region); `traffic` is the per-launch HBM byte count from
-                the rocprofv3 PMC passes committed under profiles/ (null if absent).
+                profiled replay of the warm-up + timed steps); `traffic` and `valu.wave_insts_per_launch` are NOT measured in
+                this run: they are read from the rocprofv3 --pmc passes committed under profiles/ (`traffic_source`), null if absent.
   cpu_baseline  the CPU oracle ("port": restatement of the ti.cpu path, not Taichi) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only): for dfsph / wcsph scenes it continues
+                from the device's state at the start of the timed window (same phase of the collapse as `value`).
+  strong_scaling_base   N = 1, default workload only: the N > 1 workload (dfsph_10m) on this one GPU with the same flags, so that
+                the strong-scaling series the driver assembles from N = 2, 4, 8 has its one-GPU point.
 """
 import argparse
 import json
@@ -52,6 +59,9 @@ def parse():
     ap.add_argument("--workload", default=None, help="scene name from cfd_taichi_amd.scenes (default dfsph_1m)")
     ap.add_argument("--profile-steps", type=int, default=1, help="0 = skip the HIP-event profiled replay (roofline leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll", type=int, default=int(os.environ.get("SPH_BENCH_PREROLL", "50")),
+                    help="untimed steps before the warm-up (reported as config.preroll_steps and timed as early_phase)")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N=1: skip the dfsph_10m one-GPU point")
     ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
                     help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
     return ap.parse_args()
@@ -72,29 +82,48 @@ def host_cores():
 CPU_BASELINE_SECONDS = 10.0     # bounded sample of the same workload on the host cores
 
 
-def cpu_baseline(scene_name, solver_kind):
-    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+def cpu_baseline(scene_name, solver_kind, state=None, first_step=1):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload.  `state` = (pos, vel, warm_start_k, dt) of the
+    device at the start of the timed window (dfsph / wcsph without a body): the oracle continues from there, so the sample is the
+    same phase of the collapse `value` is measured in; otherwise whole steps from rest."""
     from cfd_taichi_amd import scenes
     from oracle import oracle as orc
     cores = host_cores()
     cfg = scenes.get(scene_name)
-    o = orc.Oracle(cfg, num_threads=cores)
-    # one untimed step (from rest the first step is atypical: zero divergence residual), then whole steps until ~10 s of CPU work
+    rigid = None
+    if cfg.get("solid"):
+        from cfd_taichi_amd import mesh
+        rigid = mesh.rigid_from_config(cfg)
+    o = orc.Oracle(cfg, num_threads=cores, rigid=rigid)
+    rigid_active = bool(rigid and rigid.get("active"))
     if solver_kind == "pcisph":
-        one = lambda: o.step_pcisph(1)
+        step = lambda: o.step_pcisph(1)
     elif solver_kind == "iisph":
-        one = lambda: o.step_iisph(1)
+        step = lambda: o.step_iisph(1)
     elif solver_kind == "dfsph":
-        one = lambda: o.step_dfsph(1, 100)
+        step = lambda: o.step_dfsph(1, 100)
     else:
-        one = lambda: o.step_wcsph(1)
-    one()
+        step = lambda: o.step_wcsph(1)
+
+    def one():
+        step()
+        if rigid_active:
+            o.rigid_step()                # main.py:169-171
+    if state is not None:
+        pos, vel, warm, dt = state
+        o.set(orc.F_POS, pos); o.set(orc.F_VEL, vel)
+        if warm is not None:
+            o.set(orc.F_WARM_K, warm); o.set_dt(dt)
+        start = first_step
+    else:
+        one()        # one untimed step (from rest the first step is atypical: zero divergence residual)
+        start = 2
     timed, t0 = 0, time.perf_counter()
     while True:
         one()
         timed += 1
-        dt = time.perf_counter() - t0
-        if dt >= CPU_BASELINE_SECONDS or timed >= 2000:
+        dt_s = time.perf_counter() - t0
+        if dt_s >= CPU_BASELINE_SECONDS or timed >= 2000:
             break
     if solver_kind == "dfsph":
         detail = ", n_div=%d, n_dens=%d in the last step" % (o.last_stats.n_div, o.last_stats.n_dens)
@@ -102,11 +131,12 @@ def cpu_baseline(scene_name, solver_kind):
         detail = ", %d pressure iterations in the last step" % o.last_stats.n_dens
     else:
         detail = ""
-    sample = "steps 2-%d of %s (N=%d%s) after 1 untimed step" % (timed + 1, scene_name, o.N, detail)
-    value = o.N * timed / dt / 1e6
+    how = "continuing from the device state at the start of the timed window" if state is not None else "after 1 untimed step from rest"
+    sample = "steps %d-%d of %s (N=%d%s) %s" % (start, start + timed - 1, scene_name, o.N, detail, how)
+    value = o.N * timed / dt_s / 1e6
     o.close()
     return {"value": value, "unit": "Mparticle-steps/s", "cores": cores, "kind": "port",
-            "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt}
+            "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt_s}
 
 
 def load_traffic(kernel, key="hbm_bytes_per_launch"):
@@ -121,8 +151,21 @@ def load_traffic(kernel, key="hbm_bytes_per_launch"):
         return None
 
 
-# wave64 VALU issue peak: one non-packed f32 instruction per cycle per CU (4 SIMDs x 16 lanes), 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+def load_ceiling():
+    """G wave64-instructions/s that tools/valu_issue.hip sustained on an MI355X (committed under profiles/; None if absent)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_issue.json")) as f:
+            return json.load(f).get("valu_issue_ginst_measured")
+    except Exception:
+        return None
+
+
+# wave64 VALU issue rate: one f32 instruction per cycle per CU (4 SIMDs x 16 lanes), 256 CUs x 2.4 GHz (MI355X_MICROARCH.md) = 614.4 G
+# wave-instructions/s.  An unpacked FMA stream at that rate is 78.6 TFLOP/s; the guide's 157.3 TFLOP/s FP32 vector peak needs every
+# instruction to be a packed v_pk_fma_f32 (2 lanes' worth of work per lane-slot).  tools/valu_issue.hip measures both on the box
+# (profiles/r02*/valu_issue.json); `valu.frac` prices the kernel against the ISSUE rate, `valu.frac_of_fp32_peak` against 157.3.
 VALU_PEAK_GINST = 256 * 2.4
+FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
 def make_sim(nat, scenes, scene_name, world, rank, local_rank, transport_group, rebalance=0, discipline=None):
@@ -278,49 +321,68 @@ def main():
     n_total = sim.n_fluid
 
     has_rigid = bool(cfg.get("solid")) and world == 1
+    rigid_active = has_rigid and bool(cfg["solid"].get("active", False))     # main.py:169-171: rs.step() only if ps.active_rigid[None] == 1
 
-    def run(nsteps, stats=None):
-        if solver_kind == "dfsph":
-            for _ in range(nsteps):
-                st = sim.step_dfsph(1)
-                if has_rigid:
-                    sim.rigid_step()          # main.py:169-171
-                if stats is not None:
-                    stats.append((st.n_div, st.n_dens, st.n_div_evals))
-        elif solver_kind in ("pcisph", "iisph"):
-            step = sim.step_pcisph if solver_kind == "pcisph" else sim.step_iisph
-            for _ in range(nsteps):
-                st = step(1)
-                if has_rigid:
+    def make_run(sim, kind, with_body):
+        def run(nsteps, stats=None):
+            if kind == "dfsph":
+                for _ in range(nsteps):
+                    st = sim.step_dfsph(1)
+                    if with_body:
+                        sim.rigid_step()
+                    if stats is not None:
+                        stats.append((st.n_div, st.n_dens, st.n_div_evals))
+            elif kind in ("pcisph", "iisph"):
+                step = sim.step_pcisph if kind == "pcisph" else sim.step_iisph
+                for _ in range(nsteps):
+                    st = step(1)
+                    if with_body:
+                        sim.rigid_step()
+                    if stats is not None:
+                        stats.append((0, st.n_dens, 0))
+            elif with_body:
+                for _ in range(nsteps):
+                    sim.step_wcsph(1)
                     sim.rigid_step()
-                if stats is not None:
-                    stats.append((0, st.n_dens, 0))
-        elif has_rigid:
-            for _ in range(nsteps):
-                sim.step_wcsph(1)
-                sim.rigid_step()
-        else:
-            sim.step_wcsph(nsteps)
+            else:
+                sim.step_wcsph(nsteps)
+        return run
 
-    def fence():
+    def fence(sim):
         sim.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    run(args.warmup)
-    fence()
-    stats = []
-    t0 = time.perf_counter()
-    run(args.steps, stats)
-    sim.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
+    def timed_window(sim, run, want_state=False):
+        """pre-roll (timed on the side as the early phase), warm-up, then EXACTLY args.steps steps between two fences; max over ranks"""
+        fence(sim)
+        t0 = time.perf_counter()
+        run(args.preroll)
+        fence(sim)
+        early = time.perf_counter() - t0
+        run(args.warmup)
+        state = None
+        if want_state:       # the device state the CPU baseline continues from (host copies, outside the timed region)
+            warm = sim.download(nat.F_WARM_K) if solver_kind == "dfsph" else None
+            state = (sim.download(nat.F_POS), sim.download(nat.F_VEL), warm, sim.scalar(nat.S_DELTA_TIME))
+        fence(sim)
+        stats = []
+        t0 = time.perf_counter()
+        run(args.steps, stats)
+        sim.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed, early], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, early = float(t[0].item()), float(t[1].item())
+            dist.barrier()
+        return elapsed, early, stats, state
+
+    run = make_run(sim, solver_kind, rigid_active)
+    want_state = rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid and solver_kind in ("dfsph", "wcsph")
+    elapsed, early, stats, state = timed_window(sim, run, want_state)
 
     value = n_total * args.steps / elapsed / 1e6
     slab_info = sim.slab_info() if world > 1 else None
@@ -331,9 +393,13 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
-                   "grid": list(sim.grid),
+                   "grid": list(sim.grid), "preroll_steps": args.preroll,
+                   "timed_steps": "%d-%d" % (args.preroll + args.warmup + 1, args.preroll + args.warmup + args.steps),
                    "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s, cuts re-balanced every %d steps" % (world, transport, args.rebalance)},
     }
+    if args.preroll > 0:
+        out["early_phase"] = {"steps": "1-%d" % args.preroll, "value": n_total * args.preroll / early / 1e6, "ms_per_step": early / args.preroll * 1e3,
+                              "note": "the pre-roll from rest (density loop at its minimum of 2 iterations for most of it); not the headline"}
     if slab_info is not None:
         out["config"]["rank0_slab"] = slab_info
         out["config"]["rank0_comm"] = slab.comm.stats if slab.comm is not None else "native transport (no callbacks)"
@@ -348,11 +414,14 @@ def main():
             out["config"].pop("n_div_mean"); out["config"].pop("n_div_evals_mean")
             out["config"]["pressure_iterations_mean"] = out["config"].pop("n_dens_mean")
 
-    # ---- roofline leg: HIP-event timing of every kernel, replaying the SAME steps (warm-up + timed) on a
-    # fresh handle, so the per-kernel means cover the same launches a rocprofv3 trace of this command sees ----
+    # ---- roofline leg: HIP-event timing of every kernel on a fresh handle that replays the same steps; the events cover the
+    # warm-up + timed steps (the pre-roll runs unprofiled), a rocprofv3 trace of this command additionally sees both pre-rolls ----
     if args.profile_steps > 0:
         sim.close()
         sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, group_for, args.rebalance, discipline)
+        run = make_run(sim, solver_kind, rigid_active)
+        run(args.preroll)
+        sim.synchronize()
         sim.profile_enable(True)
         nprof = args.warmup + args.steps
         run(nprof)
@@ -367,24 +436,44 @@ def main():
         avg_s = ms / n / 1e3
         algo = ALGO_BYTES[dom] * n_local
         achieved = algo / avg_s / 1e9
+        committed = world == 1 and scene_name == "dfsph_1m"       # the committed PMC passes were taken on this workload
+        traffic = load_traffic(dom) if committed else None
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(dom) if world == 1 and scene_name == "dfsph_1m" else None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload; NOT measured in this run)" if traffic else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
-                           "note": "neighbour sweep, bound by f32 instruction issue, not by HBM: ~52 VALU instructions per pair (the reference's IEEE sqrt and divides) for < 1 algorithmic byte; see roofline.valu and DESIGN.md section 6c"}
-        insts = load_traffic(dom, "sq_insts_valu_per_launch") if world == 1 and scene_name == "dfsph_1m" else None
+                           "binding_limit": "valu",
+                           "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s); the kernel's binding limit is f32 "
+                                   "instruction issue, not HBM: ~50 VALU instructions per pair (the reference's correctly rounded sqrt and divides) for < 1 "
+                                   "algorithmic byte -- see roofline.valu and DESIGN.md section 6c"}
+        insts = load_traffic(dom, "sq_insts_valu_per_launch") if committed else None
         if insts:
-            # second opinion on the same kernel: the reference's arithmetic needs ~50 f32 instructions per pair for < 1 algorithmic byte,
-            # so the instruction-issue ceiling is reached long before the HBM one (PMC count from profiles/pmc_traffic.json)
-            out["roofline"]["valu"] = {"wave_insts_per_launch": insts, "achieved": insts / avg_s / 1e9, "peak": VALU_PEAK_GINST,
-                                       "unit": "G wave64-inst/s", "frac": insts / avg_s / 1e9 / VALU_PEAK_GINST}
+            g_inst = insts / avg_s / 1e9
+            out["roofline"]["valu"] = {"wave_insts_per_launch": insts, "source": "profiles/pmc_traffic.json (committed SQ_INSTS_VALU pass; NOT measured in this run)",
+                                       "achieved": g_inst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s", "frac": g_inst / VALU_PEAK_GINST,
+                                       "peak_note": "issue rate of one wave64 VALU instruction per CU per cycle; as unpacked FMAs that is 78.6 TFLOP/s = half of the "
+                                                    "157.3 TFLOP/s FP32 vector peak, which needs packed v_pk_* instructions throughout (tools/valu_issue.hip)",
+                                       "measured_issue_ceiling": load_ceiling()}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     if has_rigid:
         out["config"]["rigid_particles"] = sim.n_rigid
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid:
-        out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind)
+        out["config"]["rigid_active"] = rigid_active
     sim.close()
+    # ---- N = 1, default workload: the one-GPU point of the strong-scaling series (the N > 1 workload on this GPU, same flags) ----
+    if world == 1 and args.workload is None and not args.no_scaling_base:
+        base_name = "dfsph_10m"
+        bsim, _ = make_sim(nat, scenes, base_name, 1, 0, local_rank, None)
+        b_elapsed, b_early, b_stats, _ = timed_window(bsim, make_run(bsim, "dfsph", False))
+        out["strong_scaling_base"] = {"workload": base_name, "n_gpus": 1, "particles": bsim.n_fluid, "value": bsim.n_fluid * args.steps / b_elapsed / 1e6,
+                                      "unit": "Mparticle-steps/s", "ms_per_step": b_elapsed / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                                      "preroll_steps": args.preroll, "n_dens_mean": sum(x[1] for x in b_stats) / len(b_stats),
+                                      "note": "bench.py --gpus N (N > 1) runs this workload sharded into N x-slabs (scaling: strong); this is its N = 1 point"}
+        bsim.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind, state, args.preroll + args.warmup + 1)
+        out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,7 +30,7 @@ EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
-    "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_tune_time",
+    "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
     "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
@@ -175,6 +175,7 @@ def load(build_if_missing=True):
     lib.sph_profile_kernel_name.restype = ctypes.c_char_p
     lib.sph_profile_get.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
     lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
+    lib.sph_selftest_wave.argtypes = [ci, ci, vp, vp, ctypes.c_size_t]
     lib.sph_tune_time.argtypes = [vp, ci, ctypes.c_uint, ci, ctypes.POINTER(ctypes.c_double)]
     lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
     lib.sph_rigid_step.argtypes = [vp]
@@ -447,6 +448,17 @@ def selftest_math(op, a, b, device=0):
     b = np.ascontiguousarray(b, dtype=np.float32)
     out = np.empty_like(a)
     rc = lib.sph_selftest_math(device, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    if rc != SPH_OK:
+        raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
+    return out
+
+
+def selftest_wave(op, values, device=0):
+    """Per-lane results of one wave primitive (see sph_selftest_wave); len(values) must be a multiple of 256."""
+    lib = load()
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.empty_like(a)
+    rc = lib.sph_selftest_wave(device, op, a.ctypes.data, out.ctypes.data, a.size)
     if rc != SPH_OK:
         raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
     return out

@@ -283,29 +283,63 @@ __device__ __forceinline__ float tait_pressure(float rho)
     return 70000.0f * (r3 * a4 - 1.0f);
 }
 
-// ---- wave / block reductions (wave64; fixed lane order => deterministic) -------------------------
-__device__ __forceinline__ double wave_sum(double v)
+// ---- wave reductions and scans without LDS traffic or address registers (wave64) ------------------
+// Cross-lane moves by data-path permutes instead of ds_bpermute (which needs a per-lane address and a round trip through the LDS
+// crossbar per step): DPP modifiers inside a 16-lane row (quad_perm, row_ror, row_shr, row_bcast), ds_swizzle across the two rows
+// of a 32-lane half, gfx950's v_permlane32_swap across the halves.
+//   lane ^ 32   v_permlane32_swap_b32 (swaps lanes 32..63 of one operand with lanes 0..31 of the other)
+//   lane ^ 16   ds_swizzle_b32 swizzle(SWAP,16)
+//   lane ^  8   DPP row_ror:8
+//   lane ^  4   ds_swizzle_b32 swizzle(SWAP,4)
+//   lane ^  2   DPP quad_perm:[2,3,0,1]
+//   lane ^  1   DPP quad_perm:[1,0,3,2]
+// A reduction is the butterfly over 32, 16, 8, 4, 2, 1 IN THAT ORDER: for every lane i < off the partner i ^ off is i + off, so lane 0
+// ends up with exactly the tree a `v += shfl_down(v, off)` ladder builds -- ((v0 + v32) + (v16 + v48)) + ... -- and the f64 block
+// partials keep their bits whatever the mechanism (tests/test_parity_gpu.py::test_wave_primitives checks the tree against numpy).
+template <int XOR>
+__device__ __forceinline__ int lane_xor(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    static_assert(XOR == 32 || XOR == 16 || XOR == 8 || XOR == 4 || XOR == 2 || XOR == 1, "butterfly step");
+    if (XOR == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // r[0] = (lo, lo), r[1] = (hi, hi)
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+    if (XOR == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);                // bit mode: and 0x1f, or 0, xor 0x10
+    if (XOR == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+    if (XOR == 4) return __builtin_amdgcn_ds_swizzle(v, 0x101F);                 // xor 0x04
+    if (XOR == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);                  // quad_perm:[1,0,3,2]
 }
-__device__ __forceinline__ int wave_sum(int v)
+template <int XOR>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor<XOR>(__float_as_int(v))); }
+template <int XOR>
+__device__ __forceinline__ double lane_xor(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    const int lo = lane_xor<XOR>(__double2loint(v)), hi = lane_xor<XOR>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float wave_max(float v)
+#define SPH_BUTTERFLY(v, OP) \
+    v = OP(v, lane_xor<32>(v)); v = OP(v, lane_xor<16>(v)); v = OP(v, lane_xor<8>(v)); \
+    v = OP(v, lane_xor<4>(v)); v = OP(v, lane_xor<2>(v)); v = OP(v, lane_xor<1>(v));
+#define SPH_OP_ADD(a, b) ((a) + (b))
+// result in lane 0 (every lane holds a sum of all 64 values; only lane 0's association is the documented one)
+__device__ __forceinline__ double wave_sum(double v) { SPH_BUTTERFLY(v, SPH_OP_ADD) return v; }
+__device__ __forceinline__ int wave_sum(int v) { SPH_BUTTERFLY(v, SPH_OP_ADD) return v; }
+__device__ __forceinline__ float wave_max(float v) { SPH_BUTTERFLY(v, fmaxf) return v; }
+__device__ __forceinline__ int wave_max(int v) { SPH_BUTTERFLY(v, max) return v; }
+#undef SPH_BUTTERFLY
+#undef SPH_OP_ADD
+
+// inclusive prefix sum over the 64 lanes: row_shr:1,2,4,8 inside each row of 16 (lanes without a source add 0), then lane 15 of
+// rows 0 and 2 broadcast into rows 1 and 3 (row_bcast:15), then lane 31 into the upper half (row_bcast:31)
+__device__ __forceinline__ int wave_inclusive_scan(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 

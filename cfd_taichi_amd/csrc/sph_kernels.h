@@ -142,12 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(int *__restrict__ in, int
     int tsum = v[0] + v[1] + v[2] + v[3];
     // inclusive wave scan of tsum
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = tsum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
+    int inc = wave_inclusive_scan(tsum);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     int woff = 0;
@@ -173,12 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sum
         int i = base + threadIdx.x;
         int v = (i < ntiles) ? tile_sums[i] : 0;
         int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        int inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
+        int inc = wave_inclusive_scan(v);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         int woff = 0;
@@ -491,10 +481,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             own[q] = key >= 0 ? cell_start[key + 1] - cell_start[key] : 0;
             run += own[q];
         }
-        int inc = run;
+        const int inc = wave_inclusive_scan(run);
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
         if (lane == 63) s_wsum[w] = inc;
         __syncthreads();
         int before = inc - run, total = 0;
@@ -1429,6 +1417,20 @@ __global__ void k_selftest(Consts c, int op, const float *__restrict__ a, const 
         F3 g = grad_w(c, x, y, dz, rn);
         r = op == 3 ? g.x : (op == 4 ? g.y : g.z);
     }
+    out[i] = r;
+}
+
+// wave primitive self-test (sph_selftest_wave): every lane's result of one primitive over the 64 values of its wave
+__global__ void k_selftest_wave(int op, const double *__restrict__ in, double *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double x = in[i];
+    double r;
+    if (op == 0) r = wave_sum(x);
+    else if (op == 1) r = (double)wave_sum((int)x);
+    else if (op == 2) r = (double)wave_max((float)x);
+    else if (op == 3) r = (double)wave_max((int)x);
+    else r = (double)wave_inclusive_scan((int)x);
     out[i] = r;
 }
 

@@ -2777,4 +2777,23 @@ int sph_selftest_math(int device, int op, const float *a, const float *b, float 
     return rc;
 }
 
+int sph_selftest_wave(int device, int op, const double *in, double *out, size_t n)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SPH_E_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev || !in || !out || n == 0 || n % 256 != 0 || op < 0 || op > 4) return fail(nullptr, SPH_E_INVALID, "bad argument (n must be a multiple of 256)");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, SPH_E_HIP, "hipSetDevice failed");
+    double *din = nullptr, *dout = nullptr;
+    int rc = SPH_OK;
+    if (hipMalloc((void **)&din, n * 8) != hipSuccess || hipMalloc((void **)&dout, n * 8) != hipSuccess) rc = fail(nullptr, SPH_E_HIP, "hipMalloc failed");
+    if (!rc) {
+        (void)hipMemcpy(din, in, n * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(k_selftest_wave, dim3((unsigned)(n / 256)), dim3(256), 0, 0, op, din, dout);
+        if (hipDeviceSynchronize() != hipSuccess) rc = fail(nullptr, SPH_E_HIP, "selftest kernel failed");
+        else (void)hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}
+
 }  // extern "C"

@@ -156,12 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_offsets(Consts c, const int *_
             v = cell_start[slot + 1] - cell_start[slot];
         }
         int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        int inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
+        int inc = wave_inclusive_scan(v);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         int woff = 0;

@@ -29,13 +29,15 @@ extern "C" {
 #define SPH_E_INVALID (-1)   /* bad argument / size mismatch */
 #define SPH_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
 #define SPH_E_NO_DEVICE (-3) /* no gfx950 device visible: the library has no CPU fallback */
-#define SPH_E_OVERFLOW (-4)  /* a neighbour list / cell overflowed its capacity; state is unchanged for that step */
+#define SPH_E_OVERFLOW (-4)  /* a neighbour list overflowed its capacity.  Detected at the step's first read-back (wcsph: after the nsteps of the
+                              * call), i.e. after sweeps have already run on truncated lists: the handle's particle state is UNDEFINED
+                              * afterwards -- recreate the handle with a larger max_neighbors, or re-upload positions and velocities */
 #define SPH_E_STATE (-5)     /* call not valid for this handle (e.g. dfsph step on a wcsph handle) */
 
 #define SPH_SOLVER_WCSPH 0
 #define SPH_SOLVER_DFSPH 1
-#define SPH_SOLVER_PCISPH 2   /* pcisph_solver.py (single GPU, no rigid body yet) */
-#define SPH_SOLVER_IISPH 3    /* iisph_solver.py  (single GPU, no rigid body yet) */
+#define SPH_SOLVER_PCISPH 2   /* pcisph_solver.py */
+#define SPH_SOLVER_IISPH 3    /* iisph_solver.py */
 
 /* config/X.json of the reference, flattened (utils.py:3-11 reads it,
  * ParticleSystem.py:31-103 and solver_base.py:7-39 consume it).  Doubles carry the Python
@@ -158,7 +160,8 @@ typedef struct SphHandle SphHandle;
  * wall cell list and wall volumes (:309-335), and allocates every device buffer. */
 int sph_create(const SphConfig *cfg, SphHandle **out);
 /* the same with a rigid body: replaces ParticleSystem(config) with a `solid` block + rigid_solver(ps, config)   main.py:69-71.
- * DFSPH only (BASELINE config 5); not available on slab handles. */
+ * All four solvers couple to the body (wcsph_solver.py:118-127, dfsph_solver.py:204-212, pcisph_solver.py:200-211, iisph_solver.py:159-168);
+ * not available on slab handles. */
 int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out);
 /* replaces rigid_solver.step()   rigid_solver.py:216-232 */
 int sph_rigid_step(SphHandle *h);
@@ -270,6 +273,10 @@ int sph_download_ids(SphHandle *h, int32_t *host, size_t n);
  * residual, 3 sort + list build) with `lds_bytes` of dynamic LDS per block; see tools/tune_sweeps.py */
 int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us);
 int sph_selftest_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+/* wave primitive self-test: out[i] = what lane i % 64 holds after one cross-lane primitive over the 64 values in[64*(i/64) ..]
+ * (op 0: f64 sum, 1: i32 sum, 2: f32 max, 3: i32 max -- reductions, documented result in lane 0; 4: i32 inclusive prefix sum).
+ * The primitives are DPP / ds_swizzle / v_permlane32_swap butterflies (csrc/sph_device.h); n must be a multiple of 256. */
+int sph_selftest_wave(int device, int op, const double *in, double *out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -63,9 +63,17 @@ class OrcStepStats(ctypes.Structure):
     ]
 
 
+def _stale():
+    libs = [os.path.join(_HERE, n) for n in ("liborc_f32.so", "liborc_f64.so")]
+    if not all(os.path.exists(p) for p in libs):
+        return True
+    newest = max(os.path.getmtime(os.path.join(_HERE, n)) for n in ("sph_oracle.c", "sph_oracle.h", "Makefile"))
+    return any(os.path.getmtime(p) < newest for p in libs)
+
+
 def build(force=False):
     """Compile liborc_f32.so / liborc_f64.so with gcc (oracle/Makefile)."""
-    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liborc_f32.so", "liborc_f64.so")):
+    if force or _stale():
         subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
                        stdout=subprocess.DEVNULL)
 
@@ -89,6 +97,7 @@ def _lib(precision):
         lib.orc_get.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         lib.orc_set.restype = ctypes.c_long
         lib.orc_set.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.orc_set_scalar.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
         lib.orc_get_scalar.restype = ctypes.c_double
         lib.orc_get_scalar.argtypes = [ctypes.c_void_p, ctypes.c_int]
         for name in ("orc_build_grid", "orc_compute_rho", "orc_compute_alpha", "orc_compute_nbr_count"):
@@ -184,6 +193,10 @@ class Oracle:
     @property
     def dt(self):
         return self._lib.orc_get_scalar(self._h, 0)
+
+    def set_dt(self, value):
+        """delta_time, delta_time_2 and ps.delta_time as a dfsph step leaves them: continue from a state produced elsewhere."""
+        assert self._lib.orc_set_scalar(self._h, 0, float(value)) == 0
 
     @property
     def particle_m(self):

@@ -559,6 +559,17 @@ long orc_set(Orc *o, int field, const float *in)
     return n;
 }
 
+/* which 0: delta_time (and delta_time_2 = dt * dt, ps.delta_time = dt as compute_all_vel_adv leaves them, dfsph_solver.py:118-119):
+ * lets a test or the CPU baseline continue from a state produced elsewhere (positions, velocities, warm_start_k through orc_set) */
+int orc_set_scalar(Orc *o, int which, double value)
+{
+    if (which != 0) return -1;
+    o->dt = R(value);
+    o->dt2 = o->dt * o->dt;
+    o->ps_dt = o->dt;
+    return 0;
+}
+
 double orc_get_scalar(const Orc *o, int which)
 {
     switch (which) {

@@ -54,6 +54,25 @@ def test_device_divide_sqrt_are_ieee():
     assert_same(nat.selftest_math(6, s, s), np.sqrt(s).astype(np.float32), "sqrt_rn(s)")
 
 
+def test_wave_primitives():
+    """The DPP / ds_swizzle / v_permlane32_swap butterflies of csrc/sph_device.h: lane 0 of a reduction holds exactly the tree a
+    shfl_down ladder over 32, 16, ..., 1 builds (the f64 block partials depend on that association), the scan is the inclusive sum."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(1024) * 10.0 ** rng.integers(-8, 9, 1024)
+    tree = x.reshape(-1, 64).copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        tree[:, :off] = tree[:, :off] + tree[:, off:2 * off]
+    got = nat.selftest_wave(0, x).reshape(-1, 64)
+    assert np.array_equal(got[:, 0], tree[:, 0])
+    assert np.allclose(got, x.reshape(-1, 64).sum(1, keepdims=True), rtol=1e-9, atol=1e-9 * np.abs(x).max())   # every lane holds a full sum
+    n = rng.integers(-1000, 1000, 1024).astype(np.float64)
+    assert np.array_equal(nat.selftest_wave(1, n).reshape(-1, 64), np.repeat(n.reshape(-1, 64).sum(1, keepdims=True), 64, 1))
+    f = x.astype(np.float32).astype(np.float64)
+    assert np.array_equal(nat.selftest_wave(2, f).reshape(-1, 64), np.repeat(f.reshape(-1, 64).max(1, keepdims=True), 64, 1))
+    assert np.array_equal(nat.selftest_wave(3, n).reshape(-1, 64), np.repeat(n.reshape(-1, 64).max(1, keepdims=True), 64, 1))
+    assert np.array_equal(nat.selftest_wave(4, n).reshape(-1, 64), np.cumsum(n.reshape(-1, 64), axis=1))
+
+
 def test_device_kernel_functions_match_oracle():
     rng = np.random.default_rng(11)
     # the device divides by h and by h*r with shortened exact sequences (sph_device.h): cover the whole support densely
@@ -217,4 +236,33 @@ def test_particles_outside_the_grid(solver):
         assert_same(sim.download(nat.F_POS), o.get(orc.F_POS), "pos")
         assert_same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "vel")
     assert_same(sim.download(nat.F_RHO), o.get(orc.F_RHO), "rho")
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("scene,pre,post", [("dfsph_small", 40, 6), ("wcsph_small", 150, 20)])
+def test_oracle_continues_from_device_state(scene, pre, post):
+    """The hand-over bench.py's cpu_baseline uses: the device runs `pre` steps, its positions, velocities (dfsph: warm_start_k and
+    delta_time too) are handed to a fresh oracle, and both continue -- bit for bit the same.  Everything else a step reads is
+    recomputed from those (grid, rho, alpha), so the state is complete."""
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    dfsph = scene.startswith("dfsph")
+    if dfsph:
+        sim.step_dfsph(pre)
+    else:
+        sim.step_wcsph(pre)
+    o = orc.Oracle(cfg, num_threads=4)
+    o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
+    if dfsph:
+        o.set(orc.F_WARM_K, sim.download(nat.F_WARM_K)); o.set_dt(sim.scalar(nat.S_DELTA_TIME))
+    for _ in range(post):
+        if dfsph:
+            st = sim.step_dfsph(1)
+            o.step_dfsph(1, 100)
+            assert (st.n_div, st.n_dens, st.div_err, st.dens_err, st.dt) == (o.last_stats.n_div, o.last_stats.n_dens, o.last_stats.div_err,
+                                                                            o.last_stats.dens_err, o.last_stats.dt)
+        else:
+            sim.step_wcsph(1); o.step_wcsph(1)
+    assert_same(sim.download(nat.F_POS), o.get(orc.F_POS), "pos")
+    assert_same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "vel")
     sim.close(); o.close()
