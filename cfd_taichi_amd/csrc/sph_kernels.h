@@ -906,6 +906,43 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
     }
 }
 
+// ---- staged walks with the pair bodies of a group in ONE basic block ---------------------------------------------------------
+// The walkers above run `body` under an EXEC-masked region per neighbour (`if (kk + u < cnt) body(...)`): four separate basic blocks
+// per group, each a single dependent chain (difference -> square root -> Newton division -> dot product), and a wave issues a
+// dependent VALU instruction only every ~6-7 cycles (one every 4 when independent; the SIMD itself takes one wave64 instruction
+// per 2 cycles, MI355X_MICROARCH.md "cycle constants", tools/valu_issue.hip).  At 4 waves per SIMD, 37 % of them parked on a
+// wait, the SIMD idled half of the time (SQ_ACTIVE_INST_VALU 29 % of SQ_WAVE_CYCLES per wave, profiles/r02a/anat_report.txt).
+// Here `eval` is a pure function of the neighbour's operands (no side effects, no branches) evaluated for all four entries of a
+// group unconditionally -- entries past a lane's count are stale but valid indices, their terms are computed and dropped -- and
+// `add(term, valid)` accumulates in list order: `acc = valid ? acc + term : acc`, the same additions in the same order as the
+// masked form.  The scheduler interleaves the four chains.
+template <bool SCALED, class Eval, class Add>
+__device__ __forceinline__ void walk_staged_p(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A, Eval eval, Add add)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const float4 a0 = s_A[jj.x], a1 = s_A[jj.y], a2 = s_A[jj.z], a3 = s_A[jj.w];
+        ahead.advance(kk);
+        const auto t0 = eval(a0), t1 = eval(a1), t2 = eval(a2), t3 = eval(a3);
+        add(t0, true); add(t1, kk + 1 < cnt); add(t2, kk + 2 < cnt); add(t3, kk + 3 < cnt);
+    }
+}
+template <bool SCALED, class Eval, class Add>
+__device__ __forceinline__ void walk_staged_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                               const float2 *__restrict__ s_B, Eval eval, Add add)
+{
+    NlAhead ahead(base);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint4 jj = ahead.front();
+        const float4 a0 = s_A[jj.x], a1 = s_A[jj.y], a2 = s_A[jj.z], a3 = s_A[jj.w];
+        const float2 b0 = s_B[jj.x], b1 = s_B[jj.y], b2 = s_B[jj.z], b3 = s_B[jj.w];
+        ahead.advance(kk);
+        const auto t0 = eval(a0, b0), t1 = eval(a1, b1), t2 = eval(a2, b2), t3 = eval(a3, b3);
+        add(t0, true); add(t1, kk + 1 < cnt); add(t2, kk + 2 < cnt); add(t3, kk + 3 < cnt);
+    }
+}
+
 template <bool DFSPH, bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
@@ -1139,7 +1176,23 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             }
         }
     };
-    if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
+    if (staged && !RIGID)
+        walk_staged_p<true>(nlp, kf, s_operand, [&](const float4 pj) -> F3 {
+            const float dx = sx_i - pj.x, dy = sy_i - pj.y, dz = sz_i - pj.z;
+            const float r = norm3_scaled(dx, dy, dz);
+            const F3 g = grad_w_scaled(c, dx, dy, dz, r);
+            const float ks = kr_i + pj.w;
+            // The 1e-5 gate of the divergence solve (:367) as a factor instead of a branch: a skipped pair contributes s = +0, i.e.
+            // terms of +-0, and x + (+-0) == x bit for bit unless x is -0 -- which a sum that starts at +0 never is (in round-to-
+            // nearest a sum is -0 only if both operands are).  g is finite (grad_w_scaled selects 0 at r = 0).  A select on the
+            // terms instead would let the compiler sink the whole gradient under the gate: four masked regions per group again.
+            const float s = (MODE != CORR_DIV || ks > 1e-5f) ? c.m * ks : 0.0f;   // :337 / :369 / :203
+            return {s * g.x, s * g.y, s * g.z};
+        }, [&](const F3 &t, bool valid) {
+            const float nx = ax + t.x, ny = ay + t.y, nz = az + t.z;
+            ax = valid ? nx : ax; ay = valid ? ny : ay; az = valid ? nz : az;
+        });
+    else if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -1215,7 +1268,14 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);
         }
     };
-    if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
+    if (staged && !RIGID)
+        walk_staged_pv<true>(nlp, skip ? 0 : kf, s_operand, s_v2, [&](const float4 pa, const float2 pb) -> float {   // (x, y, z, vx) (vy, vz)
+            const float dx = sx_i - pa.x, dy = sy_i - pa.y, dz = sz_i - pa.z;
+            const float r = norm3_scaled(dx, dy, dz);
+            const F3 g = grad_w_scaled(c, dx, dy, dz, r);
+            return c.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);                                 // :287 / :162
+        }, [&](float t, bool valid) { const float n = acc + t; acc = valid ? n : acc; });
+    else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float accb = 0.f;
     for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {

@@ -1,9 +1,18 @@
 #!/bin/bash
-# TCP / SQ / TCC counters of the sweeps (a pass with the TA_* counters hung rocprofv3 on this pool: left out) (separate --pmc passes on a short run) -> gpurun_out/anat_*/ ; tools/pmc_sweep_report.py prints per-kernel means
+# SQ / LDS counters of the sweeps, separate --pmc passes over a short run; prints per-kernel means (tools/pmc_sweep_report.py) into
+# gpurun_out/anat_report[_TAG].txt and removes the (large) rocpd databases.  (A pass with the TA_* counters hung rocprofv3 on this pool: left out.)
+# Usage: [SPH_LIB=alt.so] [TAG=name] tools/pmc_sweep_anatomy.sh [bench args]       values are means per (launch, XCD x SE instance): x 32 = per launch
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ARGS=${@:---preroll 30 --steps 3 --warmup 1}
+OUT=$R/gpurun_out/anat_report${TAG:+_$TAG}.txt
+: > $OUT
 pass() { name=$1; shift
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc "$@" -d $R/gpurun_out/anat_$name -o a -- python3 $R/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/anat_$name.err || return 1; }
-pass tcp TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_FLAT_READ_WAVEFRONTS_sum &&
-pass sq SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE &&
-pass l2 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/anat_$name -o a -- python3 $R/bench.py $ARGS --profile-steps 0 --no-cpu-baseline --no-scaling-base > /dev/null 2> /tmp/anat_$name.err
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "pass $name failed rc=$rc" >> $OUT; tail -5 /tmp/anat_$name.err >> $OUT; return 0; fi
+  python3 $R/tools/pmc_sweep_report.py $(find /tmp/anat_$name -name "*.db") >> $OUT 2>&1; rm -rf /tmp/anat_$name; }
+pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU
+pass sq2 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM
+pass sq3 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_RD SQ_LEVEL_WAVES
+[ -n "$QUIET" ] || cut -c1-1200 $OUT

@@ -1,5 +1,6 @@
 """Per-kernel means of the counters tools/pmc_sweep_anatomy.sh collected (rocpd databases): tools/pmc_sweep_report.py gpurun_out/anat_*/a_results.db"""
 import collections
+import os
 import re
 import sqlite3
 import sys
@@ -14,7 +15,7 @@ for path in sys.argv[1:]:
             per[m.group(1) + (m.group(2) or "")][cn].append(cv)
     print(path)
     for k in sorted(per, key=lambda k: -sum(len(v) for v in per[k].values())):
-        if not re.match(r"k_(residual|correct|density|dfsph_ext|build_nl)", k):
+        if not re.match(os.environ.get("ANAT_KERNELS", r"k_(residual|correct|density|dfsph_ext|build_nl)"), k):
             continue
         # launches of a gated sweep that exit at once count almost nothing: keep launches above half of the maximum of the first counter
         first = sorted(per[k])[0]
