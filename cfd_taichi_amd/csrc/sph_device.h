@@ -52,6 +52,7 @@ struct Consts {
     int tbits, tnx, tnxz; // tiles of 2^tbits cells per axis; tile strides: tiles along x, tiles along x times tiles along z
     const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
     int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
+    int nl16;             // fluid lists of staged workgroups hold 16-bit local indices, eight per 16-byte group (NlWriter)
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).
@@ -194,6 +195,14 @@ __device__ __forceinline__ float cubic_w_in(const Consts &c, float r)
     return q <= 0.5f ? w1 : (q <= 1.0f ? w2 : 0.0f);      // 0 <= q holds; the upper compare stays for q = NaN (a particle that blew up
                                                           // passes the reference's `norm > h` skip and must contribute 0, solver_base.py:84-87)
 }
+// The 1e-5 gate (:97) is applied to the SCALAR s, once, instead of to the three components: on gfx950 a v_cndmask_b32 whose mask
+// does not come straight out of the preceding v_cmp costs ~23 cycles (the mask is fetched through the CU's scalar register port,
+// tools/valu_issue.hip), so "one compare, three selects" was 55 of the body's 212 cycles.  With s = 0 the numerators are +-0 and so
+// are the quotients; every consumer ADDS the components (times a finite factor) to an accumulator that starts at +0, and
+// x + (+-0) == x bit for bit for every x but -0, which such a sum never is.  The divisor of a gated pair (r = 0: coincident
+// particles) is raised to a finite value so that 0 / den stays 0; for any pair that passes the gate h * r >= 1e-7 and the max is
+// the identity.
+constexpr float kDenFloor = 1e-30f;
 __device__ __forceinline__ F3 grad_w_in(const Consts &c, float dx, float dy, float dz, float r_norm)
 {
     float q = div_by_h(c, r_norm);
@@ -202,13 +211,10 @@ __device__ __forceinline__ F3 grad_w_in(const Consts &c, float dx, float dy, flo
     float t = 1.0f - q;
     float s2 = c.neg_kg6 * (t * t);
     float s = q <= 0.5f ? s1 : s2;
-    const Recip den = recip_prepare(c.h * r_norm);
-    float ox = div_shared(s * dx, den), oy = div_shared(s * dy, den), oz = div_shared(s * dz, den);
-    const bool in = 1e-5f < q;                            // :97 (q <= 1 holds for every list member)
+    s = 1e-5f < q ? s : 0.0f;                             // :97 (q <= 1 holds for every list member)
+    const Recip den = recip_prepare(__builtin_fmaxf(c.h * r_norm, kDenFloor));
     F3 o;
-    o.x = in ? ox : 0.0f;
-    o.y = in ? oy : 0.0f;
-    o.z = in ? oz : 0.0f;
+    o.x = div_shared(s * dx, den); o.y = div_shared(s * dy, den); o.z = div_shared(s * dz, den);
     return o;
 }
 
@@ -258,13 +264,10 @@ __device__ __forceinline__ F3 grad_w_scaled(const Consts &c, float dxs, float dy
     float t = 1.0f - q;
     float s2 = c.neg_kg6 * (t * t);
     float s = q <= 0.5f ? s1 : s2;
-    const Recip den = recip_prepare(c.h * rs);                     // (h * r) * 2^32
-    float ox = div_shared(s * dxs, den), oy = div_shared(s * dys, den), oz = div_shared(s * dzs, den);
-    const bool in = 1e-5f < q;
+    s = 1e-5f < q ? s : 0.0f;                                      // the gate on the scalar (see grad_w_in)
+    const Recip den = recip_prepare(__builtin_fmaxf(c.h * rs, kDenFloor));   // (h * r) * 2^32
     F3 o;
-    o.x = in ? ox : 0.0f;
-    o.y = in ? oy : 0.0f;
-    o.z = in ? oz : 0.0f;
+    o.x = div_shared(s * dxs, den); o.y = div_shared(s * dys, den); o.z = div_shared(s * dzs, den);
     return o;
 }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)

@@ -380,23 +380,52 @@ __device__ __forceinline__ unsigned near_mask4(f32x2 pi_xy, float pi_z, const fl
 }
 
 // List append through an LDS staging row per lane (transposed: slot s of thread t at [s * kBlock + t], conflict-free): no
-// register shuffling on (k & 3), one 16-byte store per completed group of four.
+// register shuffling on (k & 3), one 16-byte store per completed group.
+// Two entry formats.  32-bit: four entries per 16-byte group.  16-bit (`half`: fluid lists of a staged workgroup on an nl16 handle,
+// whose entries are indices local to the workgroup's staged set, < stage_cap <= 2560): EIGHT entries per group, entry 2q in the low
+// and 2q + 1 in the high half of word q -- the index stream, the one part of a sweep that always comes from HBM, is halved.
 struct NlWriter {
     uint32_t *stage;        // this thread's column of the block's staging area
     uint32_t *base;
     int k, kcap;
+    bool half;
+    uint32_t pend;
+    bool zero_next;
     __device__ __forceinline__ void push(uint32_t j)
     {
-        const int s = k & 3;
-        stage[s * kBlock] = j;
-        if (s == 3 && k < kcap)
-            *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], j);
+        if (half) {
+            const int s = k & 7;
+            if (s & 1) {
+                const uint32_t w = pend | (j << 16);
+                stage[(s >> 1) * kBlock] = w;
+                if (s == 7 && k < kcap)
+                    *reinterpret_cast<uint4 *>(base + (size_t)(k >> 3) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], w);
+            } else {
+                pend = j;
+            }
+        } else {
+            const int s = k & 3;
+            stage[s * kBlock] = j;
+            if (s == 3 && k < kcap)
+                *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], j);
+        }
         ++k;
     }
     __device__ __forceinline__ void flush()
     {
-        if ((k & 3) != 0 && k < kcap)   // tail slots: stale but valid indices
-            *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
+        if (half) {
+            if ((k & 1) != 0) stage[((k & 7) >> 1) * kBlock] = pend;       // odd count: the high half is entry 0 of the set, a valid index
+            if ((k & 7) != 0 && k < kcap)
+                *reinterpret_cast<uint4 *>(base + (size_t)(k >> 3) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
+        } else {
+            if ((k & 3) != 0 && k < kcap)   // tail slots: stale but valid indices
+                *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
+            // The 32-bit walks request one group past a list's end and gather through it speculatively ("stale but valid indices").
+            // On an nl16 handle a stale group may hold PACKED pairs from a step in which this workgroup was staged -- as a 32-bit
+            // index far outside the arrays (this faulted in the mixed-capacity test).  Such a workgroup zeroes the one group its
+            // walks can read ahead (the tile pitch keeps a spare group beyond kmax entries).
+            if (zero_next && k <= kcap) *reinterpret_cast<uint4 *>(base + (size_t)((k + 3) >> 2) * 256) = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 };
 
@@ -509,8 +538,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         const f32x2 pi_xy = {pi.x, pi.y};
         int cx, cy, cz;
         cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
-        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kpitch), 0, c.kmax};
-        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbpitch), 0, c.kbmax};
+        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
+        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
         int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
         const int my_id = RIGID ? id[i] : 0;
         const bool tiled = c.order == CELL_ORDER_TILED;
@@ -762,6 +791,11 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
 // the workgroup's operand array through stage_src into LDS (see the staging plan in k_build_nl); returns false when this
 // workgroup keeps global indices.  Uniform per workgroup; every thread of the workgroup must call it.
 // SCALED: the positions are staged multiplied by 2^32 (exact; see norm3_scaled in sph_device.h), .w unchanged
+// The copy is two dependent gathers per element (src[e], then A[src[e]]: ~700 cycles each out of L2, more from HBM).  All of a
+// thread's source indices are requested first, then all of its operands, then the LDS stores: two round trips per workgroup instead
+// of two per element (kStageBatch elements per thread and trip; a clamped index keeps the loads branch-free so that the compiler
+// leaves them in one batch; only the store is predicated).  Staging was 12 of the residual sweep's 64 us at 1 M particles.
+constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
                                               const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
@@ -769,9 +803,17 @@ __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restric
     const int nst = stage_cnt[blk];
     if (nst < 0) return false;
     const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int e = threadIdx.x; e < nst; e += kBlock) {
-        const float4 a = A[src[e]];
-        s_A[e] = SCALED ? make_float4(a.x * 0x1p32f, a.y * 0x1p32f, a.z * 0x1p32f, a.w) : a;
+    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
+        uint32_t j[kStageBatch];
+        float4 a[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[j[u]];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst)
+                s_A[base + u * kBlock] = SCALED ? make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, a[u].w) : a[u];
     }
     __syncthreads();
     return true;
@@ -785,7 +827,17 @@ __device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__res
     const int nst = stage_cnt[blk];
     if (nst < 0) return false;
     const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int e = threadIdx.x; e < nst; e += kBlock) { const uint32_t j = src[e]; s_src[e] = j; s_A[e] = A[j]; }
+    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
+        uint32_t j[kStageBatch];
+        float4 a[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[j[u]];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) { s_src[base + u * kBlock] = j[u]; s_A[base + u * kBlock] = a[u]; }
+    }
     __syncthreads();
     return true;
 }
@@ -857,12 +909,23 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
     const int nst = stage_cnt[blk];
     if (nst < 0) return false;
     const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int e = threadIdx.x; e < nst; e += kBlock) {
-        const uint32_t j = src[e];
-        const float4 a = A[j], b = B[j];
-        s_A[e] = SCALED ? make_float4(a.x * 0x1p32f, a.y * 0x1p32f, a.z * 0x1p32f, b.x) : make_float4(a.x, a.y, a.z, b.x);
-        s_B[e] = make_float2(b.y, b.z);
+#ifndef SPH_X_NOSTAGE
+    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
+        uint32_t j[kStageBatch];
+        float4 a[kStageBatch], b[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[j[u]]; b[u] = B[j[u]]; }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) {
+                const int e = base + u * kBlock;
+                s_A[e] = SCALED ? make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, b[u].x) : make_float4(a[u].x, a[u].y, a[u].z, b[u].x);
+                s_B[e] = make_float2(b[u].y, b[u].z);
+            }
     }
+#endif
     __syncthreads();
     return true;
 }
@@ -870,10 +933,19 @@ template <bool RIGID, bool SCALED = false, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                     const float2 *__restrict__ s_B, const RigidView &rv, Body body)
 {
+#ifdef SPH_X_SYNIDX
+    uint32_t jsyn = threadIdx.x * 5u;
+#else
     NlAhead ahead(base);
+#endif
     for (int kk = 0; kk < cnt; kk += 4) {
+#ifdef SPH_X_SYNIDX
+        const uint32_t j[4] = {(jsyn + 3u) % 1024u, (jsyn + 11u) % 1024u, (jsyn + 17u) % 1024u, (jsyn + 29u) % 1024u};
+        jsyn = jsyn * 3u + 1u;
+#else
         const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
+#endif
         float4 a[4], b[4];
         if (RIGID && __any(((j[0] | j[1] | j[2] | j[3]) & kRigidTag) != 0)) {      // wave-uniform, rare (see for_staged_nbrs)
 #pragma unroll
@@ -898,7 +970,9 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
                 b[u] = make_float4(pa.w, pb.x, pb.y, 0.f);
             }
         }
+#ifndef SPH_X_SYNIDX
         ahead.advance(kk);
+#endif
         body(a[0], b[0], j[0]);
         if (kk + 1 < cnt) body(a[1], b[1], j[1]);
         if (kk + 2 < cnt) body(a[2], b[2], j[2]);
@@ -906,41 +980,65 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
     }
 }
 
-// ---- staged walks with the pair bodies of a group in ONE basic block ---------------------------------------------------------
-// The walkers above run `body` under an EXEC-masked region per neighbour (`if (kk + u < cnt) body(...)`): four separate basic blocks
-// per group, each a single dependent chain (difference -> square root -> Newton division -> dot product), and a wave issues a
-// dependent VALU instruction only every ~6-7 cycles (one every 4 when independent; the SIMD itself takes one wave64 instruction
-// per 2 cycles, MI355X_MICROARCH.md "cycle constants", tools/valu_issue.hip).  At 4 waves per SIMD, 37 % of them parked on a
-// wait, the SIMD idled half of the time (SQ_ACTIVE_INST_VALU 29 % of SQ_WAVE_CYCLES per wave, profiles/r02a/anat_report.txt).
-// Here `eval` is a pure function of the neighbour's operands (no side effects, no branches) evaluated for all four entries of a
-// group unconditionally -- entries past a lane's count are stale but valid indices, their terms are computed and dropped -- and
-// `add(term, valid)` accumulates in list order: `acc = valid ? acc + term : acc`, the same additions in the same order as the
-// masked form.  The scheduler interleaves the four chains.
-template <bool SCALED, class Eval, class Add>
-__device__ __forceinline__ void walk_staged_p(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A, Eval eval, Add add)
+// ---- walks of a 16-bit list (staged workgroup of an nl16 handle; no rigid entries): one 16-byte load = eight neighbours, taken
+// four at a time so that the registers in flight stay those of the 32-bit walk.  The next group is requested before the bodies
+// run, and only by lanes whose list goes on (the 32-bit walks read one stale group past the end: 16 B per particle and sweep).
+struct Nl16Group {
+    uint32_t w[4];
+    __device__ __forceinline__ uint32_t lo(int q) const { return w[q] & 0xffffu; }
+    __device__ __forceinline__ uint32_t hi(int q) const { return w[q] >> 16; }
+};
+template <class Fetch4>
+__device__ __forceinline__ void walk_list16(const uint32_t *__restrict__ base, int cnt, Fetch4 fetch4)
 {
-    NlAhead ahead(base);
-    for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = ahead.front();
-        const float4 a0 = s_A[jj.x], a1 = s_A[jj.y], a2 = s_A[jj.z], a3 = s_A[jj.w];
-        ahead.advance(kk);
-        const auto t0 = eval(a0), t1 = eval(a1), t2 = eval(a2), t3 = eval(a3);
-        add(t0, true); add(t1, kk + 1 < cnt); add(t2, kk + 2 < cnt); add(t3, kk + 3 < cnt);
+    if (cnt <= 0) return;
+    uint4 jn = nl_load(base);
+    for (int kk = 0; kk < cnt; kk += 8) {
+        const Nl16Group g = {{jn.x, jn.y, jn.z, jn.w}};
+        if (kk + 8 < cnt) jn = nl_load(base + (size_t)((kk >> 3) + 1) * 256);
+        fetch4(g.lo(0), g.hi(0), g.lo(1), g.hi(1), kk);
+        if (kk + 4 < cnt) fetch4(g.lo(2), g.hi(2), g.lo(3), g.hi(3), kk + 4);
     }
 }
-template <bool SCALED, class Eval, class Add>
-__device__ __forceinline__ void walk_staged_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
-                                               const float2 *__restrict__ s_B, Eval eval, Add add)
+template <class Body>
+__device__ __forceinline__ void for_staged16_nbrs(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A, Body body)
 {
-    NlAhead ahead(base);
-    for (int kk = 0; kk < cnt; kk += 4) {
-        const uint4 jj = ahead.front();
-        const float4 a0 = s_A[jj.x], a1 = s_A[jj.y], a2 = s_A[jj.z], a3 = s_A[jj.w];
-        const float2 b0 = s_B[jj.x], b1 = s_B[jj.y], b2 = s_B[jj.z], b3 = s_B[jj.w];
-        ahead.advance(kk);
-        const auto t0 = eval(a0, b0), t1 = eval(a1, b1), t2 = eval(a2, b2), t3 = eval(a3, b3);
-        add(t0, true); add(t1, kk + 1 < cnt); add(t2, kk + 2 < cnt); add(t3, kk + 3 < cnt);
-    }
+    const float4 none = make_float4(0.f, 0.f, 0.f, 0.f);
+    walk_list16(base, cnt, [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3, int k0) {
+        const float4 a0 = s_A[j0], a1 = s_A[j1], a2 = s_A[j2], a3 = s_A[j3];
+        body(a0, none, 0u);
+        if (k0 + 1 < cnt) body(a1, none, 0u);
+        if (k0 + 2 < cnt) body(a2, none, 0u);
+        if (k0 + 3 < cnt) body(a3, none, 0u);
+    });
+}
+// A staged in LDS, B gathered from memory through the staged source index (k_dfsph_ext and the pressure solvers' three-operand sweeps)
+template <class Body>
+__device__ __forceinline__ void for_staged16_nbrs_pv(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                     const uint32_t *__restrict__ s_src, const float4 *__restrict__ B, Body body)
+{
+    walk_list16(base, cnt, [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3, int k0) {
+        const float4 b0 = B[s_src[j0]], b1 = B[s_src[j1]], b2 = B[s_src[j2]], b3 = B[s_src[j3]];
+        const float4 a0 = s_A[j0], a1 = s_A[j1], a2 = s_A[j2], a3 = s_A[j3];
+        body(a0, b0, 0u);
+        if (k0 + 1 < cnt) body(a1, b1, 0u);
+        if (k0 + 2 < cnt) body(a2, b2, 0u);
+        if (k0 + 3 < cnt) body(a3, b3, 0u);
+    });
+}
+// both operands staged: (x, y, z, vx) and (vy, vz)
+template <class Body>
+__device__ __forceinline__ void for_staged16_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
+                                                      const float2 *__restrict__ s_B, Body body)
+{
+    walk_list16(base, cnt, [&](uint32_t j0, uint32_t j1, uint32_t j2, uint32_t j3, int k0) {
+        const float4 a0 = s_A[j0], a1 = s_A[j1], a2 = s_A[j2], a3 = s_A[j3];
+        const float2 b0 = s_B[j0], b1 = s_B[j1], b2 = s_B[j2], b3 = s_B[j3];
+        body(make_float4(a0.x, a0.y, a0.z, 0.f), make_float4(a0.w, b0.x, b0.y, 0.f), 0u);
+        if (k0 + 1 < cnt) body(make_float4(a1.x, a1.y, a1.z, 0.f), make_float4(a1.w, b1.x, b1.y, 0.f), 0u);
+        if (k0 + 2 < cnt) body(make_float4(a2.x, a2.y, a2.z, 0.f), make_float4(a2.w, b2.x, b2.y, 0.f), 0u);
+        if (k0 + 3 < cnt) body(make_float4(a3.x, a3.y, a3.z, 0.f), make_float4(a3.w, b3.x, b3.y, 0.f), 0u);
+    });
 }
 
 template <bool DFSPH, bool RIGID, bool STAGED>
@@ -972,7 +1070,8 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
     };
-    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair);
+    else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
@@ -1176,22 +1275,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             }
         }
     };
-    if (staged && !RIGID)
-        walk_staged_p<true>(nlp, kf, s_operand, [&](const float4 pj) -> F3 {
-            const float dx = sx_i - pj.x, dy = sy_i - pj.y, dz = sz_i - pj.z;
-            const float r = norm3_scaled(dx, dy, dz);
-            const F3 g = grad_w_scaled(c, dx, dy, dz, r);
-            const float ks = kr_i + pj.w;
-            // The 1e-5 gate of the divergence solve (:367) as a factor instead of a branch: a skipped pair contributes s = +0, i.e.
-            // terms of +-0, and x + (+-0) == x bit for bit unless x is -0 -- which a sum that starts at +0 never is (in round-to-
-            // nearest a sum is -0 only if both operands are).  g is finite (grad_w_scaled selects 0 at r = 0).  A select on the
-            // terms instead would let the compiler sink the whole gradient under the gate: four masked regions per group again.
-            const float s = (MODE != CORR_DIV || ks > 1e-5f) ? c.m * ks : 0.0f;   // :337 / :369 / :203
-            return {s * g.x, s * g.y, s * g.z};
-        }, [&](const F3 &t, bool valid) {
-            const float nx = ax + t.x, ny = ay + t.y, nz = az + t.z;
-            ax = valid ? nx : ax; ay = valid ? ny : ay; az = valid ? nz : az;
-        });
+    if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
     else if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
@@ -1268,17 +1352,21 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);
         }
     };
-    if (staged && !RIGID)
-        walk_staged_pv<true>(nlp, skip ? 0 : kf, s_operand, s_v2, [&](const float4 pa, const float2 pb) -> float {   // (x, y, z, vx) (vy, vz)
-            const float dx = sx_i - pa.x, dy = sy_i - pa.y, dz = sz_i - pa.z;
-            const float r = norm3_scaled(dx, dy, dz);
-            const F3 g = grad_w_scaled(c, dx, dy, dz, r);
-            return c.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);                                 // :287 / :162
-        }, [&](float t, bool valid) { const float n = acc + t; acc = valid ? n : acc; });
-    else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
-    else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
+#ifdef SPH_X_NOFLUID      // removal experiments (timing only, results are wrong): tools/README.md
+    const int kf_x = 0;
+#else
+    const int kf_x = kf;
+#endif
+#ifdef SPH_X_NOWALL
+    const int kb_x = 0;
+#else
+    const int kb_x = kb;
+#endif
+    if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf_x, s_operand, s_v2, pair_scaled);
+    else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf_x, s_operand, s_v2, rv, pair_scaled);
+    else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf_x, P, V, rv, pair);
     float accb = 0.f;
-    for_nbrs_p(nlbp, skip ? 0 : kb, WP, [&](const float4 pj) {
+    for_nbrs_p(nlbp, skip ? 0 : kb_x, WP, [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w_in(c, dx, dy, dz, r);
@@ -1361,7 +1449,8 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
     };
-    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
+    if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
+    else if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float vn = -INFINITY;
     if (live) {

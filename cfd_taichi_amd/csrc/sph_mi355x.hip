@@ -390,8 +390,11 @@ int build_scene(SphHandle *h, HostScene &sc)
         // per tile walks the rows of consecutive tiles through all residues.
         const char *e = getenv("SPH_NL_PITCH_PAD");
         const int pad = e ? atoi(e) & ~3 : 4;
-        c.kpitch = c.kmax + (((c.kmax >> 2) & 1) ? 0 : pad);
-        c.kbpitch = c.kbmax + (((c.kbmax >> 2) & 1) ? 0 : pad);
+        // (every tile also keeps at least one spare group beyond kmax entries: the walks read one group ahead, NlWriter::flush)
+        c.kpitch = c.kmax + (((c.kmax >> 2) & 1) ? 2 * pad : pad);
+        c.kbpitch = c.kbmax + (((c.kbmax >> 2) & 1) ? 2 * pad : pad);
+        if (c.kpitch < c.kmax + 4) c.kpitch = c.kmax + 4;
+        if (c.kbpitch < c.kbmax + 4) c.kbpitch = c.kbmax + 4;
     }
     if ((long long)h->N >= (1LL << 28) || (long long)h->Nb >= (1LL << 28))
         return fail(h, SPH_E_INVALID, "%d fluid / %d wall particles: one handle addresses its particle arrays with 32-bit byte offsets (< 2^28 particles); shard the scene over slabs", h->N, h->Nb);
@@ -1368,6 +1371,9 @@ int stage_sort_and_lists(SphHandle *h)
         if ((rc = slab_exchange_particles(h))) return rc;
     }
     Consts &c = h->c;
+    // 16-bit local indices in the fluid lists of staged workgroups: the dfsph sweeps without rigid entries (tagged rigid entries need
+    // 32 bits; the pcisph / iisph sweeps keep the 32-bit walks).  SPH_NL16=0 turns it off (A/B, tests/test_cell_order_gpu.py)
+    { const char *e = getenv("SPH_NL16"); c.nl16 = (h->staged && is_dfsph(h) && !rigid_coupled(h) && !(e && atoi(e) == 0)) ? 1 : 0; }
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
     const dim3 b(kBlock);

@@ -9,11 +9,57 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 #include "sph_device.h"
 using namespace sph;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr int kCap = 1664;
+
+// ---- candidate forms of the body (KIND >= 2); each must reproduce KIND 0 bit for bit --------------------------------------
+struct PairK { float rh_s, h_s, kg6, neg_kg6, h, m; };
+template <bool PIN>
+__device__ __forceinline__ PairK pair_consts(const Consts &c)
+{
+    PairK k = {c.rh_s, c.h_s, c.kg6, c.neg_kg6, c.h, c.m};
+    if (PIN) asm volatile("" : "+v"(k.rh_s), "+v"(k.h_s), "+v"(k.kg6), "+v"(k.neg_kg6), "+v"(k.h), "+v"(k.m));   // VGPR residents: an SGPR operand halves the issue rate
+    return k;
+}
+__device__ __forceinline__ float sqrt_fma(float x)      // LLVM's correctly rounded f32 sqrt for the no-denormal case: rsq + 2 mul + 5 fma, no selects
+{
+    const float r0 = __builtin_amdgcn_rsqf(x);
+    float s = x * r0, h = 0.5f * r0;
+    const float e = __builtin_fmaf(-h, s, 0.5f);
+    h = __builtin_fmaf(h, e, h);
+    s = __builtin_fmaf(s, e, s);
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
+}
+template <bool FMASQRT>
+__device__ __forceinline__ float norm3_scaled2(float xs, float ys, float zs)
+{
+    const float x = (xs * xs + ys * ys) + zs * zs;
+    if (FMASQRT) return sqrt_fma(x);
+    return norm3_scaled(xs, ys, zs);
+}
+__device__ __forceinline__ F3 grad_w_scaled2(const PairK &k, float dxs, float dys, float dzs, float rs)
+{
+    float q0 = rs * k.rh_s;
+    float e = __builtin_fmaf(-q0, k.h_s, rs);
+    float q = __builtin_fmaf(e, k.rh_s, q0);
+    float q2 = q * q;
+    float s1 = k.kg6 * (3.0f * q2 - 2.0f * q);
+    float t = 1.0f - q;
+    float s2 = k.neg_kg6 * (t * t);
+    float s = q <= 0.5f ? s1 : s2;
+    s = 1e-5f < q ? s : 0.0f;                                      // ONE select on the scalar instead of three on the components (a v_cndmask whose
+                                                                   // mask does not come straight from the preceding v_cmp costs ~23 cycles)
+    const Recip den = recip_prepare(__builtin_fmaxf(k.h * rs, 1e-30f));   // r = 0 (coincident particles): finite divisor, numerators are 0
+    F3 o;
+    o.x = div_shared(s * dxs, den); o.y = div_shared(s * dys, den); o.z = div_shared(s * dzs, den);
+    return o;
+}
 
 template <int KIND, bool SCATTER>
 __global__ __launch_bounds__(256) void k_body(Consts c, float *out, int groups, const uint32_t *idx)
@@ -31,8 +77,14 @@ __global__ __launch_bounds__(256) void k_body(Consts c, float *out, int groups, 
     float acc = 0.f;
     const int cnt = groups * 4 - (threadIdx.x & 3);          // ragged like a real list
     uint32_t j0 = SCATTER ? idx[threadIdx.x] : 0u;
+    const PairK pk = pair_consts<(KIND >= 3)>(c);
     auto eval = [&](const float4 pa, const float2 pb) -> float {
         const float dx = sx_i - pa.x, dy = sy_i - pa.y, dz = sz_i - pa.z;
+        if (KIND >= 2) {
+            const float r = norm3_scaled2<(KIND >= 4)>(dx, dy, dz);
+            const F3 g = grad_w_scaled2(pk, dx, dy, dz, r);
+            return pk.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);
+        }
         const float r = norm3_scaled(dx, dy, dz);
         const F3 g = grad_w_scaled(c, dx, dy, dz, r);
         return c.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);
@@ -43,7 +95,7 @@ __global__ __launch_bounds__(256) void k_body(Consts c, float *out, int groups, 
         for (int u = 0; u < 4; ++u) { j0 = (j0 * 5u + 7u + (SCATTER ? 0u : 0u)) % kCap; j[u] = SCATTER ? j0 : (uint32_t)((kk + u) % kCap); }
         const float4 a0 = s_A[j[0]], a1 = s_A[j[1]], a2 = s_A[j[2]], a3 = s_A[j[3]];
         const float2 b0 = s_B[j[0]], b1 = s_B[j[1]], b2 = s_B[j[2]], b3 = s_B[j[3]];
-        if (KIND == 0) {
+        if (KIND != 1) {
             acc += eval(a0, b0);
             if (kk + 1 < cnt) acc += eval(a1, b1);
             if (kk + 2 < cnt) acc += eval(a2, b2);
@@ -84,7 +136,7 @@ double run(const Consts &c, int cus, float *dout, const uint32_t *didx, int grou
 
 int main(int argc, char **argv)
 {
-    const double target = argc > 1 ? atof(argv[1]) : 38e6;
+    const double target = argc > 1 ? atof(argv[1]) : 31.1e6;    // wave-level body executions x 64 of one sweep over dfsph_1m at step 60 (tools/nbr_stats.py)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -101,11 +153,33 @@ int main(int argc, char **argv)
     for (int t = 0; t < 256; ++t) hidx[t] = (uint32_t)((t * 2654435761u) % kCap);
     CHECK(hipMemcpy(didx, hidx, sizeof(hidx), hipMemcpyHostToDevice));
     const int groups = 250;
-    const double r[4] = {run<0, true>(c, cus, dout, didx, groups), run<1, true>(c, cus, dout, didx, groups), run<0, false>(c, cus, dout, didx, groups),
-                         run<1, false>(c, cus, dout, didx, groups)};
-    const char *names[4] = {"seq_x", "ilp_x", "seq_c", "ilp_c"};
-    printf("{\"pairs_per_sweep\": %.3g, \"results\": {", target);
-    for (int k = 0; k < 4; ++k) printf("\"%s\": {\"Gpairs_per_s\": %.1f, \"us_per_sweep\": %.1f}%s", names[k], r[k] / 1e9, target / r[k] * 1e6, k == 3 ? "" : ", ");
+    const int nout = cus * 16 * 256;
+    std::vector<float> ref(nout), got(nout);
+    const char *names[5] = {"seq (current body)", "one basic block", "seq, gate on the scalar + max(den)", "+ constants in VGPRs", "+ fma square root"};
+    printf("{\"pairs_per_sweep\": %.3g, \"results\": {\n", target);
+    for (int kind = 0; kind < 5; ++kind) {
+        double rx, rc;
+        switch (kind) {
+        case 0: rx = run<0, true>(c, cus, dout, didx, groups); break;
+        case 1: rx = run<1, true>(c, cus, dout, didx, groups); break;
+        case 2: rx = run<2, true>(c, cus, dout, didx, groups); break;
+        case 3: rx = run<3, true>(c, cus, dout, didx, groups); break;
+        default: rx = run<4, true>(c, cus, dout, didx, groups); break;
+        }
+        CHECK(hipMemcpy(got.data(), dout, (size_t)nout * 4, hipMemcpyDeviceToHost));
+        if (kind == 0) ref = got;
+        size_t bad = 0;
+        for (int i = 0; i < nout; ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+        switch (kind) {
+        case 0: rc = run<0, false>(c, cus, dout, didx, groups); break;
+        case 1: rc = run<1, false>(c, cus, dout, didx, groups); break;
+        case 2: rc = run<2, false>(c, cus, dout, didx, groups); break;
+        case 3: rc = run<3, false>(c, cus, dout, didx, groups); break;
+        default: rc = run<4, false>(c, cus, dout, didx, groups); break;
+        }
+        printf("  \"%s\": {\"scattered_us\": %.1f, \"conflict_free_us\": %.1f, \"outputs_differing_from_current\": %zu}%s\n", names[kind], target / rx * 1e6,
+               target / rc * 1e6, bad, kind == 4 ? "" : ",");
+    }
     printf("}}\n");
     return 0;
 }

@@ -1,6 +1,8 @@
 """Interleaved timing of the DFSPH sweeps for SEVERAL builds of the library inside one process (one clock state):
     tools/tune_libs.py scene advance_steps name=path[:lds[:ENV=value]] ...      (ENV is set while that handle is created)
-Each build gets its own handle on the same scene advanced by the same steps; rounds alternate between the builds."""
+Each build gets its own handle on the same scene advanced by the same steps; rounds alternate between the builds.
+TUNE_COPY_STATE=1: only the first build advances the scene, the others receive its positions / velocities / warm_start_k (for
+removal-experiment builds whose results are wrong on purpose)."""
 import os
 import random
 import statistics
@@ -21,7 +23,12 @@ for spec in sys.argv[3:]:
     sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
     if env:
         del os.environ[env.split("=")[0]]
-    sim.step_dfsph(advance)
+    if not (os.environ.get("TUNE_COPY_STATE") == "1" and sims):
+        sim.step_dfsph(advance)
+        state = [sim.download(f) for f in (nat.F_POS, nat.F_VEL, nat.F_WARM_K)]
+    else:
+        for f, v in zip((nat.F_POS, nat.F_VEL, nat.F_WARM_K), state):
+            sim.upload(f, v)
     sim.build_neighbors()
     sims[name] = (sim, int(lds or 0))
 for which, label in ((0, "div_residual"), (2, "dens_residual"), (1, "div_correct"), (3, "sort+build_nl")):
