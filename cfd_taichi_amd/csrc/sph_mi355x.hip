@@ -2740,6 +2740,19 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
         if (which == 0) launch_div_residual(h, GATE_NONE);
         else if (which == 1) launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         else if (which == 2) launch_dens_residual(h, GATE_NONE);
+        else if (which == 4) {      // a sweep followed by the single-workgroup reduction of its block partials, as in the solver loops
+            launch_div_residual(h, GATE_NONE);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+        } else if (which == 5) {    // the reduction alone
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+        } else if (which == 6) {    // two different sweeps alternating (residual, correct), no reduction between them
+            launch_div_residual(h, GATE_NONE);
+            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
+        } else if (which == 7) {    // the same with the reduction after the residual: one solver iteration
+            launch_div_residual(h, GATE_NONE);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
+        }
         else if ((rc = stage_sort_and_lists(h))) break;
     }
     HIP_TRY(h, hipEventRecord(b, h->stream));
