@@ -72,6 +72,7 @@ class ParticleSystem:
             self.rigid_vertices = DeviceField(self, nat.F_RIGID_VERT, nat.SPECIES_RIGID)
             self.rigid_centriod = ScalarField(lambda: np.asarray(self._sim.rigid_scalars()["centroid"], dtype=np.float32))
             self.mesh_faces = self._rigid_input["faces"]
+            self.mesh = _mesh.Mesh(self._rigid_input["vertices"], self.mesh_faces)                  # :42-44 (placed by update_mesh_vextics)
         self.delta_time = ScalarField(lambda: self._sim.scalar(nat.S_PS_DELTA_TIME))   # :37
         print("Boundary particle count: {}k".format(self.boundary_particles_num / 1000))   # :96
         print("Fluid particle count: {}k".format(self.particle_num / 1000))                # :124-127
@@ -110,8 +111,10 @@ class ParticleSystem:
         return self._sim.download(nat.F_NBR_COUNT).astype(np.int32)
 
     def update_mesh_vextics(self):                        # :298-299 (sic)
-        """Current mesh vertices (Nv, 3), as main.py:196-200 needs them for the OBJ export."""
-        return self.rigid_vertices.to_numpy()
+        """`self.mesh.vertices = self.rigid_vertices.to_numpy()`: the mesh follows the body (main.py:196-200 exports it next);
+        also returns the (Nv, 3) array."""
+        self.mesh.vertices = self.rigid_vertices.to_numpy()
+        return self.mesh.vertices
 
     def compute_boundary_particles_count(self):          # :129-137
         box = self.box_max - self.box_min

@@ -10,7 +10,7 @@ from .solver_base import solver_base
 class dfsph_solver(solver_base):
     _kind = "dfsph"
 
-    def __init__(self, particle_system, config, verbose=False):
+    def __init__(self, particle_system, config, verbose=True):
         super().__init__(particle_system, config)
         self.min_iteration_density = 2                  # dfsph_solver.py:21-29
         self.density_threshold = 0.1

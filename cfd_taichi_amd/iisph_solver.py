@@ -9,7 +9,7 @@ from .solver_base import solver_base
 class iisph_solver(solver_base):
     _kind = "iisph"
 
-    def __init__(self, particle_system, config, verbose=False):
+    def __init__(self, particle_system, config, verbose=True):
         super().__init__(particle_system, config)
         self.omega = 0.5                                # iisph_solver.py:26-29
         self.max_iter_cnt = 180

@@ -46,6 +46,22 @@ def load_mesh(path):
     return uniq[order], rank[inv.reshape(-1)].reshape(-1, 3)
 
 
+class Mesh:
+    """What the caller needs of `ps.mesh` (a trimesh.Trimesh in the reference, ParticleSystem.py:42-44): `.vertices` (assigned by
+    `update_mesh_vextics`, :298-299), `.faces`, and `.export(file_type='obj')` returning the Wavefront text main.py:196-200 writes."""
+
+    def __init__(self, vertices, faces):
+        self.vertices = np.asarray(vertices, dtype=np.float64)
+        self.faces = np.asarray(faces, dtype=np.int64)
+
+    def export(self, file_type="obj"):
+        if file_type != "obj":
+            raise ValueError("only file_type='obj' is provided (main.py:199)")
+        lines = ["v %.8f %.8f %.8f" % tuple(v) for v in np.asarray(self.vertices, dtype=np.float64)]
+        lines += ["f %d %d %d" % tuple(int(k) + 1 for k in t) for t in self.faces]
+        return "\n".join(lines) + "\n"
+
+
 def _subdivided_voxels(vertices, faces, pitch, max_iter=10):
     """Voxel indices hit by the vertices of the mesh subdivided until every edge is at most pitch/2 -- trimesh's
     `voxelize_subdivide(mesh, pitch, max_iter=10, edge_factor=2.0)`: four-way midpoint subdivision of every triangle that still has an

@@ -10,7 +10,7 @@ from .solver_base import solver_base
 class pcisph_solver(solver_base):
     _kind = "pcisph"
 
-    def __init__(self, particle_system, config, verbose=False):
+    def __init__(self, particle_system, config, verbose=True):
         super().__init__(particle_system, config)
         self.rho_max_err_percent = .1                   # pcisph_solver.py:19-21
         self.min_iteration = 1

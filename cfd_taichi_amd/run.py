@@ -28,14 +28,6 @@ def write_ply_ascii(path, pos, rgba):
         np.savetxt(f, np.hstack([pos, rgba]), fmt="%.6f")
 
 
-def write_obj(path, vertices, faces):
-    with open(path, "w") as f:
-        for v in vertices:
-            f.write("v %.8f %.8f %.8f\n" % tuple(v))
-        for t in faces:
-            f.write("f %d %d %d\n" % tuple(int(k) + 1 for k in t))
-
-
 def main_sharded(args, config):
     """WORLD_SIZE > 1 (launched by torchrun): one x-slab per rank, native RCCL transport when every rank has its own GPU (else
     torch.distributed callbacks); rank 0 gathers the positions for the PLY frames."""
@@ -128,8 +120,10 @@ def main(argv=None):
         t += iter_cnt * solver.delta_time[None]
         if ply_dir and (t / frame_time) > ply_cnt:                               # :189
             write_ply_ascii(os.path.join(ply_dir, "output_%06d.ply" % ply_cnt), ps.fluid_particles.pos.to_numpy(), np_rgba)
-            if ps.exist_rigid[None] == 1:
-                write_obj(os.path.join(ply_dir, "obj_%06d.obj" % ply_cnt), ps.update_mesh_vextics(), ps.mesh_faces)
+            if ps.exist_rigid[None] == 1:                                        # :196-200
+                ps.update_mesh_vextics()
+                with open(os.path.join(ply_dir, "obj_%06d.obj" % ply_cnt), "w") as f:
+                    f.write(ps.mesh.export(file_type="obj"))
             ply_cnt += 1
         if (args.steps and frame_cnt >= args.steps) or t > args.until:           # :205
             break

@@ -25,10 +25,24 @@ class solver_base:
         self.fs_couple = 1 if solver_config.get("fs_couple", True) else 0               # :32
         self.artificial_friction = 0.9999                    # :37
         self.delta_time = ScalarField(lambda: self._sim.scalar(nat.S_DELTA_TIME))        # :15-16
-        self.simulate_cnt = ScalarField(lambda: int(self._sim.scalar(nat.S_SIMULATE_CNT)))   # :21
+        self._prologue_cnt = 0
+        self.simulate_cnt = ScalarField(lambda: int(self._sim.scalar(nat.S_SIMULATE_CNT)) + self._prologue_cnt)   # :21
         self.rho = DeviceField(self, nat.F_RHO)               # :14
         print("\033[32m[Solver]: {}\033[0m".format(solver_config.get("name")))   # :39
 
     def compute_all_rho(self):
         """solver_base.compute_all_rho (:41-51) as a stand-alone stage (rebuilds the lists if needed)."""
         self._sim.compute_density()
+
+    def reset(self):
+        """solver_base.reset (:131-133): acc <- gravity * (0, -1, 0).  The native force sweeps start every step from that value
+        themselves (wcsph_solver.py:42-47 adds to it); nothing is stored in between, so there is nothing to do here."""
+
+    def step(self):
+        """The prologue every solver's step() starts with (:136-143): count, rebuild the cell lists, reset().  The native
+        `<name>_solver.step()` runs it as part of the fused step; calling it on its own leaves the grid (and the per-step
+        neighbour lists) matching the current positions, e.g. before `compute_all_rho()` / `ps.get_neighbour_count()`."""
+        self._prologue_cnt += 1
+        self.ps.reset_grid()
+        self.ps.update_grid()
+        self.reset()

@@ -28,17 +28,26 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts(tmp_path):
-    """ctypes mirrors vs the header, as seen by a C compiler."""
+    """ctypes mirrors vs the header, as seen by a C compiler: sizes of all five structs and the offsets of the members where
+    mirrors drift most easily (pointers, size_t, function pointers, the first field after a block of doubles)."""
     import subprocess
+    probes = [("sizeof(SphConfig)", ctypes.sizeof(_native.SphConfig)), ("sizeof(SphStepStats)", ctypes.sizeof(_native.SphStepStats)),
+              ("sizeof(SphSizes)", ctypes.sizeof(_native.SphSizes)), ("sizeof(SphRigid)", ctypes.sizeof(_native.SphRigid)),
+              ("sizeof(SphComm)", ctypes.sizeof(_native.SphComm))]
+    for struct, cls, fields in (("SphConfig", _native.SphConfig, ["boundary_handle", "max_density_iters", "slab_rebalance_every", "reserved"]),
+                                ("SphStepStats", _native.SphStepStats, ["capped", "div_first_err", "dt", "lost"]),
+                                ("SphRigid", _native.SphRigid, ["points", "vertices", "rho_0", "pos_offset", "attitude_offset", "active"]),
+                                ("SphComm", _native.SphComm, ["exchange_counts", "exchange_buffers", "allreduce", "send_left", "recv_right", "capacity", "on_host",
+                                                              "stream_ordered", "allreduce_stream", "reduce_buf"])):
+        for f in fields:
+            probes.append(("offsetof(%s, %s)" % (struct, f), getattr(cls, f).offset))
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "sph_mi355x.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu\\n", sizeof(SphConfig), sizeof(SphStepStats), sizeof(SphSizes),'
-                   ' offsetof(SphConfig, boundary_handle));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sph_mi355x.h"\nint main(void){\n' +
+                   "".join('printf("%%zu\\n", (size_t)%s);\n' % expr for expr, _ in probes) + "return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert [int(v) for v in out] == [ctypes.sizeof(_native.SphConfig), ctypes.sizeof(_native.SphStepStats),
-                                     ctypes.sizeof(_native.SphSizes), _native.SphConfig.boundary_handle.offset]
+    assert {expr: int(v) for (expr, _), v in zip(probes, out)} == dict(probes)
 
 
 def test_profile_kernel_names():

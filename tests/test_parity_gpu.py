@@ -201,18 +201,78 @@ def test_neighbour_overflow_is_reported():
 
 
 def test_headless_runner_writes_ply_and_obj(tmp_path):
+    """The frame loop of main.py:165-205 without the window: the PLY payload is the device state (6 decimals, original particle order,
+    the constant RGBA of ParticleSystem.py:152) and equals the oracle's positions after the same steps; the OBJ is `ps.mesh.export`
+    of the vertices that followed the body."""
     import json
-    from cfd_taichi_amd import run
+    from cfd_taichi_amd import mesh, run
     cfg = scenes.get("dfsph_rigid_small")
     cfg["scene"]["output_fps"] = 500
     path = tmp_path / "scene.json"
     path.write_text(json.dumps(cfg))
     frames, t, plys = run.main(["--config", str(path), "--steps", "6", "--ply-dir", str(tmp_path / "out")])
     assert frames == 6 and plys >= 2 and t > 0
-    head = (tmp_path / "out" / "output_000000.ply").read_text().splitlines()
-    assert head[0] == "ply" and head[3] == "element vertex 5759" and len(head) == 5759 + 12
-    obj = (tmp_path / "out" / "obj_000000.obj").read_text().splitlines()
-    assert sum(1 for l in obj if l.startswith("v ")) == 8 and sum(1 for l in obj if l.startswith("f ")) == 12
+    # the same frame loop on the oracle (main.py:165-173, 189): a frame is written whenever t / frame_time passes the frame counter
+    rg = mesh.rigid_from_config(cfg)
+    o = orc.Oracle(cfg, num_threads=4, rigid=rg)
+    t_o, frame = 0.0, 0
+    for _ in range(6):
+        o.step_dfsph(1, 100); o.rigid_step()
+        t_o += o.dt
+        if not t_o / (1.0 / 500) > frame:
+            continue
+        text = (tmp_path / "out" / ("output_%06d.ply" % frame)).read_text().splitlines()
+        assert text[0] == "ply" and text[1] == "format ascii 1.0" and text[3] == "element vertex 5759" and text[11] == "end_header"
+        assert [l.split()[-1] for l in text[4:11]] == ["x", "y", "z", "red", "green", "blue", "alpha"]
+        body = np.loadtxt(text[12:], dtype=np.float64)
+        assert body.shape == (5759, 7)
+        want = np.array([["%.6f" % v for v in row] for row in o.get(orc.F_POS)], dtype=np.float64)
+        assert np.array_equal(body[:, :3], want), frame
+        assert np.allclose(body[:, 3:], [0.0, 0.26, 0.68, 1.0], atol=1e-6)
+        obj = (tmp_path / "out" / ("obj_%06d.obj" % frame)).read_text().splitlines()
+        v = np.array([[float(x) for x in l.split()[1:]] for l in obj if l.startswith("v ")])
+        assert v.shape == (8, 3) and sum(1 for l in obj if l.startswith("f ")) == 12
+        assert np.allclose(v, o.get(orc.F_RIGID_VERT), atol=1e-7), frame
+        frame += 1
+    assert frame == plys and t_o == t
+    o.close()
+
+
+def test_mirror_api_prologue_and_mesh_export():
+    """The pieces of the caller contract beside step(): solver_base.step() (the prologue alone, solver_base.py:136-143), the prints
+    the reference makes every step (dfsph_solver.py:233, :416), ps.mesh.export (main.py:196-200)."""
+    import contextlib
+    import io
+    from cfd_taichi_amd import ParticleSystem, dfsph_solver, rigid_solver, solver_base
+    cfg = scenes.get("dfsph_rigid_small")
+    ps = ParticleSystem(cfg)
+    solver = dfsph_solver(ps, cfg)
+    rs = rigid_solver(ps, cfg)
+    o = orc.Oracle(cfg, num_threads=4, rigid=mesh_rigid(cfg))
+    solver_base.step(solver)                               # count + grid rebuild + reset()
+    assert solver.simulate_cnt[None] == 1
+    o.compute_nbr_count()
+    assert np.array_equal(ps.get_neighbour_count(), o.get(orc.F_NBR_COUNT).astype(np.int32))
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        solver.step(); rs.step()
+    o.step_dfsph(1, 100); o.rigid_step()
+    lines = out.getvalue().splitlines()
+    assert lines[0] == "[divergence iteration] count: {}, first error {}, error {}".format(o.last_stats.n_div, solver.last_stats.div_first_err, solver.last_stats.div_err)
+    assert lines[1].startswith("[density iteration] count: %d, error " % o.last_stats.n_dens)
+    assert solver.simulate_cnt[None] == 2
+    text = ps.mesh.export(file_type="obj")
+    before = np.array([[float(x) for x in l.split()[1:]] for l in text.splitlines() if l.startswith("v ")])
+    ps.update_mesh_vextics()
+    after = np.array([[float(x) for x in l.split()[1:]] for l in ps.mesh.export(file_type="obj").splitlines() if l.startswith("v ")])
+    assert np.allclose(after, o.get(orc.F_RIGID_VERT), atol=1e-7) and not np.allclose(before, after)     # placed and moved with the body
+    assert text.count("\nf ") == 12
+    o.close()
+
+
+def mesh_rigid(cfg):
+    from cfd_taichi_amd import mesh
+    return mesh.rigid_from_config(cfg)
 
 
 @pytest.mark.parametrize("solver", ["wcsph", "dfsph"])

@@ -129,3 +129,26 @@ def test_random_scenes_on_slabs(tmp_path, seed):
     world = int(rng.integers(2, 5))
     r = run_slabs(tmp_path, str(path), world, 60, rebalance=3)
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], (cfg, {k: r[k] for k in ("pos_rel_err", "slabs")})
+
+
+def test_bench_multi_rank_path_end_to_end(tmp_path):
+    """The command the driver runs for N > 1, end to end on this box: `torch.distributed.run ... bench.py --gpus 2` on its default
+    workload (config 4, dfsph_10m, sharded into x-slabs), both ranks on GPU 0 over gloo (SPH_BENCH_REHEARSAL), with the transport
+    self-check (SPH_BENCH_VERIFY: the synchronous discipline's bytes against the faster ones; native RCCL cannot open two ranks on one
+    GPU and must fall through without hanging).  One valid JSON line: strong scaling, the slab description, all particles owned once."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_BENCH_REHEARSAL="1", SPH_BENCH_VERIFY="1", SPH_BENCH_PREROLL="2")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["unit"] == "Mparticle-steps/s"
+    assert d["config"]["workload"] == "dfsph_10m" and d["config"]["particles"] == 10000000 and d["config"]["preroll_steps"] == 2
+    assert "2 x-slabs" in d["config"]["parallelism"] and "discipline" in d["config"]["parallelism"]
+    slab0 = d["config"]["rank0_slab"]
+    assert 0 < slab0["owned"] < 10000000 and slab0["ghosts"] > 50000 and slab0["x_lo"] == 0
+    assert d["value"] > 0 and abs(d["value"] - 10.0 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["particles_on_rank"] == slab0["owned"] + slab0["ghosts"] or d["roofline"]["particles_on_rank"] > 0
+    assert "cpu_baseline" not in d and "strong_scaling_base" not in d
