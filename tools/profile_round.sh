@@ -10,9 +10,9 @@ mkdir -p $R/gpurun_out
 cd $R && python3 bench.py > gpurun_out/${tag}_bench_dfsph_1m.json 2> gpurun_out/${tag}_bench.err || exit 1
 tail -c 1500 gpurun_out/${tag}_bench_dfsph_1m.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_bench_dfsph_1m_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-scaling-base > $R/gpurun_out/${tag}_bench_dfsph_1m_under_rocprof.json 2> $R/gpurun_out/${tag}_stats.err || exit 1
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES"; do
   set -- $pass; name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -o pmc -- python3 $R/bench.py --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/${tag}_$name.err || exit 1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/${tag}_$name -o pmc -- python3 $R/bench.py --preroll 30 --steps 4 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-scaling-base > /dev/null 2> $R/gpurun_out/${tag}_$name.err || exit 1
 done
 cd $R && python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write 1000000 gpurun_out/${tag}_pmc_traffic.json gpurun_out/${tag}_sq
