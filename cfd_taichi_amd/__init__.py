@@ -17,6 +17,7 @@ from .wcsph_solver import wcsph_solver  # noqa: F401
 from .dfsph_solver import dfsph_solver  # noqa: F401
 from .pcisph_solver import pcisph_solver  # noqa: F401
 from .iisph_solver import iisph_solver  # noqa: F401
+from .pbf_solver import pbf_solver  # noqa: F401
 from .rigid_solver import rigid_solver  # noqa: F401
 
-__all__ = ["utils", "ParticleSystem", "solver_base", "wcsph_solver", "dfsph_solver", "pcisph_solver", "iisph_solver", "rigid_solver"]
+__all__ = ["utils", "ParticleSystem", "solver_base", "wcsph_solver", "dfsph_solver", "pcisph_solver", "iisph_solver", "pbf_solver", "rigid_solver"]

@@ -13,22 +13,24 @@ from . import build as _build
 
 SPH_OK = 0
 SPH_E_INVALID, SPH_E_HIP, SPH_E_NO_DEVICE, SPH_E_OVERFLOW, SPH_E_STATE = -1, -2, -3, -4, -5
-SOLVER_WCSPH, SOLVER_DFSPH, SOLVER_PCISPH, SOLVER_IISPH = 0, 1, 2, 3
-SOLVER_IDS = {"wcsph": SOLVER_WCSPH, "dfsph": SOLVER_DFSPH, "pcisph": SOLVER_PCISPH, "iisph": SOLVER_IISPH}
+SOLVER_WCSPH, SOLVER_DFSPH, SOLVER_PCISPH, SOLVER_IISPH, SOLVER_PBF = 0, 1, 2, 3, 4
+SOLVER_IDS = {"wcsph": SOLVER_WCSPH, "dfsph": SOLVER_DFSPH, "pcisph": SOLVER_PCISPH, "iisph": SOLVER_IISPH, "pbf": SOLVER_PBF}
 SPECIES_FLUID, SPECIES_WALL, SPECIES_RIGID = 0, 1, 2
 F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER, F_VEL_ADV = range(10)
 F_NBR_COUNT = 14
 F_PRESS_ITER, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_A_II, F_D_IJ = range(16, 22)
+F_PBF_LAMBDA, F_PBF_DELTA_POS = 22, 23
 F_WALL_POS, F_WALL_VOL = 32, 33
 F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
 S_RIGID_CENTROID, S_RIGID_OMEGA, S_RIGID_VEL, S_RIGID_MASS, S_RIGID_INERTIA_INV = 10, 13, 16, 19, 20
 S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME, S_GRAPH_LAUNCHES = range(6)
 S_PCISPH_DELTA, S_PCISPH_BETA, S_PCISPH_MAX_INDEX, S_PCISPH_MAX_COUNT = range(6, 10)
-VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ}
+VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ,
+                 F_PBF_DELTA_POS}
 
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
-    "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
+    "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
     "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
@@ -163,6 +165,7 @@ def load(build_if_missing=True):
     lib.sph_upload.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
     lib.sph_download.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
     lib.sph_step_wcsph.argtypes = [vp, ci]
+    lib.sph_step_pbf.argtypes = [vp, ci]
     lib.sph_step_dfsph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
     lib.sph_step_pcisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
     lib.sph_step_iisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
@@ -215,7 +218,7 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.boundary_handle = 1 if sol.get("boundary_handle", True) else 0   # solver_base.py:31
     c.fs_couple = 1 if sol.get("fs_couple", True) else 0              # solver_base.py:32
     if name not in SOLVER_IDS:
-        raise NotImplementedError("solver %r: this library covers %s (pbf is out of scope, SURVEY.md section 8f)" % (name, sorted(SOLVER_IDS)))
+        raise NotImplementedError("solver %r: this library covers %s" % (name, sorted(SOLVER_IDS)))
     c.solver = SOLVER_IDS[name]
     c.device = int(device)
     c.max_neighbors = int(max_neighbors)
@@ -344,11 +347,16 @@ class Simulation:
         self._check(self._lib.sph_step_iisph(self._h, nsteps, ctypes.byref(self.last_stats)))
         return self.last_stats
 
+    def step_pbf(self, nsteps=1):
+        self._check(self._lib.sph_step_pbf(self._h, nsteps))
+
     def step(self, nsteps=1):
         """One call for any solver; returns the last step's SphStepStats (None for wcsph)."""
         sid = self.cfg.solver
         if sid == SOLVER_WCSPH:
             return self.step_wcsph(nsteps)
+        if sid == SOLVER_PBF:
+            return self.step_pbf(nsteps)
         return {SOLVER_DFSPH: self.step_dfsph, SOLVER_PCISPH: self.step_pcisph, SOLVER_IISPH: self.step_iisph}[sid](nsteps)
 
     def rigid_step(self):

@@ -21,6 +21,7 @@
 #include "sph_slab_kernels.h"
 #include "sph_pressure_kernels.h"
 #include "sph_rigid_kernels.h"
+#include "sph_pbf_kernels.h"
 
 using namespace sph;
 
@@ -30,14 +31,14 @@ enum KernelId {
     K_HASH = 0, K_SCAN, K_SCATTER, K_ORDER_GATHER, K_BUILD_NL, K_W_DENSITY, K_W_FORCE, K_D_DENSITY_ALPHA,
     K_D_WARM, K_D_DIV_RESIDUAL, K_D_DIV_CORRECT, K_D_EXT, K_D_DENS_RESIDUAL, K_D_DENS_CORRECT, K_D_INTEGRATE,
     K_FINALIZE, K_TRANSFER, K_SLAB, K_RIGID, K_P_EXT, K_P_PREDICT_RHO, K_P_PRESS, K_P_INTEGRATE, K_I_ADVECT, K_I_RHO_ADV, K_I_DIJ,
-    K_I_UPDATE_P, K_I_INTEGRATE, K_COUNT
+    K_I_UPDATE_P, K_I_INTEGRATE, K_B_LAMBDA, K_B_DELTA, K_B_XSPH, K_COUNT
 };
 const char *kKernelNames[K_COUNT] = {
     "hash_count", "scan", "scatter", "order_gather", "build_nl", "wcsph_density", "wcsph_force", "dfsph_density_alpha",
     "dfsph_warm_start", "dfsph_div_residual", "dfsph_div_correct", "dfsph_ext_force", "dfsph_dens_residual",
     "dfsph_dens_correct", "dfsph_integrate", "finalize", "transfer", "slab_exchange", "rigid",
     "pcisph_ext_force", "pcisph_predict_rho", "pcisph_press_force", "pcisph_integrate", "iisph_advect", "iisph_rho_adv", "iisph_d_ij",
-    "iisph_update_p", "iisph_integrate"};
+    "iisph_update_p", "iisph_integrate", "pbf_lambda", "pbf_delta_pos", "pbf_xsph"};
 
 thread_local std::string g_create_error;
 
@@ -651,8 +652,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if ((rc = dalloc(h, &h->warm[k], n))) return rc;
         if ((rc = dalloc(h, &h->id[k], n))) return rc;
     }
-    if (is_pressure_solver(h))
-        for (int k = 0; k < 5; ++k) {
+    if (is_pressure_solver(h) || h->cfg.solver == SPH_SOLVER_PBF)      // pbf: delta_pos, new position, phase-1 velocity
+        for (int k = 0; k < (is_pressure_solver(h) ? 5 : 3); ++k) {
             if ((rc = dalloc(h, &h->X[k], n))) return rc;
         }
     if ((rc = dalloc(h, &h->rho, n))) return rc;
@@ -666,7 +667,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     {
         // LDS staging of the gather operands (plan in k_build_nl): DFSPH, PCISPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
         const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
-        h->staged = c.order == CELL_ORDER_TILED && h->cfg.solver != SPH_SOLVER_WCSPH && !(e && atoi(e) == 0);
+        h->staged = c.order == CELL_ORDER_TILED && h->cfg.solver != SPH_SOLVER_WCSPH && h->cfg.solver != SPH_SOLVER_PBF && !(e && atoi(e) == 0);
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap))) return rc;
@@ -1790,6 +1791,56 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
 }
 
 // ---------------------------------------------------------------------------------------------
+// PBF (csrc/sph_pbf_kernels.h)                                pbf_solver.py:176-187
+// ---------------------------------------------------------------------------------------------
+PbfConsts pbf_consts(const SphHandle *h)
+{
+    const Consts &c = h->c;
+    PbfConsts k;
+    const double pi = 3.141592653589793, r = h->cfg.particle_radius;
+    k.kpoly = 315.0f / ((float)(64 * pi) * (c.h * (c.h * c.h)));                         // solver_base.py:128 (64 * pi folds in f64)
+    k.pih4 = (float)pi * ((c.h * c.h) * (c.h * c.h));                                    // :120
+    k.neg_k = -(float)1e-7; k.c_visc = (float)9e-6; k.eps = (float)1.0e-6;               // pbf_solver.py:17-21
+    {   // poly_kernel(s_corr_factor * kernel_h, kernel_h), the argument a Python float (:148)
+        const float rc = (float)(0.3 * (r * 4)), q = rc / c.h, q2 = q * q, t = 1.0f - q2;
+        k.w_corr = q <= 1.0f ? k.kpoly * (t * (t * t)) : 0.0f;
+    }
+    for (int a = 0; a < 3; ++a) {                                                        // :74-81
+        k.lo[a] = (float)h->cfg.box_min[a] + (float)r;
+        k.hi[a] = (float)h->cfg.box_max[a] - (float)r;
+    }
+    return k;
+}
+
+int step_pbf_once(SphHandle *h)
+{
+    int rc;
+    h->simulate_cnt += 1;                                   // solver_base.py:137
+    if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
+    const Consts &c = h->c;
+    const PbfConsts k = pbf_consts(h);
+    const dim3 g = grid_for(c.n), b(kBlock);
+    hipStream_t s = h->stream;
+    {
+        ProfScope ps(h, K_B_LAMBDA);                          // compute_all_lambda :32-52
+        hipLaunchKernelGGL(k_pbf_lambda, g, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
+    }
+    {
+        ProfScope ps(h, K_B_DELTA);                           // compute_all_delta_pos :55-64, the prediction :26-29, update_all_pos phase 1 :66-84
+        hipLaunchKernelGGL(k_pbf_delta, g, b, 0, s, c, k, h->dt_wcsph, h->P[1 - h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->X[0], h->X[1], h->X[2]);
+    }
+    {
+        ProfScope ps(h, K_B_XSPH);                            // update_all_pos phases 2-3 :86-98
+        hipLaunchKernelGGL(k_pbf_xsph, g, b, 0, s, c, k, h->P[h->pcur], h->X[1], h->X[2], h->cell_start, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+    }
+    h->pcur ^= 1; h->vcur ^= 1;
+    HIP_TRY(h, hipGetLastError());
+    h->nl_valid = false;
+    h->density_valid = false;
+    return SPH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // PCISPH / IISPH (SURVEY.md section 8f "next": the solvers coupling_demo.json and breaking_dam_30k.json name)
 // ---------------------------------------------------------------------------------------------
 int launch_pressure_finalize(SphHandle *h, int mode)
@@ -2107,10 +2158,10 @@ int field_floats(SphHandle *h, int species, int field, size_t *count, bool *vec)
     if (species == SPH_SPECIES_FLUID) {
         switch (field) {
         case SPH_F_POS: case SPH_F_VEL: case SPH_F_ACC: case SPH_F_VEL_ADV: case SPH_F_PRESS_FORCE: case SPH_F_POS_PREDICT: case SPH_F_D_II:
-        case SPH_F_D_IJ:
+        case SPH_F_D_IJ: case SPH_F_PBF_DELTA_POS:
             *vec = true; *count = 3 * (size_t)h->N; return SPH_OK;
         case SPH_F_RHO: case SPH_F_PRESSURE: case SPH_F_ALPHA: case SPH_F_WARM_K: case SPH_F_RHO_ADV: case SPH_F_RHO_DER:
-        case SPH_F_NBR_COUNT: case SPH_F_PRESS_ITER: case SPH_F_A_II:
+        case SPH_F_NBR_COUNT: case SPH_F_PRESS_ITER: case SPH_F_A_II: case SPH_F_PBF_LAMBDA:
             *count = (size_t)h->N; return SPH_OK;
         default: break;
         }
@@ -2138,7 +2189,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
 {
     if (!cfg || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
     *out = nullptr;
-    if (cfg->solver < SPH_SOLVER_WCSPH || cfg->solver > SPH_SOLVER_IISPH)
+    if (cfg->solver < SPH_SOLVER_WCSPH || cfg->solver > SPH_SOLVER_PBF)
         return fail(nullptr, SPH_E_INVALID, "unknown solver %d", cfg->solver);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -2179,6 +2230,7 @@ int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **ou
     if (!cfg || !rigid || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
     if (cfg->slab_count > 1) return fail(nullptr, SPH_E_INVALID, "rigid coupling is not available on slab handles");
     if (rigid->n_particles <= 0 || !rigid->points) return fail(nullptr, SPH_E_INVALID, "rigid body has no sample points");
+    if (cfg->solver == SPH_SOLVER_PBF) return fail(nullptr, SPH_E_INVALID, "pbf has no rigid coupling (pbf_solver.py has no material branches)");
     int rc = sph_create(cfg, out);
     if (rc) return rc;
     SphHandle *h = *out;
@@ -2309,8 +2361,16 @@ int sph_download(SphHandle *h, int species, int field, float *host, size_t n_flo
             if (!is_pressure_solver(h)) return fail(h, SPH_E_STATE, "press_force / f_press is a pcisph / iisph field");
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[pcisph ? 1 : 2], id, h->staging); break;
         case SPH_F_POS_PREDICT:
-            if (!pcisph) return fail(h, SPH_E_STATE, "pos_predict is a pcisph field");
+            if (h->cfg.solver == SPH_SOLVER_PBF) { hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->P[h->pcur], id, h->staging); break; }   // pos = pos_predict after a step (:84)
+            if (!pcisph) return fail(h, SPH_E_STATE, "pos_predict is a pcisph / pbf field");
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[2], id, h->staging); break;
+        case SPH_F_PBF_LAMBDA: case SPH_F_PBF_DELTA_POS:
+            if (h->cfg.solver != SPH_SOLVER_PBF) return fail(h, SPH_E_STATE, "pbf_lambda / delta_pos are pbf fields");
+            if (h->simulate_cnt == 0) return fail(h, SPH_E_STATE, "pbf_lambda / delta_pos exist after the first step");
+            // (the device order does not change inside a step: the ids of the current generation apply)
+            if (field == SPH_F_PBF_LAMBDA) hipLaunchKernelGGL(k_unsort_scalar, g, b, 0, s, h->N, h->aux, id, h->staging);
+            else hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[0], id, h->staging);
+            break;
         case SPH_F_D_II: case SPH_F_D_IJ:
             if (!iisph) return fail(h, SPH_E_STATE, "d_ii / d_ij are iisph fields");
             hipLaunchKernelGGL(k_unsort_vec, g, b, 0, s, h->N, h->X[field == SPH_F_D_II ? 0 : 1], id, h->staging); break;
@@ -2652,6 +2712,24 @@ int sph_step_iisph(SphHandle *h, int nsteps, SphStepStats *last)
         if (rc) return rc;
     }
     if (last) *last = st;
+    return SPH_OK;
+}
+
+int sph_step_pbf(SphHandle *h, int nsteps)
+{
+    if (!h || nsteps < 0) return SPH_E_INVALID;
+    if (h->cfg.solver != SPH_SOLVER_PBF) return fail(h, SPH_E_STATE, "handle was not created with solver = SPH_SOLVER_PBF");
+    if (h->slab) return fail(h, SPH_E_STATE, "pbf is not available on slab handles");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (int k = 0; k < nsteps; ++k) {
+        int rc = step_pbf_once(h);
+        if (rc) return rc;
+    }
+    if (nsteps > 0) {
+        int rc = read_scalars(h);
+        if (rc) return rc;
+        if ((rc = check_overflow(h))) return rc;
+    }
     return SPH_OK;
 }
 

@@ -79,7 +79,7 @@ def main_sharded(args, config):
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--config", default="./default.json")          # main.py:14
-    ap.add_argument("--solver", default=None, help="override solver.name (wcsph | dfsph | pcisph | iisph)")
+    ap.add_argument("--solver", default=None, help="override solver.name (wcsph | dfsph | pcisph | iisph | pbf)")
     ap.add_argument("--until", type=float, default=4.0, help="stop when simulated time exceeds this (main.py:205)")
     ap.add_argument("--steps", type=int, default=0, help="stop after this many frames (0 = use --until)")
     ap.add_argument("--ply-dir", default=None)
@@ -96,8 +96,8 @@ def main(argv=None):
     start_time = time.time()
     ps = ParticleSystem(config, device=args.device)
     name = solver_config.get("name")
-    if name not in ("wcsph", "dfsph", "pcisph", "iisph"):
-        raise SystemExit("solver '%s' is not covered (pbf is out of scope); pass --solver wcsph | dfsph | pcisph | iisph" % name)
+    if name not in ("wcsph", "dfsph", "pcisph", "iisph", "pbf"):
+        raise SystemExit("solver '%s' is not covered; pass --solver wcsph | dfsph | pcisph | iisph | pbf" % name)
     module = importlib.import_module("cfd_taichi_amd." + name + "_solver")      # main.py:65-68
     solver = getattr(module, name + "_solver")(ps, config)
     rs = rigid_solver(ps, config) if config.get("solid", {}) else None           # :69-71

@@ -51,6 +51,12 @@ SCENES = {
     "pcisph_1m": lambda: _scene("pcisph", 1e-3, [16.0, 7.0, 5.2], [5.0, 5.0, 5.0]),
     "dfsph_tiny_wall_pcisph": lambda: _scene("pcisph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
     "dfsph_tiny_wall_iisph": lambda: _scene("iisph", 1e-3, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
+    # reference config/pbf_config_backup.json (geometry of dfsph_config_backup.json, solver pbf, dt 2.5e-4), a column on the floor
+    # next to a wall (constraints and wall terms active from the first steps), the same with clamp walls, and the 30 k dam
+    "pbf_small": lambda: _scene("pbf", 2.5e-4, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    "pbf_tiny_wall": lambda: _scene("pbf", 2.5e-4, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.05, 0.05, 0.05)),
+    "pbf_tiny_clamp": lambda: _scene("pbf", 2.5e-4, [1.0, 1.0, 1.0], [0.4, 0.5, 0.4], start_pos=(0.1, 0.1, 0.1), boundary_handle=False),
+    "breaking_dam_30k_pbf": lambda: _scene("pbf", 2.5e-4, [5.0, 3.0, 1.5], [1.0, 2.8, 1.3]),
 }
 
 

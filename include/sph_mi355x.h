@@ -38,6 +38,7 @@ extern "C" {
 #define SPH_SOLVER_DFSPH 1
 #define SPH_SOLVER_PCISPH 2   /* pcisph_solver.py */
 #define SPH_SOLVER_IISPH 3    /* iisph_solver.py */
+#define SPH_SOLVER_PBF 4      /* pbf_solver.py (stale in the reference: read as csrc/sph_pbf_kernels.h states; single GPU, no rigid body) */
 
 /* config/X.json of the reference, flattened (utils.py:3-11 reads it,
  * ParticleSystem.py:31-103 and solver_base.py:7-39 consume it).  Doubles carry the Python
@@ -124,10 +125,12 @@ typedef struct SphRigid {
 #define SPH_F_NBR_COUNT 14 /* ps.get_neighbour_count(i), as float */
 #define SPH_F_PRESS_ITER 16  /* pcisph solver.press_iter / iisph solver.p_iter after the last step */
 #define SPH_F_PRESS_FORCE 17 /* pcisph solver.press_force / iisph solver.f_press */
-#define SPH_F_POS_PREDICT 18 /* pcisph solver.pos_predict */
+#define SPH_F_POS_PREDICT 18 /* pcisph solver.pos_predict (pbf: equals pos after a step, pbf_solver.py:84) */
 #define SPH_F_D_II 19        /* iisph solver.d_ii */
 #define SPH_F_A_II 20        /* iisph solver.a_ii */
 #define SPH_F_D_IJ 21        /* iisph solver.d_ij */
+#define SPH_F_PBF_LAMBDA 22  /* pbf solver.pbf_lambda of the last step */
+#define SPH_F_PBF_DELTA_POS 23 /* pbf solver.delta_pos of the last step */
 #define SPH_F_WALL_POS 32  /* boundary_particles.pos    (species WALL) */
 #define SPH_F_WALL_VOL 33  /* boundary_particles.volume (species WALL) */
 #define SPH_F_RIGID_POS 48    /* rigid_particles.pos    (species RIGID) */
@@ -186,6 +189,8 @@ int sph_step_pcisph(SphHandle *h, int nsteps, SphStepStats *last);
 /* replaces iisph_solver.step() x nsteps   iisph_solver.py:340-347.  last->n_dens = l and last->dens_err = residual as printed at :102;
  * last->n_div = 1 when the loop left on "Iteration trend to divergence" (:97-99); last->capped = 1 at max_iter_cnt (180) */
 int sph_step_iisph(SphHandle *h, int nsteps, SphStepStats *last);
+/* replaces pbf_solver.step() x nsteps     pbf_solver.py:176-187 (update_all_pos under the barrier-synchronised schedule, csrc/sph_pbf_kernels.h) */
+int sph_step_pbf(SphHandle *h, int nsteps);
 /* stages of the step, for parity tests against the oracle's stages:
  * ps.reset_grid()+update_grid() (+ neighbour-list build), solver.compute_all_rho(), dfsph compute_all_alpha() */
 int sph_build_neighbors(SphHandle *h);

@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER = range(9)
 F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_NBR_COUNT, F_FORCE_EXT = range(9, 16)
 F_PRESS_ITER, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_A_II, F_D_IJ = range(16, 22)
+F_PBF_LAMBDA, F_PBF_DELTA_POS = 22, 23
 F_WALL_POS, F_WALL_VOL = 32, 33
 F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
 _VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT,
-               F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ}
+               F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ, F_PBF_DELTA_POS}
 _RIGID_FIELDS = {F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS}
 _WALL_FIELDS = {F_WALL_POS, F_WALL_VOL}
 
@@ -107,6 +108,7 @@ def _lib(precision):
         lib.orc_step_dfsph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
         lib.orc_step_pcisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
         lib.orc_step_iisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
+        lib.orc_step_pbf.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.orc_cubic_kernel.restype = ctypes.c_float
         lib.orc_cubic_kernel.argtypes = [ctypes.c_float, ctypes.c_float]
         lib.orc_cubic_kernel_derivative.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
@@ -130,7 +132,7 @@ def config_from_dict(config, solver=None, num_threads=1):
     c.boundary_handle = 1 if sol.get("boundary_handle", True) else 0
     c.fs_couple = 1 if sol.get("fs_couple", True) else 0
     name = solver or sol["name"]
-    c.solver = {"wcsph": 0, "dfsph": 1, "pcisph": 2, "iisph": 3}[name]
+    c.solver = {"wcsph": 0, "dfsph": 1, "pcisph": 2, "iisph": 3, "pbf": 4}[name]
     c.num_threads = int(num_threads)
     return c
 
@@ -248,6 +250,11 @@ class Oracle:
     @property
     def pcisph_max_index(self):
         return int(self._lib.orc_get_scalar(self._h, 7)), int(self._lib.orc_get_scalar(self._h, 8))
+
+    def step_pbf(self, nsteps=1):
+        """pbf_solver.step under the barrier-synchronised schedule of update_all_pos (see sph_oracle.c)."""
+        rc = self._lib.orc_step_pbf(self._h, nsteps)
+        assert rc == 0, "oracle not created with solver pbf"
 
     def step_dfsph(self, nsteps=1, max_dens_iter=0):
         """Returns 1 if the (non-reference) density-iteration cap was hit."""

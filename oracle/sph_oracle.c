@@ -80,6 +80,8 @@ struct Orc {
     real *d_ii, *d_ij, *a_ii, *p_past, *p_new, *r_sum;
     real pci_delta, pci_beta;
     int pci_max_index, pci_max_count;
+    /* PBF (pbf_solver.py:12-16): constrain, constrain_derivative, pbf_lambda, delta_pos (pos_predict is shared with PCISPH) */
+    real *pbf_c, *pbf_cd, *pbf_lambda, *pbf_dpos;
     /* rigid body (config 5): particles sampled from the mesh, ParticleSystem.py:41-64 */
     int Nv;                /* mesh vertices */
     int exist_rigid, active_rigid;
@@ -465,6 +467,9 @@ Orc *orc_create(const OrcConfig *cfg)
     ALLOC(o->vel_adv, real, 3 * N); ALLOC(o->vel_adv_delta, real, 3 * N);
     ALLOC(o->force_ext, real, 3 * N); ALLOC(o->warm_k, real, N);
     ALLOC(o->nbr_cnt, int, N);
+    if (c->solver == 4) {
+        ALLOC(o->pbf_c, real, N); ALLOC(o->pbf_cd, real, 3 * N); ALLOC(o->pbf_lambda, real, N); ALLOC(o->pbf_dpos, real, 3 * N);
+    }
     if (c->solver >= 2) {
         ALLOC(o->pos_predict, real, 3 * N); ALLOC(o->vel_predict, real, 3 * N); ALLOC(o->press_force, real, 3 * N);
         ALLOC(o->rho_err, real, N); ALLOC(o->press_iter, real, N);
@@ -494,6 +499,7 @@ void orc_destroy(Orc *o)
     free(o->pos_predict); free(o->vel_predict); free(o->press_force); free(o->rho_err); free(o->press_iter);
     free(o->d_ii); free(o->d_ij); free(o->a_ii); free(o->p_past); free(o->p_new); free(o->r_sum);
     free(o->rpos); free(o->rvol); free(o->rmass); free(o->rforce); free(o->rvert); free(o->rcell3);
+    free(o->pbf_c); free(o->pbf_cd); free(o->pbf_lambda); free(o->pbf_dpos);
     free(o);
 }
 
@@ -528,6 +534,8 @@ static real *field_ptr(Orc *o, int field, long *count, int *is_int)
     case ORC_F_D_II: *count = o->d_ii ? 3L * o->N : -1; return o->d_ii;
     case ORC_F_A_II: *count = o->a_ii ? o->N : -1; return o->a_ii;
     case ORC_F_D_IJ: *count = o->d_ij ? 3L * o->N : -1; return o->d_ij;
+    case ORC_F_PBF_LAMBDA: *count = o->pbf_lambda ? o->N : -1; return o->pbf_lambda;
+    case ORC_F_PBF_DELTA_POS: *count = o->pbf_dpos ? 3L * o->N : -1; return o->pbf_dpos;
     case ORC_F_WALL_POS: *count = 3L * o->Nb; return o->bpos;
     case ORC_F_WALL_VOL: *count = o->Nb; return o->bvol;
     case ORC_F_NBR_COUNT: *count = o->N; *is_int = 1; return NULL;
@@ -2020,4 +2028,170 @@ int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last)
         if (last) *last = st;
     }
     return capped;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * PBF                                                                        pbf_solver.py
+ *
+ * The file is STALE at the surveyed commit: its fluid callbacks are written against an older ParticleSystem.for_all_neighbor that
+ * passed particle INDICES (compute_rho(self, i, j) reads fluid_particles.pos[i], :169-170), while for_all_neighbor now passes particle
+ * STRUCTS (ParticleSystem.py:469; the index form is the commented-out line :468) -- as committed the solver does not compile.  The
+ * restatement reads every callback the way the other solvers' callbacks were updated: `fluid_particles.X[i]` -> particle_i.X,
+ * `fluid_particles.X[j]` -> particle_j.X, `pbf_lambda[j]` -> pbf_lambda[particle_j.index]; the boundary callbacks still take indices
+ * (for_all_boundary_neighbor, ParticleSystem.py:337-366) and are restated as written.
+ *
+ * update_all_pos (:63-95) is one parallel loop in which every particle first WRITES its own pos_predict / vel / pos and then READS
+ * its neighbours' pos and vel, and finally adds the viscosity term to its own vel: a data race, the outcome depends on the thread
+ * schedule.  The schedule restated here (and by the HIP kernels) is the one every barrier-synchronised implementation produces:
+ *   phase 1  all particles: pos_predict += delta_pos, vel = (pos_predict - pos) / dt, clamp, pos = pos_predict
+ *   phase 2  all particles: v_i = sum_j (vel_j - vel_i) W_poly6(|pos_i - pos_j|)   on the NEW positions and phase-1 velocities,
+ *            the candidates being those of the cell lists of the step's start (belong_grid is not updated inside a step)
+ *   phase 3  all particles: vel_i += c * v_i
+ * i.e. the interleaving "every write of phase 1 before any read of phase 2, every read of phase 2 before any write of phase 3",
+ * which is one legal execution of the reference loop.  The wall part of the viscosity sum is computed and discarded by the
+ * reference (:91 is commented out); it is not restated.  No rigid coupling (the callbacks have no material branches).
+ * ------------------------------------------------------------------------------------- */
+static inline real poly_kernel(real r, real h)                          /* solver_base.py:123-129 */
+{
+    real q = r / h;
+    real q2 = q * q;
+    real ret = R(0.0);
+    if (q <= R(1.0)) ret = R(315.0) / (R(64 * ORC_PI) * pow3(h)) * pow3(R(1.0) - q2);
+    return ret;
+}
+static inline void spiky_kernel_derivative(real rx, real ry, real rz, real h, real out[3])   /* solver_base.py:114-121 */
+{
+    real r_norm = r_sqrt((rx * rx + ry * ry) + rz * rz);
+    real q = r_norm / h;
+    out[0] = out[1] = out[2] = R(0.0);
+    if (q <= R(1.0) && q > R(0.0)) {
+        real a = -(R(45.0) * pow2(R(1.0) - q));
+        real den = R(ORC_PI) * pow2(pow2(h)) * r_norm;
+        out[0] = a * rx / den; out[1] = a * ry / den; out[2] = a * rz / den;
+    }
+}
+
+int orc_step_pbf(Orc *o, int nsteps)
+{
+    if (o->cfg.solver != 4) return -1;
+    const real eps = R(1.0e-6), k_tension = R(1e-7), c_visc = R(9e-6);                  /* :17-21 */
+    const real corr_r = R(0.3 * (o->cfg.particle_radius * 4));                          /* s_corr_factor * kernel_h, both Python floats */
+    real lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {                                                       /* :74-81: clamp at particle_radius */
+        lo[a] = R(o->cfg.box_min[a]) + R(o->cfg.particle_radius);
+        hi[a] = R(o->cfg.box_max[a]) - R(o->cfg.particle_radius);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        o->simulate_cnt += 1;                                                           /* solver_base.py:137 */
+        orc_build_grid(o);                                                              /* :139-141 */
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            o->acc[3 * i] = o->gravity * R(0.0);                                        /* reset(), solver_base.py:131-133 */
+            o->acc[3 * i + 1] = o->gravity * R(-1.0);
+            o->acc[3 * i + 2] = o->gravity * R(0.0);
+            for (int a = 0; a < 3; ++a) {                                               /* externel_force_predict_pos :26-29 */
+                o->vel[3 * i + a] += o->dt * o->acc[3 * i + a];
+                o->pos_predict[3 * i + a] = o->pos[3 * i + a] + o->dt * o->vel[3 * i + a];
+            }
+        }
+        /* compute_all_lambda :32-52: rho (poly6), constrain, constrain_derivative, lambda -- all on the CURRENT positions */
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            real rho = R(0.001);                                                        /* solver_base.py:44 */
+            FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) rho += o->m * poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h); });   /* :169-170 */
+            if (o->cfg.boundary_handle) {
+                real rb = R(0.0);
+                FOR_WALL_NEIGHBORS_OF_FLUID(o, i, { rb += o->bvol[j] * poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h); });   /* :173-176 */
+                o->rho[i] = rho + rb * o->rho0;
+            } else {
+                o->rho[i] = rho;
+            }
+            o->pbf_c[i] = r_max(o->rho[i] / o->rho0 - R(1.0), R(0.0));                  /* :127-128 */
+        }
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            real cd[3] = {0, 0, 0}, cdb[3] = {0, 0, 0}, g[3];
+            FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) { spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                                                        cd[0] += g[0] / o->rho0; cd[1] += g[1] / o->rho0; cd[2] += g[2] / o->rho0; } });   /* :116-117 */
+            if (o->cfg.boundary_handle) {
+                FOR_WALL_NEIGHBORS_OF_FLUID(o, i, { spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                                                    cdb[0] += g[0] / o->rho0; cdb[1] += g[1] / o->rho0; cdb[2] += g[2] / o->rho0; });    /* :120-122 */
+                for (int a = 0; a < 3; ++a) o->pbf_cd[3 * i + a] = cd[a] + cdb[a];      /* :112 */
+            } else {
+                for (int a = 0; a < 3; ++a) o->pbf_cd[3 * i + a] = cd[a];
+            }
+        }
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            if (o->pbf_c[i] == R(0.0)) { o->pbf_lambda[i] = R(0.0); continue; }         /* :39-40 */
+            real sum = R(0.0), g[3];
+            FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) { spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                                                        real gx = g[0] / o->rho0, gy = g[1] / o->rho0, gz = g[2] / o->rho0;
+                                                        sum += (gx * gx + gy * gy) + gz * gz; } });                                       /* :133-134 */
+            const real *cd = o->pbf_cd + 3 * i;
+            const real cdcd = (cd[0] * cd[0] + cd[1] * cd[1]) + cd[2] * cd[2];
+            if (o->cfg.boundary_handle) {
+                real sb = R(0.0);
+                FOR_WALL_NEIGHBORS_OF_FLUID(o, i, { spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                                                    real gx = g[0] / o->rho0, gy = g[1] / o->rho0, gz = g[2] / o->rho0;
+                                                    sb += (gx * gx + gy * gy) + gz * gz; });                                              /* :139-140 */
+                sum = (cdcd + sum) + sb;                                                /* :48 */
+            } else {
+                sum = cdcd + sum;                                                       /* :50 */
+            }
+            o->pbf_lambda[i] = -o->pbf_c[i] / (sum + eps);                              /* :52 */
+        }
+        /* compute_all_delta_pos :55-64 */
+        const real w_corr = poly_kernel(corr_r, o->h);
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            real dp[3] = {0, 0, 0}, dpb[3] = {0, 0, 0}, g[3];
+            const real li = o->pbf_lambda[i];
+            FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) {
+                real sc = poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h) / w_corr;                                        /* :148 */
+                sc *= sc; sc *= sc; sc *= -k_tension;                                                                                     /* :149-151 */
+                spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                const real f = (li + o->pbf_lambda[j]) + sc;                                                                              /* :153 */
+                dp[0] += f * g[0]; dp[1] += f * g[1]; dp[2] += f * g[2]; } });
+            if (o->cfg.boundary_handle) {
+                FOR_WALL_NEIGHBORS_OF_FLUID(o, i, {
+                    real sc = poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h) / w_corr;
+                    sc *= sc; sc *= sc; sc *= -k_tension;
+                    spiky_kernel_derivative(xij, yij, zij, o->h, g);
+                    const real f = li + sc;                                                                                               /* :164 */
+                    dpb[0] += f * g[0]; dpb[1] += f * g[1]; dpb[2] += f * g[2]; });
+                for (int a = 0; a < 3; ++a) o->pbf_dpos[3 * i + a] = (dp[a] + dpb[a]) / o->rho0;                                          /* :62 */
+            } else {
+                for (int a = 0; a < 3; ++a) o->pbf_dpos[3 * i + a] = dp[a] / o->rho0;                                                     /* :64 */
+            }
+        }
+        /* update_all_pos :66-95, phase 1 */
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            for (int a = 0; a < 3; ++a) {
+                const int k = 3 * i + a;
+                o->pos_predict[k] += o->pbf_dpos[k];                                    /* :69 */
+                o->vel[k] = (o->pos_predict[k] - o->pos[k]) / o->dt;                    /* :70 */
+                if (!o->cfg.boundary_handle) {                                          /* :73-81 */
+                    if (o->pos_predict[k] <= lo[a]) { o->pos_predict[k] = lo[a]; o->vel[k] *= R(0.5); }
+                    if (o->pos_predict[k] >= hi[a]) { o->pos_predict[k] = hi[a]; o->vel[k] *= R(0.5); }
+                }
+                o->pos[k] = o->pos_predict[k];                                          /* :84 */
+            }
+        }
+        /* phases 2 and 3: new positions, the step's cell lists (cell3 is not rebuilt), phase-1 velocities */
+        real *v = o->vel_predict;
+        PARFOR
+        for (int i = 0; i < o->N; ++i) {
+            real acc[3] = {0, 0, 0};
+            FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) {
+                const real w = poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h);                                            /* :98 */
+                acc[0] += (o->vel[3 * j] - o->vel[3 * i]) * w; acc[1] += (o->vel[3 * j + 1] - o->vel[3 * i + 1]) * w;
+                acc[2] += (o->vel[3 * j + 2] - o->vel[3 * i + 2]) * w; } });
+            v[3 * i] = acc[0]; v[3 * i + 1] = acc[1]; v[3 * i + 2] = acc[2];
+        }
+        PARFOR
+        for (int i = 0; i < 3 * o->N; ++i) o->vel[i] += c_visc * v[i];                  /* :92 / :94 */
+    }
+    return 0;
 }

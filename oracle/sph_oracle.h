@@ -35,7 +35,7 @@ typedef struct OrcConfig {
     double water_size[3];
     int boundary_handle; /* 1 = Akinci wall particles (default), 0 = clamp walls */
     int fs_couple;       /* unused until rigid coupling is restated */
-    int solver;          /* 0 = wcsph, 1 = dfsph, 2 = pcisph, 3 = iisph */
+    int solver;          /* 0 = wcsph, 1 = dfsph, 2 = pcisph, 3 = iisph, 4 = pbf */
     int num_threads;     /* OpenMP threads for the sweeps; results do not depend on it */
 } OrcConfig;
 
@@ -58,6 +58,7 @@ enum {
     ORC_F_PRESS_ITER = 16,   /* pcisph press_iter / iisph p_iter */
     ORC_F_PRESS_FORCE = 17,  /* pcisph press_force / iisph f_press */
     ORC_F_POS_PREDICT = 18, ORC_F_D_II = 19, ORC_F_A_II = 20, ORC_F_D_IJ = 21,
+    ORC_F_PBF_LAMBDA = 22, ORC_F_PBF_DELTA_POS = 23,
     ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33,
     ORC_F_RIGID_POS = 48, ORC_F_RIGID_VOL = 49, ORC_F_RIGID_FORCE = 50, ORC_F_RIGID_MASS = 51, ORC_F_RIGID_VERT = 52
 };
@@ -96,6 +97,8 @@ int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last);
 /* pcisph_solver.step / iisph_solver.step: last->n_dens = pressure iterations, last->dens_err = the printed residual */
 int orc_step_pcisph(Orc *o, int nsteps, OrcStepStats *last);
 int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last);
+/* pbf_solver.step (pbf_solver.py:176-187) under the schedule stated in sph_oracle.c */
+int orc_step_pbf(Orc *o, int nsteps);
 
 /* scalar kernels, for the known-answer tests */
 float orc_cubic_kernel(float r, float h);

@@ -72,11 +72,13 @@ def test_no_gpu_is_a_loud_error():
     assert e.value.code == _native.SPH_E_NO_DEVICE
 
 
-def test_out_of_scope_solver_rejected():
+def test_unknown_solver_rejected():
     cfg = scenes.get("wcsph_tiny_wall")
-    cfg["solver"]["name"] = "pbf"
+    cfg["solver"]["name"] = "mpm"
     with pytest.raises(NotImplementedError):
         _native.config_from_dict(cfg)
+    cfg["solver"]["name"] = "pbf"
+    assert _native.config_from_dict(cfg).solver == _native.SOLVER_PBF
 
 
 def test_product_does_not_import_the_oracle():
