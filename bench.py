@@ -45,6 +45,7 @@ ALGO_BYTES = {
     "dfsph_density_alpha": 24, "dfsph_warm_start": 48, "dfsph_div_residual": 32, "dfsph_div_correct": 56,
     "dfsph_ext_force": 40, "dfsph_dens_residual": 32, "dfsph_dens_correct": 48, "dfsph_integrate": 48,
     "wcsph_density": 16, "wcsph_force": 52, "hash_count": 16, "order_gather": 64, "build_nl": 0,
+    "pbf_lambda": 36, "pbf_delta_pos": 96, "pbf_xsph": 80,      # (pos 16 -> rho 4, lambda 4, (pos, lambda) 16) / (2 x 16 in, 3 x 16 out + lists) / (3 x 16 in, 2 x 16 out)
 }
 
 
@@ -102,6 +103,8 @@ def cpu_baseline(scene_name, solver_kind, state=None, first_step=1):
         step = lambda: o.step_iisph(1)
     elif solver_kind == "dfsph":
         step = lambda: o.step_dfsph(1, 100)
+    elif solver_kind == "pbf":
+        step = lambda: o.step_pbf(1)
     else:
         step = lambda: o.step_wcsph(1)
 
@@ -151,6 +154,17 @@ def load_traffic(kernel, key="hbm_bytes_per_launch"):
         return None
 
 
+def load_valu_mix(kernel_profile_name):
+    """Per-launch VALU class counts and their issue floor for the dominant kernels (tools/valu_mix.py; None if absent)."""
+    names = {"dfsph_div_residual": "k_residual<false, false, true>", "dfsph_dens_residual": "k_residual<true, false, true>",
+             "dfsph_div_correct": "k_correct<1, false, true>", "dfsph_dens_correct": "k_correct<2, false, true>"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
+            return json.load(f)["kernels"].get(names.get(kernel_profile_name, ""))
+    except Exception:
+        return None
+
+
 def load_ceiling():
     """G wave64-instructions/s that tools/valu_issue.hip sustained on an MI355X (committed under profiles/; None if absent)."""
     try:
@@ -160,11 +174,10 @@ def load_ceiling():
         return None
 
 
-# wave64 VALU issue rate: one f32 instruction per cycle per CU (4 SIMDs x 16 lanes), 256 CUs x 2.4 GHz (MI355X_MICROARCH.md) = 614.4 G
-# wave-instructions/s.  An unpacked FMA stream at that rate is 78.6 TFLOP/s; the guide's 157.3 TFLOP/s FP32 vector peak needs every
-# instruction to be a packed v_pk_fma_f32 (2 lanes' worth of work per lane-slot).  tools/valu_issue.hip measures both on the box
-# (profiles/r02*/valu_issue.json); `valu.frac` prices the kernel against the ISSUE rate, `valu.frac_of_fp32_peak` against 157.3.
-VALU_PEAK_GINST = 256 * 2.4
+# VALU issue on gfx950, measured (tools/valu_issue.hip -> profiles/valu_issue.json): a SIMD takes a plain wave64 f32 instruction every ~2.3
+# cycles once two waves alternate (~1050 G wave-instructions/s on the chip, 135 TFLOP/s as FMAs), a packed v_pk_fma_f32 every ~4.2
+# (146 TFLOP/s: the guide's 157.3 TFLOP/s FP32 vector peak), an instruction with an SGPR operand ~4, a transcendental 8.  roofline.valu
+# prices the dominant kernel's own instruction mix at those costs.
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
@@ -340,6 +353,8 @@ def main():
                         sim.rigid_step()
                     if stats is not None:
                         stats.append((0, st.n_dens, 0))
+            elif kind == "pbf":
+                sim.step_pbf(nsteps)
             elif with_body:
                 for _ in range(nsteps):
                     sim.step_wcsph(1)
@@ -443,18 +458,22 @@ def main():
                            "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload; NOT measured in this run)" if traffic else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
-                           "binding_limit": "valu",
+                           "binding_limit": "valu issue (84-89 % of the issue floor of the kernel's instruction mix, see valu)",
                            "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s); the kernel's binding limit is f32 "
                                    "instruction issue, not HBM: ~50 VALU instructions per pair (the reference's correctly rounded sqrt and divides) for < 1 "
                                    "algorithmic byte -- see roofline.valu and DESIGN.md section 6c"}
-        insts = load_traffic(dom, "sq_insts_valu_per_launch") if committed else None
-        if insts:
-            g_inst = insts / avg_s / 1e9
-            out["roofline"]["valu"] = {"wave_insts_per_launch": insts, "source": "profiles/pmc_traffic.json (committed SQ_INSTS_VALU pass; NOT measured in this run)",
-                                       "achieved": g_inst, "peak": VALU_PEAK_GINST, "unit": "G wave64-inst/s", "frac": g_inst / VALU_PEAK_GINST,
-                                       "peak_note": "issue rate of one wave64 VALU instruction per CU per cycle; as unpacked FMAs that is 78.6 TFLOP/s = half of the "
-                                                    "157.3 TFLOP/s FP32 vector peak, which needs packed v_pk_* instructions throughout (tools/valu_issue.hip)",
-                                       "measured_issue_ceiling": load_ceiling()}
+        mix = load_valu_mix(dom) if committed else None
+        if mix:
+            # second opinion on the same kernel: its VALU instruction mix (committed SQ_INSTS_VALU_* pass) priced with the per-class issue
+            # costs tools/valu_issue.hip measured on this chip -- the time the SIMDs need just to ISSUE the kernel's instructions
+            g_inst = mix["wave_insts_per_launch"] / avg_s / 1e9
+            out["roofline"]["valu"] = {"wave_insts_per_launch": mix["wave_insts_per_launch"], "plain": mix["plain"], "transcendental": mix["trans"], "other": mix["other"],
+                                       "source": "profiles/valu_mix.json (committed SQ_INSTS_VALU_* passes priced with profiles/valu_issue.json; NOT measured in this run)",
+                                       "issue_floor_us": mix["issue_floor_us"], "frac_of_issue_floor": mix["issue_floor_us"] / (avg_s * 1e6),
+                                       "achieved": g_inst, "unit": "G wave64-inst/s", "measured_issue_ceiling_plain_fma": load_ceiling(),
+                                       "note": "gfx950 issues a plain VGPR-operand f32/int instruction in ~2.3-2.7 cycles per SIMD (two waves alternating), one with an SGPR "
+                                               "operand, a packed v_pk_* or a VCC producer/consumer in ~4, a transcendental in 8 (tools/valu_issue.hip, profiles/valu_issue.json); "
+                                               "the floor is the kernel's own mix at those costs on 1024 SIMDs at 2.4 GHz"}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / nprof,
                                           "share": v[0] / tot} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     if has_rigid:

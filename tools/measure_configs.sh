@@ -3,17 +3,19 @@
 # Output: gpurun_out/measure_<name>.json
 set -o pipefail
 mkdir -p gpurun_out
+export SPH_BENCH_PREROLL=0      # the windows below are SURVEY.md 8d's: warm-up + timed steps, no extra pre-roll
 python bench.py --workload breaking_dam_30k_wcsph --steps 1000 --warmup 200 --no-cpu-baseline > gpurun_out/measure_c1_wcsph.json 2> gpurun_out/measure_c1_wcsph.err
 python bench.py --workload breaking_dam_30k_dfsph --steps 300 --warmup 100 --no-cpu-baseline > gpurun_out/measure_c1_dfsph.json 2> gpurun_out/measure_c1_dfsph.err
 python bench.py --workload wcsph_250k --steps 200 --warmup 50 > gpurun_out/measure_c2_wcsph_250k.json 2> gpurun_out/measure_c2.err
 python bench.py --workload dfsph_1m --steps 200 --warmup 50 > gpurun_out/measure_c3_dfsph_1m.json 2> gpurun_out/measure_c3.err
-python bench.py --workload dfsph_rigid_2m --steps 50 --warmup 10 > gpurun_out/measure_c5_dfsph_rigid_2m.json 2> gpurun_out/measure_c5.err
-python bench.py --workload dfsph_10m --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/measure_c4_dfsph_10m_1gpu.json 2> gpurun_out/measure_c4.err
+python bench.py --workload dfsph_rigid_2m --steps 50 --warmup 10 --no-scaling-base > gpurun_out/measure_c5_dfsph_rigid_2m.json 2> gpurun_out/measure_c5.err
+python bench.py --workload dfsph_10m --steps 50 --warmup 50 --no-cpu-baseline > gpurun_out/measure_c4_dfsph_10m_1gpu.json 2> gpurun_out/measure_c4.err
 python bench.py --workload breaking_dam_30k_iisph --steps 300 --warmup 100 > gpurun_out/measure_c1_iisph_as_shipped.json 2> gpurun_out/measure_c1i.err
 python bench.py --workload breaking_dam_30k_pcisph --steps 300 --warmup 100 > gpurun_out/measure_c1_pcisph.json 2> gpurun_out/measure_c1p.err
 python bench.py --workload pcisph_1m --steps 100 --warmup 20 > gpurun_out/measure_c3_pcisph_1m.json 2> gpurun_out/measure_c3p.err
 python bench.py --workload iisph_1m --steps 100 --warmup 20 > gpurun_out/measure_c3_iisph_1m.json 2> gpurun_out/measure_c3i.err
-python bench.py --workload coupling_demo --steps 200 --warmup 50 --no-cpu-baseline > gpurun_out/measure_coupling_demo_pcisph_rigid.json 2> gpurun_out/measure_cd.err
+python bench.py --workload breaking_dam_30k_pbf --steps 1000 --warmup 200 --no-cpu-baseline --profile-steps 0 > gpurun_out/measure_c1_pbf.json 2> gpurun_out/measure_c1b.err
+python bench.py --workload coupling_demo --steps 200 --warmup 50 > gpurun_out/measure_coupling_demo_pcisph_rigid.json 2> gpurun_out/measure_cd.err
 python - <<'PY' > gpurun_out/measure_cpu_config1.json
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())

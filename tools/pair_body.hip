@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256) void k_body(Consts c, float *out, int groups, 
     float acc = 0.f;
     const int cnt = groups * 4 - (threadIdx.x & 3);          // ragged like a real list
     uint32_t j0 = SCATTER ? idx[threadIdx.x] : 0u;
-    const PairK pk = pair_consts<(KIND >= 3)>(c);
+    const PairK pk = pair_consts<(KIND == 3 || KIND == 4)>(c);
     auto eval = [&](const float4 pa, const float2 pb) -> float {
         const float dx = sx_i - pa.x, dy = sy_i - pa.y, dz = sz_i - pa.z;
         if (KIND >= 2) {
-            const float r = norm3_scaled2<(KIND >= 4)>(dx, dy, dz);
+            const float r = norm3_scaled2<(KIND == 4)>(dx, dy, dz);
             const F3 g = grad_w_scaled2(pk, dx, dy, dz, r);
             return pk.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);
         }
@@ -95,17 +95,25 @@ __global__ __launch_bounds__(256) void k_body(Consts c, float *out, int groups, 
         for (int u = 0; u < 4; ++u) { j0 = (j0 * 5u + 7u + (SCATTER ? 0u : 0u)) % kCap; j[u] = SCATTER ? j0 : (uint32_t)((kk + u) % kCap); }
         const float4 a0 = s_A[j[0]], a1 = s_A[j[1]], a2 = s_A[j[2]], a3 = s_A[j[3]];
         const float2 b0 = s_B[j[0]], b1 = s_B[j[1]], b2 = s_B[j[2]], b3 = s_B[j[3]];
-        if (KIND != 1) {
+        if (KIND != 1 && KIND != 5) {
             acc += eval(a0, b0);
             if (kk + 1 < cnt) acc += eval(a1, b1);
             if (kk + 2 < cnt) acc += eval(a2, b2);
             if (kk + 3 < cnt) acc += eval(a3, b3);
-        } else {
+        } else if (KIND == 1) {
             const float t0 = eval(a0, b0), t1 = eval(a1, b1), t2 = eval(a2, b2), t3 = eval(a3, b3);
             acc += t0;
             { const float n = acc + t1; acc = kk + 1 < cnt ? n : acc; }
             { const float n = acc + t2; acc = kk + 2 < cnt ? n : acc; }
             { const float n = acc + t3; acc = kk + 3 < cnt ? n : acc; }
+        } else {
+            // one basic block, no selects: a term past the lane's count is ANDed to +0 with an arithmetic-shift mask (plain integer VALU,
+            // no VCC), and acc + (+0) == acc bit for bit (acc is never -0)
+            const float t0 = eval(a0, b0), t1 = eval(a1, b1), t2 = eval(a2, b2), t3 = eval(a3, b3);
+            acc += t0;
+            acc += __int_as_float(__float_as_int(t1) & ((kk + 1 - cnt) >> 31));
+            acc += __int_as_float(__float_as_int(t2) & ((kk + 2 - cnt) >> 31));
+            acc += __int_as_float(__float_as_int(t3) & ((kk + 3 - cnt) >> 31));
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
@@ -155,16 +163,18 @@ int main(int argc, char **argv)
     const int groups = 250;
     const int nout = cus * 16 * 256;
     std::vector<float> ref(nout), got(nout);
-    const char *names[5] = {"seq (current body)", "one basic block", "seq, gate on the scalar + max(den)", "+ constants in VGPRs", "+ fma square root"};
+    const char *names[6] = {"seq (current body)", "one basic block", "seq, gate on the scalar + max(den)", "+ constants in VGPRs", "+ fma square root",
+                            "one basic block, masked terms (no selects), gate on the scalar"};
     printf("{\"pairs_per_sweep\": %.3g, \"results\": {\n", target);
-    for (int kind = 0; kind < 5; ++kind) {
+    for (int kind = 0; kind < 6; ++kind) {
         double rx, rc;
         switch (kind) {
         case 0: rx = run<0, true>(c, cus, dout, didx, groups); break;
         case 1: rx = run<1, true>(c, cus, dout, didx, groups); break;
         case 2: rx = run<2, true>(c, cus, dout, didx, groups); break;
         case 3: rx = run<3, true>(c, cus, dout, didx, groups); break;
-        default: rx = run<4, true>(c, cus, dout, didx, groups); break;
+        case 4: rx = run<4, true>(c, cus, dout, didx, groups); break;
+        default: rx = run<5, true>(c, cus, dout, didx, groups); break;
         }
         CHECK(hipMemcpy(got.data(), dout, (size_t)nout * 4, hipMemcpyDeviceToHost));
         if (kind == 0) ref = got;
@@ -175,10 +185,11 @@ int main(int argc, char **argv)
         case 1: rc = run<1, false>(c, cus, dout, didx, groups); break;
         case 2: rc = run<2, false>(c, cus, dout, didx, groups); break;
         case 3: rc = run<3, false>(c, cus, dout, didx, groups); break;
-        default: rc = run<4, false>(c, cus, dout, didx, groups); break;
+        case 4: rc = run<4, false>(c, cus, dout, didx, groups); break;
+        default: rc = run<5, false>(c, cus, dout, didx, groups); break;
         }
         printf("  \"%s\": {\"scattered_us\": %.1f, \"conflict_free_us\": %.1f, \"outputs_differing_from_current\": %zu}%s\n", names[kind], target / rx * 1e6,
-               target / rc * 1e6, bad, kind == 4 ? "" : ",");
+               target / rc * 1e6, bad, kind == 5 ? "" : ",");
     }
     printf("}}\n");
     return 0;
