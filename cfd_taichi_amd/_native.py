@@ -138,6 +138,49 @@ def library_path():
     return os.environ.get("SPH_LIB") or _build.LIB
 
 
+# the per-step path of include/sph_mi355x.h: what any implementation of the ABI exports (the device-specific entry points --
+# slabs / RCCL, profiling, tuning, self-tests -- are bound by load() for libsph_mi355x.so only)
+CORE_EXPORTS = [
+    "sph_create", "sph_create_rigid", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
+    "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_rigid_step",
+    "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_get_scalar", "sph_synchronize",
+]
+
+
+def _bind_core(lib):
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.sph_create.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(vp)]
+    lib.sph_create.restype = ci
+    lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
+    lib.sph_rigid_step.argtypes = [vp]
+    lib.sph_destroy.argtypes = [vp]
+    lib.sph_destroy.restype = None
+    lib.sph_get_sizes.argtypes = [vp, ctypes.POINTER(SphSizes)]
+    lib.sph_last_error.argtypes = [vp]
+    lib.sph_last_error.restype = ctypes.c_char_p
+    lib.sph_upload.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
+    lib.sph_download.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
+    lib.sph_step_wcsph.argtypes = [vp, ci]
+    lib.sph_step_pbf.argtypes = [vp, ci]
+    lib.sph_step_dfsph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
+    lib.sph_step_pcisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
+    lib.sph_step_iisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
+    for name in ("sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_synchronize"):
+        getattr(lib, name).argtypes = [vp]
+    lib.sph_get_scalar.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    return lib
+
+
+def bind_core(path):
+    """Any shared library that implements the per-step path of include/sph_mi355x.h (CORE_EXPORTS), ready for Simulation(cfg, lib=...):
+    a test written against the ABI runs unchanged on another implementation of it."""
+    lib = ctypes.CDLL(path)
+    missing = [n for n in CORE_EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise RuntimeError("%s does not export %s" % (path, missing))
+    return _bind_core(lib)
+
+
 def load(build_if_missing=True):
     """Load libsph_mi355x.so; raises RuntimeError if it cannot be found or built."""
     global _lib
@@ -155,23 +198,8 @@ def load(build_if_missing=True):
     except OSError as e:
         raise RuntimeError("cannot load %s (%s); the HIP extension is required, there is no CPU fallback" % (path, e))
     vp, ci = ctypes.c_void_p, ctypes.c_int
-    lib.sph_create.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(vp)]
-    lib.sph_create.restype = ci
-    lib.sph_destroy.argtypes = [vp]
-    lib.sph_destroy.restype = None
-    lib.sph_get_sizes.argtypes = [vp, ctypes.POINTER(SphSizes)]
-    lib.sph_last_error.argtypes = [vp]
-    lib.sph_last_error.restype = ctypes.c_char_p
-    lib.sph_upload.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
-    lib.sph_download.argtypes = [vp, ci, ci, vp, ctypes.c_size_t]
-    lib.sph_step_wcsph.argtypes = [vp, ci]
-    lib.sph_step_pbf.argtypes = [vp, ci]
-    lib.sph_step_dfsph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
-    lib.sph_step_pcisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
-    lib.sph_step_iisph.argtypes = [vp, ci, ctypes.POINTER(SphStepStats)]
-    for name in ("sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_synchronize", "sph_profile_reset"):
-        getattr(lib, name).argtypes = [vp]
-    lib.sph_get_scalar.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    _bind_core(lib)
+    lib.sph_profile_reset.argtypes = [vp]
     lib.sph_profile_enable.argtypes = [vp, ci]
     lib.sph_profile_kernel_count.argtypes = []
     lib.sph_profile_kernel_name.argtypes = [ci]
@@ -180,8 +208,6 @@ def load(build_if_missing=True):
     lib.sph_selftest_math.argtypes = [ci, ci, vp, vp, vp, ctypes.c_size_t]
     lib.sph_selftest_wave.argtypes = [ci, ci, vp, vp, ctypes.c_size_t]
     lib.sph_tune_time.argtypes = [vp, ci, ctypes.c_uint, ci, ctypes.POINTER(ctypes.c_double)]
-    lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]
-    lib.sph_rigid_step.argtypes = [vp]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
     lib.sph_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.sph_rccl_unique_id.argtypes = [vp]
@@ -268,9 +294,10 @@ def replan_slabs(column_histogram, old_cuts):
 class Simulation:
     """Owns one SphHandle: device buffers of one ParticleSystem + one fluid solver."""
 
-    def __init__(self, cfg, rigid=None):
-        """rigid: dict(points, vertices, rho_0, pos_offset, attitude_offset (degrees), active) from mesh.rigid_from_config"""
-        self._lib = load()
+    def __init__(self, cfg, rigid=None, lib=None):
+        """rigid: dict(points, vertices, rho_0, pos_offset, attitude_offset (degrees), active) from mesh.rigid_from_config;
+        lib: another implementation of the ABI's per-step path (bind_core), default libsph_mi355x.so"""
+        self._lib = lib or load()
         self.cfg = cfg
         handle = ctypes.c_void_p()
         self.n_vertices = 0

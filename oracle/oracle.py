@@ -65,10 +65,11 @@ class OrcStepStats(ctypes.Structure):
 
 
 def _stale():
-    libs = [os.path.join(_HERE, n) for n in ("liborc_f32.so", "liborc_f64.so")]
+    libs = [os.path.join(_HERE, n) for n in ("liborc_f32.so", "liborc_f64.so", "liborc_abi.so")]
     if not all(os.path.exists(p) for p in libs):
         return True
-    newest = max(os.path.getmtime(os.path.join(_HERE, n)) for n in ("sph_oracle.c", "sph_oracle.h", "Makefile"))
+    newest = max(os.path.getmtime(p) for p in [os.path.join(_HERE, n) for n in ("sph_oracle.c", "sph_oracle.h", "sph_oracle_abi.c", "Makefile")] +
+                 [os.path.join(os.path.dirname(_HERE), "include", "sph_mi355x.h")])
     return any(os.path.getmtime(p) < newest for p in libs)
 
 
@@ -78,6 +79,8 @@ def build(force=False):
         subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
                        stdout=subprocess.DEVNULL)
 
+
+ABI_LIB = os.path.join(_HERE, "liborc_abi.so")     # include/sph_mi355x.h's per-step entry points on the oracle (sph_oracle_abi.c)
 
 _libs = {}
 

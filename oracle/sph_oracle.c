@@ -548,6 +548,13 @@ static real *field_ptr(Orc *o, int field, long *count, int *is_int)
     }
 }
 
+long orc_field_floats(Orc *o, int field)          /* element count of a field, -1 if it does not exist on this handle */
+{
+    long n; int is_int;
+    (void)field_ptr(o, field, &n, &is_int);
+    return n;
+}
+
 long orc_get(Orc *o, int field, float *out)
 {
     long n; int is_int;
@@ -590,6 +597,7 @@ double orc_get_scalar(const Orc *o, int which)
     case 6: return (double)o->pci_beta;
     case 7: return (double)o->pci_max_index;
     case 8: return (double)o->pci_max_count;
+    case 9: return (double)o->ps_dt;
     case 10: case 11: case 12: return (double)o->centroid[which - 10];
     case 13: case 14: case 15: return (double)o->rs_omega[which - 13];
     case 16: case 17: case 18: return (double)o->r_vel[which - 16];

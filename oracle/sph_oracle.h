@@ -82,10 +82,11 @@ void orc_destroy(Orc *o);
 /* out[0]=N fluid, out[1]=Nb wall, out[2]=Nr rigid, out[3..5]=grid_num, out[6]=C */
 void orc_sizes(const Orc *o, int *out7);
 /* copies the whole field as float (3 floats per particle for vectors); returns element count or -1 */
+long orc_field_floats(Orc *o, int field);
 long orc_get(Orc *o, int field, float *out);
 long orc_set(Orc *o, int field, const float *in);
 int orc_set_scalar(Orc *o, int which, double value);   /* 0: delta_time (with delta_time_2 and ps.delta_time) */
-double orc_get_scalar(const Orc *o, int which); /* 0 dt, 1 simulate_cnt, 2 particle_m, 3 h, 4 lost, 5 pcisph delta, 6 pcisph beta, 7/8 pcisph max-neighbour index/count */
+double orc_get_scalar(const Orc *o, int which); /* 0 dt, 1 simulate_cnt, 2 particle_m, 3 h, 4 lost, 5 pcisph delta, 6 pcisph beta, 7/8 pcisph max-neighbour index/count, 9 ps.delta_time */
 
 void orc_build_grid(Orc *o);               /* reset_grid + update_grid */
 void orc_compute_rho(Orc *o);              /* solver_base.compute_all_rho */
