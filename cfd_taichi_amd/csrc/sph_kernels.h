@@ -683,31 +683,42 @@ enum { FIN_PLAIN = 0, FIN_DIV_FIRST = 1, FIN_DIV_LOOP = 2, FIN_DENS = 3 };
 // FINP_REDUCE writes this slab's (sum, count) to red[0..1]; FINP_DECIDE takes the decision from the reduced pair in red.
 enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
 
-__global__ __launch_bounds__(kBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                          DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
+// One workgroup of kFinBlock threads: every thread adds the partials t, t + kFinBlock, ... in ascending order (one batch of loads at
+// 1 M particles: 3907 partials), a wave butterfly, then thread 0 adds the 16 wave sums in order -- one barrier.  (With 256 threads,
+// two load rounds and an eight-level LDS tree this kernel took 5.2 us, 29 times per step.)  The order is fixed, hence deterministic.
+constexpr int kFinBlock = 1024;
+__global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
 {
     if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
     if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
-    __shared__ double s_sum[kBlock];
-    __shared__ long long s_cnt[kBlock];
+    __shared__ double s_sum[kFinBlock / 64];
+    __shared__ long long s_cnt[kFinBlock / 64];
     if (phase != FINP_DECIDE) {
-        // thread t adds the partials t, t + 256, ... in ascending order (the order is part of the result); eight loads are in flight at a
-        // time, the additions keep their sequence
-        double t = 0.0; long long n = 0;
+        double t = 0.0; int n = 0;
         int k = threadIdx.x;
-        for (; k + 7 * kBlock < nblocks; k += 8 * kBlock) {
-            double v[8]; int m[8];
+        for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
+            double v[4]; int m[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { v[u] = psum[k + u * kBlock]; m[u] = pcnt[k + u * kBlock]; }
+            for (int u = 0; u < 4; ++u) { v[u] = psum[k + u * kFinBlock]; m[u] = pcnt[k + u * kFinBlock]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { t += v[u]; n += m[u]; }
+            for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
         }
-        for (; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
-        s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
+        {   // the rest, still as one batch of (predicated) loads
+            double v[4]; int m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = k + u * kFinBlock; v[u] = e < nblocks ? psum[e] : 0.0; m[u] = e < nblocks ? pcnt[e] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
+        }
+        const double ws = wave_sum(t);
+        const int wn = wave_sum(n);
+        if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_cnt[threadIdx.x >> 6] = wn; }
         __syncthreads();
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
-            if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
-            __syncthreads();
+        if (threadIdx.x == 0) {
+            double tt = 0.0; long long nn = 0;
+            for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_sum[w]; nn += s_cnt[w]; }
+            s_sum[0] = tt; s_cnt[0] = nn;
         }
     }
     if (threadIdx.x != 0) return;

@@ -1572,16 +1572,16 @@ int launch_finalize(SphHandle *h, int mode)
     if (slab_async(h)) {       // this slab's (sum, count) -> all-reduce over the slabs -> the loop decision, all on the stream
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev);
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev);
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr);
     return SPH_OK;
 }
 
@@ -1596,7 +1596,7 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
 int reduce_mean_host(SphHandle *h, float dflt, float *mean)
 {
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
     int rc = read_scalars(h);
     if (rc) return rc;
     double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
@@ -2820,15 +2820,15 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
         else if (which == 2) launch_dens_residual(h, GATE_NONE);
         else if (which == 4) {      // a sweep followed by the single-workgroup reduction of its block partials, as in the solver loops
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
         } else if (which == 5) {    // the reduction alone
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
         } else if (which == 6) {    // two different sweeps alternating (residual, correct), no reduction between them
             launch_div_residual(h, GATE_NONE);
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         } else if (which == 7) {    // the same with the reduction after the residual: one solver iteration
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         }
         else if ((rc = stage_sort_and_lists(h))) break;
