@@ -53,6 +53,7 @@ struct Consts {
     const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
     int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
     int nl16;             // fluid lists of staged workgroups hold 16-bit local indices, eight per 16-byte group (NlWriter)
+    int kr_split;         // dfsph sweeps hand k / rho to the next sweep in a 4-byte array instead of a (pos, k / rho) float4 (k_correct)
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

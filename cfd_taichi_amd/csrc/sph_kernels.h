@@ -459,11 +459,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
-                                                     RigidView rv, int *__restrict__ ncount, uint32_t *__restrict__ stage_src,
+                                                     RigidView rv, int *__restrict__ ncount, uint2 *__restrict__ stage_runs,
                                                      int *__restrict__ stage_cnt)
 {
     __shared__ uint32_t s_stage[2][4 * kBlock];
-    __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_ncell, s_ok;
+    __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok;
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     int i = blk * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
@@ -510,24 +510,32 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             own[q] = key >= 0 ? cell_start[key + 1] - cell_start[key] : 0;
             run += own[q];
         }
-        const int inc = wave_inclusive_scan(run);
+        int nonempty = 0;
+#pragma unroll
+        for (int q = 0; q < kStageHash / kBlock; ++q) nonempty += own[q] > 0 ? 1 : 0;
+        const int inc = wave_inclusive_scan(run), inc_ne = wave_inclusive_scan(nonempty);     // particles / non-empty cells before this thread's entries
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        if (lane == 63) s_wsum[w] = inc;
+        if (lane == 63) { s_wsum[w] = inc; s_wsum_ne[w] = inc_ne; }
         __syncthreads();
-        int before = inc - run, total = 0;
-        for (int k = 0; k < kBlock / 64; ++k) { if (k < w) before += s_wsum[k]; total += s_wsum[k]; }
-        const bool staged = ok && total <= c.stage_cap;
+        int before = inc - run, run_idx = inc_ne - nonempty, total = 0, nruns = 0;
+        for (int k = 0; k < kBlock / 64; ++k) {
+            if (k < w) { before += s_wsum[k]; run_idx += s_wsum_ne[k]; }
+            total += s_wsum[k]; nruns += s_wsum_ne[k];
+        }
+        const bool staged = ok && total <= c.stage_cap;          // (ok: at most kStageMaxCells cells, so nruns fits the run table)
+        // The ordered source list of the set, as RUNS: a cell's particles are contiguous in the sorted arrays, so (first index, local
+        // base | count << 16) per non-empty cell describes it -- ~1.2 KB per workgroup where the flat list was 5.2 KB, re-read by every sweep.
 #pragma unroll
         for (int q = 0; q < kStageHash / kBlock; ++q) {
             const int e = threadIdx.x * (kStageHash / kBlock) + q;
             s_base[e] = before;
             if (staged && own[q] > 0) {
-                const int a = cell_start[s_key[e]];
-                for (int r = 0; r < own[q]; ++r) stage_src[(size_t)blk * c.stage_cap + before + r] = (uint32_t)(a + r);
+                stage_runs[(size_t)blk * kStageMaxCells + run_idx] = make_uint2((uint32_t)cell_start[s_key[e]], (uint32_t)before | ((uint32_t)own[q] << 16));
+                ++run_idx;
             }
             before += own[q];
         }
-        if (threadIdx.x == 0) { stage_cnt[blk] = staged ? total : -1; s_ok = staged ? 1 : 0; }
+        if (threadIdx.x == 0) { stage_cnt[blk] = staged ? (total | (nruns << 16)) : -1; s_ok = staged ? 1 : 0; }
         __syncthreads();
     }
     const bool staged = STAGED && s_ok != 0;
@@ -802,25 +810,63 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
 // the workgroup's operand array through stage_src into LDS (see the staging plan in k_build_nl); returns false when this
 // workgroup keeps global indices.  Uniform per workgroup; every thread of the workgroup must call it.
 // SCALED: the positions are staged multiplied by 2^32 (exact; see norm3_scaled in sph_device.h), .w unchanged
-// The copy is two dependent gathers per element (src[e], then A[src[e]]: ~700 cycles each out of L2, more from HBM).  All of a
-// thread's source indices are requested first, then all of its operands, then the LDS stores: two round trips per workgroup instead
-// of two per element (kStageBatch elements per thread and trip; a clamped index keeps the loads branch-free so that the compiler
-// leaves them in one batch; only the store is predicated).  Staging was 12 of the residual sweep's 64 us at 1 M particles.
+// The staged set of a workgroup is described by cell runs (k_build_nl): stage_cnt[blk] = particles | runs << 16 (-1: not staged),
+// stage_runs[blk][r] = (first sorted index, local base | count << 16).  stage_expand turns them into the flat list s_idx[e] = sorted
+// index of staged element e, in LDS.  In the kernels that do not keep that list, s_idx ALIASES the start of the operand array it
+// helps to fill (4 B per element inside a 16-B-per-element array): every thread first reads all of its indices into registers,
+// the workgroup synchronises, and only then do the gathered operands overwrite the list.
+// The copy itself is two dependent steps per element (the index, then A[index]: ~700 cycles out of L2, more from HBM): all of a
+// thread's operands are requested in one batch, then the LDS stores (kStageBatch elements per thread and trip, two trips cover the
+// largest capacity; a clamped index keeps the loads branch-free so that the compiler leaves them in one batch).
 constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip
+constexpr int kStageTrips = 2;          // 2 x 1792 >= the largest capacity (2560)
+__device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, uint32_t *__restrict__ s_idx)
+{
+    const int w = stage_cnt[blk];
+    if (w < 0) return -1;                                   // uniform per workgroup
+    const int nst = w & 0xffff, nruns = w >> 16;
+    const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
+    for (int r = threadIdx.x; r < nruns; r += kBlock) {
+        const uint2 rn = runs[r];
+        const int base = (int)(rn.y & 0xffffu), n = (int)(rn.y >> 16);
+        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;
+    }
+    __syncthreads();
+    return nst;
+}
+struct StageIdx { uint32_t j[kStageTrips][kStageBatch]; };
+// this thread's indices of all trips, then the barrier after which s_idx may be overwritten
+__device__ __forceinline__ StageIdx stage_take(const uint32_t *__restrict__ s_idx, int nst)
+{
+    StageIdx x;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        if (t > 0 && t * kStageBatch * kBlock >= nst) {     // uniform: the default capacity needs one trip
+#pragma unroll
+            for (int u = 0; u < kStageBatch; ++u) x.j[t][u] = 0u;
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) x.j[t][u] = s_idx[min((int)threadIdx.x + (t * kStageBatch + u) * kBlock, nst - 1)];
+    }
+    __syncthreads();
+    return x;
+}
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
-                                              const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
+                                              const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    const int nst = stage_cnt[blk];
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
     if (nst < 0) return false;
-    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
-        uint32_t j[kStageBatch];
+    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
         float4 a[kStageBatch];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) a[u] = A[j[u]];
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[x.j[t][u]];
 #pragma unroll
         for (int u = 0; u < kStageBatch; ++u)
             if (base + u * kBlock < nst)
@@ -830,24 +876,44 @@ __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restric
     return true;
 }
 
-// two-operand variant: A staged in LDS, the global index of every staged element next to it (B is gathered from HBM/L2 through it)
-__device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__restrict__ s_A, uint32_t *__restrict__ s_src,
-                                                  const float4 *__restrict__ A, const uint32_t *__restrict__ stage_src,
-                                                  const int *__restrict__ stage_cnt, int blk)
+// kr_split handles: positions from the step's position array and the per-sweep scalar k / rho from its own 4-byte array (the sweeps
+// then write 4 B per particle for their neighbours instead of a fresh (pos, k / rho) float4: 12 MB less written per launch at 1 M)
+__device__ __forceinline__ bool stage_operand_ps_scaled(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    const int nst = stage_cnt[blk];
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
     if (nst < 0) return false;
-    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
-        uint32_t j[kStageBatch];
-        float4 a[kStageBatch];
+    if (nst == 0) return true;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+        float4 a[kStageBatch]; float sc[kStageBatch];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) a[u] = A[j[u]];
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; sc[u] = S[x.j[t][u]]; }
 #pragma unroll
         for (int u = 0; u < kStageBatch; ++u)
-            if (base + u * kBlock < nst) { s_src[base + u * kBlock] = j[u]; s_A[base + u * kBlock] = a[u]; }
+            if (base + u * kBlock < nst) s_A[base + u * kBlock] = make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, sc[u]);
+    }
+    __syncthreads();
+    return true;
+}
+
+// two-operand variant: A staged in LDS, the global index of every staged element next to it (B is gathered from HBM/L2 through it)
+__device__ __forceinline__ bool stage_operand_src(const Consts &c, float4 *__restrict__ s_A, uint32_t *__restrict__ s_src,
+                                                  const float4 *__restrict__ A, const uint2 *__restrict__ stage_runs,
+                                                  const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, s_src);      // the list stays: B is gathered through it
+    if (nst < 0) return false;
+    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
+        float4 a[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[s_src[min(base + u * kBlock, nst - 1)]];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) s_A[base + u * kBlock] = a[u];
     }
     __syncthreads();
     return true;
@@ -915,19 +981,20 @@ __device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ 
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
                                                  const float4 *__restrict__ A, const float4 *__restrict__ B,
-                                                 const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt, int blk)
+                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    const int nst = stage_cnt[blk];
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
     if (nst < 0) return false;
-    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
+    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #ifndef SPH_X_NOSTAGE
-    for (int base = threadIdx.x; base < nst; base += kStageBatch * kBlock) {
-        uint32_t j[kStageBatch];
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
         float4 a[kStageBatch], b[kStageBatch];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) j[u] = src[min(base + u * kBlock, nst - 1)];
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[j[u]]; b[u] = B[j[u]]; }
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }
 #pragma unroll
         for (int u = 0; u < kStageBatch; ++u)
             if (base + u * kBlock < nst) {
@@ -1060,7 +1127,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
                                                     float *__restrict__ rho_out, float *__restrict__ aux_out,
                                                     float4 *__restrict__ Pout, float4 *Vout, RigidView rv,
                                                     const int *__restrict__ id, float *__restrict__ rho_orig,
-                                                    const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
 {
     extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
@@ -1112,7 +1179,8 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
         aux_out[i] = alpha;
         float dt = ds->dt;
         float k_i = warm[i] / dt;                            // dfsph_solver.py:333
-        Pout[i] = make_float4(pi.x, pi.y, pi.z, k_i / rho_i);
+        if (c.kr_split) krho[i] = k_i / rho_i;
+        else Pout[i] = make_float4(pi.x, pi.y, pi.z, k_i / rho_i);
         Vout[i] = make_float4(vi.x, vi.y, vi.z, rho_i);      // velocity buffers carry rho in .w (read by D5)
     } else {
         float p = tait_pressure(rho_i);                      // wcsph_solver.py:86-90
@@ -1240,12 +1308,15 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
-                                                    const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     SPH_SWEEP_PROLOGUE
-    const bool staged = STAGED && stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk);     // positions * 2^32
+    // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
+    const bool split = STAGED && !RIGID && c.kr_split;
+    const bool staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk)
+                                         : stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk));     // positions * 2^32
     const float dt = ds->dt;
     const float rho_i = rho[ii];
     float k_i;
@@ -1286,8 +1357,12 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
             }
         }
     };
+    struct OperandPS { float4 a; float s; };
     if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
     else if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
+    else if (split)          // a workgroup of a kr_split handle whose set did not fit: two global gathers per neighbour
+        walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) { o.a = P[j]; o.s = krho[j]; },
+                             [&](const OperandPS &o, uint32_t j) { pair(make_float4(o.a.x, o.a.y, o.a.z, o.s), make_float4(0.f, 0.f, 0.f, 0.f), j); });
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float bx = 0.f, by = 0.f, bz = 0.f;
     for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
@@ -1327,7 +1402,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
-                                                     const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -1402,7 +1477,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             kr = (val * alpha[i] / ds->dt) / rho_i;                                           // :363,367
         }
         out[i] = val;
-        Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
+        if (c.kr_split) krho[i] = kr;
+        else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
     }
     block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
@@ -1416,7 +1492,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
                                                       float *__restrict__ pmax, RigidView rv,
-                                                      const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;

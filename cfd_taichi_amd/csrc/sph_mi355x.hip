@@ -66,7 +66,7 @@ struct SphHandle {
     int *id[2] = {nullptr, nullptr};
     int pcur = 0, vcur = 0, vacur = 0, wcur = 0, icur = 0;
 
-    float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr;
+    float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr, *krho = nullptr /* k / rho (kr_split) */;
     float4 *X[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pcisph: EF, PF, PP, PB0, PB1; iisph: DII, DIJ, f_press, PB0, PB1
     int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
     unsigned sweep_lds = 0;      // experiment knob SPH_SWEEP_LDS: dynamic LDS bytes per block on the DFSPH sweeps (caps the waves per CU)
@@ -85,7 +85,8 @@ struct SphHandle {
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
-    uint32_t *stage_src = nullptr;
+    bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
+    uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
     int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
     DevScalars *ds = nullptr;    // device
@@ -660,6 +661,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->aux, n))) return rc;
     if ((rc = dalloc(h, &h->drho, n))) return rc;
     if ((rc = dalloc(h, &h->rho_adv, n))) return rc;
+    if ((rc = dalloc(h, &h->krho, n))) return rc;
     if ((rc = dalloc(h, &h->cnt, n))) return rc;
     // one spare 64-particle tile at the end: the software-pipelined walks read one row ahead
     if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
@@ -670,7 +672,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         h->staged = c.order == CELL_ORDER_TILED && h->cfg.solver != SPH_SOLVER_WCSPH && h->cfg.solver != SPH_SOLVER_PBF && !(e && atoi(e) == 0);
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
-            if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap))) return rc;
+            if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
         }
     }
@@ -1373,8 +1375,10 @@ int stage_sort_and_lists(SphHandle *h)
     }
     Consts &c = h->c;
     // 16-bit local indices in the fluid lists of staged workgroups: the dfsph sweeps without rigid entries (tagged rigid entries need
-    // 32 bits; the pcisph / iisph sweeps keep the 32-bit walks).  SPH_NL16=0 turns it off (A/B, tests/test_cell_order_gpu.py)
-    { const char *e = getenv("SPH_NL16"); c.nl16 = (h->staged && is_dfsph(h) && !rigid_coupled(h) && !(e && atoi(e) == 0)) ? 1 : 0; }
+    // 32 bits; the pcisph / iisph sweeps keep the 32-bit walks).  SPH_NL16=0 at sph_create turns it off (A/B, tests/test_cell_order_gpu.py)
+    c.nl16 = (h->staged && is_dfsph(h) && !rigid_coupled(h) && h->opt_nl16) ? 1 : 0;
+    // k / rho in its own array: single-GPU dfsph handles with staged sweeps and no rigid entries (the ghost refresh of slab handles ships P.w)
+    c.kr_split = (c.nl16 && !h->slab && h->opt_kr_split) ? 1 : 0;
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
     const dim3 b(kBlock);
@@ -1441,7 +1445,7 @@ int stage_sort_and_lists(SphHandle *h)
         HIP_TRY(h, hipMemcpyAsync(sc.data(), h->stage_cnt, sizeof(int) * sc.size(), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
         long long tot = 0; int bad = 0, mx = 0;
-        for (int v : sc) { if (v < 0) ++bad; else { tot += v; mx = std::max(mx, v); } }
+        for (int v : sc) { if (v < 0) ++bad; else { tot += v & 0xffff; mx = std::max(mx, v & 0xffff); } }
         fprintf(stderr, "[stage] %d workgroups, %d unstaged, mean %.0f max %d staged particles\n", h->nblocks, bad, sc.size() > (size_t)bad ? (double)tot / (sc.size() - bad) : 0.0, mx);
     }
     h->nl_valid = true;
@@ -1475,12 +1479,12 @@ int stage_density(SphHandle *h)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
         SPH_LAUNCH_RS(k_density, true, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, h->stage_src, h->stage_cnt);
+                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
     } else {
         ProfScope ps(h, K_W_DENSITY);
         SPH_LAUNCH_RS(k_density, false, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, h->stage_src, h->stage_cnt);
+                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1546,7 +1550,7 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     SPH_LAUNCH_RS(k_residual, false, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 template <int MODE>
@@ -1554,8 +1558,9 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
-    SPH_LAUNCH_RS(k_correct, MODE, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[1 - h->pcur], h->WP,
-                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt);
+    SPH_LAUNCH_RS(k_correct, MODE, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c,
+                  c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -1564,7 +1569,7 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     SPH_LAUNCH_RS(k_residual, true, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -2202,6 +2207,8 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->device = cfg->device;
     { const char *e = getenv("SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
     { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
+    { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     int rc = SPH_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }

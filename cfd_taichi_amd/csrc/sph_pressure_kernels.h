@@ -84,13 +84,21 @@ __device__ __forceinline__ void for_staged_nbrs_ps(const uint32_t *__restrict__ 
 }
 // first operand and a per-particle scalar both staged (20 B per staged particle)
 __device__ __forceinline__ bool stage_operand_scalar(const Consts &c, float4 *__restrict__ s_A, float *__restrict__ s_S, const float4 *__restrict__ A,
-                                                     const float *__restrict__ S, const uint32_t *__restrict__ stage_src,
+                                                     const float *__restrict__ S, const uint2 *__restrict__ stage_runs,
                                                      const int *__restrict__ stage_cnt, int blk)
 {
-    const int nst = stage_cnt[blk];
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
     if (nst < 0) return false;
-    const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
-    for (int e = threadIdx.x; e < nst; e += kBlock) { const uint32_t j = src[e]; s_A[e] = A[j]; s_S[e] = S[j]; }
+    if (nst == 0) return true;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) { s_A[base + u * kBlock] = A[x.j[t][u]]; s_S[base + u * kBlock] = S[x.j[t][u]]; }
+    }
     __syncthreads();
     return true;
 }
@@ -261,7 +269,7 @@ template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                     float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
-                                                    float4 *__restrict__ PP, RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                    float4 *__restrict__ PP, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
                                                             const DevScalars *__restrict__ ds, const float4 *__restrict__ PBin,
                                                             float4 *__restrict__ PBout, float *__restrict__ rho_predict,
                                                             double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
-                                                            const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                            const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
                                                       const float4 *__restrict__ V, const float4 *__restrict__ EF,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
-                                                      float4 *__restrict__ PP, int gate, RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                      float4 *__restrict__ PP, int gate, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                       float4 *__restrict__ VA, float4 *__restrict__ DII, RigidView rv,
-                                                      const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                        const float4 *__restrict__ DII, const float *__restrict__ p_past,
                                                        float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0,
-                                                       RigidView rv, const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                       RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE
@@ -584,7 +592,7 @@ template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                    const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv,
-                                                   const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                   const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -618,21 +626,20 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
                                                         const float *__restrict__ rho_adv, const float *__restrict__ a_ii,
                                                         const DevScalars *__restrict__ ds, float4 *__restrict__ PBout,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
-                                                        const uint32_t *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
     float *s_ex = reinterpret_cast<float *>(s_src + c.stage_cap), *s_ey = s_ex + c.stage_cap, *s_ez = s_ey + c.stage_cap;
-    const int nst = STAGED ? stage_cnt[blk] : -1;
+    const int nst = STAGED ? stage_expand(stage_src, stage_cnt, blk, s_src) : -1;      // the list stays: DII is gathered through it
     const bool staged = nst >= 0;
     if (staged) {
-        const uint32_t *src = stage_src + (size_t)blk * c.stage_cap;
         for (int e = threadIdx.x; e < nst; e += kBlock) {
-            const uint32_t j = src[e];
+            const uint32_t j = s_src[e];
             const float4 ev = DIJ[j];
-            s_src[e] = j; s_operand[e] = P[j];
+            s_operand[e] = P[j];
             s_ex[e] = ev.x; s_ey[e] = ev.y; s_ez[e] = ev.z;
         }
         __syncthreads();

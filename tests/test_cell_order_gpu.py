@@ -131,6 +131,28 @@ def test_lds_staging_is_invisible(scene, steps, cap, monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("cap", ["1664", "300"])
+def test_list_and_scalar_formats_are_invisible(cap, monkeypatch):
+    """The storage formats of the staged DFSPH sweeps -- 16-bit local list indices (SPH_NL16) and k / rho in its own 4-byte array
+    (SPH_KR_SPLIT) -- change no bit: all on, the scalar array off, both off, at a capacity where staged and unstaged workgroups mix."""
+    cfg = scenes.get("breaking_dam_30k_dfsph")
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    sims = []
+    for nl16, split in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("SPH_NL16", nl16)
+        monkeypatch.setenv("SPH_KR_SPLIT", split)
+        sims.append(make(cfg, "morton", monkeypatch))
+    for s_ in range(15):
+        st = [sim.step(1) for sim in sims]
+        for other in st[1:]:
+            assert (st[0].n_div, st[0].n_dens, st[0].div_err, st[0].dens_err, st[0].dt) == (other.n_div, other.n_dens, other.div_err, other.dens_err, other.dt), s_
+    for f in FIELDS:
+        ref = sims[0].download(f)
+        assert all(np.array_equal(ref, sim.download(f)) for sim in sims[1:]), f
+    for sim in sims:
+        sim.close()
+
+
 @pytest.mark.parametrize("cap", ["1664", "200"])
 def test_lds_staging_with_a_rigid_body(cap, monkeypatch):
     """Tagged rigid entries stay global inside staged lists; the coupled run equals the unstaged one, body included."""
