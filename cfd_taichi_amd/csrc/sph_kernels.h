@@ -433,9 +433,9 @@ struct NlWriter {
 // The sweeps are bound by L1 tag look-ups: a 64-lane gather of P[j] touches ~44 cache lines (TCP_TOTAL_CACHE_ACCESSES / wave
 // read), one look-up per cycle and CU -- 54 M look-ups = 88 us of a 104 us residual sweep at 1 M particles.  On the Morton curve
 // the particles a 256-particle workgroup can see (all cells around its own cells) are only ~1300 (max ~1800): the list build
-// also writes, per workgroup, the ordered set of those particles (stage_src) and the lists in indices LOCAL to that set; a
-// sweep then copies its operand array through stage_src into LDS once (coalesced: ~150 line look-ups per workgroup instead of
-// ~8000) and gathers from LDS.  A workgroup whose neighbourhood does not fit (sparse regions) keeps global indices: stage_cnt < 0.
+// also writes, per workgroup, the ordered set of those particles (as cell runs, stage_runs) and the lists in indices LOCAL to that
+// set; a sweep then copies its operand array through that set into LDS once (coalesced: ~150 line look-ups per workgroup instead
+// of ~8000) and gathers from LDS.  A workgroup whose neighbourhood does not fit (sparse regions) keeps global indices: stage_cnt < 0.
 constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
 constexpr int kStageMaxCells = 640;
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
