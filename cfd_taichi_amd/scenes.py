@@ -95,6 +95,33 @@ SCENES.update({
 })
 
 
+def _as_shipped(cfg, drop_boundary_handle=False, solid1=False):
+    """Key-level details of the reference's shipped files that exercise the config defaults (solver_base.py:31-32, main.py:70)."""
+    if drop_boundary_handle:
+        del cfg["solver"]["boundary_handle"]           # wcsph_config_backup.json has no such key: the default is True
+    if solid1:
+        # default.json and breaking_dam_demo.json name their body block "solid1": config.get('solid', {}) is empty, no body is built
+        cfg["solver"]["fs_couple"] = True
+        cfg["solid1"] = {"mesh": _CUBE, "voxel_radius": 0.025, "rho_0": 500, "scale": 1, "pos_offset": [4.7, 0.9, 0.7],
+                         "attitude_offset": [0.0, 0.0, 90.0], "fill": True, "active": True}
+    return cfg
+
+
+SCENES.update({
+    # the reference's remaining shipped files, geometry / solver / dt as shipped (dfsph_config_backup.json = dfsph_small and
+    # pbf_config_backup.json = pbf_small above)
+    "wcsph_config_backup": lambda: _as_shipped(_scene("wcsph", 5e-4, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+                                               drop_boundary_handle=True),
+    "pcisph_config_backup": lambda: _scene("pcisph", 1.5e-4, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    "iisph_config_backup": lambda: _scene("iisph", 1e-3, [1.5, 3.0, 1.5], [0.7, 1.5, 0.7], start_pos=(0.3, 0.5, 0.3)),
+    # config/breaking_dam_demo.json (dfsph, clamp walls) and default.json (pcisph, clamp walls): "solid1" blocks, i.e. fluid only
+    "breaking_dam_demo": lambda: _as_shipped(_scene("dfsph", 7e-4, [10.0, 7.0, 3.0], [2.0, 3.5, 2.8], start_pos=(0.2, 0.1, 0.1),
+                                                    boundary_handle=False), solid1=True),
+    "default": lambda: _as_shipped(_scene("pcisph", 1e-3, [7.0, 7.0, 2.5], [2.0, 3.6, 2.3], start_pos=(0.2, 0.1, 0.1),
+                                          boundary_handle=False), solid1=True),
+})
+
+
 def get(name):
     return SCENES[name]()
 
