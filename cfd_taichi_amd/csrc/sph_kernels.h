@@ -436,6 +436,7 @@ struct NlWriter {
 // also writes, per workgroup, the ordered set of those particles (as cell runs, stage_runs) and the lists in indices LOCAL to that
 // set; a sweep then copies its operand array through that set into LDS once (coalesced: ~150 line look-ups per workgroup instead
 // of ~8000) and gathers from LDS.  A workgroup whose neighbourhood does not fit (sparse regions) keeps global indices: stage_cnt < 0.
+constexpr int kRunCap = 16;          // runs of equal cell per wave whose 27 cells k_build_nl looks up cooperatively (mean 9, p99 16)
 constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
 constexpr int kStageMaxCells = 640;
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
@@ -464,6 +465,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
 {
     __shared__ uint32_t s_stage[2][4 * kBlock];
     __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok;
+    __shared__ uint4 s_cell[kBlock / 64][kRunCap * 9];
+    __shared__ int s_cslot[RIGID ? kBlock / 64 : 1][RIGID ? kRunCap * 9 : 1], s_runc[kBlock / 64][kRunCap][3];
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     int i = blk * kBlock + threadIdx.x;
     int kf = 0, kb = 0;
@@ -539,81 +542,130 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         __syncthreads();
     }
     const bool staged = STAGED && s_ok != 0;
-    if (i < c.n && id[i] < 0) {
-        cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
-    } else if (i < c.n) {
-        const float4 pi = P[i];
-        const f32x2 pi_xy = {pi.x, pi.y};
-        int cx, cy, cz;
-        cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
-        NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
-        NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
-        int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
-        const int my_id = RIGID ? id[i] : 0;
-        const bool tiled = c.order == CELL_ORDER_TILED;
-        for (int dx = -1; dx <= 1; ++dx) {
-            const SlotPart sx = tiled ? slot_part(c, cx + dx, 0, 1) : SlotPart{0, 0};   // the slot of a cell, one coordinate per loop level
-            for (int dy = -1; dy <= 1; ++dy) {
-                const SlotPart sy = tiled ? slot_part(c, cy + dy, 1, c.tnxz) : SlotPart{0, 0};
-                for (int dz = -1; dz <= 1; ++dz) {
-                    int x = cx + dx, y = cy + dy, z = cz + dz;
-                    if (x >= c.gx || y >= c.gy || z >= c.gz) continue;   // :453-456
-                    if (x < 0 || y < 0 || z < 0) continue;
-                    const int cid = x + y * c.sy + z * c.sz;
-                    const int slot = tiled ? slot_of_parts(c, sx, sy, slot_part(c, z, 2, c.tnx)) : cid;
-                    const int a = cell_start[slot], b = cell_start[slot + 1];
-                    const int lbase = staged ? stage_lookup(s_key, s_base, slot, ds) - a : 0;      // local index = lbase + j
-                    // four candidates at a time: branch-free accept mask, then the (few) accepted ones are appended in order
-                    // (one 32-bit byte offset per batch, the four loads differ by immediates; reading up to three slots past the cell
-                    // is harmless: the arrays carry 64 spare elements and the accept mask drops them)
-                    for (int j0 = a; j0 < b; j0 += 4) {
-                        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);
-                        unsigned m = near_mask4(pi_xy, pi.z, pb, c.r2_cut);                          // :466 (norm > h)
-                        m &= (b - j0 >= 4 ? 15u : (1u << (b - j0)) - 1u);                            // candidates of this cell only
-                        const unsigned self = (unsigned)(i - j0);                                    // :461 (j != i)
-                        if (self < 4u) m &= ~(1u << self);
-                        if (RIGID) nq += __popc(m);
-                        while (m) {
-                            const int u = __ffs(m) - 1;
-                            m &= m - 1;
-                            wf.push((uint32_t)(lbase + j0 + u));       // staged workgroups keep LOCAL indices
+    // (3) the walk.  What a particle needs to know about each of its 27 cells -- where the cell's fluid and wall particles start, how
+    // many there are, the cell's base in the staged set -- used to be worked out by every lane for itself (the slot on the curve
+    // through the tile-rank table, four dependent loads of cell bounds, a hash probe: ~100 instructions and two round trips to memory
+    // per cell, a third of the kernel).  But the lanes of a wave are ~9 runs of particles of the SAME cell: per dx-plane the wave
+    // now fills a table of (run, cell) entries with all lanes working (9 runs x 9 cells = 81 entries on 64 lanes) and every lane
+    // reads its run's entry from LDS.  A wave with more runs than the table holds (sparse spray) works the entries out per lane.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool walker = i < c.n && id[i] >= 0;
+    if (i < c.n && !walker) cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
+    const float4 pi = P[i < c.n ? i : 0];
+    const f32x2 pi_xy = {pi.x, pi.y};
+    int cx, cy, cz;
+    cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+    const int pcx = __shfl_up(cx, 1, 64), pcy = __shfl_up(cy, 1, 64), pcz = __shfl_up(cz, 1, 64);
+    const bool pwalker = __shfl_up(walker ? 1 : 0, 1, 64) != 0;
+    const bool rhead = walker && (lane == 0 || !pwalker || pcx != cx || pcy != cy || pcz != cz);
+    const unsigned long long rheads = __ballot(rhead);
+    const int nruns = __popcll(rheads);
+    const int run = __popcll(rheads & ((2ull << lane) - 1ull)) - 1;          // this lane's run (walkers only)
+    const bool table = nruns <= kRunCap;                                       // wave-uniform
+    if (table && rhead) { s_runc[wv][run][0] = cx; s_runc[wv][run][1] = cy; s_runc[wv][run][2] = cz; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
+    NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
+    int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
+    const int my_id = RIGID && walker ? id[i] : 0;
+    // one cell of a 27-neighbourhood: (first fluid particle, fluid count | staged base << 16, first wall particle, wall count[, slot])
+    auto cell_entry = [&](int ccx, int ccy, int ccz, int dx, int o9, uint4 &e, int &eslot) {
+        const int t3 = (o9 * 11) >> 5;                                          // o9 / 3 for 0 <= o9 < 9
+        const int x = ccx + dx, y = ccy + t3 - 1, z = ccz + (o9 - 3 * t3) - 1;
+        e = make_uint4(0u, 0u, 0u, 0u); eslot = -1;
+        if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) return;   // :453-456
+        const int cid = x + y * c.sy + z * c.sz;
+        const int slot = cell_slot_xyz(c, x, y, z, cid);
+        const int a = cell_start[slot], nf = min(cell_start[slot + 1] - a, 0xffff);
+        const int lbase = staged ? stage_lookup(s_key, s_base, slot, ds) : 0;
+        int wa = 0, nw = 0;
+        if (c.boundary_handle) { wa = wcell_start[cid]; nw = wcell_start[cid + 1] - wa; }
+        e = make_uint4((uint32_t)a, (uint32_t)nf | ((uint32_t)lbase << 16), (uint32_t)wa, (uint32_t)nw);
+        eslot = slot;
+    };
+    for (int dx = -1; dx <= 1; ++dx) {
+        if (table) {
+            const int nent = nruns * 9;
+            for (int t = lane; t < nent; t += 64) {
+                const int r = (t * 57) >> 9, o9 = t - 9 * r;                    // t / 9 for 0 <= t < 144
+                uint4 e; int eslot;
+                cell_entry(s_runc[wv][r][0], s_runc[wv][r][1], s_runc[wv][r][2], dx, o9, e, eslot);
+                s_cell[wv][t] = e;
+                if (RIGID) s_cslot[RIGID ? wv : 0][RIGID ? t : 0] = eslot;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (walker) {
+            for (int o9 = 0; o9 < 9; ++o9) {
+                uint4 e; int eslot = -1;
+                if (table) { e = s_cell[wv][run * 9 + o9]; if (RIGID) eslot = s_cslot[RIGID ? wv : 0][RIGID ? run * 9 + o9 : 0]; }
+                else cell_entry(cx, cy, cz, dx, o9, e, eslot);
+                const int a = (int)e.x, b = a + (int)(e.y & 0xffffu);
+                const int lbase = staged ? (int)(e.y >> 16) - a : 0;            // local index = lbase + j
+                // The accept bits of a cell's candidates are collected first (four candidates per trip, branch-free; up to 32 per chunk),
+                // then the (few) accepted ones are appended in order: the append loop runs as often as the busiest lane has bits, and
+                // per cell that is ~half of what it was per trip.  (One 32-bit byte offset per trip, the four loads differ by
+                // immediates; reading up to three slots past the cell is harmless: the arrays carry 64 spare elements and the chunk's
+                // validity mask drops them.)
+                for (int j0 = a; j0 < b; j0 += 32) {
+                    const int nb = b - j0 < 32 ? b - j0 : 32;
+                    unsigned m = 0;
+                    for (int t = 0; t < nb; t += 4) {
+                        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)(j0 + t) * 16u);
+                        m |= near_mask4(pi_xy, pi.z, pb, c.r2_cut) << t;                         // :466 (norm > h)
+                    }
+                    m &= 0xffffffffu >> (32 - nb);                                               // candidates of this cell only
+                    const unsigned self = (unsigned)(i - j0);                                    // :461 (j != i)
+                    if (self < 32u) m &= ~(1u << self);
+                    if (RIGID) nq += __popc(m);
+                    while (m) {
+                        const int u = __ffs(m) - 1;
+                        m &= m - 1;
+                        wf.push((uint32_t)(lbase + j0 + u));       // staged workgroups keep LOCAL indices
+                    }
+                }
+                if (RIGID && eslot >= 0) {
+                    // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
+                    const int ra = rv.rcell_start[eslot], rb = rv.rcell_start[eslot + 1];
+                    for (int j = ra; j < rb; ++j) {
+                        const float4 pj = rv.RP[j];
+                        float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                        float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                        if (!(r2 > c.r2_cut)) wf.push((uint32_t)j | kRigidTag);
+                        // get_neighbour_count (:436-444): skips when particle_j.index == i (the rigid particle's LOCAL index) and
+                        // measures the distance to fluid_particles.pos[particle_j.index]
+                        const int jl = rv.rid[j];
+                        if (jl != my_id && jl < rv.n_fluid) {
+                            const float4 pq = rv.pos_orig[jl];
+                            float ex = pi.x - pq.x, ey = pi.y - pq.y, ez = pi.z - pq.z;
+                            float e2 = (ex * ex + ey * ey) + ez * ez;
+                            if (!(e2 > c.r2_cut)) ++nq;
                         }
                     }
-                    if (RIGID) {
-                        // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
-                        const int ra = rv.rcell_start[slot], rb = rv.rcell_start[slot + 1];
-                        for (int j = ra; j < rb; ++j) {
-                            const float4 pj = rv.RP[j];
-                            float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
-                            float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
-                            if (!(r2 > c.r2_cut)) wf.push((uint32_t)j | kRigidTag);
-                            // get_neighbour_count (:436-444): skips when particle_j.index == i (the rigid particle's LOCAL index) and
-                            // measures the distance to fluid_particles.pos[particle_j.index]
-                            const int jl = rv.rid[j];
-                            if (jl != my_id && jl < rv.n_fluid) {
-                                const float4 pq = rv.pos_orig[jl];
-                                float ex = pi.x - pq.x, ey = pi.y - pq.y, ez = pi.z - pq.z;
-                                float e2 = (ex * ex + ey * ey) + ez * ez;
-                                if (!(e2 > c.r2_cut)) ++nq;
-                            }
-                        }
+                }
+                const int wa = (int)e.z, wb = wa + (int)e.w;
+                for (int j0 = wa; j0 < wb; j0 += 32) {
+                    const int nb = wb - j0 < 32 ? wb - j0 : 32;
+                    unsigned m = 0;
+                    for (int t = 0; t < nb; t += 4) {
+                        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(WP) + (unsigned)(j0 + t) * 16u);
+                        m |= near_mask4(pi_xy, pi.z, pb, c.r2_cut) << t;                         // :364
                     }
-                    if (c.boundary_handle) {
-                        const int wa = wcell_start[cid], wb = wcell_start[cid + 1];
-                        for (int j0 = wa; j0 < wb; j0 += 4) {
-                            const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(WP) + (unsigned)j0 * 16u);
-                            unsigned m = near_mask4(pi_xy, pi.z, pb, c.r2_cut);                      // :364
-                            m &= (wb - j0 >= 4 ? 15u : (1u << (wb - j0)) - 1u);
-                            while (m) {
-                                const int u = __ffs(m) - 1;
-                                m &= m - 1;
-                                ww.push((uint32_t)(j0 + u));
-                            }
-                        }
+                    m &= 0xffffffffu >> (32 - nb);
+                    while (m) {
+                        const int u = __ffs(m) - 1;
+                        m &= m - 1;
+                        ww.push((uint32_t)(j0 + u));
                     }
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (walker) {
         wf.flush();
         ww.flush();
         kf = wf.k; kb = ww.k;
