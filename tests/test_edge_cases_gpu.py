@@ -93,3 +93,36 @@ def test_long_runs_with_wall_leaks_match_oracle(scene, solver, steps):
     leaked = int(((pos < 0) | (pos > box)).any(axis=1).sum())
     print(scene, "particles outside the box at the end:", leaked)
     sim.close(); o.close()
+
+
+@pytest.mark.parametrize("solver", ["wcsph", "dfsph"])
+@pytest.mark.parametrize("morton", [False, True])
+def test_spray_and_clump(solver, morton, monkeypatch):
+    """The two ends of the cell occupancy the list build sees: spray -- every particle alone in its cell, so a wave holds 64 runs of
+    equal cell (more than its per-wave table of cell entries takes: the per-lane path) -- and a clump of 40 particles inside one
+    cell (more candidates than one 32-bit accept mask holds).  Both against the oracle, on the reference's cell order and on the curve."""
+    if morton:
+        monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+        monkeypatch.setenv("SPH_STAGE", "1")              # dfsph: staged workgroups (16-bit local lists) next to unstaged ones
+    cfg = scenes.get("dfsph_tiny_clamp")
+    cfg["solver"]["name"] = solver
+    cfg["solver"]["delta_time"] = 2.5e-4 if solver == "wcsph" else 1e-3
+    cfg["scene"]["box_max"] = [2.0, 2.0, 2.0]
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=2)
+    n = o.N
+    rng = np.random.default_rng(5)
+    pos = np.empty((n, 3), dtype=np.float32)
+    # spray: one particle per cell on a jittered lattice of pitch 0.1 = h (neighbours in adjacent cells, 0.06 .. 0.14 apart)
+    side = int(np.ceil((n - 40) ** (1.0 / 3.0)))
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)[: n - 40]
+    pos[: n - 40] = (0.15 + 0.1 * g + rng.uniform(-0.02, 0.02, (n - 40, 3))).astype(np.float32)
+    # clump: 40 particles inside the cell (15, 15, 15), 0.012 apart on average
+    pos[n - 40:] = (1.5 + rng.uniform(0.02, 0.08, (40, 3))).astype(np.float32)
+    pos = pos[rng.permutation(n)]
+    o.set(orc.F_POS, pos)
+    sim.upload(nat.F_POS, pos)
+    sim.build_neighbors()
+    assert sim.download(nat.F_NBR_COUNT).max() >= 39      # the clump is there
+    step_both(sim, o, solver, 6)
+    sim.close(); o.close()
