@@ -379,6 +379,26 @@ __device__ __forceinline__ unsigned near_mask4(f32x2 pi_xy, float pi_z, const fl
     return m;
 }
 
+// The same test for the list build, as a REJECT mask built without compares: squared distances are non-negative floats, whose order is
+// the order of their bit patterns, so the sign of (bits(r2_cut) - bits(r2)) says r2 > r2_cut; v_alignbit shifts each sign into the mask
+// (one subtract and one funnel shift per candidate where a compare + select pair through VCC costs ~10 cycles, tools/valu_issue.hip).
+// bit u set <=> |x_i - x_u|^2 > r2_cut.  (A NaN distance -- a particle with a NaN coordinate, whose cell is unspecified anyway -- counts as far.)
+__device__ __forceinline__ unsigned far_mask4(f32x2 pi_xy, float pi_z, const float4 *__restrict__ pb, unsigned cut_bits)
+{
+    unsigned rej = 0;
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+        const float4 pc = pb[u];
+        const f32x2 c_xy = {pc.x, pc.y};
+        const f32x2 d = pi_xy - c_xy;
+        const f32x2 sq = d * d;
+        const float dz = pi_z - pc.z;
+        const float r2 = (sq.x + sq.y) + dz * dz;
+        rej = __builtin_amdgcn_alignbit(rej, cut_bits - __float_as_uint(r2), 31);
+    }
+    return rej;
+}
+
 // List append through an LDS staging row per lane (transposed: slot s of thread t at [s * kBlock + t], conflict-free): no
 // register shuffling on (k & 3), one 16-byte store per completed group.
 // Two entry formats.  32-bit: four entries per 16-byte group.  16-bit (`half`: fluid lists of a staged workgroup on an nl16 handle,
@@ -411,6 +431,14 @@ struct NlWriter {
         }
         ++k;
     }
+    // wall lists: few particles have any, so their entries go straight to memory (4-byte stores into the 16-byte groups; the slots
+    // of a last, partial group keep stale but valid indices) and the staging rows of a second writer are not needed: 4 KiB of LDS
+    // less per workgroup, which is what lets eight workgroups of the staged build share a CU
+    __device__ __forceinline__ void push_direct(uint32_t j)
+    {
+        if (k < kcap) base[(size_t)(k >> 2) * 256 + (k & 3)] = j;
+        ++k;
+    }
     __device__ __forceinline__ void flush()
     {
         if (half) {
@@ -436,7 +464,8 @@ struct NlWriter {
 // also writes, per workgroup, the ordered set of those particles (as cell runs, stage_runs) and the lists in indices LOCAL to that
 // set; a sweep then copies its operand array through that set into LDS once (coalesced: ~150 line look-ups per workgroup instead
 // of ~8000) and gathers from LDS.  A workgroup whose neighbourhood does not fit (sparse regions) keeps global indices: stage_cnt < 0.
-constexpr int kRunCap = 16;          // runs of equal cell per wave whose 27 cells k_build_nl looks up cooperatively (mean 9, p99 16)
+constexpr int kRunCap = 13;          // runs of equal cell per wave whose 27 cells k_build_nl looks up cooperatively (mean 9, p99 13-16);
+                                     // 13: the staged build's LDS stays under 20 KiB, eight workgroups per CU
 constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
 constexpr int kStageMaxCells = 640;
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
@@ -455,7 +484,10 @@ __device__ __forceinline__ int stage_lookup(const int *key, const int *base, int
     return 0;
 }
 
-template <bool RIGID, bool STAGED>
+// CHUNK: candidates of a cell requested in one batch (4 or 12).  A scene of less than a wave per SIMD is bound by the latency of
+// the chain cell entry -> candidate loads -> append and gains from twelve loads in flight (30 k particles: 54 -> 48 us); larger
+// scenes are bound by instruction issue and lose to the tests of candidates past the cell's end (250 k: 68 -> 75 us): see the launch.
+template <bool RIGID, bool STAGED, int CHUNK>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      RigidView rv, int *__restrict__ ncount, uint2 *__restrict__ stage_runs,
                                                      int *__restrict__ stage_cnt)
 {
-    __shared__ uint32_t s_stage[2][4 * kBlock];
+    __shared__ uint32_t s_stage[4 * kBlock];
     __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok;
     __shared__ uint4 s_cell[kBlock / 64][kRunCap * 9];
     __shared__ int s_cslot[RIGID ? kBlock / 64 : 1][RIGID ? kRunCap * 9 : 1], s_runc[kBlock / 64][kRunCap][3];
@@ -472,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     int kf = 0, kb = 0;
     if (i == 0) ds->lost = cell_start[c.S + 1] - cell_start[c.S];   // size of the "outside the grid" bucket
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { s_stage[0][q * kBlock + threadIdx.x] = 0; s_stage[1][q * kBlock + threadIdx.x] = 0; }
+    for (int q = 0; q < 4; ++q) s_stage[q * kBlock + threadIdx.x] = 0;
     if (STAGED) {
         // (1) the set of cell slots around the cells of this workgroup's own particles
         for (int q = threadIdx.x; q < kStageHash; q += kBlock) s_key[q] = -1;
@@ -553,6 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     if (i < c.n && !walker) cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
     const float4 pi = P[i < c.n ? i : 0];
     const f32x2 pi_xy = {pi.x, pi.y};
+    const unsigned cut_bits = __float_as_uint(c.r2_cut);
     int cx, cy, cz;
     cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
     const int pcx = __shfl_up(cx, 1, 64), pcy = __shfl_up(cy, 1, 64), pcz = __shfl_up(cz, 1, 64);
@@ -565,8 +598,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     if (table && rhead) { s_runc[wv][run][0] = cx; s_runc[wv][run][1] = cy; s_runc[wv][run][2] = cz; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    NlWriter wf{&s_stage[0][threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
-    NlWriter ww{&s_stage[1][threadIdx.x], nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
+    NlWriter wf{&s_stage[threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
+    NlWriter ww{nullptr, nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
     int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
     const int my_id = RIGID && walker ? id[i] : 0;
     // one cell of a 27-neighbourhood: (first fluid particle, fluid count | staged base << 16, first wall particle, wall count[, slot])
@@ -609,16 +642,15 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                 // per cell that is ~half of what it was per trip.  (One 32-bit byte offset per trip, the four loads differ by
                 // immediates; reading up to three slots past the cell is harmless: the arrays carry 64 spare elements and the chunk's
                 // validity mask drops them.)
-                for (int j0 = a; j0 < b; j0 += 32) {
-                    const int nb = b - j0 < 32 ? b - j0 : 32;
-                    unsigned m = 0;
-                    for (int t = 0; t < nb; t += 4) {
-                        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)(j0 + t) * 16u);
-                        m |= near_mask4(pi_xy, pi.z, pb, c.r2_cut) << t;                         // :466 (norm > h)
-                    }
-                    m &= 0xffffffffu >> (32 - nb);                                               // candidates of this cell only
+                for (int j0 = a; j0 < b; j0 += CHUNK) {
+                    const int nb = b - j0 < CHUNK ? b - j0 : CHUNK;
+                    const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);
+                    unsigned far = 0;
+#pragma unroll
+                    for (int t = 0; t < CHUNK; t += 4) far |= far_mask4(pi_xy, pi.z, pb + t, cut_bits) << t;   // :466 (norm > h)
+                    unsigned m = ~far & (0xffffffffu >> (32 - nb));                              // candidates of this cell only
                     const unsigned self = (unsigned)(i - j0);                                    // :461 (j != i)
-                    if (self < 32u) m &= ~(1u << self);
+                    if (self < (unsigned)CHUNK) m &= ~(1u << self);
                     if (RIGID) nq += __popc(m);
                     while (m) {
                         const int u = __ffs(m) - 1;
@@ -648,16 +680,16 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                 const int wa = (int)e.z, wb = wa + (int)e.w;
                 for (int j0 = wa; j0 < wb; j0 += 32) {
                     const int nb = wb - j0 < 32 ? wb - j0 : 32;
-                    unsigned m = 0;
+                    unsigned far = 0;
                     for (int t = 0; t < nb; t += 4) {
                         const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(WP) + (unsigned)(j0 + t) * 16u);
-                        m |= near_mask4(pi_xy, pi.z, pb, c.r2_cut) << t;                         // :364
+                        far |= far_mask4(pi_xy, pi.z, pb, cut_bits) << t;                        // :364
                     }
-                    m &= 0xffffffffu >> (32 - nb);
+                    unsigned m = ~far & (0xffffffffu >> (32 - nb));
                     while (m) {
                         const int u = __ffs(m) - 1;
                         m &= m - 1;
-                        ww.push((uint32_t)(j0 + u));
+                        ww.push_direct((uint32_t)(j0 + u));
                     }
                 }
             }
@@ -667,7 +699,6 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     }
     if (walker) {
         wf.flush();
-        ww.flush();
         kf = wf.k; kb = ww.k;
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
         cnt[i] = kfc | (kbc << 16);

@@ -563,6 +563,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if (st) hipLaunchKernelGGL((K<T0, false, true>), g, b, lds, s, __VA_ARGS__);            \
         else hipLaunchKernelGGL((K<T0, false, false>), g, b, lds, s, __VA_ARGS__);                   \
     } while (0)
+constexpr int kBnlWideBelow = 100000;     // k_build_nl requests 12 candidates per batch below this many particles (see its CHUNK)
 #define SPH_LAUNCH_RS0(K, rg, st, g, b, lds, s, ...)                                                 \
     do {                                                                                             \
         if ((rg) && (st)) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, __VA_ARGS__);            \
@@ -1432,8 +1433,16 @@ int stage_sort_and_lists(SphHandle *h)
     {
         ProfScope ps(h, K_BUILD_NL);
         // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
-        SPH_LAUNCH_RS0(k_build_nl, rigid_coupled(h), h->staged, g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur],
-                       h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt);
+#define SPH_BNL(R, S, CH) hipLaunchKernelGGL((k_build_nl<R, S, CH>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
+                                             h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt)
+        const bool rg = rigid_coupled(h), wide = !h->staged && c.n <= kBnlWideBelow;     // wide batches: less than ~1.5 waves per SIMD
+        if (rg && h->staged) SPH_BNL(true, true, 4);
+        else if (h->staged) SPH_BNL(false, true, 4);
+        else if (rg && wide) SPH_BNL(true, false, 12);
+        else if (rg) SPH_BNL(true, false, 4);
+        else if (wide) SPH_BNL(false, false, 12);
+        else SPH_BNL(false, false, 4);
+#undef SPH_BNL
     }
     if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
         ProfScope ps(h, K_RIGID);
