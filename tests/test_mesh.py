@@ -99,3 +99,29 @@ def test_rigid_from_config_relative_asset_path(tmp_path):
     assert mesh.rigid_from_config(cfg)["points"].shape == (1001, 3)
     cfg["solid"]["fill"] = False
     assert len(mesh.rigid_from_config(cfg)["points"]) == 11 * 7 * 13 - 9 * 5 * 11
+
+
+REF_OBJ = "/root/reference/obj"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OBJ), reason="the reference's mesh assets are only mounted in the build container")
+@pytest.mark.parametrize("name,nv,nf,scale", [("ball.STL", 2850, 5696, 1.0), ("spot.obj", 2930, 5856, 1.0), ("cube2.STL", 8, 12, 0.5)])
+def test_reference_assets_load_and_voxelise(name, nv, nf, scale):
+    """The bodies the reference ships next to cube1 (binary STL, Wavefront OBJ with quads/normals): loader and voxeliser on the real
+    files, read in place.  Filled voxel volume against the mesh volume (divergence theorem): the voxel layer reaches up to pitch/2
+    outside the surface, so the ratio is above 1 and below (1 + pitch / size)^3-ish; the surface voxels are a subset of the filled set."""
+    v, f = mesh.load_mesh(os.path.join(REF_OBJ, name))
+    assert v.shape == (nv, 3) and f.shape == (nf, 3) and f.min() == 0 and f.max() == nv - 1
+    v = v * scale
+    tri = v[f]
+    volume = abs(np.einsum("ij,ij->i", tri[:, 0], np.cross(tri[:, 1], tri[:, 2])).sum()) / 6.0
+    pitch = 0.05
+    filled = mesh.voxelize(v, f, pitch, fill=True)
+    shell = mesh.voxelize(v, f, pitch, fill=False)
+    ratio = len(filled) * pitch ** 3 / volume
+    assert 1.0 < ratio < 1.5, ratio
+    assert len(shell) < len(filled)
+    as_set = lambda p: set(map(tuple, np.round(p / pitch).astype(int)))
+    assert as_set(shell) <= as_set(filled)
+    assert (filled >= v.min(0) - pitch / 2 - 1e-9).all() and (filled <= v.max(0) + pitch / 2 + 1e-9).all()
+    assert np.allclose(filled / pitch, np.round(filled / pitch))          # centres on the global lattice {k * pitch}
