@@ -594,7 +594,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     const unsigned long long rheads = __ballot(rhead);
     const int nruns = __popcll(rheads);
     const int run = __popcll(rheads & ((2ull << lane) - 1ull)) - 1;          // this lane's run (walkers only)
+#ifdef SPH_X_BNL_NOTABLE
+    const bool table = false;                                                  // soak builds: every wave works its cell entries out per lane
+#else
     const bool table = nruns <= kRunCap;                                       // wave-uniform
+#endif
     if (table && rhead) { s_runc[wv][run][0] = cx; s_runc[wv][run][1] = cy; s_runc[wv][run][2] = cz; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
