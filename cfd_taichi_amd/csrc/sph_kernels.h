@@ -12,6 +12,7 @@
 // One thread per particle; a wave's 64 lanes are 64 consecutive sorted particles (about 8 cells),
 // so gathers of P[j]/V[j] hit the same few cache lines across lanes.
 #pragma once
+#include <type_traits>
 #include "sph_device.h"
 
 namespace sph {
@@ -484,9 +485,9 @@ __device__ __forceinline__ int stage_lookup(const int *key, const int *base, int
     return 0;
 }
 
-// CHUNK: candidates of a cell requested in one batch (4 or 12).  A scene of less than a wave per SIMD is bound by the latency of
-// the chain cell entry -> candidate loads -> append and gains from twelve loads in flight (30 k particles: 54 -> 48 us); larger
-// scenes are bound by instruction issue and lose to the tests of candidates past the cell's end (250 k: 68 -> 75 us): see the launch.
+// CHUNK: candidates of a cell requested in one batch (a multiple of 4).  Larger scenes are bound by instruction issue and lose to the
+// tests of candidates past the cell's end (12 instead of 4 at 250 k particles: 68 -> 75 us); scenes of less than a wave per SIMD gain from
+// more loads in flight (30 k: 54 -> 48 us) but gain far more from k_build_nl_split below, which the launch picks for them.
 template <bool RIGID, bool STAGED, int CHUNK>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
@@ -709,6 +710,172 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         if (RIGID) ncount[i] = nq;
     }
     note_list_lengths(c, kf, kb, ds);
+}
+
+// ---- the list build for small scenes: one wave per dx-plane -------------------------------------------------------------
+// Below about a wave per SIMD (config 1: 29 k particles = 455 waves on 1024 SIMDs) k_build_nl is as long as ONE wave's walk of its
+// 27 cells, and the chip idles.  Here a workgroup of three waves builds the lists of 64 particles: wave p walks the nine cells of the
+// plane dx = p - 1 for the same 64 particles, so the walk is a third as long and three times as many waves are in flight.  A
+// particle's list is the concatenation of its planes' entries (the reference's dx-outermost order), and a plane's position in the
+// list is only known once the planes before it have been counted -- two passes:
+//   1. every wave tests its plane's candidates, keeps the accept masks (LDS, one word per cell and lane) and counts;
+//   2. after a barrier every wave knows where its entries start and writes them (4-byte stores into the 16-byte groups of the tiled
+//      layout; at this size the store count does not matter).  Only the first 32 candidates of a cell have a kept mask; a fuller
+//      cell, rigid entries and wall candidates are tested again in pass 2.
+// Same lists, counts and health counters as k_build_nl<RIGID, false, *>; unstaged handles only (the launch picks it by size).
+struct CellEntry { int a, nf, wa, nw, slot; };
+__device__ __forceinline__ CellEntry split_cell_entry(const Consts &c, const int *__restrict__ cell_start, const int *__restrict__ wcell_start,
+                                                       int ccx, int ccy, int ccz, int o27)
+{
+    const int t9 = (o27 * 57) >> 9, o9 = o27 - 9 * t9, t3 = (o9 * 11) >> 5;    // o27 / 9 and o9 / 3 for 0 <= o27 < 27
+    const int x = ccx + t9 - 1, y = ccy + t3 - 1, z = ccz + (o9 - 3 * t3) - 1;
+    CellEntry e = {0, 0, 0, 0, -1};
+    if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) return e;     // :453-456
+    const int cid = x + y * c.sy + z * c.sz;
+    e.slot = cell_slot_xyz(c, x, y, z, cid);
+    e.a = cell_start[e.slot];
+    e.nf = cell_start[e.slot + 1] - e.a;
+    if (c.boundary_handle) { e.wa = wcell_start[cid]; e.nw = wcell_start[cid + 1] - e.wa; }
+    return e;
+}
+// accept bits of up to 32 candidates A[j0 .. j0 + nb): twelve candidates per batch of loads
+__device__ __forceinline__ unsigned split_accept32(const float4 *__restrict__ A, int j0, int nb, f32x2 pi_xy, float pi_z, unsigned cut_bits)
+{
+    unsigned far = 0;
+    for (int t = 0; t < nb; t += 12) {
+        const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(A) + (unsigned)(j0 + t) * 16u);
+        unsigned f = far_mask4(pi_xy, pi_z, pb, cut_bits) | far_mask4(pi_xy, pi_z, pb + 4, cut_bits) << 4 | far_mask4(pi_xy, pi_z, pb + 8, cut_bits) << 8;
+        far |= f << t;                                                          // (t = 24: the bits past 32 fall off, nb <= 32 masks them anyway)
+    }
+    return ~far & (0xffffffffu >> (32 - nb));
+}
+template <bool RIGID, int NW>
+__global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
+                                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
+                                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
+                                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
+                                                                      RigidView rv, int *__restrict__ ncount)
+{
+    constexpr int CPW = 27 / NW;                                                  // cells per wave: 9 (a dx-plane) or 3 (a (dx, dy) column)
+    __shared__ uint4 s_cell[NW][kRunCap * CPW];
+    __shared__ int s_cslot[RIGID ? NW : 1][RIGID ? kRunCap * CPW : 1], s_runc[NW][kRunCap][3];
+    __shared__ uint32_t s_mask[NW][CPW][64];
+    __shared__ int s_cf[NW][64], s_cw[NW][64], s_nq[RIGID ? NW : 1][64];
+    const int lane = threadIdx.x & 63, plane = threadIdx.x >> 6, o_first = plane * CPW;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int i = blk * 64 + lane;
+    if (i == 0 && plane == 0) ds->lost = cell_start[c.S + 1] - cell_start[c.S];   // size of the "outside the grid" bucket
+    const bool walker = i < c.n && id[i] >= 0;
+    if (i < c.n && !walker && plane == 0) cnt[i] = (int)0x80000000;               // ghost (multi-GPU)
+    const float4 pi = P[i < c.n ? i : 0];
+    const f32x2 pi_xy = {pi.x, pi.y};
+    const unsigned cut_bits = __float_as_uint(c.r2_cut);
+    int cx, cy, cz;
+    cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+    const int pcx = __shfl_up(cx, 1, 64), pcy = __shfl_up(cy, 1, 64), pcz = __shfl_up(cz, 1, 64);
+    const bool pwalker = __shfl_up(walker ? 1 : 0, 1, 64) != 0;
+    const bool rhead = walker && (lane == 0 || !pwalker || pcx != cx || pcy != cy || pcz != cz);
+    const unsigned long long rheads = __ballot(rhead);
+    const int nruns = __popcll(rheads);
+    const int run = __popcll(rheads & ((2ull << lane) - 1ull)) - 1;
+    const bool table = nruns <= kRunCap;                                          // wave-uniform
+    if (table && rhead) { s_runc[plane][run][0] = cx; s_runc[plane][run][1] = cy; s_runc[plane][run][2] = cz; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (table) {
+        for (int t = lane; t < nruns * CPW; t += 64) {
+            const int r = CPW == 9 ? (t * 57) >> 9 : (t * 171) >> 9, oc = t - CPW * r;     // t / 9 (t < 144), t / 3 (t < 48)
+            const CellEntry e = split_cell_entry(c, cell_start, wcell_start, s_runc[plane][r][0], s_runc[plane][r][1], s_runc[plane][r][2], o_first + oc);
+            s_cell[plane][t] = make_uint4((uint32_t)e.a, (uint32_t)e.nf, (uint32_t)e.wa, (uint32_t)e.nw);
+            if (RIGID) s_cslot[RIGID ? plane : 0][RIGID ? t : 0] = e.slot;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto entry = [&](int oc) {
+        if (!table) return split_cell_entry(c, cell_start, wcell_start, cx, cy, cz, o_first + oc);
+        const uint4 w = s_cell[plane][run * CPW + oc];
+        CellEntry e = {(int)w.x, (int)w.y, (int)w.z, (int)w.w, RIGID ? s_cslot[RIGID ? plane : 0][RIGID ? run * CPW + oc : 0] : 0};
+        return e;
+    };
+    const int my_id = RIGID && walker ? id[i] : 0;
+    // the walk of this plane's nine cells; WRITE = false counts (and keeps the first accept mask of every cell), WRITE = true stores
+    int kf = 0, kb = 0, nq = 0;
+    auto walk = [&](auto write_tag, int kf0, int kb0) {
+        constexpr bool WRITE = decltype(write_tag)::value;
+        uint32_t *lf = nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), *lw = nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch);
+        int k = kf0, kw = kb0;
+        auto put_f = [&](uint32_t j) { if (WRITE && k < c.kmax) lf[(size_t)(k >> 2) * 256 + (k & 3)] = j; ++k; };
+        auto put_w = [&](uint32_t j) { if (WRITE && kw < c.kbmax) lw[(size_t)(kw >> 2) * 256 + (kw & 3)] = j; ++kw; };
+        for (int o9 = 0; o9 < CPW; ++o9) {
+            const CellEntry e = entry(o9);
+            for (int j0 = e.a; j0 < e.a + e.nf; j0 += 32) {
+                const int nb = e.a + e.nf - j0 < 32 ? e.a + e.nf - j0 : 32;
+                unsigned m;
+                if (WRITE && j0 == e.a) {
+                    m = s_mask[plane][o9][lane];
+                } else {
+                    m = split_accept32(P, j0, nb, pi_xy, pi.z, cut_bits);                    // :466 (norm > h)
+                    const unsigned self = (unsigned)(i - j0);                                // :461 (j != i)
+                    if (self < 32u) m &= ~(1u << self);
+                    if (!WRITE && j0 == e.a) s_mask[plane][o9][lane] = m;
+                }
+                if (WRITE) {
+                    while (m) { const int u = __ffs(m) - 1; m &= m - 1; put_f((uint32_t)(j0 + u)); }
+                } else {
+                    k += __popc(m);
+                    if (RIGID) nq += __popc(m);
+                }
+            }
+            if (RIGID && e.slot >= 0) {
+                // rigid entries of the cell come after its fluid entries (update_grid, :383-386)
+                const int ra = rv.rcell_start[e.slot], rb = rv.rcell_start[e.slot + 1];
+                for (int j = ra; j < rb; ++j) {
+                    const float4 pj = rv.RP[j];
+                    const float ddx = pi.x - pj.x, ddy = pi.y - pj.y, ddz = pi.z - pj.z;
+                    const float r2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                    if (!(r2 > c.r2_cut)) put_f((uint32_t)j | kRigidTag);
+                    if (!WRITE) {
+                        // get_neighbour_count (:436-444): skips when particle_j.index == i (the rigid particle's LOCAL index) and
+                        // measures the distance to fluid_particles.pos[particle_j.index]
+                        const int jl = rv.rid[j];
+                        if (jl != my_id && jl < rv.n_fluid) {
+                            const float4 pq = rv.pos_orig[jl];
+                            const float ex = pi.x - pq.x, ey = pi.y - pq.y, ez = pi.z - pq.z;
+                            const float e2 = (ex * ex + ey * ey) + ez * ez;
+                            if (!(e2 > c.r2_cut)) ++nq;
+                        }
+                    }
+                }
+            }
+            for (int j0 = e.wa; j0 < e.wa + e.nw; j0 += 32) {
+                const int nb = e.wa + e.nw - j0 < 32 ? e.wa + e.nw - j0 : 32;
+                unsigned m = split_accept32(WP, j0, nb, pi_xy, pi.z, cut_bits);              // :364
+                if (WRITE) { while (m) { const int u = __ffs(m) - 1; m &= m - 1; put_w((uint32_t)(j0 + u)); } }
+                else kw += __popc(m);
+            }
+        }
+        kf = k; kb = kw;
+    };
+    if (walker) walk(std::false_type{}, 0, 0);
+    s_cf[plane][lane] = kf; s_cw[plane][lane] = kb;
+    if (RIGID) s_nq[RIGID ? plane : 0][lane] = nq;
+    __syncthreads();
+    int kf0 = 0, kb0 = 0, kft = 0, kbt = 0, nqt = 0;
+#pragma unroll
+    for (int p = 0; p < NW; ++p) {
+        if (p < plane) { kf0 += s_cf[p][lane]; kb0 += s_cw[p][lane]; }
+        kft += s_cf[p][lane]; kbt += s_cw[p][lane];
+        if (RIGID) nqt += s_nq[RIGID ? p : 0][lane];
+    }
+    if (walker) walk(std::true_type{}, kf0, kb0);
+    if (plane == 0) {
+        if (walker) {
+            cnt[i] = (kft < c.kmax ? kft : c.kmax) | ((kbt < c.kbmax ? kbt : c.kbmax) << 16);
+            if (RIGID) ncount[i] = nqt;
+        }
+        note_list_lengths(c, walker ? kft : 0, walker ? kbt : 0, ds);
+    }
 }
 
 // ======================================================================================

@@ -85,6 +85,7 @@ struct SphHandle {
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
+    int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
     int *stage_cnt = nullptr;
@@ -563,7 +564,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if (st) hipLaunchKernelGGL((K<T0, false, true>), g, b, lds, s, __VA_ARGS__);            \
         else hipLaunchKernelGGL((K<T0, false, false>), g, b, lds, s, __VA_ARGS__);                   \
     } while (0)
-constexpr int kBnlWideBelow = 100000;     // k_build_nl requests 12 candidates per batch below this many particles (see its CHUNK)
+constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_split with nine / three waves per 64 particles up to these sizes (unstaged handles)
 #define SPH_LAUNCH_RS0(K, rg, st, g, b, lds, s, ...)                                                 \
     do {                                                                                             \
         if ((rg) && (st)) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, __VA_ARGS__);            \
@@ -1435,14 +1436,20 @@ int stage_sort_and_lists(SphHandle *h)
         // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
 #define SPH_BNL(R, S, CH) hipLaunchKernelGGL((k_build_nl<R, S, CH>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
                                              h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt)
-        const bool rg = rigid_coupled(h), wide = !h->staged && c.n <= kBnlWideBelow;     // wide batches: less than ~1.5 waves per SIMD
+#define SPH_BNL_SPLIT(R, NW) hipLaunchKernelGGL((k_build_nl_split<R, NW>), dim3((unsigned)std::max(1, (c.n + 63) / 64)), dim3(NW * 64), 0, s, c, h->P[h->pcur], \
+                                                h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount)
+        // small unstaged scenes: one wave per dx-plane (3) or per (dx, dy) column (9) of the same 64 particles.  Measured (tools/split_sweep.sh):
+        // 22 k particles 77 -> 55 -> 34 us, 29 k 54 -> 32 -> 27 us, 55 k 146 -> 81 -> 64 us (rigid) / 56 -> 44 -> 48 us; 250 k 69 -> 87 -> 122 us.
+        const bool rg = rigid_coupled(h);
+        const int split = h->staged ? 0 : h->opt_bnl_split >= 0 ? h->opt_bnl_split : c.n <= kBnlSplit9Below ? 9 : c.n <= kBnlSplitBelow ? 3 : 0;
         if (rg && h->staged) SPH_BNL(true, true, 4);
         else if (h->staged) SPH_BNL(false, true, 4);
-        else if (rg && wide) SPH_BNL(true, false, 12);
+        else if (rg && split) { if (split == 9) SPH_BNL_SPLIT(true, 9); else SPH_BNL_SPLIT(true, 3); }
         else if (rg) SPH_BNL(true, false, 4);
-        else if (wide) SPH_BNL(false, false, 12);
+        else if (split) { if (split == 9) SPH_BNL_SPLIT(false, 9); else SPH_BNL_SPLIT(false, 3); }
         else SPH_BNL(false, false, 4);
 #undef SPH_BNL
+#undef SPH_BNL_SPLIT
     }
     if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
         ProfScope ps(h, K_RIGID);
@@ -2218,6 +2225,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
     int rc = SPH_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }

@@ -254,3 +254,48 @@ def test_rigid_coupling_of_the_other_solvers_on_the_morton_curve(solver, dt, ste
         assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), (solver, k)
     assert pushed, "the fluid never pushed the body: coupling not exercised"
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("waves", ["0", "3", "9"])
+@pytest.mark.parametrize("solver,seed", [("wcsph", 0), ("dfsph", 1), ("iisph", 2)])
+def test_list_build_variants_match_oracle(waves, solver, seed, monkeypatch):
+    """Small unstaged scenes build their lists with k_build_nl_split (one wave per dx-plane or per (dx, dy) column of the same 64
+    particles, two passes) and larger ones with k_build_nl; SPH_BNL_SPLIT forces one: each against the oracle on random scenes (the
+    other suites run their small scenes on the size-picked variant only), neighbour counts and step statistics included."""
+    monkeypatch.setenv("SPH_BNL_SPLIT", waves)
+    rng = np.random.default_rng(4100 + seed)
+    cfg = random_scene(rng, solver)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, solver=solver, num_threads=4)
+    for s in range(25):
+        st = sim.step(1)
+        {"wcsph": o.step_wcsph, "iisph": o.step_iisph}.get(solver, lambda n: o.step_dfsph(n, 100))(1)
+        if solver != "wcsph":
+            assert st.n_dens == o.last_stats.n_dens, (s, waves)
+    for f, of in ((nat.F_POS, orc.F_POS), (nat.F_VEL, orc.F_VEL), (nat.F_RHO, orc.F_RHO)):
+        assert np.array_equal(sim.download(f), o.get(of), equal_nan=True), (solver, seed, waves, f, cfg)
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("waves", ["0", "3", "9"])
+def test_list_build_variants_with_a_rigid_body(waves, monkeypatch):
+    """The same three builds with rigid entries in the lists (tagged entries after a cell's fluid entries, the neighbour count with its
+    rigid-entry quirk): coupled steps of the tilted box against the size-picked build, bit for bit, force on the body included."""
+    cfg = scenes.get("dfsph_rigid_tilted")
+    rg = mesh.rigid_from_config(cfg)
+    sims = []
+    for w in (waves, None):
+        if w is None:
+            monkeypatch.delenv("SPH_BNL_SPLIT")
+        else:
+            monkeypatch.setenv("SPH_BNL_SPLIT", w)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg), rigid=rg))
+    a, b = sims
+    for s in range(40):
+        sa, sb = a.step(1), b.step(1)
+        assert (sa.n_div, sa.n_dens, sa.dens_err, sa.max_nbrs) == (sb.n_div, sb.n_dens, sb.dens_err, sb.max_nbrs), s
+        assert np.array_equal(a.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), b.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)), s
+        a.rigid_step(); b.rigid_step()
+    for f in FIELDS + (nat.F_NBR_COUNT,):
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), f
+    a.close(); b.close()
