@@ -340,6 +340,64 @@ __device__ __forceinline__ void for_fluid_nbrs(const uint32_t *__restrict__ base
         }, [&](const Operand1 &o, uint32_t j) { body(o.a, make_float4(0.f, 0.f, 0.f, 0.f), j); });
 }
 
+// ---- four lanes per particle (small scenes) ---------------------------------------------------------------------------------
+// A sweep's sums are sequential per particle (the reference adds a particle's neighbours one after the other and f32 addition does
+// not reassociate), so a scene of less than a wave per SIMD is as slow as ONE lane walking ~30 pairs of ~60 instructions, at one
+// instruction per 4+ cycles, while most of the chip idles.  The expensive part of a pair is its TERM, not the addition: in the quad
+// walks the four lanes of a quad serve one particle, lane q evaluates entry q of every group of four into zeroed accumulators
+// (0 + t = t exactly; the accumulators of a sweep start at +0 or 0.001 and a sum of terms is never -0), and all four lanes then add
+// the four terms in list order through DPP quad broadcasts: the same additions in the same order, a quarter of the pair bodies per
+// lane.  Per group of four: one body + 4 adds per accumulator instead of four bodies.  A pair body must add to each accumulator at
+// most once.  Sweep kernels select it with MODE == SWEEP_QUAD (unstaged handles below kQuadBelow particles; four times the lanes).
+enum { SWEEP_PLAIN = 0, SWEEP_STAGED = 1, SWEEP_QUAD = 2 };
+template <int U> __device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), U * 0x55, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t quad_pick(const uint4 g, int q) { return q == 0 ? g.x : q == 1 ? g.y : q == 2 ? g.z : g.w; }
+template <int N, class T, class Fetch, class Use>
+__device__ __forceinline__ void walk_list_quad(const uint32_t *__restrict__ base, int cnt, int q, float (&acc)[N], Fetch fetch, Use use)
+{
+    if (cnt <= 0) return;
+    uint32_t jq = quad_pick(nl_load(base), q);
+    T cur, nxt;
+    fetch(jq, cur);
+    for (int kk = 0; kk < cnt; kk += 4) {
+        const uint32_t jn = quad_pick(nl_load(base + (size_t)((kk >> 2) + 1) * 256), q);      // one group past the end: stale but valid
+        fetch(jn, nxt);
+        float save[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) { save[n] = acc[n]; acc[n] = 0.0f; }
+        if (kk + q < cnt) use(cur, jq);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float t = acc[n];
+            float a = save[n];
+            a += quad_bcast<0>(t); a += quad_bcast<1>(t); a += quad_bcast<2>(t); a += quad_bcast<3>(t);
+            acc[n] = a;
+        }
+        cur = nxt; jq = jn;
+    }
+}
+template <bool RIGID, bool WITHV, int N, class Body>
+__device__ __forceinline__ void for_fluid_nbrs_quad(const uint32_t *__restrict__ base, int cnt, int q, float (&acc)[N], const float4 *__restrict__ A,
+                                                    const float4 *__restrict__ B, const RigidView &rv, Body body)
+{
+    if (WITHV)
+        walk_list_quad<N, Operand2>(base, cnt, q, acc, [&](uint32_t j, Operand2 &o) {
+            const bool rg = RIGID && (j & kRigidTag);
+            const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+            o.a = rg ? rv.RP[idx] : A[idx];
+            o.b = B[rg ? 0u : idx];
+        }, [&](const Operand2 &o, uint32_t j) { body(o.a, o.b, j); });
+    else
+        walk_list_quad<N, Operand1>(base, cnt, q, acc, [&](uint32_t j, Operand1 &o) {
+            const bool rg = RIGID && (j & kRigidTag);
+            const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+            o.a = rg ? rv.RP[idx] : A[idx];
+        }, [&](const Operand1 &o, uint32_t j) { body(o.a, make_float4(0.f, 0.f, 0.f, 0.f), j); });
+}
+
 // ======================================================================================
 // neighbour-list build: the 27-cell walk of for_all_neighbor / for_all_boundary_neighbor
 // (ParticleSystem.py:447-469, 337-366), done once per step because positions are frozen
@@ -881,6 +939,24 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
 // ======================================================================================
 // helpers for the list-driven sweeps
 // ======================================================================================
+// QUAD sweeps: 64 particles per workgroup, lane q = threadIdx.x & 3 of the quad serving particle blk * 64 + threadIdx.x / 4; every lane of a quad
+// carries the same accumulators, lane 0 writes the results (`owner`)
+#define SPH_SWEEP_PROLOGUE_M(QUAD)                           \
+    const int blk = xcd_block(blockIdx.x, gridDim.x);        \
+    const int q = (QUAD) ? (int)(threadIdx.x & 3) : 0;       \
+    (void)q;                                                 \
+    int i = (QUAD) ? blk * (kBlock / 4) + (int)(threadIdx.x >> 2) : blk * kBlock + (int)threadIdx.x; \
+    const bool live = i < c.n;                               \
+    const bool owner = live && q == 0;                       \
+    (void)owner;                                             \
+    const int ii = live ? i : 0;                             \
+    const int cw = live ? cnt[ii] : 0;                       \
+    const int kf = cw & 0xffff, kb = (cw >> 16) & 0x7fff;    \
+    const bool ghost = cw < 0;                               \
+    (void)ghost;                                             \
+    const float4 pi = P[ii];                                 \
+    const uint32_t *nlp = nl + nl_index(ii, 0, c.kpitch);     \
+    const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbpitch) : nullptr;
 #define SPH_SWEEP_PROLOGUE                                   \
     const int blk = xcd_block(blockIdx.x, gridDim.x);        \
     int i = blk * kBlock + threadIdx.x;                      \
@@ -904,6 +980,11 @@ __device__ __forceinline__ void for_nbrs_p(const uint32_t *__restrict__ base, in
 {
     walk_list<Operand1>(base, cnt, [&](uint32_t j, Operand1 &o) { o.a = A[j]; }, [&](const Operand1 &o, uint32_t) { body(o.a); });
 }
+template <int N, class Body>
+__device__ __forceinline__ void for_nbrs_p_quad(const uint32_t *__restrict__ base, int cnt, int q, float (&acc)[N], const float4 *__restrict__ A, Body body)
+{
+    walk_list_quad<N, Operand1>(base, cnt, q, acc, [&](uint32_t j, Operand1 &o) { o.a = A[j]; }, [&](const Operand1 &o, uint32_t) { body(o.a); });
+}
 
 // block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
 __device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
@@ -920,6 +1001,22 @@ __device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, 
         for (int k = 0; k < kBlock / 64; ++k) { t += s_sum[k]; n += s_cnt[k]; }
         psum[blk] = t;
         pcnt[blk] = n;
+    }
+}
+// QUAD sweeps: a workgroup holds 64 particles, one per quad -- exactly one WAVE of a one-lane-per-particle workgroup.  Its partial is
+// that wave's butterfly: the owners' values go through LDS into particle order and wave 0 reduces them with the same tree.
+// psum / pcnt then hold one entry per 64 particles; k_finalize_mean (group = 4) first adds four consecutive entries in order, which is
+// the serial sum over the four waves of the 256-particle block above: same bits.
+__device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int flag, bool owner_lane, double *__restrict__ psum, int *__restrict__ pcnt)
+{
+    __shared__ double s_v[kBlock / 4];
+    __shared__ int s_f[kBlock / 4];
+    if ((threadIdx.x & 3) == 0) { s_v[threadIdx.x >> 2] = (owner_lane && flag) ? v : 0.0; s_f[threadIdx.x >> 2] = (owner_lane && flag) ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const double ws = wave_sum(s_v[threadIdx.x]);
+        const int wc = wave_sum(s_f[threadIdx.x]);
+        if (threadIdx.x == 0) { psum[blk] = ws; pcnt[blk] = wc; }
     }
 }
 
@@ -949,8 +1046,21 @@ enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
 // 1 M particles: 3907 partials), a wave butterfly, then thread 0 adds the 16 wave sums in order -- one barrier.  (With 256 threads,
 // two load rounds and an eight-level LDS tree this kernel took 5.2 us, 29 times per step.)  The order is fixed, hence deterministic.
 constexpr int kFinBlock = 1024;
+// group = 4: psum / pcnt hold one entry per 64 particles (QUAD sweeps, block_partial_mean_quad); `nblocks` still counts blocks of 256 particles and
+// `nparts` the entries: a block's partial is the in-order sum of its (up to) four entries.
+__device__ __forceinline__ void fin_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, int nblocks, int group, int nparts, double &v, int &m)
+{
+    v = 0.0; m = 0;
+    if (e >= nblocks) return;
+    if (group == 1) { v = psum[e]; m = pcnt[e]; return; }
+    for (int u = 0; u < group; ++u) {
+        const int k = e * group + u;
+        if (k < nparts) { v += psum[k]; m += pcnt[k]; }          // 0.0 + w0 = w0: the serial sum over the block's waves
+    }
+}
 __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
+                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                             int group = 1, int nparts = 0)
 {
     if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
     if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
@@ -962,14 +1072,14 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
         for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
             double v[4]; int m[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { v[u] = psum[k + u * kFinBlock]; m[u] = pcnt[k + u * kFinBlock]; }
+            for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
         }
         {   // the rest, still as one batch of (predicated) loads
             double v[4]; int m[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = k + u * kFinBlock; v[u] = e < nblocks ? psum[e] : 0.0; m[u] = e < nblocks ? pcnt[e] : 0; }
+            for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
         }
@@ -1373,7 +1483,7 @@ __device__ __forceinline__ void for_staged16_nbrs_pv2(const uint32_t *__restrict
     });
 }
 
-template <bool DFSPH, bool RIGID, bool STAGED>
+template <bool DFSPH, bool RIGID, int MODE>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -1383,11 +1493,12 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
                                                     const int *__restrict__ id, float *__restrict__ rho_orig,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
 {
+    constexpr bool STAGED = MODE == SWEEP_STAGED, QUAD = MODE == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
-    float rho = 0.001f;                                      // solver_base.py:44
-    float sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
+    float fa[5] = {0.001f, 0.f, 0.f, 0.f, 0.f};              // rho starts at 0.001, solver_base.py:44
+    float &rho = fa[0], &sx = fa[1], &sy = fa[2], &sz = fa[3], &sq = fa[4];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -1402,11 +1513,13 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             sq += (rx * rx + ry * ry) + rz * rz;             // :71
         }
     };
-    if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
+    else if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair);
     else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
-    float rho_b = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bsq = 0.f;
-    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {          // pj = (x, y, z, V_b)
+    float wa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float &rho_b = wa[0], &bx = wa[1], &by = wa[2], &bz = wa[3], &bsq = wa[4];
+    auto wall = [&](const float4 pj) {                       // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         rho_b += pj.w * cubic_w_in(c, r);                       // solver_base.py:70-71
@@ -1417,9 +1530,11 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             bx += rx; by += ry; bz += rz;
             bsq += (rx * rx + ry * ry) + rz * rz;
         }
-    });
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, kb, WP, wall);
     float rho_i = c.boundary_handle ? rho + rho_b * c.rho0 : rho;   // solver_base.py:49,51
-    if (!live) return;
+    if (!owner) return;
     rho_out[i] = rho_i;
     if (RIGID) rho_orig[id[i]] = rho_i;
     const float4 vi = V[i];
@@ -1467,22 +1582,23 @@ __device__ __forceinline__ void rigid_viscosity(const Consts &c, const RigidView
 //     wcsph_solver.py:70-129, solver_base.py:170-217, wcsph_solver.py:40-63
 //   reads P = (pos, rho), V = (vel, p/rho^2); writes the next state Pn = (pos', .), Vn = (vel', .), acc
 // ======================================================================================
-template <bool RIGID>
+template <bool RIGID, bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                         const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                         const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                         const float *__restrict__ pressure, float4 *__restrict__ Pn,
                                                         float4 *__restrict__ Vn, float4 *__restrict__ acc_out, RigidView rv)
 {
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     const float4 vi = V[ii];
     const float rho_i = pi.w;
     const float a_i = vi.w;                                  // p_i / rho_i_2
-    float gx = 0.f, gy = 0.f, gz = 0.f;                      // pressure gradient
-    float wx = 0.f, wy = 0.f, wz = 0.f;                      // viscosity
-    float tx = 0.f, ty = 0.f, tz = 0.f;                      // tension
+    float fa[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float &gx = fa[0], &gy = fa[1], &gz = fa[2];             // pressure gradient
+    float &wx = fa[3], &wy = fa[4], &wz = fa[5];             // viscosity
+    float &tx = fa[6], &ty = fa[7], &tz = fa[8];             // tension
     const float p_own = (RIGID || c.boundary_handle) ? (live ? pressure[ii] : 0.f) : 0.f;
-    for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, [&](const float4 pj, const float4 vj, const uint32_t j) {
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w_in(c, dx, dy, dz, r);
@@ -1505,20 +1621,25 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
         }
         float st = c.tens_c * cubic_w_in(c, r);                 // :216
         tx += st * dx; ty += st * dy; tz += st * dz;
-    });
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    };
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
+    else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
+    float wa[3] = {0.f, 0.f, 0.f};
+    float &bx = wa[0], &by = wa[1], &bz = wa[2];
     if (c.boundary_handle) {
         const float p_i = p_own;
         const float rho_i_2 = rho_i * rho_i;
-        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w_in(c, dx, dy, dz, r);
             float s = pj.w * p_i / rho_i_2;                  // wcsph_solver.py:99
             bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
-        });
+        };
+        if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+        else for_nbrs_p(nlbp, kb, WP, wall);
     }
-    if (!live) return;
+    if (!owner) return;
     float pg[3] = {gx, gy, gz};
     float vis[3] = {wx * c.m, wy * c.m, wz * c.m};           // solver_base.py:175
     float ten[3] = {tx * c.m, ty * c.m, tz * c.m};           // solver_base.py:209
@@ -1555,7 +1676,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
 // ======================================================================================
 enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
 
-template <int MODE, bool RIGID, bool STAGED>
+template <int MODE, bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
@@ -1564,9 +1685,10 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && !RIGID && c.kr_split;
     const bool staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk)
@@ -1578,7 +1700,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     else if (MODE == CORR_DIV) k_i = src[ii] * alpha[ii] / dt;                    // :363
     else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
     const float kr_i = k_i / rho_i;
-    float ax = 0.f, ay = 0.f, az = 0.f;
+    float fa[3] = {0.f, 0.f, 0.f};
+    float &ax = fa[0], &ay = fa[1], &az = fa[2];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -1612,21 +1735,25 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         }
     };
     struct OperandPS { float4 a; float s; };
-    if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
+    else if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
     else if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
     else if (split)          // a workgroup of a kr_split handle whose set did not fit: two global gathers per neighbour
         walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) { o.a = P[j]; o.s = krho[j]; },
                              [&](const OperandPS &o, uint32_t j) { pair(make_float4(o.a.x, o.a.y, o.a.z, o.s), make_float4(0.f, 0.f, 0.f, 0.f), j); });
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
-    float bx = 0.f, by = 0.f, bz = 0.f;
-    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+    float wa[3] = {0.f, 0.f, 0.f};
+    float &bx = wa[0], &by = wa[1], &bz = wa[2];
+    auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w_in(c, dx, dy, dz, r);
         float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219
         bx += s * g.x; by += s * g.y; bz += s * g.z;
-    });
-    if (!live) return;
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, kb, WP, wall);
+    if (!owner) return;
     float4 v = Vin[i];
     if (c.boundary_handle) {
         // :322 / :310 ; for D7 :187 then :191 -- same association: (a + b*rho0) * dt
@@ -1648,7 +1775,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
 //   D6 (dfsph_solver.py:124-176): rho*_i = max(rho_i + dt (same sums with v*), rho0)
 // Writes Pout.w = k/rho for the correction sweep that follows and the block partials of the mean.
 // ======================================================================================
-template <bool DENS, bool RIGID, bool STAGED>
+template <bool DENS, bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -1658,13 +1785,15 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
     const float4 vi = V[ii];
-    float acc = 0.f;
+    float fa[1] = {0.f};
+    float &acc = fa[0];
     const int nq = RIGID ? (live ? ncount[ii] : 0) : kf;                          // ps.get_neighbour_count(i)
     const bool skip = !DENS && nq < 20;                                           // :258-261
     const float dt_r = RIGID ? ds->dt : 0.f;
@@ -1702,16 +1831,20 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
 #else
     const int kb_x = kb;
 #endif
-    if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf_x, s_operand, s_v2, pair_scaled);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, skip ? 0 : kf_x, q, fa, P, V, rv, pair);
+    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf_x, s_operand, s_v2, pair_scaled);
     else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf_x, s_operand, s_v2, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf_x, P, V, rv, pair);
-    float accb = 0.f;
-    for_nbrs_p(nlbp, skip ? 0 : kb_x, WP, [&](const float4 pj) {
+    float wa[1] = {0.f};
+    float &accb = wa[0];
+    auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
         F3 g = grad_w_in(c, dx, dy, dz, r);
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
-    });
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, skip ? 0 : kb_x, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, skip ? 0 : kb_x, WP, wall);
     float val = 0.f;
     int flag = 0;
     if (live) {
@@ -1730,34 +1863,39 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             flag = val > 0.f && !ghost;                                                       // :275
             kr = (val * alpha[i] / ds->dt) / rho_i;                                           // :363,367
         }
-        out[i] = val;
-        if (c.kr_split) krho[i] = kr;
-        else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
+        if (owner) {
+            out[i] = val;
+            if (c.kr_split) krho[i] = kr;
+            else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
+        }
     }
-    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
+    else block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // ======================================================================================
 // D5: tension + viscosity + external force + v* and max |v*|
 //     solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
 // ======================================================================================
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
                                                       float *__restrict__ pmax, RigidView rv,
                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     (void)kb; (void)nlbp;
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);      // (vel, rho) needs 16 B: gathered from memory
     const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = vi.w;
-    float wx = 0.f, wy = 0.f, wz = 0.f;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
+    float fa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float &wx = fa[0], &wy = fa[1], &wz = fa[2];
+    float &tx = fa[3], &ty = fa[4], &tz = fa[5];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -1790,7 +1928,8 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
     };
-    if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
+    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
     else if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float vn = -INFINITY;
@@ -1806,7 +1945,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             float f = (g[a] + ten[a]) + vis[a];              // dfsph_solver.py:96
             va[a] = v[a] + dt * f / c.m;                     // :102
         }
-        VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
+        if (owner) VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
         if (!ghost) vn = norm3(va[0], va[1], va[2]);         // :103
     }
     block_partial_max(blk, vn, pmax);

@@ -85,6 +85,7 @@ struct SphHandle {
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
+    bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
@@ -564,6 +565,28 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if (st) hipLaunchKernelGGL((K<T0, false, true>), g, b, lds, s, __VA_ARGS__);            \
         else hipLaunchKernelGGL((K<T0, false, false>), g, b, lds, s, __VA_ARGS__);                   \
     } while (0)
+// sweeps with a MODE parameter (SWEEP_PLAIN / SWEEP_STAGED / SWEEP_QUAD, sph_kernels.h); the grid follows the mode (quad sweeps: 64 particles per workgroup)
+#define SPH_LAUNCH_RM(K, T0, rg, mode, n, lds, s, ...)                                                                                   \
+    do {                                                                                                                                 \
+        const dim3 g_ = (mode) == SWEEP_QUAD ? dim3((unsigned)std::max(1, ((n) + 63) / 64)) : grid_for(n), b_(kBlock);                   \
+        if ((rg) && (mode) == SWEEP_STAGED) hipLaunchKernelGGL((K<T0, true, SWEEP_STAGED>), g_, b_, lds, s, __VA_ARGS__);                \
+        else if ((rg) && (mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<T0, true, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                 \
+        else if (rg) hipLaunchKernelGGL((K<T0, true, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                        \
+        else if ((mode) == SWEEP_STAGED) hipLaunchKernelGGL((K<T0, false, SWEEP_STAGED>), g_, b_, lds, s, __VA_ARGS__);                  \
+        else if ((mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<T0, false, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                        \
+        else hipLaunchKernelGGL((K<T0, false, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                               \
+    } while (0)
+#define SPH_LAUNCH_RM0(K, rg, mode, n, lds, s, ...)                                                                                      \
+    do {                                                                                                                                 \
+        const dim3 g_ = (mode) == SWEEP_QUAD ? dim3((unsigned)std::max(1, ((n) + 63) / 64)) : grid_for(n), b_(kBlock);                   \
+        if ((rg) && (mode) == SWEEP_STAGED) hipLaunchKernelGGL((K<true, SWEEP_STAGED>), g_, b_, lds, s, __VA_ARGS__);                    \
+        else if ((rg) && (mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<true, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                     \
+        else if (rg) hipLaunchKernelGGL((K<true, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                            \
+        else if ((mode) == SWEEP_STAGED) hipLaunchKernelGGL((K<false, SWEEP_STAGED>), g_, b_, lds, s, __VA_ARGS__);                      \
+        else if ((mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<false, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                            \
+        else hipLaunchKernelGGL((K<false, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                                   \
+    } while (0)
+constexpr int kQuadBelow = 65536;          // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
 constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_split with nine / three waves per 64 particles up to these sizes (unstaged handles)
 #define SPH_LAUNCH_RS0(K, rg, st, g, b, lds, s, ...)                                                 \
     do {                                                                                             \
@@ -573,6 +596,14 @@ constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_
         else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, __VA_ARGS__);                       \
     } while (0)
 // dynamic LDS of a staged sweep: bytes per staged particle x capacity (else the occupancy-experiment knob)
+inline int sweep_mode(const SphHandle *h)
+{
+    if (h->staged) return SWEEP_STAGED;
+    return (!h->slab && h->opt_quad && h->c.n <= kQuadBelow) ? SWEEP_QUAD : SWEEP_PLAIN;
+}
+// partials of the block reductions: one per 256 particles, or one per 64 from quad sweeps (k_finalize_mean adds them in groups of four)
+inline int partial_group(const SphHandle *h) { return sweep_mode(h) == SWEEP_QUAD ? 4 : 1; }
+inline int partial_count(const SphHandle *h) { return sweep_mode(h) == SWEEP_QUAD ? (h->c.n + 63) / 64 : h->nblocks; }
 inline size_t sweep_lds(const SphHandle *h, size_t bytes_per_staged) { return h->staged ? (size_t)h->c.stage_cap * bytes_per_staged : (size_t)h->sweep_lds; }
 inline RigidView rigid_view_or_none(const SphHandle *h);
 
@@ -689,7 +720,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->WP, (size_t)h->Nb + 64))) return rc;
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
-    const size_t nblocks_cap = (n + kBlock - 1) / kBlock;
+    const size_t nblocks_cap = n <= (size_t)kQuadBelow ? (n + 63) / 64 : (n + kBlock - 1) / kBlock;    // quad sweeps: one partial per 64 particles
     if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
@@ -1486,19 +1517,19 @@ int stage_density(SphHandle *h)
 {
     const Consts &c = h->c;
     hipStream_t s = h->stream;
-    const dim3 g = grid_for(c.n), b(kBlock);
+    (void)kBlock;
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     if (dfsph) {
         // DFSPH buffer roles for the whole step: P[pcur] = sorted positions (never written until the integrator),
         // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
         // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
-        SPH_LAUNCH_RS(k_density, true, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+        SPH_LAUNCH_RM(k_density, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
                       h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
     } else {
         ProfScope ps(h, K_W_DENSITY);
-        SPH_LAUNCH_RS(k_density, false, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+        SPH_LAUNCH_RM(k_density, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
                       h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
@@ -1532,12 +1563,13 @@ int step_wcsph_once(SphHandle *h)
     if (rigid_coupled(h)) launch_rigid_force_p<RF_WCSPH>(h, h->P[h->pcur], nullptr, GATE_NONE);   // wcsph_solver.py:127, positions of this step
     {
         ProfScope ps(h, K_W_FORCE);                          // wcsph_solver.py:36-38 + kinematic_phase :40-63
-        if (rigid_coupled(h))
-            hipLaunchKernelGGL(k_wcsph_force<true>, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
-                               h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], rigid_view(h));
-        else
-            hipLaunchKernelGGL(k_wcsph_force<false>, grid_for(c.n), dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP,
-                               h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], RigidView());
+        const bool quad = sweep_mode(h) == SWEEP_QUAD;
+        const dim3 gf = quad ? dim3((unsigned)std::max(1, (c.n + 63) / 64)) : grid_for(c.n);
+#define SPH_WFORCE(R, Q, RV) hipLaunchKernelGGL((k_wcsph_force<R, Q>), gf, dim3(kBlock), 0, h->stream, c, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->WP, \
+                                                h->nl, h->nlb, h->cnt, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], RV)
+        if (rigid_coupled(h)) { if (quad) SPH_WFORCE(true, true, rigid_view(h)); else SPH_WFORCE(true, false, rigid_view(h)); }
+        else { if (quad) SPH_WFORCE(false, true, RigidView()); else SPH_WFORCE(false, false, RigidView()); }
+#undef SPH_WFORCE
         h->pcur ^= 1; h->vcur ^= 1;
     }
     HIP_TRY(h, hipGetLastError());
@@ -1564,7 +1596,7 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
-    SPH_LAUNCH_RS(k_residual, false, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
@@ -1574,7 +1606,7 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
-    SPH_LAUNCH_RS(k_correct, MODE, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c,
+    SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho);
 }
@@ -1583,7 +1615,7 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
-    SPH_LAUNCH_RS(k_residual, true, rigid_coupled(h), h->staged, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
@@ -1593,16 +1625,16 @@ int launch_finalize(SphHandle *h, int mode)
     if (slab_async(h)) {       // this slab's (sum, count) -> all-reduce over the slabs -> the loop decision, all on the stream
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     return SPH_OK;
 }
 
@@ -1617,7 +1649,7 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
 int reduce_mean_host(SphHandle *h, float dflt, float *mean)
 {
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     int rc = read_scalars(h);
     if (rc) return rc;
     double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
@@ -1631,11 +1663,11 @@ int dfsph_ext_and_dt(SphHandle *h)
 {
     const Consts &c = h->c;
     hipStream_t s = h->stream;
-    const dim3 g = grid_for(c.n), b(kBlock);
+    const dim3 b(kBlock);
     int rc;
     {
         ProfScope ps(h, K_D_EXT);
-        SPH_LAUNCH_RS0(k_dfsph_ext, rigid_coupled(h), h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
+        SPH_LAUNCH_RM0(k_dfsph_ext, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
                        h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt);
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
@@ -1647,7 +1679,7 @@ int dfsph_ext_and_dt(SphHandle *h)
     const bool async = slab_async(h);
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, h->nblocks, h->ds, async ? h->red_dev : (double *)nullptr);
+        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, async ? h->red_dev : (double *)nullptr);
     }
     if (h->slab) {
         if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
@@ -2225,6 +2257,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
     int rc = SPH_OK;
     do {
@@ -2844,15 +2877,15 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
         else if (which == 2) launch_dens_residual(h, GATE_NONE);
         else if (which == 4) {      // a sweep followed by the single-workgroup reduction of its block partials, as in the solver loops
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
         } else if (which == 5) {    // the reduction alone
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
         } else if (which == 6) {    // two different sweeps alternating (residual, correct), no reduction between them
             launch_div_residual(h, GATE_NONE);
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         } else if (which == 7) {    // the same with the reduction after the residual: one solver iteration
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         }
         else if ((rc = stage_sort_and_lists(h))) break;

@@ -299,3 +299,40 @@ def test_list_build_variants_with_a_rigid_body(waves, monkeypatch):
     for f in FIELDS + (nat.F_NBR_COUNT,):
         assert np.array_equal(a.download(f), b.download(f), equal_nan=True), f
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("scene,steps", [("wcsph_small", 80), ("dfsph_small", 40), ("dfsph_tiny_clamp", 60), ("breaking_dam_30k_dfsph", 8)])
+def test_quad_sweeps_are_invisible(scene, steps, monkeypatch):
+    """Small unstaged scenes run their sweeps with four lanes per particle (lane q evaluates entry q of every group of four, the four
+    terms are added in list order through DPP quad broadcasts; block partials per 64 particles, added in groups of four by the
+    finalize): SPH_QUAD=0 keeps one lane per particle.  Same bits, same iteration counts and residuals, every step."""
+    cfg = scenes.get(scene)
+    monkeypatch.setenv("SPH_QUAD", "1")
+    a = nat.Simulation(nat.config_from_dict(cfg))
+    monkeypatch.setenv("SPH_QUAD", "0")
+    b = nat.Simulation(nat.config_from_dict(cfg))
+    for s_ in range(steps):
+        sa, sb = a.step(1), b.step(1)
+        if cfg["solver"]["name"] != "wcsph":
+            assert (sa.n_div, sa.n_dens, sa.div_err, sa.dens_err, sa.dt, sa.max_nbrs) == (sb.n_div, sb.n_dens, sb.div_err, sb.dens_err, sb.dt, sb.max_nbrs), (scene, s_)
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), (scene, f)
+    a.close(); b.close()
+
+
+def test_quad_sweeps_with_a_rigid_body(monkeypatch):
+    cfg = scenes.get("dfsph_rigid_tilted")
+    rg = mesh.rigid_from_config(cfg)
+    sims = []
+    for qd in ("1", "0"):
+        monkeypatch.setenv("SPH_QUAD", qd)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg), rigid=rg))
+    a, b = sims
+    for s_ in range(40):
+        sa, sb = a.step(1), b.step(1)
+        assert (sa.n_div, sa.n_dens, sa.dens_err, sa.div_err) == (sb.n_div, sb.n_dens, sb.dens_err, sb.div_err), s_
+        assert np.array_equal(a.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), b.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)), s_
+        a.rigid_step(); b.rigid_step()
+    for f in FIELDS:
+        assert np.array_equal(a.download(f), b.download(f), equal_nan=True), f
+    a.close(); b.close()
