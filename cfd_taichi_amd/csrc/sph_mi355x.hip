@@ -599,6 +599,7 @@ constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_
 inline int sweep_mode(const SphHandle *h)
 {
     if (h->staged) return SWEEP_STAGED;
+    if (h->cfg.solver == SPH_SOLVER_PBF) return SWEEP_PLAIN;      // its sweeps have no quad form
     return (!h->slab && h->opt_quad && h->c.n <= kQuadBelow) ? SWEEP_QUAD : SWEEP_PLAIN;
 }
 // partials of the block reductions: one per 256 particles, or one per 64 from quad sweeps (k_finalize_mean adds them in groups of four)
@@ -1901,16 +1902,16 @@ int launch_pressure_finalize(SphHandle *h, int mode)
     if (h->slab) {
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev);
+            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev);
+        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr);
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     return SPH_OK;
 }
 
@@ -1942,7 +1943,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
-        SPH_LAUNCH_RS0(k_pci_ext, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF,
+        SPH_LAUNCH_RM0(k_pci_ext, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF,
                        PB[0], PP, rv, h->stage_src, h->stage_cnt);
     }
     // sharded: the ghosts' predicted positions / pressures come from their owners after the sweep that produced them
@@ -1951,7 +1952,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     if ((rc = ghosts_xyz(PP))) return rc;
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
-        SPH_LAUNCH_RS0(k_pci_predict_rho, rg, h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
+        SPH_LAUNCH_RM0(k_pci_predict_rho, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
                        PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv, h->stage_src, h->stage_cnt);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
@@ -1962,7 +1963,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
-                SPH_LAUNCH_RS0(k_pci_press, rg, h->staged, g, b, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
+                SPH_LAUNCH_RM0(k_pci_press, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
                                EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
@@ -2018,7 +2019,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_I_ADVECT);                        // :43-56
-        SPH_LAUNCH_RS0(k_ii_advect, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+        SPH_LAUNCH_RM0(k_ii_advect, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                        h->cnt, VA, DII, rv, h->stage_src, h->stage_cnt);
     }
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
@@ -2027,7 +2028,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     if ((rc = ghosts_xyz(DII))) return rc;
     {
         ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
-        SPH_LAUNCH_RS0(k_ii_rho_adv, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
+        SPH_LAUNCH_RM0(k_ii_rho_adv, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
                        DII, h->warm[h->wcur], h->rho_adv, h->aux, PB[0], rv, h->stage_src, h->stage_cnt);
     }
     bool first = true;
@@ -2035,13 +2036,13 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
-                SPH_LAUNCH_RS0(k_ii_dij, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
+                SPH_LAUNCH_RM0(k_ii_dij, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
                                DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
-                SPH_LAUNCH_RS0(k_ii_update_p, rg, h->staged, g, b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
+                SPH_LAUNCH_RM0(k_ii_update_p, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
                                h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_w(PB[k & 1]))) return rc;

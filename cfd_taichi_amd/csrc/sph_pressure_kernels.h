@@ -57,6 +57,33 @@ __device__ __forceinline__ void for_nbrs_3(const uint32_t *__restrict__ base, in
     }, [&](const Op &o, uint32_t j) { body(o.a, o.b, o.c, j); });
 }
 
+// quad forms (small scenes, four lanes per particle: walk_list_quad in sph_kernels.h)
+template <bool RIGID, int N, class Body>
+__device__ __forceinline__ void for_nbrs_ps_quad(const uint32_t *__restrict__ base, int cnt, int q, float (&acc)[N], const float4 *__restrict__ A,
+                                                 const float *__restrict__ S, const RigidView &rv, Body body)
+{
+    struct Op { float4 a; float s; };
+    walk_list_quad<N, Op>(base, cnt, q, acc, [&](uint32_t j, Op &o) {
+        const bool rg = RIGID && (j & kRigidTag);
+        const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+        o.a = rg ? rv.RP[idx] : A[idx];
+        o.s = S[rg ? 0u : idx];
+    }, [&](const Op &o, uint32_t j) { body(o.a, o.s, j); });
+}
+template <bool RIGID, int N, class Body>
+__device__ __forceinline__ void for_nbrs_3_quad(const uint32_t *__restrict__ base, int cnt, int q, float (&acc)[N], const float4 *__restrict__ A,
+                                                const float4 *__restrict__ B, const float4 *__restrict__ C, const RigidView &rv, Body body)
+{
+    struct Op { float4 a, b, c; };
+    walk_list_quad<N, Op>(base, cnt, q, acc, [&](uint32_t j, Op &o) {
+        const bool rg = RIGID && (j & kRigidTag);
+        const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+        o.a = rg ? rv.RP[idx] : A[idx];
+        o.b = B[rg ? 0u : idx];
+        o.c = C[rg ? 0u : idx];
+    }, [&](const Op &o, uint32_t j) { body(o.a, o.b, o.c, j); });
+}
+
 // staged forms (LDS staging plan of k_build_nl, IISPH on the Morton curve): the first operand comes from LDS, the others are
 // gathered from memory through the staged source index
 template <bool RIGID, class Body>
@@ -199,8 +226,10 @@ __device__ __forceinline__ void clamp_walls(const Consts &c, float pos[3], float
 enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
 
 // phase / red: as k_finalize_mean (FINP_ALL on one GPU; FINP_REDUCE -> all-reduce over the slabs -> FINP_DECIDE when sharded)
+// group / nparts: as k_finalize_mean (quad sweeps write one partial per 64 particles; a block's partial is the in-order sum of its four)
 __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red)
+                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                              int group = 1, int nparts = 0)
 {
     if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
     __shared__ double s_sum[kBlock];
@@ -211,11 +240,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__re
         for (; k + 7 * kBlock < nblocks; k += 8 * kBlock) {
             double v[8]; int m[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { v[u] = psum[k + u * kBlock]; m[u] = pcnt[k + u * kBlock]; }
+            for (int u = 0; u < 8; ++u) fin_partial(psum, pcnt, k + u * kBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
             for (int u = 0; u < 8; ++u) { t += v[u]; n += m[u]; }
         }
-        for (; k < nblocks; k += kBlock) { t += psum[k]; n += pcnt[k]; }
+        for (; k < nblocks; k += kBlock) { double v1; int m1; fin_partial(psum, pcnt, k, nblocks, group, nparts, v1, m1); t += v1; n += m1; }
         s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
         __syncthreads();
         for (int off = kBlock / 2; off > 0; off >>= 1) {
@@ -265,22 +294,24 @@ __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 // ======================================================================================
 // compute_ext_force (:237-244: tension, viscosity, gravity) + reset() (:247-250) + the first predict_vel_pos (:73-89)
 //   reads P = (pos, rho), V = (vel, -)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                     float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
                                                     float4 *__restrict__ PP, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     (void)kb; (void)nlbp;
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = pi.w;
-    float wx = 0.f, wy = 0.f, wz = 0.f;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
+    float fa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float &wx = fa[0], &wy = fa[1], &wz = fa[2];
+    float &tx = fa[3], &ty = fa[4], &tz = fa[5];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -298,9 +329,10 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
     };
-    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
+    else if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
-    if (!live) return;
+    if (!owner) return;
     float ten[3] = {tx * c.m, ty * c.m, tz * c.m};           // :209
     float vis[3] = {wx * c.m, wy * c.m, wz * c.m};           // :175
     float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
 
 // predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
 //   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delta, const float4 *__restrict__ P,
                                                             const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                             const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -331,41 +363,48 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
                                                             double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
                                                             const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
-    float rp = 0.f;
+    float fa[1] = {0.f};
+    float &rp = fa[0];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;   // rigid entries: the body where it is now (:159-161)
         if (RIGID && (j & kRigidTag)) rp += cubic_w(c, norm3(dx, dy, dz)) * pj.w * c.rho0;
         else rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;      // :155-156
     };
-    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
+    else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
-    float rb = 0.f;
-    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+    float wa[1] = {0.f};
+    float &rb = wa[0];
+    auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         rb += cubic_w(c, norm3(dx, dy, dz)) * pj.w;          // :167-168
-    });
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, kb, WP, wall);
     float val = 0.f;
     int flag = 0;
     if (live) {
         const float rho_p = c.boundary_handle ? rp + rb * c.rho0 : rp;   // :100 / :102
         const float err = rho_p - c.rho0;                    // :103
-        rho_predict[i] = rho_p;
+        if (owner) rho_predict[i] = rho_p;
         const float4 pb = PBin[i];
         float pr = pb.w + err * delta;                       // :107
         pr = rmax(0.0f, pr);                                 // :108
-        PBout[i] = make_float4(pb.x, pb.y, pb.z, pr);
+        if (owner) PBout[i] = make_float4(pb.x, pb.y, pb.z, pr);
         val = rmax(err, 0.0f);                               // :132
         flag = val > 0.0f && !ghost;                         // ghosts (multi-GPU) are counted by their owner
     }
-    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
+    else block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // update_press_force (:111-124, :192-224) + predict_vel_pos (:73-89).   P here is PB = (pos, press_iter)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                       const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
@@ -373,14 +412,16 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
                                                       float4 *__restrict__ PP, int gate, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     const float p_i = pi.w;
     constexpr float kRho0Sq = 1000000.0f;                    // self.rho_0 ** 2 (Python int)
     constexpr float kRcpRho0Sq = 1.0f / 1000000.0f;
-    float fx = 0.f, fy = 0.f, fz = 0.f;
+    float fa[3] = {0.f, 0.f, 0.f};
+    float &fx = fa[0], &fy = fa[1], &fz = fa[2];
     const float rho_own = (RIGID || c.boundary_handle) ? rho[ii] : 1.0f;
     const Recip rden = recip_prepare(rho_own * rho_own);     // rho_i ** 2, the divisor of every rigid term (:208)
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
@@ -397,20 +438,24 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
         fy += div_const(ps * g.y, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
         fz += div_const(ps * g.z, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
     };
-    if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
+    else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    float wa[3] = {0.f, 0.f, 0.f};
+    float &bx = wa[0], &by = wa[1], &bz = wa[2];
     if (c.boundary_handle) {
         const float rho_i_2 = rho_own * rho_own;             // :221
-        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w(c, dx, dy, dz, r);
             float s = pj.w * p_i / rho_i_2;                  // :223
             bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
-        });
+        };
+        if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+        else for_nbrs_p(nlbp, kb, WP, wall);
     }
-    if (!live) return;
+    if (!owner) return;
     float pf[3];
     if (c.boundary_handle) {
         pf[0] = -fx + bx * c.rho0 * c.m; pf[1] = -fy + by * c.rho0 * c.m; pf[2] = -fz + bz * c.rho0 * c.m;   // :120
@@ -458,23 +503,25 @@ __global__ __launch_bounds__(kBlock) void k_pci_integrate(Consts c, float dt, co
 // IISPH
 // ======================================================================================
 // predict_advection, first half (:43-56): tension, viscosity, f_adv, v_adv, d_ii.   P = (pos, rho), V = (vel, -)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                       float4 *__restrict__ VA, float4 *__restrict__ DII, RigidView rv,
                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
     const float4 vi = V[ii];
     const float rho_i = pi.w;
     const float s_f = c.neg_m / (rho_i * rho_i);             // compute_d_ii :280 (same value for every fluid neighbour)
-    float wx = 0.f, wy = 0.f, wz = 0.f;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
-    float ex = 0.f, ey = 0.f, ez = 0.f;
+    float fa[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float &wx = fa[0], &wy = fa[1], &wz = fa[2];
+    float &tx = fa[3], &ty = fa[4], &tz = fa[5];
+    float &ex = fa[6], &ey = fa[7], &ez = fa[8];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -498,20 +545,24 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
             wx += sv * g.x; wy += sv * g.y; wz += sv * g.z;
         }
     };
-    if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
+    else if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
-    float bx = 0.f, by = 0.f, bz = 0.f;
+    float wa[3] = {0.f, 0.f, 0.f};
+    float &bx = wa[0], &by = wa[1], &bz = wa[2];
     if (c.boundary_handle) {
         const float den = rho_i * rho_i;
-        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w(c, dx, dy, dz, r);
             float s = -pj.w / den;                           // compute_boundary_d_ii :292
             bx += s * g.x; by += s * g.y; bz += s * g.z;
-        });
+        };
+        if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+        else for_nbrs_p(nlbp, kb, WP, wall);
     }
-    if (!live) return;
+    if (!owner) return;
     float ten[3] = {tx * c.m, ty * c.m, tz * c.m};
     float vis[3] = {wx * c.m, wy * c.m, wz * c.m};
     float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
@@ -533,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
 }
 
 // predict_advection, second half (:58-82): rho_adv, p_iter = 0.5 p_past, a_ii.   P = (pos, rho), V = VA = (v_adv, -)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -541,14 +592,16 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
                                                        float *__restrict__ rho_adv, float *__restrict__ a_ii, float4 *__restrict__ PB0,
                                                        RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_pv(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
     const float4 vi = V[ii], di = DII[ii];
     const float rho_i = pi.w;
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // scalar prefix of d_ji, compute_a_ii :302-303
-    float ra = 0.f, aii = 0.f;
+    float fa[2] = {0.f, 0.f};
+    float &ra = fa[0], &aii = fa[1];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -563,20 +616,24 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
         ra += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);        // compute_rho_adv :332
         aii += c.m * dot3(ex, ey, ez, g.x, g.y, g.z);                                  // compute_a_ii :304
     };
-    if (staged) for_staged_nbrs_pv2<RIGID>(nlp, kf, s_operand, s_v2, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
+    else if (staged) for_staged_nbrs_pv2<RIGID>(nlp, kf, s_operand, s_v2, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
-    float rb = 0.f, ab = 0.f;
+    float wa[2] = {0.f, 0.f};
+    float &rb = wa[0], &ab = wa[1];
     if (c.boundary_handle) {
-        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w(c, dx, dy, dz, r);
             rb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                        // compute_rho_adv_boundary :349
             float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;
             ab += pj.w * dot3(ex, ey, ez, g.x, g.y, g.z);                              // compute_a_ii_boundary :322
-        });
+        };
+        if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+        else for_nbrs_p(nlbp, kb, WP, wall);
     }
-    if (!live) return;
+    if (!owner) return;
     if (c.boundary_handle) {
         rho_adv[i] = (ra + rb * c.rho0) * dt + rho_i;        // :64
         a_ii[i] = aii + ab * c.rho0;                         // :75
@@ -588,20 +645,22 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
 }
 
 // compute_all_d_ij (:130-135, :324-327).   P here is PB = (pos, p_iter)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                    const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv,
                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     (void)kb; (void)nlbp;
     float *s_rho = reinterpret_cast<float *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_scalar(c, s_operand, s_rho, P, rho, stage_src, stage_cnt, blk);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    float fa[3] = {0.f, 0.f, 0.f};
+    float &sx = fa[0], &sy = fa[1], &sz = fa[2];
     auto pair = [&](const float4 pj, const float rho_j, const uint32_t j) {
         if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
@@ -611,14 +670,15 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
     };
-    if (staged) for_staged_nbrs_ps2<RIGID>(nlp, kf, s_operand, s_rho, rv, pair);
+    if (QUAD) for_nbrs_ps_quad<RIGID>(nlp, kf, q, fa, P, rho, rv, pair);
+    else if (staged) for_staged_nbrs_ps2<RIGID>(nlp, kf, s_operand, s_rho, rv, pair);
     else for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, pair);
-    if (!live) return;
+    if (!owner) return;
     DIJ[i] = make_float4(sx * dt * dt, sy * dt * dt, sz * dt * dt, 0.f);   // :135
 }
 
 // update_p (:137-157) + compute_residual partials (:110-121).   P = PBin = (pos, p_iter); writes PBout = (pos, new p_iter)
-template <bool RIGID, bool STAGED>
+template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ DII,
                                                         const float4 *__restrict__ DIJ, const float4 *__restrict__ WP,
                                                         const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
@@ -628,9 +688,10 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate, RigidView rv,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
+    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
     float *s_ex = reinterpret_cast<float *>(s_src + c.stage_cap), *s_ey = s_ex + c.stage_cap, *s_ez = s_ey + c.stage_cap;
     const int nst = STAGED ? stage_expand(stage_src, stage_cnt, blk, s_src) : -1;      // the list stays: DII is gathered through it
@@ -648,7 +709,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     const float rho_i = rho[ii];
     const float cji = -dt * dt * c.m / (rho_i * rho_i);      // :252-253
     const float4 a = DIJ[ii];
-    float sum = 0.f;
+    float fa[1] = {0.f};
+    float &sum = fa[0];
     auto pair = [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -663,16 +725,20 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         float tz = a.z - dj.z * pj.w - (ej.z - jz);
         sum += c.m * dot3(tx, ty, tz, g.x, g.y, g.z);        // sum_factor :254
     };
-    if (staged) for_staged_nbrs_3e<RIGID>(nlp, kf, s_operand, s_src, s_ex, s_ey, s_ez, DII, rv, pair);
+    if (QUAD) for_nbrs_3_quad<RIGID>(nlp, kf, q, fa, P, DII, DIJ, rv, pair);
+    else if (staged) for_staged_nbrs_3e<RIGID>(nlp, kf, s_operand, s_src, s_ex, s_ey, s_ez, DII, rv, pair);
     else for_nbrs_3<RIGID>(nlp, kf, P, DII, DIJ, rv, pair);
-    float bsum = 0.f;
+    float wa[1] = {0.f};
+    float &bsum = wa[0];
     if (c.boundary_handle) {
-        for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+        auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
             F3 g = grad_w(c, dx, dy, dz, r);
             bsum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor_boundary :240
-        });
+        };
+        if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+        else for_nbrs_p(nlbp, kb, WP, wall);
     }
     float val = 0.f;
     int flag = 0;
@@ -683,11 +749,12 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         if (fabsf(aii) > 1e-7f) p_new = 0.5f * p_i + 0.5f * ((c.rho0 - radv) - r_sum) / aii;   // :150-151 (omega = 0.5)
         else p_new = 0.0f;
         const float p = rmax(p_new, 0.0f);                   // :156
-        PBout[i] = make_float4(pi.x, pi.y, pi.z, p);
+        if (owner) PBout[i] = make_float4(pi.x, pi.y, pi.z, p);
         flag = p > 0.0f && !ghost;                           // :115; ghosts (multi-GPU) are counted by their owner
         val = ((aii * p + r_sum) + radv) - 1000.0f;          // :116
     }
-    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
+    else block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // intergation (:189-210) with compute_all_press_force (:172-176)
