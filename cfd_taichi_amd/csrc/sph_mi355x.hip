@@ -85,6 +85,7 @@ struct SphHandle {
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
+    int quad_below = 65536;              // = kQuadBelow (SPH_QUAD_BELOW: experiments)
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
@@ -600,7 +601,7 @@ inline int sweep_mode(const SphHandle *h)
 {
     if (h->staged) return SWEEP_STAGED;
     if (h->cfg.solver == SPH_SOLVER_PBF) return SWEEP_PLAIN;      // its sweeps have no quad form
-    return (!h->slab && h->opt_quad && h->c.n <= kQuadBelow) ? SWEEP_QUAD : SWEEP_PLAIN;
+    return (!h->slab && h->opt_quad && h->c.n <= h->quad_below) ? SWEEP_QUAD : SWEEP_PLAIN;
 }
 // partials of the block reductions: one per 256 particles, or one per 64 from quad sweeps (k_finalize_mean adds them in groups of four)
 inline int partial_group(const SphHandle *h) { return sweep_mode(h) == SWEEP_QUAD ? 4 : 1; }
@@ -721,7 +722,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->WP, (size_t)h->Nb + 64))) return rc;
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
-    const size_t nblocks_cap = n <= (size_t)kQuadBelow ? (n + 63) / 64 : (n + kBlock - 1) / kBlock;    // quad sweeps: one partial per 64 particles
+    const size_t nblocks_cap = n <= (size_t)h->quad_below ? (n + 63) / 64 : (n + kBlock - 1) / kBlock;    // quad sweeps: one partial per 64 particles
     if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
@@ -2259,6 +2260,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
     { const char *e = getenv("SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
     int rc = SPH_OK;
     do {
