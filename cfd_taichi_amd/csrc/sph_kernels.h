@@ -543,10 +543,9 @@ __device__ __forceinline__ int stage_lookup(const int *key, const int *base, int
     return 0;
 }
 
-// CHUNK: candidates of a cell requested in one batch (a multiple of 4).  Larger scenes are bound by instruction issue and lose to the
-// tests of candidates past the cell's end (12 instead of 4 at 250 k particles: 68 -> 75 us); scenes of less than a wave per SIMD gain from
-// more loads in flight (30 k: 54 -> 48 us) but gain far more from k_build_nl_split below, which the launch picks for them.
-template <bool RIGID, bool STAGED, int CHUNK>
+// (Candidates are requested four at a time: twelve per batch gain where there is less than a wave per SIMD -- 30 k particles: 54 -> 48 us --
+// and lose to the tests of candidates past the cell's end where issue is the limit -- 250 k: 68 -> 75 us; small scenes use k_build_nl_split.)
+template <bool RIGID, bool STAGED>
 __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__restrict__ P, const int *__restrict__ cell_start,
                                                      const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
@@ -632,6 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         if (threadIdx.x == 0) { stage_cnt[blk] = staged ? (total | (nruns << 16)) : -1; s_ok = staged ? 1 : 0; }
         __syncthreads();
     }
+    constexpr int CHUNK = 4;
     const bool staged = STAGED && s_ok != 0;
     // (3) the walk.  What a particle needs to know about each of its 27 cells -- where the cell's fluid and wall particles start, how
     // many there are, the cell's base in the staged set -- used to be worked out by every lane for itself (the slot on the curve

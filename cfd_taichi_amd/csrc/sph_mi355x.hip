@@ -558,14 +558,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     return SPH_OK;
 }
 
-// kernel<T0, RIGID, STAGED> / kernel<RIGID, STAGED> chosen at run time (rigid coupling active, LDS staging on)
-#define SPH_LAUNCH_RS(K, T0, rg, st, g, b, lds, s, ...)                                              \
-    do {                                                                                             \
-        if ((rg) && (st)) hipLaunchKernelGGL((K<T0, true, true>), g, b, lds, s, __VA_ARGS__);        \
-        else if (rg) hipLaunchKernelGGL((K<T0, true, false>), g, b, lds, s, __VA_ARGS__);            \
-        else if (st) hipLaunchKernelGGL((K<T0, false, true>), g, b, lds, s, __VA_ARGS__);            \
-        else hipLaunchKernelGGL((K<T0, false, false>), g, b, lds, s, __VA_ARGS__);                   \
-    } while (0)
+// kernel<T0, RIGID, MODE> / kernel<RIGID, MODE> chosen at run time (rigid coupling active; the sweep mode of the handle):
 // sweeps with a MODE parameter (SWEEP_PLAIN / SWEEP_STAGED / SWEEP_QUAD, sph_kernels.h); the grid follows the mode (quad sweeps: 64 particles per workgroup)
 #define SPH_LAUNCH_RM(K, T0, rg, mode, n, lds, s, ...)                                                                                   \
     do {                                                                                                                                 \
@@ -589,13 +582,6 @@ int build_scene(SphHandle *h, HostScene &sc)
     } while (0)
 constexpr int kQuadBelow = 65536;          // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
 constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_split with nine / three waves per 64 particles up to these sizes (unstaged handles)
-#define SPH_LAUNCH_RS0(K, rg, st, g, b, lds, s, ...)                                                 \
-    do {                                                                                             \
-        if ((rg) && (st)) hipLaunchKernelGGL((K<true, true>), g, b, lds, s, __VA_ARGS__);            \
-        else if (rg) hipLaunchKernelGGL((K<true, false>), g, b, lds, s, __VA_ARGS__);                \
-        else if (st) hipLaunchKernelGGL((K<false, true>), g, b, lds, s, __VA_ARGS__);                \
-        else hipLaunchKernelGGL((K<false, false>), g, b, lds, s, __VA_ARGS__);                       \
-    } while (0)
 // dynamic LDS of a staged sweep: bytes per staged particle x capacity (else the occupancy-experiment knob)
 inline int sweep_mode(const SphHandle *h)
 {
@@ -1467,7 +1453,7 @@ int stage_sort_and_lists(SphHandle *h)
     {
         ProfScope ps(h, K_BUILD_NL);
         // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
-#define SPH_BNL(R, S, CH) hipLaunchKernelGGL((k_build_nl<R, S, CH>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
+#define SPH_BNL(R, S) hipLaunchKernelGGL((k_build_nl<R, S>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
                                              h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt)
 #define SPH_BNL_SPLIT(R, NW) hipLaunchKernelGGL((k_build_nl_split<R, NW>), dim3((unsigned)std::max(1, (c.n + 63) / 64)), dim3(NW * 64), 0, s, c, h->P[h->pcur], \
                                                 h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount)
@@ -1475,12 +1461,12 @@ int stage_sort_and_lists(SphHandle *h)
         // 22 k particles 77 -> 55 -> 34 us, 29 k 54 -> 32 -> 27 us, 55 k 146 -> 81 -> 64 us (rigid) / 56 -> 44 -> 48 us; 250 k 69 -> 87 -> 122 us.
         const bool rg = rigid_coupled(h);
         const int split = h->staged ? 0 : h->opt_bnl_split >= 0 ? h->opt_bnl_split : c.n <= kBnlSplit9Below ? 9 : c.n <= kBnlSplitBelow ? 3 : 0;
-        if (rg && h->staged) SPH_BNL(true, true, 4);
-        else if (h->staged) SPH_BNL(false, true, 4);
+        if (rg && h->staged) SPH_BNL(true, true);
+        else if (h->staged) SPH_BNL(false, true);
         else if (rg && split) { if (split == 9) SPH_BNL_SPLIT(true, 9); else SPH_BNL_SPLIT(true, 3); }
-        else if (rg) SPH_BNL(true, false, 4);
+        else if (rg) SPH_BNL(true, false);
         else if (split) { if (split == 9) SPH_BNL_SPLIT(false, 9); else SPH_BNL_SPLIT(false, 3); }
-        else SPH_BNL(false, false, 4);
+        else SPH_BNL(false, false);
 #undef SPH_BNL
 #undef SPH_BNL_SPLIT
     }
