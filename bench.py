@@ -156,11 +156,16 @@ def load_traffic(kernel, key="hbm_bytes_per_launch"):
 
 def load_valu_mix(kernel_profile_name):
     """Per-launch VALU class counts and their issue floor for the dominant kernels (tools/valu_mix.py; None if absent)."""
-    names = {"dfsph_div_residual": "k_residual<false, false, true>", "dfsph_dens_residual": "k_residual<true, false, true>",
-             "dfsph_div_correct": "k_correct<1, false, true>", "dfsph_dens_correct": "k_correct<2, false, true>"}
+    # staged, non-rigid instantiations (the third template argument is the sweep mode: 1 = staged; "true" in profiles taken before it became one)
+    names = {"dfsph_div_residual": "k_residual<false, false, %s>", "dfsph_dens_residual": "k_residual<true, false, %s>",
+             "dfsph_div_correct": "k_correct<1, false, %s>", "dfsph_dens_correct": "k_correct<2, false, %s>"}
     try:
         with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
-            return json.load(f)["kernels"].get(names.get(kernel_profile_name, ""))
+            kernels = json.load(f)["kernels"]
+        pattern = names.get(kernel_profile_name)
+        if pattern is None:
+            return None
+        return kernels.get(pattern % "1") or kernels.get(pattern % "true")
     except Exception:
         return None
 
