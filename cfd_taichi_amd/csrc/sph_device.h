@@ -57,19 +57,6 @@ struct Consts {
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).
-// Device-side control of the reference's host loops (correct_divergence_error dfsph_solver.py:393-416, correct_density_error :221-233)
-// on a single GPU: kernels of an iteration that the loop would not have run exit at once.  The pcisph / iisph pressure loops reuse
-// dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds res_*.
-// DevScalars holds TWO copies.  The finalize kernels update the current copy in place.  With quad sweeps (small scenes) the decision is
-// taken by the first kernel that needs it, every workgroup for itself from the block partials, and workgroup 0 writes the updated block
-// into the OTHER copy -- nobody reads that one during the kernel -- which becomes the current copy for everything enqueued afterwards.
-struct DevCtrl {
-    int div_active, div_it, div_evals, dens_active;
-    int dens_d7_active, dens_it, dens_cap, dens_capped;
-    float div_err, div_past, div_first, dens_avg;
-    float res_prev;
-    int res_have_prev, res_diverged, pad2;
-};
 struct DevScalars {
     float dt;          // solver.delta_time[None]
     float dt2;         // solver.delta_time_2[None]
@@ -84,8 +71,14 @@ struct DevScalars {
     int pad[2];
     double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
     long long cnt;
-    // device-side control of the reference's host loops: two copies (see DevCtrl); a kernel's `gate` argument names the copy it reads
-    DevCtrl ctrl[2];
+    // device-side control of the reference's host loops (correct_divergence_error dfsph_solver.py:393-416,
+    // correct_density_error :221-233) on a single GPU: kernels of an iteration that the loop would not have run exit at once
+    int div_active, div_it, div_evals, dens_active;
+    int dens_d7_active, dens_it, dens_cap, dens_capped;
+    float div_err, div_past, div_first, dens_avg;
+    // pcisph / iisph pressure loops reuse dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds:
+    float res_prev;
+    int res_have_prev, res_diverged, pad2;
     // Per-build maxima of the list lengths, sharded: workgroup w raises shard w % kNoteShards, the host takes the maximum over the
     // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
     // list build: same-address traffic serialises even when it is only loads.)
@@ -93,21 +86,13 @@ struct DevScalars {
 };
 constexpr int kNoteShards = 64;
 
-// a kernel's `gate` argument: the flag that must be set for the kernel to run (low byte) | the copy of the control block to read << 8
 enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3 };
-__device__ __forceinline__ int gate_copy(int gate) { return (gate >> 8) & 1; }
-__device__ __forceinline__ bool ctrl_closed(const DevCtrl &c, int gate)
-{
-    const int kind = gate & 0xff;
-    if (kind == GATE_DIV) return c.div_active == 0;
-    if (kind == GATE_DENS) return c.dens_active == 0;
-    if (kind == GATE_DENS_D7) return c.dens_d7_active == 0;
-    return false;
-}
 __device__ __forceinline__ bool gate_closed(const DevScalars *ds, int gate)
 {
-    if ((gate & 0xff) == GATE_NONE) return false;
-    return ctrl_closed(ds->ctrl[gate_copy(gate)], gate);
+    if (gate == GATE_DIV) return ds->div_active == 0;
+    if (gate == GATE_DENS) return ds->dens_active == 0;
+    if (gate == GATE_DENS_D7) return ds->dens_d7_active == 0;
+    return false;
 }
 
 struct F3 {

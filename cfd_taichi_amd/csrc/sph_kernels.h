@@ -1046,40 +1046,6 @@ enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
 // 1 M particles: 3907 partials), a wave butterfly, then thread 0 adds the 16 wave sums in order -- one barrier.  (With 256 threads,
 // two load rounds and an eight-level LDS tree this kernel took 5.2 us, 29 times per step.)  The order is fixed, hence deterministic.
 constexpr int kFinBlock = 1024;
-// the loop decisions of correct_divergence_error (dfsph_solver.py:393-416) and correct_density_error (:221-233) from a reduced (sum, count),
-// applied to a control block: by thread 0 of k_finalize_mean (in place), or by a quad correction sweep that takes the decision itself
-__device__ __forceinline__ void fin_decide_mean(DevCtrl *ctl, int mode, double sum, long long cnt)
-{
-    if (mode == FIN_PLAIN) return;
-    // the reference's host logic, evaluated where the data is (same f64 compares as the Python host code)
-    if (mode == FIN_DIV_FIRST || mode == FIN_DIV_LOOP) {
-        const float err = cnt > 0 ? (float)(sum / (double)cnt) : 0.0f;   // dfsph_solver.py:278-279
-        int it = ctl->div_it;
-        int active;
-        if (mode == FIN_DIV_FIRST) {                                     // :398-399
-            ctl->div_first = err; ctl->div_err = err; ctl->div_evals = 1;
-            active = 1;
-        } else {                                                         // :406-414
-            const float past = ctl->div_err;
-            ctl->div_past = past; ctl->div_err = err; ctl->div_evals += 1;
-            if (fabs((double)err - (double)past) < 1e-5) active = 0;    // break before iter_cnt += 1
-            else { it += 1; active = 1; }
-        }
-        if (active) active = ((it < 1 || (double)err > 10.0) && it < 15) ? 1 : 0;   // :400
-        ctl->div_it = it;
-        ctl->div_active = active;
-    } else {
-        const float avg = cnt > 0 ? (float)(sum / (double)cnt) : 1000.0f;  // :148-149
-        ctl->dens_avg = avg;
-        ctl->dens_d7_active = 1;                                          // iter_all_vel_adv of this iteration runs (:229)
-        const int it = ctl->dens_it + 1;                                  // :231
-        ctl->dens_it = it;
-        int active = (it < 2 || (double)avg - 1000.0 > 0.1 * 1000 * 0.01) ? 1 : 0;      // :225
-        if (active && it >= ctl->dens_cap) { active = 0; ctl->dens_capped = 1; }
-        ctl->dens_active = active;
-    }
-}
-
 // group = 4: psum / pcnt hold one entry per 64 particles (QUAD sweeps, block_partial_mean_quad); `nblocks` still counts blocks of 256 particles and
 // `nparts` the entries: a block's partial is the in-order sum of its (up to) four entries.
 __device__ __forceinline__ void fin_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, int nblocks, int group, int nparts, double &v, int &m)
@@ -1094,11 +1060,10 @@ __device__ __forceinline__ void fin_partial(const double *__restrict__ psum, con
 }
 __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                             int group = 1, int nparts = 0, int copy = 0)
+                                                             int group = 1, int nparts = 0)
 {
-    DevCtrl *ctl = &ds->ctrl[copy];
-    if (mode == FIN_DIV_LOOP && ctl->div_active == 0) return;
-    if (mode == FIN_DENS && ctl->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ctl->dens_d7_active = 0; return; }
+    if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
+    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
     __shared__ double s_sum[kFinBlock / 64];
     __shared__ long long s_cnt[kFinBlock / 64];
     if (phase != FINP_DECIDE) {
@@ -1132,15 +1097,41 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
     if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
     ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
-    fin_decide_mean(ctl, mode, s_sum[0], s_cnt[0]);
+    if (mode == FIN_PLAIN) return;
+    // the reference's host logic, evaluated where the data is (same f64 compares as the Python host code)
+    if (mode == FIN_DIV_FIRST || mode == FIN_DIV_LOOP) {
+        const float err = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // dfsph_solver.py:278-279
+        int it = ds->div_it;
+        int active;
+        if (mode == FIN_DIV_FIRST) {                                     // :398-399
+            ds->div_first = err; ds->div_err = err; ds->div_evals = 1;
+            active = 1;
+        } else {                                                         // :406-414
+            const float past = ds->div_err;
+            ds->div_past = past; ds->div_err = err; ds->div_evals += 1;
+            if (fabs((double)err - (double)past) < 1e-5) active = 0;    // break before iter_cnt += 1
+            else { it += 1; active = 1; }
+        }
+        if (active) active = ((it < 1 || (double)err > 10.0) && it < 15) ? 1 : 0;   // :400
+        ds->div_it = it;
+        ds->div_active = active;
+    } else {
+        const float avg = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 1000.0f;  // :148-149
+        ds->dens_avg = avg;
+        ds->dens_d7_active = 1;                                          // iter_all_vel_adv of this iteration runs (:229)
+        const int it = ds->dens_it + 1;                                  // :231
+        ds->dens_it = it;
+        int active = (it < 2 || (double)avg - 1000.0 > 0.1 * 1000 * 0.01) ? 1 : 0;      // :225
+        if (active && it >= ds->dens_cap) { active = 0; ds->dens_capped = 1; }
+        ds->dens_active = active;
+    }
 }
 
 __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 {
-    DevCtrl *c = &ds->ctrl[0];                                   // a step starts on copy 0
-    c->div_active = 1; c->div_it = 0; c->div_evals = 0;
-    c->dens_active = 1; c->dens_d7_active = 0; c->dens_it = 0; c->dens_cap = dens_cap; c->dens_capped = 0;
-    c->div_err = 0.f; c->div_past = 0.f; c->div_first = 0.f; c->dens_avg = 0.f;
+    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0;
+    ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
+    ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
 }
 
 // max |v*| over the block partials                              dfsph_solver.py:100-103

@@ -87,7 +87,6 @@ struct SphHandle {
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
     int quad_below = 65536;              // = kQuadBelow (SPH_QUAD_BELOW: experiments)
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
-    int ctrl_copy = 0;                   // which DevCtrl copy is current (see sph_device.h); flips at every decision a quad sweep takes itself
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
@@ -593,8 +592,6 @@ inline int sweep_mode(const SphHandle *h)
 // partials of the block reductions: one per 256 particles, or one per 64 from quad sweeps (k_finalize_mean adds them in groups of four)
 inline int partial_group(const SphHandle *h) { return sweep_mode(h) == SWEEP_QUAD ? 4 : 1; }
 inline int partial_count(const SphHandle *h) { return sweep_mode(h) == SWEEP_QUAD ? (h->c.n + 63) / 64 : h->nblocks; }
-// a kernel's gate argument: the flag it depends on | the current copy of the control block (sph_device.h)
-inline int gate_arg(const SphHandle *h, int gate) { return gate | (h->ctrl_copy << 8); }
 inline size_t sweep_lds(const SphHandle *h, size_t bytes_per_staged) { return h->staged ? (size_t)h->c.stage_cap * bytes_per_staged : (size_t)h->sweep_lds; }
 inline RigidView rigid_view_or_none(const SphHandle *h);
 
@@ -1541,7 +1538,7 @@ void launch_rigid_force_p(SphHandle *h, const float4 *P, const float4 *PB, int g
 {
     ProfScope ps(h, K_RIGID);
     hipLaunchKernelGGL(k_rigid_force_p<MODE>, grid_for(h->Nr), dim3(kBlock), 0, h->stream, h->c, h->Nr, h->RPs, h->rid, P, h->rnl, h->rcnt, h->rho,
-                       h->aux, PB, h->ds, h->rforce, gate_arg(h, gate));
+                       h->aux, PB, h->ds, h->rforce, gate);
 }
 
 int step_wcsph_once(SphHandle *h)
@@ -1589,7 +1586,7 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate_arg(h, gate), h->stage_src, h->stage_cnt, h->krho);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 template <int MODE>
@@ -1599,7 +1596,7 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     ProfScope ps(h, kid);
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
-                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate_arg(h, gate), h->stage_src, h->stage_cnt, h->krho);
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -1608,7 +1605,7 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate_arg(h, gate), h->stage_src, h->stage_cnt, h->krho);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -1616,16 +1613,16 @@ int launch_finalize(SphHandle *h, int mode)
     if (slab_async(h)) {       // this slab's (sum, count) -> all-reduce over the slabs -> the loop decision, all on the stream
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h), h->ctrl_copy);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h), h->ctrl_copy);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     return SPH_OK;
 }
 
@@ -1634,13 +1631,13 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
     const Consts &c = h->c;
     ProfScope ps(h, K_RIGID);
     hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), dim3(kBlock), 0, h->stream, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->rnl, h->rcnt, h->rho,
-                       h->rho_adv, h->aux, h->ds, h->rforce, gate_arg(h, gate));
+                       h->rho_adv, h->aux, h->ds, h->rforce, gate);
 }
 
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
 int reduce_mean_host(SphHandle *h, float dflt, float *mean)
 {
-    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     int rc = read_scalars(h);
     if (rc) return rc;
     double v[2] = {h->ds_host->sum, (double)h->ds_host->cnt};
@@ -1713,7 +1710,6 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     int rc;
     hipStream_t s = h->stream;
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
-    h->ctrl_copy = 0;
     hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
     // On a slab handle every sweep whose output the neighbours read is followed by the refresh of that field on the ghosts (enqueued,
@@ -1752,19 +1748,19 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
             if ((rc = check_overflow_all(h))) return rc;     // first read-back of the step: list overflow?
             first = false;
         }
-        if (!h->ds_host->ctrl[h->ctrl_copy].dens_active) break;
+        if (!h->ds_host->dens_active) break;
     }
-    h->last_iters = h->ds_host->ctrl[h->ctrl_copy].dens_it;
+    h->last_iters = h->ds_host->dens_it;
     st->max_nbrs = h->ds_host->max_nbrs;
     st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
     st->lost = h->ds_host->lost;
-    st->n_div = h->ds_host->ctrl[h->ctrl_copy].div_it;
-    st->n_div_evals = h->ds_host->ctrl[h->ctrl_copy].div_evals;
-    st->div_first_err = h->ds_host->ctrl[h->ctrl_copy].div_first;
-    st->div_err = h->ds_host->ctrl[h->ctrl_copy].div_err;
-    st->n_dens = h->ds_host->ctrl[h->ctrl_copy].dens_it;
-    st->capped = h->ds_host->ctrl[h->ctrl_copy].dens_capped;
-    st->dens_err = (float)((double)h->ds_host->ctrl[h->ctrl_copy].dens_avg - 1000.0);
+    st->n_div = h->ds_host->div_it;
+    st->n_div_evals = h->ds_host->div_evals;
+    st->div_first_err = h->ds_host->div_first;
+    st->div_err = h->ds_host->div_err;
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->dens_err = (float)((double)h->ds_host->dens_avg - 1000.0);
     st->dt = h->ds_host->dt;
     return dfsph_integrate(h);
 }
@@ -1893,16 +1889,16 @@ int launch_pressure_finalize(SphHandle *h, int mode)
     if (h->slab) {
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h), h->ctrl_copy);
+            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h), h->ctrl_copy);
+        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     return SPH_OK;
 }
 
@@ -1931,7 +1927,6 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     const RigidView rv = rg ? rigid_view(h) : RigidView();
     float4 *EF = h->X[0], *PF = h->X[1], *PP = h->X[2], *PB[2] = {h->X[3], h->X[4]};
     const int cap = 80;                                     // max_iteration :21
-    h->ctrl_copy = 0;
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
@@ -1945,7 +1940,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
         SPH_LAUNCH_RM0(k_pci_predict_rho, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
-                       PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate_arg(h, gate), rv, h->stage_src, h->stage_cnt);
+                       PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv, h->stage_src, h->stage_cnt);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
     if ((rc = ghosts_w(PB[1]))) return rc;
@@ -1956,7 +1951,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
                 SPH_LAUNCH_RM0(k_pci_press, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
-                               EF, h->ds, PF, PP, gate_arg(h, GATE_DENS), rv, h->stage_src, h->stage_cnt);
+                               EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
             if ((rc = ghosts_xyz(PP))) return rc;
@@ -1969,17 +1964,17 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
             if ((rc = check_overflow_all(h))) return rc;
             first = false;
         }
-        if (!h->ds_host->ctrl[h->ctrl_copy].dens_active) break;
+        if (!h->ds_host->dens_active) break;
     }
     st->max_nbrs = h->ds_host->max_nbrs;
     st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
     st->lost = h->ds_host->lost;
-    st->n_dens = h->ds_host->ctrl[h->ctrl_copy].dens_it;
-    st->capped = h->ds_host->ctrl[h->ctrl_copy].dens_capped;
-    st->dens_err = h->ds_host->ctrl[h->ctrl_copy].dens_avg;
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->dens_err = h->ds_host->dens_avg;
     st->dt = dt;
-    h->pb_final = h->ds_host->ctrl[h->ctrl_copy].dens_it & 1;
-    h->last_iters = h->ds_host->ctrl[h->ctrl_copy].dens_it;
+    h->pb_final = h->ds_host->dens_it & 1;
+    h->last_iters = h->ds_host->dens_it;
     {
         ProfScope ps(h, K_P_INTEGRATE);
         hipLaunchKernelGGL(k_pci_integrate, g, b, 0, s, c, dt, h->P[h->pcur], h->V[h->vcur], EF, PF, h->P[1 - h->pcur], h->V[1 - h->vcur]);
@@ -2008,7 +2003,6 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     const RigidView rv = rg ? rigid_view(h) : RigidView();
     float4 *DII = h->X[0], *DIJ = h->X[1], *FP = h->X[2], *PB[2] = {h->X[3], h->X[4]}, *VA = h->VA[0];
     const int cap = 180;                                    // max_iter_cnt :27
-    h->ctrl_copy = 0;
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_I_ADVECT);                        // :43-56
@@ -2030,13 +2024,13 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
                 SPH_LAUNCH_RM0(k_ii_dij, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
-                               DIJ, gate_arg(h, GATE_DENS), rv, h->stage_src, h->stage_cnt);
+                               DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
                 SPH_LAUNCH_RM0(k_ii_update_p, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
-                               h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, gate_arg(h, GATE_DENS), rv, h->stage_src, h->stage_cnt);
+                               h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_w(PB[k & 1]))) return rc;
             if ((rc = launch_pressure_finalize(h, PFIN_II_LOOP))) return rc;
@@ -2046,18 +2040,18 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
             if ((rc = check_overflow_all(h))) return rc;
             first = false;
         }
-        if (!h->ds_host->ctrl[h->ctrl_copy].dens_active) break;
+        if (!h->ds_host->dens_active) break;
     }
     st->max_nbrs = h->ds_host->max_nbrs;
     st->max_wall_nbrs = h->ds_host->max_wall_nbrs;
     st->lost = h->ds_host->lost;
-    st->n_dens = h->ds_host->ctrl[h->ctrl_copy].dens_it;
-    st->capped = h->ds_host->ctrl[h->ctrl_copy].dens_capped;
-    st->n_div = h->ds_host->ctrl[h->ctrl_copy].res_diverged;                   // 1: the loop left on "Iteration trend to divergence" (:97-99)
-    st->dens_err = h->ds_host->ctrl[h->ctrl_copy].dens_avg;
+    st->n_dens = h->ds_host->dens_it;
+    st->capped = h->ds_host->dens_capped;
+    st->n_div = h->ds_host->res_diverged;                   // 1: the loop left on "Iteration trend to divergence" (:97-99)
+    st->dens_err = h->ds_host->dens_avg;
     st->dt = dt;
-    h->pb_final = h->ds_host->ctrl[h->ctrl_copy].dens_it & 1;
-    h->last_iters = h->ds_host->ctrl[h->ctrl_copy].dens_it;
+    h->pb_final = h->ds_host->dens_it & 1;
+    h->last_iters = h->ds_host->dens_it;
     if (rg) launch_rigid_force_p<RF_IISPH>(h, h->P[h->pcur], PB[h->pb_final], GATE_NONE);   // compute_all_press_force :172-179
     {
         ProfScope ps(h, K_I_INTEGRATE);
@@ -2872,15 +2866,15 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
         else if (which == 2) launch_dens_residual(h, GATE_NONE);
         else if (which == 4) {      // a sweep followed by the single-workgroup reduction of its block partials, as in the solver loops
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
         } else if (which == 5) {    // the reduction alone
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
         } else if (which == 6) {    // two different sweeps alternating (residual, correct), no reduction between them
             launch_div_residual(h, GATE_NONE);
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         } else if (which == 7) {    // the same with the reduction after the residual: one solver iteration
             launch_div_residual(h, GATE_NONE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h), h->ctrl_copy);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, (int)FIN_PLAIN, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         }
         else if ((rc = stage_sort_and_lists(h))) break;

@@ -227,42 +227,11 @@ enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
 
 // phase / red: as k_finalize_mean (FINP_ALL on one GPU; FINP_REDUCE -> all-reduce over the slabs -> FINP_DECIDE when sharded)
 // group / nparts: as k_finalize_mean (quad sweeps write one partial per 64 particles; a block's partial is the in-order sum of its four)
-// the while-conditions of the pressure loops from a reduced (sum, count), applied to a control block (see fin_decide_mean)
-__device__ __forceinline__ void fin_decide_pressure(DevCtrl *ctl, int mode, double sum, long long cnt)
-{
-    const float res = cnt > 0 ? (float)(sum / (double)cnt) : 0.0f;   // pcisph :136-137, iisph :119-120
-    const int cap = ctl->dens_cap;
-    if (mode == PFIN_PCI_FIRST) {
-        ctl->dens_avg = res; ctl->dens_it = 0; ctl->dens_capped = 0; ctl->res_diverged = 0;
-        ctl->dens_active = cap > 0 ? 1 : 0;                                          // iter_cnt (0) < min_iteration (1)
-    } else if (mode == PFIN_PCI_LOOP) {
-        const int it = ctl->dens_it + 1;                                             // :70
-        ctl->dens_it = it; ctl->dens_avg = res;
-        const int active = (((double)res > 1000 * 0.1 * 0.01 || it < 1) && it < cap) ? 1 : 0;   // :58
-        if (it >= cap) ctl->dens_capped = 1;
-        ctl->dens_active = active;
-    } else {
-        const int l = ctl->dens_it + 1;                                              // iisph :94
-        ctl->dens_it = l; ctl->dens_avg = res;
-        int active;
-        if (ctl->res_have_prev && (double)res - (double)ctl->res_prev > 0) {          // :97-99 "Iteration trend to divergence"
-            ctl->res_diverged = 1;
-            active = 0;
-        } else {
-            ctl->res_prev = res; ctl->res_have_prev = 1;                              // :100
-            active = (((double)res > 0.1 * 1000 * 0.01 || l < 1) && l < cap) ? 1 : 0;   // :88-89
-        }
-        if (l >= cap) ctl->dens_capped = 1;
-        ctl->dens_active = active;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                               DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                              int group = 1, int nparts = 0, int copy = 0)
+                                                              int group = 1, int nparts = 0)
 {
-    DevCtrl *ctl = &ds->ctrl[copy];
-    if (mode != PFIN_PCI_FIRST && ctl->dens_active == 0) return;
+    if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
     __shared__ double s_sum[kBlock];
     __shared__ long long s_cnt[kBlock];
     if (phase != FINP_DECIDE) {
@@ -287,14 +256,37 @@ __global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__re
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
     if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
     ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
-    fin_decide_pressure(ctl, mode, s_sum[0], s_cnt[0]);
+    const float res = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // pcisph :136-137, iisph :119-120
+    const int cap = ds->dens_cap;
+    if (mode == PFIN_PCI_FIRST) {
+        ds->dens_avg = res; ds->dens_it = 0; ds->dens_capped = 0; ds->res_diverged = 0;
+        ds->dens_active = cap > 0 ? 1 : 0;                                          // iter_cnt (0) < min_iteration (1)
+    } else if (mode == PFIN_PCI_LOOP) {
+        const int it = ds->dens_it + 1;                                             // :70
+        ds->dens_it = it; ds->dens_avg = res;
+        const int active = (((double)res > 1000 * 0.1 * 0.01 || it < 1) && it < cap) ? 1 : 0;   // :58
+        if (it >= cap) ds->dens_capped = 1;
+        ds->dens_active = active;
+    } else {
+        const int l = ds->dens_it + 1;                                              // iisph :94
+        ds->dens_it = l; ds->dens_avg = res;
+        int active;
+        if (ds->res_have_prev && (double)res - (double)ds->res_prev > 0) {          // :97-99 "Iteration trend to divergence"
+            ds->res_diverged = 1;
+            active = 0;
+        } else {
+            ds->res_prev = res; ds->res_have_prev = 1;                              // :100
+            active = (((double)res > 0.1 * 1000 * 0.01 || l < 1) && l < cap) ? 1 : 0;   // :88-89
+        }
+        if (l >= cap) ds->dens_capped = 1;
+        ds->dens_active = active;
+    }
 }
 
 __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 {
-    DevCtrl *c = &ds->ctrl[0];                                   // a step starts on copy 0
-    c->dens_active = 1; c->dens_it = 0; c->dens_cap = cap; c->dens_capped = 0; c->dens_avg = 0.f;
-    c->res_prev = 0.f; c->res_have_prev = 0; c->res_diverged = 0;
+    ds->dens_active = 1; ds->dens_it = 0; ds->dens_cap = cap; ds->dens_capped = 0; ds->dens_avg = 0.f;
+    ds->res_prev = 0.f; ds->res_have_prev = 0; ds->res_diverged = 0;
 }
 
 // ======================================================================================
