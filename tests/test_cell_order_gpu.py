@@ -301,7 +301,8 @@ def test_list_build_variants_with_a_rigid_body(waves, monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("scene,steps", [("wcsph_small", 80), ("dfsph_small", 40), ("dfsph_tiny_clamp", 60), ("breaking_dam_30k_dfsph", 8)])
+@pytest.mark.parametrize("scene,steps", [("wcsph_small", 80), ("dfsph_small", 40), ("dfsph_tiny_clamp", 60), ("breaking_dam_30k_dfsph", 8),
+                                         ("dfsph_tiny_wall_pcisph", 40), ("dfsph_tiny_wall_iisph", 200), ("pcisph_config_backup", 30)])
 def test_quad_sweeps_are_invisible(scene, steps, monkeypatch):
     """Small unstaged scenes run their sweeps with four lanes per particle (lane q evaluates entry q of every group of four, the four
     terms are added in list order through DPP quad broadcasts; block partials per 64 particles, added in groups of four by the
