@@ -1,0 +1,29 @@
+"""Two handles of one library that differ in ONE environment knob advance the same scene in lock step and must stay bit-identical:
+    tools/soak_env.py scene steps every KNOB valueA valueB        (e.g. SPH_QUAD 1 0, SPH_BNL_SPLIT 9 0, SPH_STAGE 1 0)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfd_taichi_amd import _native as nat, scenes
+scene, steps, every, knob = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+cfg = scenes.get(scene)
+sims = []
+for v in sys.argv[5:7]:
+    os.environ[knob] = v
+    sims.append(nat.Simulation(nat.config_from_dict(cfg)))
+del os.environ[knob]
+wc = cfg["solver"]["name"] in ("wcsph", "pbf")
+t0 = time.time()
+done = 0
+while done < steps:
+    n = min(every, steps - done)
+    if wc:
+        for s in sims:
+            s.step(n)
+    else:
+        for _ in range(n):
+            a, b = sims[0].step(1), sims[1].step(1)
+            assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt, a.max_nbrs, a.lost) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt, b.max_nbrs, b.lost), done
+    done += n
+    for f in (nat.F_POS, nat.F_VEL, nat.F_RHO):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f), equal_nan=True), (done, f)
+    print("%s %s=%s|%s step %d: identical (%.0f s)" % (scene, knob, sys.argv[5], sys.argv[6], done, time.time() - t0), flush=True)
