@@ -586,7 +586,6 @@ constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_
 inline int sweep_mode(const SphHandle *h)
 {
     if (h->staged) return SWEEP_STAGED;
-    if (h->cfg.solver == SPH_SOLVER_PBF) return SWEEP_PLAIN;      // its sweeps have no quad form
     return (!h->slab && h->opt_quad && h->c.n <= h->quad_below) ? SWEEP_QUAD : SWEEP_PLAIN;
 }
 // partials of the block reductions: one per 256 particles, or one per 64 from quad sweeps (k_finalize_mean adds them in groups of four)
@@ -1860,19 +1859,23 @@ int step_pbf_once(SphHandle *h)
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     const Consts &c = h->c;
     const PbfConsts k = pbf_consts(h);
-    const dim3 g = grid_for(c.n), b(kBlock);
+    const bool quad = sweep_mode(h) == SWEEP_QUAD;          // four lanes per particle in all three sweeps (small scenes)
+    const dim3 g = grid_for(c.n), b(kBlock), gq((unsigned)std::max(1, (c.n + 63) / 64));
     hipStream_t s = h->stream;
     {
         ProfScope ps(h, K_B_LAMBDA);                          // compute_all_lambda :32-52
-        hipLaunchKernelGGL(k_pbf_lambda, g, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
+        if (quad) hipLaunchKernelGGL(k_pbf_lambda<true>, gq, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
+        else hipLaunchKernelGGL(k_pbf_lambda<false>, g, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
     }
     {
         ProfScope ps(h, K_B_DELTA);                           // compute_all_delta_pos :55-64, the prediction :26-29, update_all_pos phase 1 :66-84
-        hipLaunchKernelGGL(k_pbf_delta, g, b, 0, s, c, k, h->dt_wcsph, h->P[1 - h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->X[0], h->X[1], h->X[2]);
+        if (quad) hipLaunchKernelGGL(k_pbf_delta<true>, gq, b, 0, s, c, k, h->dt_wcsph, h->P[1 - h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->X[0], h->X[1], h->X[2]);
+        else hipLaunchKernelGGL(k_pbf_delta<false>, g, b, 0, s, c, k, h->dt_wcsph, h->P[1 - h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->X[0], h->X[1], h->X[2]);
     }
     {
         ProfScope ps(h, K_B_XSPH);                            // update_all_pos phases 2-3 :86-98
-        hipLaunchKernelGGL(k_pbf_xsph, g, b, 0, s, c, k, h->P[h->pcur], h->X[1], h->X[2], h->cell_start, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        if (quad) hipLaunchKernelGGL(k_pbf_xsph<true>, gq, b, 0, s, c, k, h->P[h->pcur], h->X[1], h->X[2], h->cell_start, h->P[1 - h->pcur], h->V[1 - h->vcur]);
+        else hipLaunchKernelGGL(k_pbf_xsph<false>, g, b, 0, s, c, k, h->P[h->pcur], h->X[1], h->X[2], h->cell_start, h->P[1 - h->pcur], h->V[1 - h->vcur]);
     }
     h->pcur ^= 1; h->vcur ^= 1;
     HIP_TRY(h, hipGetLastError());

@@ -46,15 +46,17 @@ __device__ __forceinline__ F3 spiky_grad(const Consts &c, const PbfConsts &k, fl
 }
 
 // rho, constrain, constrain_derivative, lambda.  Pout = (pos, lambda) for the gather of k_pbf_delta.
+// QUAD (both list sweeps): four lanes per particle, small scenes (walk_list_quad, sph_kernels.h)
+template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                        const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                        const int *__restrict__ cnt, float *__restrict__ rho_out, float *__restrict__ lambda_out,
                                                        float4 *__restrict__ Pout)
 {
-    SPH_SWEEP_PROLOGUE
-    float rho = 0.001f;                                            // solver_base.py:44
-    float cx = 0.f, cy = 0.f, cz = 0.f, sum = 0.f;
-    for_nbrs_p(nlp, kf, P, [&](const float4 pj) {
+    SPH_SWEEP_PROLOGUE_M(QUAD)
+    float fa[5] = {0.001f, 0.f, 0.f, 0.f, 0.f};                    // rho starts at 0.001, solver_base.py:44
+    float &rho = fa[0], &cx = fa[1], &cy = fa[2], &cz = fa[3], &sum = fa[4];
+    auto pair = [&](const float4 pj) {
         const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const float r = norm3(dx, dy, dz);
         rho += c.m * poly_w(c, k, r);                              // :169-170
@@ -62,9 +64,12 @@ __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, co
         const float gx = g.x / c.rho0, gy = g.y / c.rho0, gz = g.z / c.rho0;
         cx += gx; cy += gy; cz += gz;                              // :116-117
         sum += (gx * gx + gy * gy) + gz * gz;                      // :133-134
-    });
-    float rb = 0.f, bx = 0.f, by = 0.f, bz = 0.f, sb = 0.f;
-    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+    };
+    if (QUAD) for_nbrs_p_quad(nlp, kf, q, fa, P, pair);
+    else for_nbrs_p(nlp, kf, P, pair);
+    float wa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float &rb = wa[0], &bx = wa[1], &by = wa[2], &bz = wa[3], &sb = wa[4];
+    auto wall = [&](const float4 pj) {
         const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const float r = norm3(dx, dy, dz);
         rb += pj.w * poly_w(c, k, r);                              // :173-176
@@ -72,8 +77,10 @@ __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, co
         const float gx = g.x / c.rho0, gy = g.y / c.rho0, gz = g.z / c.rho0;
         bx += gx; by += gy; bz += gz;                              // :120-122
         sb += (gx * gx + gy * gy) + gz * gz;                       // :139-140
-    });
-    if (!live) return;
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, kb, WP, wall);
+    if (!owner) return;
     const float rho_i = c.boundary_handle ? rho + rb * c.rho0 : rho;
     const float con = rmax(rho_i / c.rho0 - 1.0f, 0.0f);          // :127-128
     float dxs = cx, dys = cy, dzs = cz;
@@ -87,16 +94,18 @@ __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, co
 }
 
 // delta_pos, the prediction and phase 1 of update_all_pos.  PL = (pos, lambda); writes Pn = new position, Vn = phase-1 velocity.
+template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_pbf_delta(Consts c, PbfConsts k, float dt, const float4 *__restrict__ PL, const float4 *__restrict__ V,
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                       float4 *__restrict__ dpos_out, float4 *__restrict__ Pn, float4 *__restrict__ Vn)
 {
     const float4 *P = PL;
-    SPH_SWEEP_PROLOGUE
+    SPH_SWEEP_PROLOGUE_M(QUAD)
     const float li = pi.w;
-    float ax = 0.f, ay = 0.f, az = 0.f;
-    for_nbrs_p(nlp, kf, PL, [&](const float4 pj) {
+    float fa[3] = {0.f, 0.f, 0.f};
+    float &ax = fa[0], &ay = fa[1], &az = fa[2];
+    auto pair = [&](const float4 pj) {
         const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const float r = norm3(dx, dy, dz);
         float sc = poly_w(c, k, r) / k.w_corr;                     // :148
@@ -104,9 +113,12 @@ __global__ __launch_bounds__(kBlock) void k_pbf_delta(Consts c, PbfConsts k, flo
         const F3 g = spiky_grad(c, k, dx, dy, dz, r);
         const float f = (li + pj.w) + sc;                          // :153
         ax += f * g.x; ay += f * g.y; az += f * g.z;
-    });
-    float bx = 0.f, by = 0.f, bz = 0.f;
-    for_nbrs_p(nlbp, kb, WP, [&](const float4 pj) {
+    };
+    if (QUAD) for_nbrs_p_quad(nlp, kf, q, fa, PL, pair);
+    else for_nbrs_p(nlp, kf, PL, pair);
+    float wa[3] = {0.f, 0.f, 0.f};
+    float &bx = wa[0], &by = wa[1], &bz = wa[2];
+    auto wall = [&](const float4 pj) {
         const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         const float r = norm3(dx, dy, dz);
         float sc = poly_w(c, k, r) / k.w_corr;
@@ -114,8 +126,10 @@ __global__ __launch_bounds__(kBlock) void k_pbf_delta(Consts c, PbfConsts k, flo
         const F3 g = spiky_grad(c, k, dx, dy, dz, r);
         const float f = li + sc;                                   // :164
         bx += f * g.x; by += f * g.y; bz += f * g.z;
-    });
-    if (!live) return;
+    };
+    if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, kb, WP, wall);
+    if (!owner) return;
     float dp[3];
     if (c.boundary_handle) { dp[0] = (ax + bx) / c.rho0; dp[1] = (ay + by) / c.rho0; dp[2] = (az + bz) / c.rho0; }   // :62
     else { dp[0] = ax / c.rho0; dp[1] = ay / c.rho0; dp[2] = az / c.rho0; }                                          // :64
@@ -141,16 +155,31 @@ __global__ __launch_bounds__(kBlock) void k_pbf_delta(Consts c, PbfConsts k, flo
 
 // phases 2 and 3 of update_all_pos: the 27-cell walk of for_all_neighbor over the cell lists of the step's start (belong_grid of the OLD
 // position), distances and kernel on the NEW positions.  Writes the final state: Pfin = new position, Vfin = vel + c * v.
+// QUAD (small scenes): the four lanes of a quad serve one particle; lane q evaluates candidate j0 + q of every batch of four of a cell and
+// all four add the four terms in candidate order (quad_bcast, sph_kernels.h) -- a candidate that is skipped contributes +0, which leaves
+// the running sums (never -0) unchanged: the same additions in the same order as the one-lane walk.
+template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_pbf_xsph(Consts c, PbfConsts k, const float4 *__restrict__ Pold, const float4 *__restrict__ Pn,
                                                      const float4 *__restrict__ Vn, const int *__restrict__ cell_start,
                                                      float4 *__restrict__ Pfin, float4 *__restrict__ Vfin)
 {
-    const int i = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x;
-    if (i >= c.n) return;
+    const int blk = xcd_block(blockIdx.x, gridDim.x);
+    const int q = QUAD ? (int)(threadIdx.x & 3) : 0;
+    const int i = QUAD ? blk * (kBlock / 4) + (int)(threadIdx.x >> 2) : blk * kBlock + (int)threadIdx.x;
+    if (i >= c.n) return;                                          // (a quad leaves together)
     const float4 po = Pold[i], pi = Pn[i], vi = Vn[i];
     int cx, cy, cz;
     cell_id_of(c, po.x, po.y, po.z, cx, cy, cz);                   // belong_grid, set by update_grid at the step's start
     float ax = 0.f, ay = 0.f, az = 0.f;
+    auto term = [&](int j, float &tx, float &ty, float &tz) {      // (vel_j - vel_i) W, or nothing
+        const float4 pj = Pn[j];
+        const float ex = pi.x - pj.x, ey = pi.y - pj.y, ez = pi.z - pj.z;
+        const float r = norm3(ex, ey, ez);
+        if (r > c.h) return;                                       // :466
+        const float4 vj = Vn[j];
+        const float w = poly_w(c, k, r);                           // pbf_solver.py:98
+        tx = (vj.x - vi.x) * w; ty = (vj.y - vi.y) * w; tz = (vj.z - vi.z) * w;
+    };
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dz = -1; dz <= 1; ++dz) {
@@ -158,17 +187,31 @@ __global__ __launch_bounds__(kBlock) void k_pbf_xsph(Consts c, PbfConsts k, cons
                 if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;          // ParticleSystem.py:453-456
                 const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
                 const int a = cell_start[slot], b = cell_start[slot + 1];
-                for (int j = a; j < b; ++j) {
-                    if (j == i) continue;                          // :461
-                    const float4 pj = Pn[j];
-                    const float ex = pi.x - pj.x, ey = pi.y - pj.y, ez = pi.z - pj.z;
-                    const float r = norm3(ex, ey, ez);
-                    if (r > c.h) continue;                         // :466
-                    const float4 vj = Vn[j];
-                    const float w = poly_w(c, k, r);               // pbf_solver.py:98
-                    ax += (vj.x - vi.x) * w; ay += (vj.y - vi.y) * w; az += (vj.z - vi.z) * w;
+                if (QUAD) {
+                    for (int j0 = a; j0 < b; j0 += 4) {
+                        const int j = j0 + q;
+                        float tx = 0.f, ty = 0.f, tz = 0.f;
+                        if (j < b && j != i) term(j, tx, ty, tz);  // :461
+                        ax += quad_bcast<0>(tx); ax += quad_bcast<1>(tx); ax += quad_bcast<2>(tx); ax += quad_bcast<3>(tx);
+                        ay += quad_bcast<0>(ty); ay += quad_bcast<1>(ty); ay += quad_bcast<2>(ty); ay += quad_bcast<3>(ty);
+                        az += quad_bcast<0>(tz); az += quad_bcast<1>(tz); az += quad_bcast<2>(tz); az += quad_bcast<3>(tz);
+                    }
+                } else {
+                    for (int j = a; j < b; ++j) {
+                        if (j == i) continue;                      // :461
+                        float tx = 0.f, ty = 0.f, tz = 0.f;
+                        const float4 pj = Pn[j];
+                        const float ex = pi.x - pj.x, ey = pi.y - pj.y, ez = pi.z - pj.z;
+                        const float r = norm3(ex, ey, ez);
+                        if (r > c.h) continue;                     // :466
+                        const float4 vj = Vn[j];
+                        const float w = poly_w(c, k, r);           // pbf_solver.py:98
+                        tx = (vj.x - vi.x) * w; ty = (vj.y - vi.y) * w; tz = (vj.z - vi.z) * w;
+                        ax += tx; ay += ty; az += tz;
+                    }
                 }
             }
+    if (q != 0) return;
     Pfin[i] = make_float4(pi.x, pi.y, pi.z, 0.f);
     Vfin[i] = make_float4(vi.x + k.c_visc * ax, vi.y + k.c_visc * ay, vi.z + k.c_visc * az, 0.f);   // :92 / :94
 }
