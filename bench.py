@@ -85,7 +85,8 @@ CPU_BASELINE_SECONDS = 10.0     # bounded sample of the same workload on the hos
 
 def cpu_baseline(scene_name, solver_kind, state=None, first_step=1):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload.  `state` = (pos, vel, warm_start_k, dt) of the
-    device at the start of the timed window (dfsph / wcsph without a body): the oracle continues from there, so the sample is the
+    device at the start of the timed window (dfsph / wcsph / pbf without a body: pos, vel and for dfsph warm_start_k, dt are the whole
+    state a step reads): the oracle continues from there, so the sample is the
     same phase of the collapse `value` is measured in; otherwise whole steps from rest."""
     from cfd_taichi_amd import scenes
     from oracle import oracle as orc
@@ -288,14 +289,31 @@ def choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, to
     return "sync", "no faster discipline reproduced it"
 
 
+def self_launch(nproc):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) as a CHILD
+    process -- nothing in this process has touched torch or HIP yet, and it never execs -- pass its output through and return its
+    exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher in the environment: starting %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
@@ -401,7 +419,7 @@ def main():
         return elapsed, early, stats, state
 
     run = make_run(sim, solver_kind, rigid_active)
-    want_state = rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid and solver_kind in ("dfsph", "wcsph")
+    want_state = rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf")
     elapsed, early, stats, state = timed_window(sim, run, want_state)
 
     value = n_total * args.steps / elapsed / 1e6
@@ -411,7 +429,8 @@ def main():
         "metric": "million particle-steps/sec (%s dam-break)" % solver_kind.upper(),
         "value": value, "unit": "Mparticle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # one series: N = 2, 4, 8 shard a FIXED workload (dfsph_10m); the N = 1 line carries that workload's one-GPU point as strong_scaling_base
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
                    "grid": list(sim.grid), "preroll_steps": args.preroll,
                    "timed_steps": "%d-%d" % (args.preroll + args.warmup + 1, args.preroll + args.warmup + args.steps),
@@ -463,12 +482,16 @@ def main():
                            "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload; NOT measured in this run)" if traffic else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
-                           "binding_limit": "valu issue (84-89 % of the issue floor of the kernel's instruction mix, see valu)",
-                           "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s); the kernel's binding limit is f32 "
-                                   "instruction issue, not HBM: ~50 VALU instructions per pair (the reference's correctly rounded sqrt and divides) for < 1 "
-                                   "algorithmic byte -- see roofline.valu and DESIGN.md section 6c"}
+                           "binding_limit": None,
+                           "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s)"}
         mix = load_valu_mix(dom) if committed else None
         if mix:
+            # stated only where an instruction mix of THIS kernel on THIS workload is committed, and computed from this run's launch time
+            out["roofline"]["binding_limit"] = "valu issue: this run's launches take %.2fx the issue floor of the kernel's own instruction mix (see valu)" % (
+                avg_s * 1e6 / mix["issue_floor_us"])
+            out["roofline"]["note"] += ("; the kernel's binding limit is f32 instruction issue, not HBM: %.1f M wave-instructions per launch (the reference's "
+                                        "correctly rounded sqrt and divides per pair) for %.0f MB of algorithmic bytes -- see roofline.valu and DESIGN.md section 4"
+                                        % (mix["wave_insts_per_launch"] / 1e6, algo / 1e6))
             # second opinion on the same kernel: its VALU instruction mix (committed SQ_INSTS_VALU_* pass) priced with the per-class issue
             # costs tools/valu_issue.hip measured on this chip -- the time the SIMDs need just to ISSUE the kernel's instructions
             g_inst = mix["wave_insts_per_launch"] / avg_s / 1e9

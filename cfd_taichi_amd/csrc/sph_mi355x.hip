@@ -707,7 +707,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->WP, (size_t)h->Nb + 64))) return rc;
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
-    const size_t nblocks_cap = n <= (size_t)h->quad_below ? (n + 63) / 64 : (n + kBlock - 1) / kBlock;    // quad sweeps: one partial per 64 particles
+    const size_t nblocks_cap = (n + 63) / 64;    // quad sweeps: one partial per 64 particles; others one per 256 (a few KB either way, and no second predicate to keep in step with sweep_mode)
     if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
@@ -1500,11 +1500,28 @@ int check_overflow(SphHandle *h)
     return SPH_OK;
 }
 
+PbfConsts pbf_consts(const SphHandle *h);
+
 int stage_density(SphHandle *h)
 {
     const Consts &c = h->c;
     hipStream_t s = h->stream;
     (void)kBlock;
+    if (h->cfg.solver == SPH_SOLVER_PBF) {
+        // compute_all_rho on a pbf solver: pbf_solver.py:166-174 overrides the two rho callbacks with the poly6 kernel.  The rho part of
+        // the lambda sweep alone: pbf_lambda (aux), the (pos, lambda) scratch and the P / V roles stay as they are.
+        ProfScope ps(h, K_B_LAMBDA);
+        const PbfConsts k = pbf_consts(h);
+        if (sweep_mode(h) == SWEEP_QUAD)
+            hipLaunchKernelGGL(k_pbf_lambda<true>, dim3((unsigned)std::max(1, (c.n + 63) / 64)), dim3(kBlock), 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb,
+                               h->cnt, h->rho, h->aux, h->P[1 - h->pcur], 1);
+        else
+            hipLaunchKernelGGL(k_pbf_lambda<false>, grid_for(c.n), dim3(kBlock), 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux,
+                               h->P[1 - h->pcur], 1);
+        HIP_TRY(h, hipGetLastError());
+        h->density_valid = true;
+        return SPH_OK;
+    }
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     if (dfsph) {
         // DFSPH buffer roles for the whole step: P[pcur] = sorted positions (never written until the integrator),
@@ -1864,8 +1881,8 @@ int step_pbf_once(SphHandle *h)
     hipStream_t s = h->stream;
     {
         ProfScope ps(h, K_B_LAMBDA);                          // compute_all_lambda :32-52
-        if (quad) hipLaunchKernelGGL(k_pbf_lambda<true>, gq, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
-        else hipLaunchKernelGGL(k_pbf_lambda<false>, g, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur]);
+        if (quad) hipLaunchKernelGGL(k_pbf_lambda<true>, gq, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur], 0);
+        else hipLaunchKernelGGL(k_pbf_lambda<false>, g, b, 0, s, c, k, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->P[1 - h->pcur], 0);
     }
     {
         ProfScope ps(h, K_B_DELTA);                           // compute_all_delta_pos :55-64, the prediction :26-29, update_all_pos phase 1 :66-84

@@ -51,7 +51,7 @@ template <bool QUAD>
 __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                        const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                        const int *__restrict__ cnt, float *__restrict__ rho_out, float *__restrict__ lambda_out,
-                                                       float4 *__restrict__ Pout)
+                                                       float4 *__restrict__ Pout, int rho_only)
 {
     SPH_SWEEP_PROLOGUE_M(QUAD)
     float fa[5] = {0.001f, 0.f, 0.f, 0.f, 0.f};                    // rho starts at 0.001, solver_base.py:44
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_pbf_lambda(Consts c, PbfConsts k, co
     else for_nbrs_p(nlbp, kb, WP, wall);
     if (!owner) return;
     const float rho_i = c.boundary_handle ? rho + rb * c.rho0 : rho;
+    if (rho_only) { rho_out[i] = rho_i; return; }                  // compute_all_rho alone (solver_base.py:36-50 with :166-174): pbf_lambda keeps its values
     const float con = rmax(rho_i / c.rho0 - 1.0f, 0.0f);          // :127-128
     float dxs = cx, dys = cy, dzs = cz;
     if (c.boundary_handle) { dxs = cx + bx; dys = cy + by; dzs = cz + bz; }   // :112

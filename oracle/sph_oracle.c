@@ -947,8 +947,10 @@ void orc_rigid_step(Orc *o)
  * shared sweeps                                                       solver_base.py:41-217
  * ------------------------------------------------------------------------------------- */
 /* compute_all_rho                                                     solver_base.py:41-72 */
+static void pbf_compute_rho(Orc *o);
 void orc_compute_rho(Orc *o)
 {
+    if (o->cfg.solver == 4) { pbf_compute_rho(o); return; }   /* pbf_solver.py:166-174 overrides compute_rho / compute_rho_from_boundary with the poly6 kernel */
     PARFOR
     for (int i = 0; i < o->N; ++i) {
         real rho = R(0.001);                                           /* :44 */
@@ -2076,6 +2078,23 @@ static inline void spiky_kernel_derivative(real rx, real ry, real rz, real h, re
         real a = -(R(45.0) * pow2(R(1.0) - q));
         real den = R(ORC_PI) * pow2(pow2(h)) * r_norm;
         out[0] = a * rx / den; out[1] = a * ry / den; out[2] = a * rz / den;
+    }
+}
+
+/* compute_all_rho (solver_base.py:36-50) with pbf_solver's callbacks (pbf_solver.py:166-174): rho only, nothing else touched */
+static void pbf_compute_rho(Orc *o)
+{
+    PARFOR
+    for (int i = 0; i < o->N; ++i) {
+        real rho = R(0.001);                                                            /* solver_base.py:44 */
+        FOR_FLUID_NEIGHBORS(o, i, { if (jm_ == 0) rho += o->m * poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h); });   /* :169-170 */
+        if (o->cfg.boundary_handle) {
+            real rb = R(0.0);
+            FOR_WALL_NEIGHBORS_OF_FLUID(o, i, { rb += o->bvol[j] * poly_kernel(r_sqrt((xij * xij + yij * yij) + zij * zij), o->h); });   /* :173-176 */
+            o->rho[i] = rho + rb * o->rho0;
+        } else {
+            o->rho[i] = rho;
+        }
     }
 }
 

@@ -1,0 +1,138 @@
+"""GPU suite: oracle parity at BASELINE.json's full sizes IN THE PHASE bench.py TIMES.
+
+The earlier full-size suites meet the oracle only in the first steps from rest (n_dens = 2, regular cells, no spray).  bench.py's timed
+window starts after 55 steps (50 pre-roll + 5 warm-up: ragged cells, n_dens ~ 12, every staged / nl16 / kr_split path busy).  Here the
+device runs INTO that phase, hands its state to a fresh oracle -- positions, velocities and, for dfsph, warm_start_k and delta_time are
+everything a step reads (test_parity_gpu.py::test_oracle_continues_from_device_state proves the hand-over complete on small scenes) --
+and both continue: bit-equal state, iteration counts and residuals.
+
+  config 3  dfsph_1m         55 device steps, then 3 steps on both        (oracle: ~4 s per step on 16 cores)
+  config 2  wcsph_250k       150 device steps, then 5 steps on both
+  config 5  dfsph_rigid_2m   2 coupled steps from rest on both at full size (2 006 400 fluid + 123 k rigid samples)
+  config 4  dfsph_10m        50 device steps, then 1 step on both           (oracle: about a minute)
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from cfd_taichi_amd import _native as nat
+from cfd_taichi_amd import mesh, scenes
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        scale = max(float(np.abs(b).max()), 1e-30)
+        raise AssertionError("%s differs at %d of %d entries, rel err %.3e, first %s: %r vs %r" % (
+            what, len(bad), a.size, float(np.abs(a.astype(np.float64) - b).max()) / scale, bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+
+
+def hand_over_dfsph(sim, cfg):
+    o = orc.Oracle(cfg, num_threads=cores())
+    o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
+    o.set(orc.F_WARM_K, sim.download(nat.F_WARM_K)); o.set_dt(sim.scalar(nat.S_DELTA_TIME))
+    return o
+
+
+def dfsph_steps_equal(sim, o, nsteps, label):
+    counts = []
+    for s in range(nsteps):
+        t0 = time.time()
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        so = o.last_stats
+        assert (st.n_div, st.n_dens, st.n_div_evals, st.div_first_err, st.div_err, st.dens_err, st.dt) == (
+            so.n_div, so.n_dens, so.n_div_evals, so.div_first_err, so.div_err, so.dens_err, so.dt), (label, s)
+        assert st.lost == 0 and st.capped == 0
+        counts.append((st.n_div, st.n_dens))
+        print("%s: step +%d (n_div, n_dens) = (%d, %d), %.1f s" % (label, s + 1, st.n_div, st.n_dens, time.time() - t0), flush=True)
+    same(sim.download(nat.F_RHO_ADV), o.get(orc.F_RHO_ADV), label + ": rho_adv")
+    same(sim.download(nat.F_WARM_K), o.get(orc.F_WARM_K), label + ": warm_start_k")
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), label + ": pos")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), label + ": vel")
+    return counts
+
+
+def test_dfsph_1m_steps_56_to_58_bit_exact():
+    """Config 3 where the bench times it: the handle of bench.py's default line (Morton order, LDS staging, 16-bit lists, k/rho array),
+    55 steps in, then steps 56-58 against the oracle."""
+    cfg = scenes.get("dfsph_1m")
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    pre = [sim.step_dfsph(1) for _ in range(55)]
+    assert pre[-1].n_dens >= 8, "expected the collapsing phase (n_dens ~ 12), got n_dens = %d" % pre[-1].n_dens
+    o = hand_over_dfsph(sim, cfg)
+    counts = dfsph_steps_equal(sim, o, 3, "dfsph_1m @55")
+    assert min(c[1] for c in counts) >= 8
+    sim.close(); o.close()
+
+
+def test_wcsph_250k_steps_151_to_155_bit_exact():
+    """Config 2 after 150 steps (the column has started to collapse, cells are ragged), then 5 steps on both."""
+    cfg = scenes.get("wcsph_250k")
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    sim.step_wcsph(150)
+    o = orc.Oracle(cfg, num_threads=cores())
+    o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
+    sim.step_wcsph(5)
+    o.step_wcsph(5)
+    same(sim.download(nat.F_RHO), o.get(orc.F_RHO), "wcsph_250k @150: rho")
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "wcsph_250k @150: pos")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "wcsph_250k @150: vel")
+    sim.close(); o.close()
+
+
+def test_dfsph_rigid_2m_two_coupled_steps_bit_exact():
+    """Config 5 at full size against the oracle (round 2 had properties only): 2 coupled steps from rest -- fluid state, force on the
+    body, body state, iteration counts, residuals."""
+    cfg = scenes.get("dfsph_rigid_2m")
+    rg = mesh.rigid_from_config(cfg)
+    sim = nat.Simulation(nat.config_from_dict(cfg), rigid=rg)
+    o = orc.Oracle(cfg, num_threads=cores(), rigid=rg)
+    assert (sim.n_fluid, sim.n_wall, sim.n_rigid) == (o.N, o.Nb, o.Nr) and sim.n_fluid == 2006400
+    for s in range(2):
+        t0 = time.time()
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        so = o.last_stats
+        assert (st.n_div, st.n_dens, st.n_div_evals, st.div_first_err, st.div_err, st.dens_err, st.dt) == (
+            so.n_div, so.n_dens, so.n_div_evals, so.div_first_err, so.div_err, so.dens_err, so.dt), s
+        same(sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), o.get(orc.F_RIGID_FORCE), "force on the body, step %d" % s)
+        sim.rigid_step()
+        o.rigid_step()
+        a, b = sim.rigid_scalars(), o.rigid_scalars()
+        for k in ("centroid", "omega", "vel", "inertia_inv"):
+            same(np.float32(a[k]), np.float32(b[k]), "%s after step %d" % (k, s))
+        print("dfsph_rigid_2m: step %d (n_div, n_dens) = (%d, %d), %.1f s" % (s + 1, st.n_div, st.n_dens, time.time() - t0), flush=True)
+    same(sim.download(nat.F_RHO_ADV), o.get(orc.F_RHO_ADV), "rho_adv")
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "fluid positions")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "fluid velocities")
+    same(sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_POS), "rigid positions")
+    sim.close(); o.close()
+
+
+def test_dfsph_10m_step_51_bit_exact():
+    """Config 4 on one GPU, 50 steps in, then ONE step on both (the oracle needs about a minute for it on 16 cores)."""
+    cfg = scenes.get("dfsph_10m")
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    pre = [sim.step_dfsph(1) for _ in range(50)]
+    assert all(s.lost == 0 and s.capped == 0 for s in pre)
+    o = hand_over_dfsph(sim, cfg)
+    dfsph_steps_equal(sim, o, 1, "dfsph_10m @50")
+    sim.close(); o.close()

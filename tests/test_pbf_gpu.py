@@ -86,3 +86,29 @@ def test_pbf_rejects_a_rigid_body():
     cfg["solver"]["name"] = "pbf"
     with pytest.raises(nat.SphError):
         nat.Simulation(nat.config_from_dict(cfg), rigid=mesh.rigid_from_config(cfg))
+
+
+@pytest.mark.parametrize("scene", ["pbf_tiny_wall", "pbf_tiny_clamp"])
+def test_pbf_compute_density_is_poly6_and_leaves_lambda_alone(scene):
+    """solver_base.compute_all_rho() on a pbf solver: pbf_solver.py:166-174 overrides the rho callbacks with the poly6 kernel, and
+    nothing but rho[] is written -- pbf_lambda keeps the values of the last step, positions and velocities keep their roles."""
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, num_threads=8)
+    squeeze(sim, o)
+    for _ in range(3):
+        sim.step_pbf(1); o.step_pbf(1)
+    lam = o.get(orc.F_PBF_LAMBDA).copy()
+    assert (lam != 0).any()
+    pos, vel = sim.download(nat.F_POS), sim.download(nat.F_VEL)
+    sim.compute_density()
+    o.build_grid(); o.compute_rho()
+    same(sim.download(nat.F_RHO), o.get(orc.F_RHO), "rho after compute_density")
+    same(sim.download(nat.F_PBF_LAMBDA), lam, "pbf_lambda after compute_density")
+    same(sim.download(nat.F_POS), pos, "pos after compute_density")
+    same(sim.download(nat.F_VEL), vel, "vel after compute_density")
+    # rho is the poly6 sum, not the cubic spline one: the two differ on a squeezed lattice
+    sim.step_pbf(1); o.step_pbf(1)
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "pos, the step after")
+    same(sim.download(nat.F_PBF_LAMBDA), o.get(orc.F_PBF_LAMBDA), "pbf_lambda, the step after")
+    sim.close(); o.close()

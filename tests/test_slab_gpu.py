@@ -131,7 +131,8 @@ def test_random_scenes_on_slabs(tmp_path, seed):
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], (cfg, {k: r[k] for k in ("pos_rel_err", "slabs")})
 
 
-def test_bench_multi_rank_path_end_to_end(tmp_path):
+@pytest.mark.parametrize("launcher", [True, False])
+def test_bench_multi_rank_path_end_to_end(tmp_path, launcher):
     """The command the driver runs for N > 1, end to end on this box: `torch.distributed.run ... bench.py --gpus 2` on its default
     workload (config 4, dfsph_10m, sharded into x-slabs), both ranks on GPU 0 over gloo (SPH_BENCH_REHEARSAL), with the transport
     self-check (SPH_BENCH_VERIFY: the synchronous discipline's bytes against the faster ones; native RCCL cannot open two ranks on one
@@ -139,6 +140,11 @@ def test_bench_multi_rank_path_end_to_end(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_BENCH_REHEARSAL="1", SPH_BENCH_VERIFY="1", SPH_BENCH_PREROLL="2")
+    if not launcher:
+        # the launcher-less form: `python bench.py --gpus 2 ...` starts torch.distributed.run itself, as a child process
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SPH_BENCH_VERIFY"):
+            env.pop(k, None)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -1,3 +1,4 @@
+#!/bin/bash
 # A/B of the cell storage order (Morton curve with tiles of 4/8/16 cells per axis, the reference's linear stride): whole steps, interleaved in one process.
 set -e
 L=cfd_taichi_amd/libsph_mi355x.so

@@ -1,3 +1,4 @@
+#!/bin/bash
 # PMC passes over tools/placement_pmc.py: which counter separates a fast handle from a slow one?
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,3 +1,4 @@
+#!/bin/bash
 set -o pipefail
 run() { # scene world steps rebalance
   timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $2 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) tests/slab_worker.py --scene $1 --steps $3 --backend gloo --rebalance $4 --out gpurun_out/soak_$1_$2.json > gpurun_out/soak_$1_$2.log 2>&1

@@ -1,3 +1,4 @@
+#!/bin/bash
 # slabs with the large-scene path forced (Morton curve, LDS staging): small leaky scenes for thousands of steps, and the 1 M scene
 set -o pipefail
 run() { # scene world steps rebalance
