@@ -12,6 +12,7 @@ import numpy as np
 from . import build as _build
 
 SPH_OK = 0
+ARITH_EXACT, ARITH_RELAXED = 0, 1      # SphConfig.arith
 SPH_E_INVALID, SPH_E_HIP, SPH_E_NO_DEVICE, SPH_E_OVERFLOW, SPH_E_STATE = -1, -2, -3, -4, -5
 SOLVER_WCSPH, SOLVER_DFSPH, SOLVER_PCISPH, SOLVER_IISPH, SOLVER_PBF = 0, 1, 2, 3, 4
 SOLVER_IDS = {"wcsph": SOLVER_WCSPH, "dfsph": SOLVER_DFSPH, "pcisph": SOLVER_PCISPH, "iisph": SOLVER_IISPH, "pbf": SOLVER_PBF}
@@ -25,13 +26,14 @@ F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50
 S_RIGID_CENTROID, S_RIGID_OMEGA, S_RIGID_VEL, S_RIGID_MASS, S_RIGID_INERTIA_INV = 10, 13, 16, 19, 20
 S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME, S_GRAPH_LAUNCHES = range(6)
 S_PCISPH_DELTA, S_PCISPH_BETA, S_PCISPH_MAX_INDEX, S_PCISPH_MAX_COUNT = range(6, 10)
+S_ARITH_RELAXED = 30
 VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ,
                  F_PBF_DELTA_POS}
 
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
-    "sph_get_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
+    "sph_get_scalar", "sph_set_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
     "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
@@ -58,7 +60,8 @@ class SphConfig(ctypes.Structure):
         ("slab_count", ctypes.c_int32),
         ("slab_capacity", ctypes.c_int32),
         ("slab_rebalance_every", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 5),
+        ("arith", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -143,7 +146,7 @@ def library_path():
 CORE_EXPORTS = [
     "sph_create", "sph_create_rigid", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_rigid_step",
-    "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_get_scalar", "sph_synchronize",
+    "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_get_scalar", "sph_set_scalar", "sph_synchronize",
 ]
 
 
@@ -168,6 +171,7 @@ def _bind_core(lib):
     for name in ("sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_synchronize"):
         getattr(lib, name).argtypes = [vp]
     lib.sph_get_scalar.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double)]
+    lib.sph_set_scalar.argtypes = [vp, ci, ctypes.c_double]
     return lib
 
 
@@ -229,7 +233,7 @@ class SphError(RuntimeError):
 
 
 def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0,
-                     slab_rank=0, slab_count=0, slab_capacity=0, slab_rebalance_every=0):
+                     slab_rank=0, slab_count=0, slab_capacity=0, slab_rebalance_every=0, arith=0):
     """Flatten a reference-style config dict (config/*.json schema) into SphConfig."""
     scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
     name = solver_name or sol["name"]
@@ -252,6 +256,7 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.max_density_iters = int(max_density_iters)
     c.slab_rank, c.slab_count, c.slab_capacity = int(slab_rank), int(slab_count), int(slab_capacity)
     c.slab_rebalance_every = int(slab_rebalance_every)
+    c.arith = int(arith)
     return c
 
 
@@ -408,6 +413,10 @@ class Simulation:
         out = ctypes.c_double()
         self._check(self._lib.sph_get_scalar(self._h, which, ctypes.byref(out)))
         return out.value
+
+    def set_dt(self, value):
+        """solver.delta_time[None] = value"""
+        self._check(self._lib.sph_set_scalar(self._h, S_DELTA_TIME, float(value)))
 
     def synchronize(self):
         self._check(self._lib.sph_synchronize(self._h))

@@ -54,6 +54,11 @@ struct Consts {
     int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
     int nl16;             // fluid lists of staged workgroups hold 16-bit local indices, eight per 16-byte group (NlWriter)
     int kr_split;         // dfsph sweeps hand k / rho to the next sweep in a 4-byte array instead of a (pos, k / rho) float4 (k_correct)
+    // tolerance-grade sweeps (SphConfig.arith = SPH_ARITH_RELAXED, sph_relaxed_kernels.h): m grad W = g x_ij with
+    // g = rx_k1a q + rx_k1b (q <= 0.5) or rx_k2 (1 - q)^2 / r (q > 0.5); constants folded in f64
+    float rx_k1a, rx_k1b; // 3 m kg6 / h^2, -2 m kg6 / h^2
+    float rx_k2;          // -m kg6 / h
+    float rx_rho0_m;      // rho0 / m (wall sums carry m like the fluid sums)
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

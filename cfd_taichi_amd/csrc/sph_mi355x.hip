@@ -22,6 +22,7 @@
 #include "sph_pressure_kernels.h"
 #include "sph_rigid_kernels.h"
 #include "sph_pbf_kernels.h"
+#include "sph_relaxed_kernels.h"
 
 using namespace sph;
 
@@ -89,6 +90,7 @@ struct SphHandle {
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
+    bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
     int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
@@ -341,6 +343,13 @@ int build_scene(SphHandle *h, HostScene &sc)
     const float kg = 48.0f / (pi_f * h3);          // :95
     c.kg6 = kg * 6.0f;
     c.neg_kg6 = -kg * 6.0f;
+    {   // the relaxed sweeps' constants (sph_relaxed_kernels.h), folded in f64
+        const double kg6d = 48.0 / (3.141592653589793 * support * support * support) * 6.0;
+        c.rx_k1a = (float)(3.0 * m * kg6d / (support * support));
+        c.rx_k1b = (float)(-2.0 * m * kg6d / (support * support));
+        c.rx_k2 = (float)(-m * kg6d / support);
+        c.rx_rho0_m = (float)(1000.0 / m);
+    }
     {   // r2_cut: largest f32 t with sqrtf(t) <= h, so that (sqrt(r2) > h) == (r2 > r2_cut) exactly
         float t = c.h * c.h;
         while (sqrtf(t) > c.h) t = nextafterf(t, 0.0f);
@@ -1596,10 +1605,18 @@ int check_overflow_all(SphHandle *h)
 }
 
 // ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
+// the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab; }
+
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
+    if (use_relaxed(h)) {
+        hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
+                           h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+        return;
+    }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
@@ -1610,6 +1627,11 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
+    if (use_relaxed(h)) {
+        hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt,
+                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho);
+        return;
+    }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho);
@@ -1619,6 +1641,11 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
+    if (use_relaxed(h)) {
+        hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
+                           h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+        return;
+    }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
@@ -2265,6 +2292,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
     { const char *e = getenv("SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
@@ -2679,7 +2707,14 @@ int sph_compute_density(SphHandle *h)
     if (!h) return SPH_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     int rc;
-    if (!h->nl_valid && (rc = sph_build_neighbors(h))) return rc;
+    if (!h->nl_valid) {
+        // pbf_lambda is a per-particle field of the solver that compute_all_rho does not touch; it lives in device order (aux), which the
+        // re-sort below changes: carry it through in API order
+        const bool keep = h->cfg.solver == SPH_SOLVER_PBF && h->simulate_cnt > 0;
+        if (keep) hipLaunchKernelGGL(k_unsort_scalar, grid_for(h->N), dim3(kBlock), 0, h->stream, h->N, h->aux, h->id[h->icur], h->staging);
+        if ((rc = sph_build_neighbors(h))) return rc;
+        if (keep) hipLaunchKernelGGL(k_sort_in_scalar, grid_for(h->N), dim3(kBlock), 0, h->stream, h->N, h->staging, h->id[h->icur], h->aux);
+    }
     if (h->density_valid) return SPH_OK;
     if ((rc = stage_density(h))) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2815,6 +2850,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PCISPH_MAX_INDEX: *out = (double)h->pci_max_index; return SPH_OK;
     case SPH_S_PCISPH_MAX_COUNT: *out = (double)h->pci_max_count; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
+    case SPH_S_ARITH_RELAXED: *out = use_relaxed(h) ? 1.0 : 0.0; return SPH_OK;      // kr_split is settled by the first list build
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {
             if (which < SPH_S_RIGID_OMEGA) *out = (double)h->centroid[which - SPH_S_RIGID_CENTROID];
@@ -2826,6 +2862,27 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
         }
         return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
     }
+}
+
+int sph_set_scalar(SphHandle *h, int which, double value)
+{
+    if (!h) return SPH_E_INVALID;
+    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: only SPH_S_DELTA_TIME > 0 can be written");
+    if (h->slab) return fail(h, SPH_E_STATE, "sph_set_scalar is not available on slab handles");
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->dt_wcsph = (float)value;                                      // the launch argument of the fixed-dt solvers
+    h->cfg.delta_time = value;
+    if (h->cfg.solver == SPH_SOLVER_DFSPH) {                         // dfsph keeps delta_time, delta_time_2 on the device (dfsph_solver.py:20, :118)
+        int rc = read_scalars(h);
+        if (rc) return rc;
+        h->ds_host->dt = (float)value;
+        h->ds_host->dt2 = h->ds_host->dt * h->ds_host->dt;
+        HIP_TRY(h, hipMemcpyAsync(h->ds, h->ds_host, offsetof(DevScalars, ps_dt), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    for (int k = 0; k < 8; ++k)                                      // captured wcsph step pairs carry the old delta_time as a launch argument
+        if (h->wcsph_graph[k]) { (void)hipGraphExecDestroy(h->wcsph_graph[k]); h->wcsph_graph[k] = nullptr; }
+    return SPH_OK;
 }
 
 int sph_synchronize(SphHandle *h)

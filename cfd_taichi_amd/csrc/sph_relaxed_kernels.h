@@ -1,0 +1,176 @@
+// sph_relaxed_kernels.h -- tolerance-grade forms of the four DFSPH sweeps that dominate a step (SphConfig.arith = SPH_ARITH_RELAXED).
+//
+// The EXACT sweeps (sph_kernels.h) evaluate the reference's f32 expressions operation for operation -- a correctly rounded square root
+// and three correctly rounded divisions per pair, no contraction, sums in the single-thread order of the reference's cell lists -- so
+// that they can be tested bit for bit against oracle/.  north_star's bar is 1e-5 relative on positions / velocities after N steps, and
+// the reference itself does not keep an order (its cell lists are appended from a parallel loop, ParticleSystem.py:388-397; its runtime's
+// default is fast-math).  These kernels use that latitude for arithmetic only -- same pairs, same lists, same staging plan, same
+// loop control, same buffers -- with
+//     grad W_ij = s(q) x_ij / (h r)  =  g x_ij,    one scalar per pair:
+//         q <= 0.5:  g = (kg6 / h^2) (3 q - 2)            no reciprocal at all
+//         q >  0.5:  g = (-kg6 / h) (1 - q)^2 / r         1 / r = v_rsq_f32(r^2), r = r^2 / r
+//     FMAs throughout, the particle mass folded into the constants, no 1e-5 gate on q (solver_base.py:97 zeroes the gradient of a pair
+//     closer than 1e-6 m, whose term here is g * x_ij with a finite g and x_ij -> 0; r^2 is floored so that coincident particles give 0).
+// ~23 VALU instructions per pair instead of ~62 (tools/pair_body_relaxed.hip: 45 -> 19 us and 39 -> 17 us per sweep-equivalent).
+// What is NOT relaxed: list membership (decided by the exact k_build_nl), the `ks > 1e-5` gate of the divergence correction
+// (dfsph_solver.py:367: semantics, not rounding), the per-particle epilogues, the f64 block partials and the device-side loop decisions.
+//
+// Used by handles with kr_split lists (single GPU, staged, 16-bit lists, no rigid body: the large scenes BASELINE.json quotes); every
+// other handle runs the exact sweeps whatever `arith` says -- relaxed is a permission, not an obligation.
+// tests/test_relaxed_gpu.py holds these against the oracle at 1e-5 after N steps and inside the reference's own nondeterminism
+// envelope (tools/envelope.py).
+#pragma once
+#include "sph_kernels.h"
+
+namespace sph {
+
+// m * s / (h r) for the difference vector (dx, dy, dz) of a list member
+__device__ __forceinline__ float rx_g(const Consts &c, float dx, float dy, float dz)
+{
+    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, 1e-30f)));
+    const float ri = __builtin_amdgcn_rsqf(r2);
+    const float q = (r2 * ri) * c.rh;
+    const float g1 = __builtin_fmaf(q, c.rx_k1a, c.rx_k1b);
+    const float t = 1.0f - q;
+    const float g2 = ((t * t) * ri) * c.rx_k2;
+    return q <= 0.5f ? g1 : g2;
+}
+
+// positions and k / rho of the workgroup's staged set, unscaled (the relaxed counterpart of stage_operand_ps_scaled)
+__device__ __forceinline__ bool stage_operand_ps(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
+                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return false;
+    if (nst == 0) return true;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+        float4 a[kStageBatch]; float sc[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; sc[u] = S[x.j[t][u]]; }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) s_A[base + u * kBlock] = make_float4(a[u].x, a[u].y, a[u].z, sc[u]);
+    }
+    __syncthreads();
+    return true;
+}
+
+// D3 / D6 (k_residual)                                           dfsph_solver.py:252-300, 124-176
+template <bool DENS>
+__global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
+                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
+                                                        const float *__restrict__ rho, const float *__restrict__ alpha,
+                                                        const DevScalars *__restrict__ ds, float *__restrict__ out,
+                                                        double *__restrict__ psum, int *__restrict__ pcnt, int gate,
+                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
+{
+    extern __shared__ float4 s_operand[];
+    if (gate_closed(ds, gate)) return;
+    SPH_SWEEP_PROLOGUE_M(false)
+    float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
+    const bool staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
+    const float4 vi = V[ii];
+    float acc = 0.f;
+    const bool skip = !DENS && kf < 20;                                           // :258-261
+    auto pair = [&](const float4 pj, const float4 vj, const uint32_t) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = rx_g(c, dx, dy, dz);
+        const float dot = __builtin_fmaf(vi.z - vj.z, dz, __builtin_fmaf(vi.y - vj.y, dy, (vi.x - vj.x) * dx));
+        acc = __builtin_fmaf(g, dot, acc);                                        // :287 / :162
+    };
+    if (staged) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair);
+    else for_fluid_nbrs<false, true>(nlp, skip ? 0 : kf, P, V, RigidView(), pair);
+    float accb = 0.f;                                                             // sum_B V_b m (v_i . grad W); m divided out below
+    auto wall = [&](const float4 pj) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = rx_g(c, dx, dy, dz);
+        const float dot = __builtin_fmaf(vi.z, dz, __builtin_fmaf(vi.y, dy, vi.x * dx));
+        accb = __builtin_fmaf(pj.w * g, dot, accb);                               // :300 / :176
+    };
+    for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);
+    float val = 0.f;
+    int flag = 0;
+    if (live) {
+        const float rho_i = rho[i];
+        const float sum = c.boundary_handle ? __builtin_fmaf(accb, c.rx_rho0_m, acc) : acc;
+        float kr;
+        if (DENS) {
+            const float dt = ds->dt;
+            val = rmax(__builtin_fmaf(dt, sum, rho_i), c.rho0);                   // :135 / :137
+            flag = !(val == c.rho0);                                              // :139
+            kr = ((val - c.rho0) * alpha[i] / ds->dt2) / rho_i;                   // :199,203
+        } else {
+            val = skip ? 0.f : rmax(sum, 0.0f);                                   // :267 / :269
+            flag = val > 0.f;                                                     // :275
+            kr = (val * alpha[i] / ds->dt) / rho_i;                               // :363,367
+        }
+        out[i] = val;
+        krho[i] = kr;
+    }
+    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+}
+
+// D2 / D4 / D7 (k_correct)                                       dfsph_solver.py:314-355, 302-312 + 357-391, 178-219
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
+                                                       const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
+                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
+                                                       const float *__restrict__ alpha, const float *__restrict__ src,
+                                                       float *__restrict__ warm, const DevScalars *__restrict__ ds,
+                                                       const float4 *Vin, float4 *Vout, int gate,
+                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho)
+{
+    extern __shared__ float4 s_operand[];
+    if (gate_closed(ds, gate)) return;
+    SPH_SWEEP_PROLOGUE_M(false)
+    const bool staged = stage_operand_ps(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+    const float dt = ds->dt;
+    const float rho_i = rho[ii];
+    float k_i;
+    if (MODE == CORR_WARM) k_i = warm[ii] / dt;                                   // :333
+    else if (MODE == CORR_DIV) k_i = src[ii] * alpha[ii] / dt;                    // :363
+    else k_i = (src[ii] - c.rho0) * alpha[ii] / ds->dt2;                          // :199
+    const float kr_i = k_i / rho_i;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    auto pair = [&](const float4 pj, const float4, const uint32_t) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float g = rx_g(c, dx, dy, dz);
+        float ks = kr_i + pj.w;
+        if (MODE == CORR_DIV) ks = ks > 1e-5f ? ks : 0.f;                         // :367
+        const float s = ks * g;                                                   // :337 / :369 / :203 (m inside g)
+        ax = __builtin_fmaf(s, dx, ax); ay = __builtin_fmaf(s, dy, ay); az = __builtin_fmaf(s, dz, az);
+    };
+    struct OperandPS { float4 a; float s; };
+    if (staged) for_staged16_nbrs(nlp, kf, s_operand, pair);
+    else        // a workgroup whose set did not fit: two global gathers per neighbour
+        walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) { o.a = P[j]; o.s = krho[j]; },
+                             [&](const OperandPS &o, uint32_t j) { pair(make_float4(o.a.x, o.a.y, o.a.z, o.s), make_float4(0.f, 0.f, 0.f, 0.f), j); });
+    float bx = 0.f, by = 0.f, bz = 0.f;                                           // sum_B V_b m grad W; k_i / rho_i and 1 / m applied below
+    auto wall = [&](const float4 pj) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const float s = pj.w * rx_g(c, dx, dy, dz);                               // :354 / :390 / :219
+        bx = __builtin_fmaf(s, dx, bx); by = __builtin_fmaf(s, dy, by); bz = __builtin_fmaf(s, dz, bz);
+    };
+    for_nbrs_p(nlbp, kb, WP, wall);
+    if (!live) return;
+    float4 v = Vin[i];
+    if (c.boundary_handle) {
+        const float kb_i = kr_i * c.rx_rho0_m;                                    // :322 / :310 / :187,191
+        v.x -= __builtin_fmaf(bx, kb_i, ax) * dt;
+        v.y -= __builtin_fmaf(by, kb_i, ay) * dt;
+        v.z -= __builtin_fmaf(bz, kb_i, az) * dt;
+    } else {
+        v.x -= ax * dt; v.y -= ay * dt; v.z -= az * dt;                           // :324 / :312 / :189
+    }
+    v.w = rho_i;
+    Vout[i] = v;
+    if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
+    if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
+}
+
+}  // namespace sph

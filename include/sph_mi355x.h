@@ -62,8 +62,15 @@ typedef struct SphConfig {
     int32_t slab_count;         /* number of slabs (world size), 0 or 1 for single GPU */
     int32_t slab_capacity;      /* particles (owned + ghosts) a slab handle can hold; 0 = default (1.75 N / slab_count + 256k) */
     int32_t slab_rebalance_every; /* re-cut the slabs from the current particle distribution every M steps; 0 = static cuts */
-    int32_t reserved[5];
+    int32_t arith;              /* SPH_ARITH_EXACT (0, default): every f32 operation of the reference in its order, bit-equal to oracle/;
+                                   SPH_ARITH_RELAXED (1): the dominant dfsph sweeps of large single-GPU scenes may use approximate
+                                   reciprocal square roots and FMA contraction (north_star's 1e-5 bar; see csrc/sph_relaxed_kernels.h).
+                                   A permission: handles the relaxed sweeps do not cover run the exact ones. */
+    int32_t reserved[4];
 } SphConfig;
+
+#define SPH_ARITH_EXACT 0
+#define SPH_ARITH_RELAXED 1
 
 typedef struct SphSizes {
     int32_t n_fluid;            /* ps.particle_num                 ParticleSystem.py:85 */
@@ -155,6 +162,7 @@ typedef struct SphRigid {
 #define SPH_S_RIGID_VEL 16        /* +0,1,2: rigid_particles.vel (uniform over the body) */
 #define SPH_S_RIGID_MASS 19       /* rigid_solver.mass[None] */
 #define SPH_S_RIGID_INERTIA_INV 20 /* +0..8: ps.rigid_inertia_tensor_inv[None], row major */
+#define SPH_S_ARITH_RELAXED 30    /* diagnostics: 1 if this handle's dfsph sweeps run the tolerance-grade kernels (SphConfig.arith asked AND the handle qualifies) */
 
 typedef struct SphHandle SphHandle;
 
@@ -198,6 +206,10 @@ int sph_compute_density(SphHandle *h);
 int sph_compute_alpha(SphHandle *h);
 
 int sph_get_scalar(SphHandle *h, int which, double *out);
+/* `solver.delta_time[None] = value` (the reference's 0-d field is writable, main.py:111; dfsph re-derives it every step from the CFL
+ * rule, dfsph_solver.py:112-119, so a written value lasts one step there).  which = SPH_S_DELTA_TIME only; with it a device state
+ * (pos, vel, warm_start_k, delta_time) can be moved into another handle, or into the oracle, completely. */
+int sph_set_scalar(SphHandle *h, int which, double value);
 int sph_synchronize(SphHandle *h);
 
 /* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).

@@ -112,6 +112,8 @@ def _lib(precision):
         lib.orc_step_pcisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
         lib.orc_step_iisph.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(OrcStepStats)]
         lib.orc_step_pbf.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.orc_set_schedule.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_int]
+        lib.orc_set_schedule.restype = None
         lib.orc_cubic_kernel.restype = ctypes.c_float
         lib.orc_cubic_kernel.argtypes = [ctypes.c_float, ctypes.c_float]
         lib.orc_cubic_kernel_derivative.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
@@ -218,6 +220,10 @@ class Oracle:
         g = lambda k: self._lib.orc_get_scalar(self._h, k)   # noqa: E731
         return {"centroid": [g(10), g(11), g(12)], "omega": [g(13), g(14), g(15)], "vel": [g(16), g(17), g(18)], "mass": g(19),
                 "inertia_inv": [g(20 + k) for k in range(9)]}
+
+    def set_schedule(self, seed, chunk=1):
+        """seed != 0: one seeded LEGAL execution of the reference's races (cell-list append order, f32 atomic means); 0 = canonical."""
+        self._lib.orc_set_schedule(self._h, int(seed), int(chunk))
 
     def build_grid(self):
         self._lib.orc_build_grid(self._h)

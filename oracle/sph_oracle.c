@@ -93,7 +93,65 @@ struct Orc {
     /* rigid_solver state, rigid_solver.py:6-31 */
     real rs_dt, rs_omega[3], rs_attitude[3], rs_mass;
     int rs_run_once, rs_cnt;
+    /* "legal schedule" mode (orc_set_schedule; 0 = the canonical single-thread order every parity test uses).  The reference appends to the
+     * cell lists from a parallel loop (ParticleSystem.py:388-397: the order inside a cell -- and with it the order of every neighbour sum --
+     * is whatever the thread schedule produced) and reduces the residual means with f32 atomics (dfsph_solver.py:139-141, 275-279).  With a
+     * seed the restatement draws ONE legal execution: every cell's entries in a seeded random order, redrawn at every rebuild, and the means
+     * accumulated in f32: `sched_chunk` consecutive particles summed in order (a thread-local partial), the partials added to the total in a
+     * seeded random order (chunk = 1: one atomic per particle).  tools/envelope.py measures how far such executions drift apart. */
+    unsigned long long sched_seed;
+    int sched_chunk;
+    unsigned long long sched_epoch;
 };
+
+static inline unsigned long long sched_mix(unsigned long long x)      /* splitmix64 */
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+static void sched_shuffle(int *a, int n, unsigned long long key)
+{
+    for (int k = n - 1; k > 0; --k) {
+        key = sched_mix(key);
+        int r = (int)(key % (unsigned long long)(k + 1));
+        int t = a[k]; a[k] = a[r]; a[r] = t;
+    }
+}
+/* sum of v[i] over the particles with take[i] != 0, the way the reference's `avg += x` inside a parallel loop may come out */
+static double sched_sum(Orc *o, const real *v, const unsigned char *take, int n)
+{
+    if (o->sched_seed == 0) {                 /* canonical: ascending, f64 (see the header: a documented deviation) */
+        double s = 0;
+        for (int i = 0; i < n; ++i) if (take[i]) s += (double)v[i];
+        return s;
+    }
+    const int chunk = o->sched_chunk > 0 ? o->sched_chunk : 1;
+    const int nch = (n + chunk - 1) / chunk;
+    float *part = (float *)malloc(sizeof(float) * (size_t)(nch > 0 ? nch : 1));
+    int *ord = (int *)malloc(sizeof(int) * (size_t)(nch > 0 ? nch : 1));
+    for (int c = 0; c < nch; ++c) {
+        float ps = 0.0f;
+        const int hi = (c + 1) * chunk < n ? (c + 1) * chunk : n;
+        for (int i = c * chunk; i < hi; ++i) if (take[i]) ps += (float)v[i];
+        part[c] = ps; ord[c] = c;
+    }
+    sched_shuffle(ord, nch, sched_mix(o->sched_seed ^ (0xA5A5ULL + (o->sched_epoch++ << 20))));
+    float tot = 0.0f;
+    for (int c = 0; c < nch; ++c) tot += part[ord[c]];
+    free(part); free(ord);
+    return (double)tot;
+}
+void orc_set_schedule(Orc *o, unsigned long long seed, int chunk)
+{
+    o->sched_seed = seed;
+    o->sched_chunk = chunk;
+    o->sched_epoch = 0;
+    if (seed != 0 && o->Nb > 0)      /* the wall lists are filled once, by the same kind of parallel loop (ParticleSystem.py:372-381) */
+        for (int c = 0; c < o->C; ++c)
+            sched_shuffle(o->bcitems + o->bcstart[c], o->bcstart[c + 1] - o->bcstart[c], sched_mix(seed ^ 0xB0B0ULL ^ ((unsigned long long)c << 24)));
+}
 
 /* ---------------------------------------------------------------------------------------
  * SPH kernels                                                         solver_base.py:74-103
@@ -206,12 +264,31 @@ static long build_lists(const Orc *o, int n, const real *pos, int *cell3, int *c
     free(ids);
     return lost;
 }
+/* legal-schedule mode: every cell's segment [lo, hi) of a list in a seeded random order */
+static void sched_shuffle_cells(Orc *o, int *citems, const int *cstart, int first_is_fluid_only)
+{
+    const unsigned long long ep = o->sched_epoch++;
+    _Pragma("omp parallel for schedule(static) num_threads(o->nt)")
+    for (int c = 0; c < o->C; ++c) {
+        int lo = cstart[c], hi = cstart[c + 1];
+        if (hi - lo < 2) continue;
+        if (first_is_fluid_only) {            /* fluid entries were appended by one kernel, rigid entries by the next: two segments */
+            int mid = lo;
+            while (mid < hi && citems[mid] < o->N) ++mid;
+            sched_shuffle(citems + lo, mid - lo, sched_mix(o->sched_seed ^ (ep << 32) ^ (unsigned long long)c));
+            sched_shuffle(citems + mid, hi - mid, sched_mix(o->sched_seed ^ (ep << 32) ^ (unsigned long long)c ^ 0x7777ULL));
+        } else {
+            sched_shuffle(citems + lo, hi - lo, sched_mix(o->sched_seed ^ (ep << 32) ^ (unsigned long long)c));
+        }
+    }
+}
 
 /* reset_grid + update_grid                               ParticleSystem.py:368-397 */
 void orc_build_grid(Orc *o)
 {
     if (!(o->exist_rigid && o->active_rigid)) {
         o->lost = build_lists(o, o->N, o->pos, o->cell3, o->cstart, o->citems);
+        if (o->sched_seed) sched_shuffle_cells(o, o->citems, o->cstart, 0);
         return;
     }
     /* fluid entries first (ascending), then rigid entries (ascending, global index i + N + Nb): the order of
@@ -239,6 +316,7 @@ void orc_build_grid(Orc *o)
     free(fill);
     free(ids);
     o->lost = lost;
+    if (o->sched_seed) sched_shuffle_cells(o, o->citems, o->cstart, 1);
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -1280,11 +1358,13 @@ static real derivative_iter_all_rho(Orc *o)
             o->rho_der[i] = r_max(rd, R(0.0));                                      /* :269 */
         }
     }
-    double avg = 0; long cnt = 0;                                                   /* :275-280 */
-    for (int i = 0; i < o->N; ++i)
-        if (o->rho_der[i] > 0) { cnt += 1; avg += (double)o->rho_der[i]; }
+    long cnt = 0;                                                                   /* :275-280 */
+    unsigned char *take = (unsigned char *)malloc((size_t)(o->N > 0 ? o->N : 1));
+    for (int i = 0; i < o->N; ++i) { take[i] = o->rho_der[i] > 0; cnt += take[i]; }
+    const double avg = sched_sum(o, o->rho_der, take, o->N);
+    free(take);
     real ret = 0;
-    if (cnt > 0) ret = R(avg / (double)cnt);
+    if (cnt > 0) ret = o->sched_seed ? (real)((float)avg / (float)cnt) : R(avg / (double)cnt);
     return ret;
 }
 
@@ -1440,11 +1520,13 @@ static real compute_all_rho_adv(Orc *o)
             o->rho_adv[i] = r_max(o->rho[i] + o->dt * delta, o->rho0);              /* :137 */
         }
     }
-    double rho_avg = 0; long cnt = 0;                                               /* :139-141 */
-    for (int i = 0; i < o->N; ++i)
-        if (!(o->rho_adv[i] == o->rho0)) { rho_avg += (double)o->rho_adv[i]; cnt += 1; }
+    long cnt = 0;                                                                   /* :139-141 */
+    unsigned char *take = (unsigned char *)malloc((size_t)(o->N > 0 ? o->N : 1));
+    for (int i = 0; i < o->N; ++i) { take[i] = !(o->rho_adv[i] == o->rho0); cnt += take[i]; }
+    const double rho_avg = sched_sum(o, o->rho_adv, take, o->N);
+    free(take);
     real ret = R(1000.0);
-    if (cnt > 0) ret = R(rho_avg / (double)cnt);                                    /* :148-149 */
+    if (cnt > 0) ret = o->sched_seed ? (real)((float)rho_avg / (float)cnt) : R(rho_avg / (double)cnt);   /* :148-149 */
     return ret;
 }
 

@@ -98,6 +98,11 @@ int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last);
 /* pcisph_solver.step / iisph_solver.step: last->n_dens = pressure iterations, last->dens_err = the printed residual */
 int orc_step_pcisph(Orc *o, int nsteps, OrcStepStats *last);
 int orc_step_iisph(Orc *o, int nsteps, OrcStepStats *last);
+/* "Legal schedule" mode: seed != 0 draws one of the executions the reference's racy cell-list append (ParticleSystem.py:388-397) and f32
+ * atomic means (dfsph_solver.py:139-141, 275-279) allow; chunk = particles per thread-local partial of a mean (1 = one atomic per particle).
+ * seed = 0 (default) is the canonical order of every parity test.  tools/envelope.py. */
+void orc_set_schedule(Orc *o, unsigned long long seed, int chunk);
+
 /* pbf_solver.step (pbf_solver.py:176-187) under the schedule stated in sph_oracle.c */
 int orc_step_pbf(Orc *o, int nsteps);
 

@@ -201,6 +201,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_SUPPORT_RADIUS: *out = orc_get_scalar(h->o, 3); return SPH_OK;
     case SPH_S_PS_DELTA_TIME: *out = orc_get_scalar(h->o, 9); return SPH_OK;
     case SPH_S_GRAPH_LAUNCHES: *out = 0.0; return SPH_OK;
+    case SPH_S_ARITH_RELAXED: *out = 0.0; return SPH_OK;          /* the restatement has one arithmetic */
     case SPH_S_PCISPH_DELTA: *out = orc_get_scalar(h->o, 5); return SPH_OK;
     case SPH_S_PCISPH_BETA: *out = orc_get_scalar(h->o, 6); return SPH_OK;
     case SPH_S_PCISPH_MAX_INDEX: *out = orc_get_scalar(h->o, 7); return SPH_OK;
@@ -209,6 +210,14 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
         if (h->has_rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) { *out = orc_get_scalar(h->o, which); return SPH_OK; }
         return fail(h, SPH_E_INVALID, "unknown scalar");
     }
+}
+
+int sph_set_scalar(SphHandle *h, int which, double value)
+{
+    if (!h) return SPH_E_INVALID;
+    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: only SPH_S_DELTA_TIME > 0 can be written");
+    orc_set_scalar(h->o, 0, value);
+    return SPH_OK;
 }
 
 int sph_synchronize(SphHandle *h) { return h ? SPH_OK : SPH_E_INVALID; }

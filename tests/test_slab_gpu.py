@@ -152,7 +152,7 @@ def test_bench_multi_rank_path_end_to_end(tmp_path, launcher):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong" and d["unit"] == "Mparticle-steps/s"
     assert d["config"]["workload"] == "dfsph_10m" and d["config"]["particles"] == 10000000 and d["config"]["preroll_steps"] == 2
-    assert "2 x-slabs" in d["config"]["parallelism"] and "discipline" in d["config"]["parallelism"]
+    assert "2 x-slabs" in d["config"]["parallelism"] and ("discipline" in d["config"]["parallelism"]) == launcher      # the self-check runs under SPH_BENCH_VERIFY
     slab0 = d["config"]["rank0_slab"]
     assert 0 < slab0["owned"] < 10000000 and slab0["ghosts"] > 50000 and slab0["x_lo"] == 0
     assert d["value"] > 0 and abs(d["value"] - 10.0 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]

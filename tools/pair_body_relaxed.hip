@@ -1,0 +1,166 @@
+// pair_body_relaxed.hip -- what does a TOLERANCE-grade pair body cost on gfx950?  
+// The residual sweep's per-neighbour arithmetic with its LDS operand reads and nothing else (the harness of tools/pair_body.hip), in
+//   exact     the product's bit-exact body: correctly rounded sqrt, three Newton divisions sharing a reciprocal, no contraction (~62 instr)
+//   rsq       v_rsq_f32 of the squared distance, FMAs, grad W as ONE scalar g = s / (h r) times the difference vector:
+//               q <= 0.5:  g = (kg6 / h^2) (3 q - 2)                 (no reciprocal at all)
+//               q >  0.5:  g = (-kg6 / h) (1 - q)^2 / r
+//             no 1e-5 gate (the term of a coincident pair is g * 0 = 0 with r^2 floored at a tiny constant), tails masked as today
+//   rsq_pad   the same without any tail masks, four bodies in one basic block: the list's tail is padded with the particle itself
+//             (d = 0, dv = 0: the term is exactly 0)
+//   rsq_pad8  eight per iteration
+// and the correction sweep's body (k_correct: a += m (k_i/rho_i + k_j/rho_j) grad W) likewise.  Prints the equivalent microseconds of one
+// sweep over dfsph_1m and the largest relative deviation of a lane's sum from the exact body's.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -I cfd_taichi_amd/csrc tools/pair_body_relaxed.hip -o gpurun_out/pair_body_relaxed
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "sph_device.h"
+using namespace sph;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+constexpr int kCap = 1664;
+
+struct RxK { float rh_s, k1a, k1b, k2, tiny; };   // rh * 2^-32; 3 m kg6 / h^2, -2 m kg6 / h^2; -m kg6 / h * 2^32 (rinv carries 2^-32); r^2 floor
+__device__ __forceinline__ float rx_g(const RxK &k, float dx, float dy, float dz)     // m * s / (h r), positions carry 2^32
+{
+    const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, k.tiny)));
+    const float ri = __builtin_amdgcn_rsqf(r2);
+    const float q = (r2 * ri) * k.rh_s;
+    const float g1 = __builtin_fmaf(q, k.k1a, k.k1b);
+    const float t = 1.0f - q;
+    const float g2 = ((t * t) * ri) * k.k2;
+    return q <= 0.5f ? g1 : g2;
+}
+
+enum { EXACT = 0, RSQ = 1, RSQ_PAD = 2, RSQ_PAD8 = 3 };
+template <int KIND, bool CORRECT>
+__global__ __launch_bounds__(256) void k_body(Consts c, RxK k, float *out, int groups, const uint32_t *idx)
+{
+    extern __shared__ float4 s_A[];
+    float2 *s_B = reinterpret_cast<float2 *>(s_A + kCap);
+    for (int e = threadIdx.x; e < kCap; e += 256) {
+        const float f = (float)(e % 97) * 0.0011f;
+        s_A[e] = make_float4((1.0f + f) * 0x1p32f, (2.0f - f * 0.6f) * 0x1p32f, (0.5f + 0.5f * f) * 0x1p32f, 0.1f * f);
+        s_B[e] = make_float2(0.3f - f, 0.2f + f);
+    }
+    __syncthreads();
+    const float sx_i = 1.03f * 0x1p32f, sy_i = 1.98f * 0x1p32f, sz_i = 0.52f * 0x1p32f;
+    const float4 vi = make_float4(0.1f, -0.2f, 0.3f, 0.f);
+    const float kr_i = 0.013f;
+    float acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    const int cnt = (KIND >= RSQ_PAD) ? groups * 4 : groups * 4 - (threadIdx.x & 3);          // ragged like a real list unless padded
+    uint32_t j0 = idx[threadIdx.x];
+    auto eval = [&](const float4 pa, const float2 pb) {
+        const float dx = sx_i - pa.x, dy = sy_i - pa.y, dz = sz_i - pa.z;
+        if (KIND == EXACT) {
+            const float r = norm3_scaled(dx, dy, dz);
+            const F3 g = grad_w_scaled(c, dx, dy, dz, r);
+            if (CORRECT) { const float s = c.m * (kr_i + pa.w); ax += s * g.x; ay += s * g.y; az += s * g.z; }
+            else acc += c.m * dot3(vi.x - pa.w, vi.y - pb.x, vi.z - pb.y, g.x, g.y, g.z);
+        } else {
+            const float g = rx_g(k, dx, dy, dz);
+            if (CORRECT) {
+                const float s = (kr_i + pa.w) * g;
+                ax = __builtin_fmaf(s, dx, ax); ay = __builtin_fmaf(s, dy, ay); az = __builtin_fmaf(s, dz, az);
+            } else {
+                const float dot = __builtin_fmaf(vi.z - pb.y, dz, __builtin_fmaf(vi.y - pb.x, dy, (vi.x - pa.w) * dx));
+                acc = __builtin_fmaf(g, dot, acc);
+            }
+        }
+    };
+    constexpr int STEP = KIND == RSQ_PAD8 ? 8 : 4;
+    for (int kk = 0; kk < cnt; kk += STEP) {
+        uint32_t j[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) { j0 = (j0 * 5u + 7u) % kCap; j[u] = j0; }
+        float4 a[STEP]; float2 b[STEP];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u) { a[u] = s_A[j[u]]; if (!CORRECT) b[u] = s_B[j[u]]; else b[u] = make_float2(0.f, 0.f); }
+        if (KIND >= RSQ_PAD) {
+#pragma unroll
+            for (int u = 0; u < STEP; ++u) eval(a[u], b[u]);
+        } else {
+            eval(a[0], b[0]);
+            if (kk + 1 < cnt) eval(a[1], b[1]);
+            if (kk + 2 < cnt) eval(a[2], b[2]);
+            if (kk + 3 < cnt) eval(a[3], b[3]);
+        }
+    }
+    // positions carry 2^32: the correction's sums of s * d carry it too
+    out[blockIdx.x * 256 + threadIdx.x] = CORRECT ? ((KIND == EXACT ? 1.0f : 0x1p-32f) * (ax + 2.0f * ay + 3.0f * az)) : acc;
+}
+
+template <int KIND, bool CORRECT>
+double run(const Consts &c, const RxK &k, int cus, float *dout, const uint32_t *didx, int groups)
+{
+    const size_t lds = (size_t)kCap * 24;       // 39 KiB: four workgroups per CU, as in the sweep
+    const int grid = cus * 4 * 4;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_body<KIND, CORRECT>), dim3(grid), dim3(256), lds, 0, c, k, dout, groups, didx);
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int rep = 0; rep < 7; ++rep) {
+        CHECK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_body<KIND, CORRECT>), dim3(grid), dim3(256), lds, 0, c, k, dout, groups, didx);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double pairs = (double)grid * 256.0 * (KIND >= RSQ_PAD ? groups * 4 : groups * 4 - 1.5);
+    return pairs / (best * 1e-3);
+}
+
+int main(int argc, char **argv)
+{
+    const double target = argc > 1 ? atof(argv[1]) : 31.1e6;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    Consts c = {};
+    c.h = 0.1f; c.m = 0.125f; c.rho0 = 1000.f;
+    const float pi_f = (float)3.141592653589793, h3 = c.h * (c.h * c.h);
+    c.kw = 8.0f / (pi_f * h3); c.rh = 1.0f / c.h; c.rh_s = c.rh * 0x1p-32f; c.h_s = c.h * 0x1p32f;
+    const float kg = 48.0f / (pi_f * h3);
+    c.kg6 = kg * 6.0f; c.neg_kg6 = -kg * 6.0f;
+    const double kg6 = 48.0 / (3.141592653589793 * 1e-3) * 6.0, h = 0.1;
+    RxK k;
+    k.rh_s = c.rh_s;
+    k.tiny = 1e-30f * 0x1p64f;
+    float *dout; uint32_t *didx;
+    const int nout = cus * 16 * 256;
+    CHECK(hipMalloc((void **)&dout, (size_t)nout * 4));
+    CHECK(hipMalloc((void **)&didx, 256 * 4));
+    uint32_t hidx[256];
+    for (int t = 0; t < 256; ++t) hidx[t] = (uint32_t)((t * 2654435761u) % kCap);
+    CHECK(hipMemcpy(didx, hidx, sizeof(hidx), hipMemcpyHostToDevice));
+    const int groups = 250;
+    std::vector<float> ref(nout), got(nout);
+    const char *names[4] = {"exact", "rsq", "rsq_pad", "rsq_pad8"};
+    printf("{\"pairs_per_sweep\": %.3g, \"results\": {\n", target);
+    for (int corr = 0; corr < 2; ++corr) {
+        // the residual folds m into the scalar; the correction multiplies by m (k_i/rho_i + k_j/rho_j) anyway: fold m there too
+        k.k1a = (float)(3.0 * 0.125 * kg6 / (h * h)); k.k1b = (float)(-2.0 * 0.125 * kg6 / (h * h)); k.k2 = (float)(-0.125 * kg6 / h) * 0x1p32f;
+        for (int kind = 0; kind < 4; ++kind) {
+            double r;
+            if (corr) switch (kind) { case 0: r = run<0, true>(c, k, cus, dout, didx, groups); break; case 1: r = run<1, true>(c, k, cus, dout, didx, groups); break;
+                                      case 2: r = run<2, true>(c, k, cus, dout, didx, groups); break; default: r = run<3, true>(c, k, cus, dout, didx, groups); }
+            else switch (kind) { case 0: r = run<0, false>(c, k, cus, dout, didx, groups); break; case 1: r = run<1, false>(c, k, cus, dout, didx, groups); break;
+                                 case 2: r = run<2, false>(c, k, cus, dout, didx, groups); break; default: r = run<3, false>(c, k, cus, dout, didx, groups); }
+            CHECK(hipMemcpy(got.data(), dout, (size_t)nout * 4, hipMemcpyDeviceToHost));
+            if (kind == 0) ref = got;
+            double worst = 0, scale = 0;
+            if (kind == 1)       // same pair set as the exact run (ragged tails); the padded kinds sum a few more pairs and are compared by time only
+                for (int i = 0; i < nout; ++i) { worst = fmax(worst, fabs((double)got[i] - ref[i])); scale = fmax(scale, fabs((double)ref[i])); }
+            printf("  \"%s %s\": {\"us_per_sweep\": %.1f, \"max_dev_rel_to_max_sum\": %.3e}%s\n", corr ? "correct" : "residual", names[kind], target / r * 1e6,
+                   kind == 1 ? worst / scale : -1.0, (corr == 1 && kind == 3) ? "" : ",");
+        }
+    }
+    printf("}}\n");
+    return 0;
+}
