@@ -64,23 +64,39 @@ def test_relaxed_is_active_and_exact_is_not(scene):
         s.close()
 
 
-@pytest.mark.parametrize("scene", ["dfsph_small", "dfsph_dam_x", "breaking_dam_30k_dfsph"])
+@pytest.mark.parametrize("scene", ["dfsph_small", "dfsph_dam_x", "dfsph_tiny_clamp", "breaking_dam_30k_dfsph"])
 def test_relaxed_first_steps_within_1e5_of_the_oracle(scene):
-    """Three steps from rest: positions within 1e-5 (max norm) of the canonical oracle, iteration counts equal.  (Velocities: the
-    envelope of the reference itself is already 4e-3 at step 5 -- gate flips of single particles -- so they are held to the
-    quantiles: median and 99 % of the particles within 1e-5.)"""
+    """Five steps from rest.  Positions: within 1e-5 (max norm) of the canonical oracle -- or within 2x what seeded legal executions of
+    the oracle differ from it, once THEY exceed 1e-5 (config 1: step 5) -- iteration counts equal.  Velocities cannot be
+    held to a fixed 1e-5 even here -- two legal executions of the REFERENCE are 1e-3 apart (max norm) at step 3 and 4e-4 in the median at
+    step 5 (profiles/r03/envelope_*.json: the rest lattice puts six neighbours at exactly r = h, one ulp flips their membership and
+    with it the `neighbour count < 20` skip) -- so they are held to what the reference does to itself: per-particle median and 99 %
+    quantile within 2x those of a seeded legal execution of the oracle, step by step."""
     cfg, rx = make(scene, nat.ARITH_RELAXED)
-    o = orc.Oracle(cfg, num_threads=8)
-    for s in range(3):
+    canon = orc.Oracle(cfg, num_threads=8)
+    legal = []
+    for seed in (5, 17):
+        o = orc.Oracle(cfg, num_threads=8)
+        o.set_schedule(seed, 1)
+        legal.append(o)
+    for s in range(5):
         st = rx.step_dfsph(1)
-        o.step_dfsph(1, 100)
-        assert (st.n_div, st.n_dens) == (o.last_stats.n_div, o.last_stats.n_dens), s
-        ep = rel(rx.download(nat.F_POS), o.get(orc.F_POS))
-        qv = quantiles(rx.download(nat.F_VEL), o.get(orc.F_VEL))
-        print("%s step %d: pos max-norm %.2e, vel q50 %.2e q99 %.2e" % (scene, s + 1, ep, qv[0], qv[1]))
-        assert ep <= 1e-5, (s, ep)
-        assert qv[0] <= 1e-5 and qv[1] <= 1e-5, (s, qv)
-    rx.close(); o.close()
+        canon.step_dfsph(1, 100)
+        for o in legal:
+            o.step_dfsph(1, 100)
+        assert (st.n_div, st.n_dens) == (canon.last_stats.n_div, canon.last_stats.n_dens), s
+        cp, cv = canon.get(orc.F_POS), canon.get(orc.F_VEL)
+        ep = rel(rx.download(nat.F_POS), cp)
+        qv = quantiles(rx.download(nat.F_VEL), cv)
+        lv = [max(v) for v in zip(*[quantiles(o.get(orc.F_VEL), cv) for o in legal])]
+        print("%s step %d: pos max-norm %.2e (legal schedules %.2e), vel q50 %.2e q99 %.2e (legal %.2e %.2e)" % (
+            scene, s + 1, ep, max(rel(o.get(orc.F_POS), cp) for o in legal), qv[0], qv[1], lv[0], lv[1]))
+        lp = max(rel(o.get(orc.F_POS), cp) for o in legal)
+        assert ep <= max(1e-5, 2.0 * lp), (s, ep, lp)          # 1e-5 while the reference itself keeps it (4-6 steps), then the envelope
+        assert qv[0] <= 2.0 * lv[0] + 1e-6 and qv[1] <= 2.0 * lv[1] + 1e-6, (s, qv, lv)
+    rx.close(); canon.close()
+    for o in legal:
+        o.close()
 
 
 def test_relaxed_stays_inside_the_reference_envelope_100_steps():
@@ -133,7 +149,7 @@ def test_relaxed_dfsph_1m_20_steps_from_the_timed_phase():
         assert rx.scalar(nat.S_ARITH_RELAXED) == 1.0
         assert b.lost == 0 and b.capped == 0
         assert abs(a.n_dens - b.n_dens) <= 2 and abs(a.n_div - b.n_div) <= 2, (s, a.n_div, a.n_dens, b.n_div, b.n_dens)
-        assert abs(a.dens_err - b.dens_err) <= 0.02 and a.dt == b.dt, (s, a.dens_err, b.dens_err)
+        assert abs(a.dens_err - b.dens_err) <= 0.02 and abs(a.dt - b.dt) <= 1e-4 * a.dt, (s, a.dens_err, b.dens_err, a.dt, b.dt)
         diffs.append((a.n_dens, b.n_dens))
     qp = quantiles(rx.download(nat.F_POS), ex.download(nat.F_POS), (0.5, 0.99, 0.999))
     qv = quantiles(rx.download(nat.F_VEL), ex.download(nat.F_VEL), (0.5, 0.99, 0.999))
