@@ -498,12 +498,21 @@ struct NlWriter {
         if (k < kcap) base[(size_t)(k >> 2) * 256 + (k & 3)] = j;
         ++k;
     }
-    __device__ __forceinline__ void flush()
+    // `self`: the particle's own local index.  The slots of a 16-bit list's last group past the count are filled with it: a walk that
+    // does not mask its tail (the relaxed sweeps) then meets the particle itself there -- x_ij = 0, v_ij = 0, a term that is exactly 0
+    __device__ __forceinline__ void flush(uint32_t self = 0u)
     {
         if (half) {
-            if ((k & 1) != 0) stage[((k & 7) >> 1) * kBlock] = pend;       // odd count: the high half is entry 0 of the set, a valid index
-            if ((k & 7) != 0 && k < kcap)
-                *reinterpret_cast<uint4 *>(base + (size_t)(k >> 3) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
+            const int s = k & 7;
+            if (s != 0 && k < kcap) {
+                uint32_t w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t have = 2 * q + 1 < s ? stage[q * kBlock] : (2 * q < s ? (pend | (self << 16)) : (self | (self << 16)));
+                    w[q] = have;
+                }
+                *reinterpret_cast<uint4 *>(base + (size_t)(k >> 3) * 256) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         } else {
             if ((k & 3) != 0 && k < kcap)   // tail slots: stale but valid indices
                 *reinterpret_cast<uint4 *>(base + (size_t)(k >> 2) * 256) = make_uint4(stage[0], stage[kBlock], stage[2 * kBlock], stage[3 * kBlock]);
@@ -623,7 +632,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             const int e = threadIdx.x * (kStageHash / kBlock) + q;
             s_base[e] = before;
             if (staged && own[q] > 0) {
-                stage_runs[(size_t)blk * kStageMaxCells + run_idx] = make_uint2((uint32_t)cell_start[s_key[e]], (uint32_t)before | ((uint32_t)own[q] << 16));
+                const uint32_t first = (uint32_t)cell_start[s_key[e]];
+                stage_runs[(size_t)blk * kStageMaxCells + run_idx] = make_uint2(first, (uint32_t)before | ((uint32_t)own[q] << 16));
                 ++run_idx;
             }
             before += own[q];
@@ -664,6 +674,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     NlWriter wf{&s_stage[threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
     NlWriter ww{nullptr, nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
     int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
+    uint32_t self_local = 0u;         // this particle's own index in the staged set (16-bit lists pad their last group with it)
     const int my_id = RIGID && walker ? id[i] : 0;
     // one cell of a 27-neighbourhood: (first fluid particle, fluid count | staged base << 16, first wall particle, wall count[, slot])
     auto cell_entry = [&](int ccx, int ccy, int ccz, int dx, int o9, uint4 &e, int &eslot) {
@@ -714,6 +725,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                     unsigned m = ~far & (0xffffffffu >> (32 - nb));                              // candidates of this cell only
                     const unsigned self = (unsigned)(i - j0);                                    // :461 (j != i)
                     if (self < (unsigned)CHUNK) m &= ~(1u << self);
+                    if (self < (unsigned)nb) self_local = (uint32_t)(lbase + i);                // (a chunk may reach past its cell: nb, not CHUNK)
                     if (RIGID) nq += __popc(m);
                     while (m) {
                         const int u = __ffs(m) - 1;
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         __builtin_amdgcn_wave_barrier();
     }
     if (walker) {
-        wf.flush();
+        wf.flush(self_local);
         kf = wf.k; kb = ww.k;
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
         cnt[i] = kfc | (kbc << 16);

@@ -91,6 +91,7 @@ struct SphHandle {
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
+    float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
     int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
@@ -703,6 +704,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
+            if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
+                if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
         }
     }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
@@ -1482,6 +1485,10 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_RIGID);
         hipLaunchKernelGGL(k_build_rnl, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->P[h->pcur], h->cell_start, h->rnl, h->rcnt, h->ds);
     }
+    if (h->wall_grad && h->c.kr_split && h->c.boundary_handle && !rigid_coupled(h)) {     // use_relaxed: the wall sums of this step's positions
+        ProfScope ps(h, K_BUILD_NL);
+        hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad);
+    }
     HIP_TRY(h, hipGetLastError());
     if (h->staged && getenv("SPH_STAGE_DEBUG")) {
         std::vector<int> sc((size_t)h->nblocks);
@@ -1606,15 +1613,14 @@ int check_overflow_all(SphHandle *h)
 
 // ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
-inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab; }
-
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
         return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
@@ -1628,7 +1634,7 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     const Consts &c = h->c;
     ProfScope ps(h, kid);
     if (use_relaxed(h)) {
-        hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->WP, h->nl, h->nlb, h->cnt,
+        hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
                            h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho);
         return;
     }
@@ -1643,7 +1649,7 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
         return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,

@@ -1,5 +1,5 @@
 """Interleaved timing of the DFSPH sweeps for SEVERAL builds of the library inside one process (one clock state):
-    tools/tune_libs.py scene advance_steps name=path[:lds[:ENV=value]] ...      (ENV is set while that handle is created)
+    tools/tune_libs.py scene advance_steps name=path[:lds[:ENV=value[,ENV2=value2]]] ...      (the ENVs are set while that handle is created)
 Each build gets its own handle on the same scene advanced by the same steps; rounds alternate between the builds.
 TUNE_COPY_STATE=1: only the first build advances the scene, the others receive its positions / velocities / warm_start_k (for
 removal-experiment builds whose results are wrong on purpose)."""
@@ -18,11 +18,12 @@ for spec in sys.argv[3:]:
     path, lds, env = (rest.split(":") + ["", ""])[:3]
     nat._lib = None
     os.environ["SPH_LIB"] = os.path.abspath(path)
-    if env:
-        os.environ[env.split("=")[0]] = env.split("=")[1]
+    envs = [e.split("=") for e in env.split(",") if e]          # ENV=value[,ENV2=value2 ...]
+    for k, v in envs:
+        os.environ[k] = v
     sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
-    if env:
-        del os.environ[env.split("=")[0]]
+    for k, _ in envs:
+        del os.environ[k]
     if not (os.environ.get("TUNE_COPY_STATE") == "1" and sims):
         sim.step_dfsph(advance)
         state = [sim.download(f) for f in (nat.F_POS, nat.F_VEL, nat.F_WARM_K)]
