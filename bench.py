@@ -20,6 +20,8 @@ Extra objects on the line:
   cpu_baseline  the CPU oracle ("port": restatement of the ti.cpu path, not Taichi) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only): for dfsph / wcsph scenes it continues
                 from the device's state at the start of the timed window (same phase of the collapse as `value`).
+  relaxed       N = 1, dfsph scenes: the same timed steps from the same state with SphConfig.arith = SPH_ARITH_RELAXED (tolerance-grade sweeps),
+                its throughput, dominant kernel and measured deviation from the exact run; the headline `value` is the exact arithmetic.
   strong_scaling_base   N = 1, default workload only: the N > 1 workload (dfsph_10m) on this one GPU with the same flags, so that
                 the strong-scaling series the driver assembles from N = 2, 4, 8 has its one-GPU point.
 """
@@ -63,6 +65,7 @@ def parse():
     ap.add_argument("--preroll", type=int, default=int(os.environ.get("SPH_BENCH_PREROLL", "50")),
                     help="untimed steps before the warm-up (reported as config.preroll_steps and timed as early_phase)")
     ap.add_argument("--no-scaling-base", action="store_true", help="N=1: skip the dfsph_10m one-GPU point")
+    ap.add_argument("--no-relaxed", action="store_true", help="N=1 dfsph: skip the tolerance-grade arithmetic leg (the `relaxed` object)")
     ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
                     help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
     return ap.parse_args()
@@ -141,6 +144,63 @@ def cpu_baseline(scene_name, solver_kind, state=None, first_step=1):
     o.close()
     return {"value": value, "unit": "Mparticle-steps/s", "cores": cores, "kind": "port",
             "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt_s}
+
+
+def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact_stats, fence):
+    """SphConfig.arith = SPH_ARITH_RELAXED on the same workload: a second handle receives the state the exact handle had at the start of
+    its timed window (pos, vel, warm_start_k, delta_time), runs the same --steps steps between two fences, and is compared with where
+    the exact handle ended: per-particle deviation quantiles (relative to max|x| resp. max|v|), iteration counts next to each other.
+    The headline `value` stays the exact arithmetic; this is the measured price list of the 1e-5 tolerance north_star states."""
+    import numpy as np
+    cfg = scenes.get(scene_name)
+    sim = nat.Simulation(nat.config_from_dict(cfg, device=device, arith=nat.ARITH_RELAXED))
+    pos, vel, warm, dt = state
+
+    def restore():
+        sim.upload(nat.F_POS, pos); sim.upload(nat.F_VEL, vel); sim.upload(nat.F_WARM_K, warm); sim.set_dt(dt)
+
+    restore()
+    st = sim.step_dfsph(1)                    # untimed: list build, graph of buffers, clocks
+    active = sim.scalar(nat.S_ARITH_RELAXED) == 1.0
+    restore()
+    fence(sim)
+    t0 = time.perf_counter()
+    stats = [sim.step_dfsph(1) for _ in range(args.steps)]
+    fence(sim)
+    elapsed = time.perf_counter() - t0
+    n = sim.n_fluid
+
+    def quant(a, b):
+        e = np.sqrt(((a.astype(np.float64) - b.astype(np.float64)) ** 2).sum(1)) / max(float(np.abs(b).max()), 1e-30)
+        return {"q50": float(np.quantile(e, 0.5)), "q99": float(np.quantile(e, 0.99)), "max": float(e.max())}
+
+    out = {"arith": "SPH_ARITH_RELAXED (csrc/sph_relaxed_kernels.h: v_rsq_f32, FMAs, grad W as one scalar, per-step wall sums)", "active": active,
+           "value": n * args.steps / elapsed / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
+           "n_dens_mean": sum(x.n_dens for x in stats) / len(stats), "n_div_mean": sum(x.n_div for x in stats) / len(stats),
+           "exact_n_dens_mean": sum(x[1] for x in exact_stats) / len(exact_stats),
+           "deviation_from_exact_after_the_timed_steps": {"pos": quant(sim.download(nat.F_POS), final_exact[0]), "vel": quant(sim.download(nat.F_VEL), final_exact[1]),
+                                                          "norm": "per-particle |a - b| / max|b|; same start state (the exact handle's at the start of its timed window)"},
+           "envelope": "two legal executions of the REFERENCE differ by more than this after as many steps (profiles/r03/envelope_*.json, tools/envelope.py)"}
+    if args.profile_steps > 0:
+        restore()
+        sim.profile_enable(True)
+        for _ in range(args.steps):
+            sim.step_dfsph(1)
+        sim.synchronize()
+        prof = sim.profile()
+        sim.profile_enable(False)
+        tot = sum(ms for ms, _ in prof.values())
+        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0}
+        dom = max(sweeps, key=lambda k: sweeps[k][0])
+        ms, cnt = prof[dom]
+        avg_s = ms / cnt / 1e3
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ALGO_BYTES[dom] * n / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ALGO_BYTES[dom] * n / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": cnt,
+                           "share_of_gpu_time": ms / tot if tot else None}
+        out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps, "share": v[0] / tot}
+                                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    sim.close()
+    return out
 
 
 def load_traffic(kernel, key="hbm_bytes_per_launch"):
@@ -419,8 +479,10 @@ def main():
         return elapsed, early, stats, state
 
     run = make_run(sim, solver_kind, rigid_active)
-    want_state = rank == 0 and world == 1 and not args.no_cpu_baseline and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf")
+    want_relaxed = rank == 0 and world == 1 and solver_kind == "dfsph" and not has_rigid and not args.no_relaxed and os.environ.get("SPH_ARITH") is None
+    want_state = rank == 0 and world == 1 and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf") and (not args.no_cpu_baseline or want_relaxed)
     elapsed, early, stats, state = timed_window(sim, run, want_state)
+    final_exact = (sim.download(nat.F_POS), sim.download(nat.F_VEL)) if want_relaxed else None
 
     value = n_total * args.steps / elapsed / 1e6
     slab_info = sim.slab_info() if world > 1 else None
@@ -518,6 +580,8 @@ def main():
                                       "preroll_steps": args.preroll, "n_dens_mean": sum(x[1] for x in b_stats) / len(b_stats),
                                       "note": "bench.py --gpus N (N > 1) runs this workload sharded into N x-slabs (scaling: strong); this is its N = 1 point"}
         bsim.close()
+    if want_relaxed:
+        out["relaxed"] = relaxed_leg(nat, scenes, scene_name, local_rank, args, state, final_exact, stats, fence)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind, state, args.preroll + args.warmup + 1)
         out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -663,11 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     const unsigned long long rheads = __ballot(rhead);
     const int nruns = __popcll(rheads);
     const int run = __popcll(rheads & ((2ull << lane) - 1ull)) - 1;          // this lane's run (walkers only)
-#ifdef SPH_X_BNL_NOTABLE
-    const bool table = false;                                                  // soak builds: every wave works its cell entries out per lane
-#else
     const bool table = nruns <= kRunCap;                                       // wave-uniform
-#endif
     if (table && rhead) { s_runc[wv][run][0] = cx; s_runc[wv][run][1] = cy; s_runc[wv][run][2] = cz; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1363,7 +1359,6 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
     if (nst < 0) return false;
     if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
-#ifndef SPH_X_NOSTAGE
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
@@ -1379,7 +1374,6 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
                 s_B[e] = make_float2(b[u].y, b[u].z);
             }
     }
-#endif
     __syncthreads();
     return true;
 }
@@ -1387,19 +1381,10 @@ template <bool RIGID, bool SCALED = false, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                     const float2 *__restrict__ s_B, const RigidView &rv, Body body)
 {
-#ifdef SPH_X_SYNIDX
-    uint32_t jsyn = threadIdx.x * 5u;
-#else
     NlAhead ahead(base);
-#endif
     for (int kk = 0; kk < cnt; kk += 4) {
-#ifdef SPH_X_SYNIDX
-        const uint32_t j[4] = {(jsyn + 3u) % 1024u, (jsyn + 11u) % 1024u, (jsyn + 17u) % 1024u, (jsyn + 29u) % 1024u};
-        jsyn = jsyn * 3u + 1u;
-#else
         const uint4 jj = ahead.front();
         const uint32_t j[4] = {jj.x, jj.y, jj.z, jj.w};
-#endif
         float4 a[4], b[4];
         if (RIGID && __any(((j[0] | j[1] | j[2] | j[3]) & kRigidTag) != 0)) {      // wave-uniform, rare (see for_staged_nbrs)
 #pragma unroll
@@ -1424,9 +1409,7 @@ __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__
                 b[u] = make_float4(pa.w, pb.x, pb.y, 0.f);
             }
         }
-#ifndef SPH_X_SYNIDX
         ahead.advance(kk);
-#endif
         body(a[0], b[0], j[0]);
         if (kk + 1 < cnt) body(a[1], b[1], j[1]);
         if (kk + 2 < cnt) body(a[2], b[2], j[2]);
@@ -1833,20 +1816,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             acc += c.m * dot3(vi.x - vj.x, vi.y - vj.y, vi.z - vj.z, g.x, g.y, g.z);
         }
     };
-#ifdef SPH_X_NOFLUID      // removal experiments (timing only, results are wrong): tools/README.md
-    const int kf_x = 0;
-#else
-    const int kf_x = kf;
-#endif
-#ifdef SPH_X_NOWALL
-    const int kb_x = 0;
-#else
-    const int kb_x = kb;
-#endif
-    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, skip ? 0 : kf_x, q, fa, P, V, rv, pair);
-    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf_x, s_operand, s_v2, pair_scaled);
-    else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf_x, s_operand, s_v2, rv, pair_scaled);
-    else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf_x, P, V, rv, pair);
+    if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, skip ? 0 : kf, q, fa, P, V, rv, pair);
+    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);
+    else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
+    else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float wa[1] = {0.f};
     float &accb = wa[0];
     auto wall = [&](const float4 pj) {
@@ -1855,8 +1828,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         F3 g = grad_w_in(c, dx, dy, dz, r);
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
     };
-    if (QUAD) for_nbrs_p_quad(nlbp, skip ? 0 : kb_x, q, wa, WP, wall);
-    else for_nbrs_p(nlbp, skip ? 0 : kb_x, WP, wall);
+    if (QUAD) for_nbrs_p_quad(nlbp, skip ? 0 : kb, q, wa, WP, wall);
+    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);
     float val = 0.f;
     int flag = 0;
     if (live) {

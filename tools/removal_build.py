@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Builds of the library for REMOVAL experiments and soak variants -- from a patched COPY of csrc/, never from switches inside the
+product kernels (`-DSPH_X_*` compiled wrong-on-purpose variants of the hot kernels).
+
+    python tools/removal_build.py nofluid nowall nogather rx_nofluid ...      ->  ab/libsph_<name>.so each
+
+Timing only: except `bnl_notable` the results of these builds are wrong on purpose.  Compare with
+    TUNE_COPY_STATE=1 python tools/tune_libs.py dfsph_1m 60 ref=cfd_taichi_amd/libsph_mi355x.so x=ab/libsph_nofluid.so
+(only the first build advances the scene; the others receive its state).  A patch is a list of (old, new) text replacements that must
+each match exactly once in the named file: a kernel that changed under a patch fails loudly instead of measuring something else."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cfd_taichi_amd import build as hip_build  # noqa: E402
+
+K, R = "sph_kernels.h", "sph_relaxed_kernels.h"
+PATCHES = {
+    # exact k_residual (sph_kernels.h): the fluid pair loop / the wall loop removed
+    "nofluid": [(K, "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);",
+                 "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
+    "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
+    # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
+    "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
+                  "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],
+    # k_build_nl: every wave works its 27 cell entries out per lane (a CORRECT variant: tools/soak_libs.py holds it against the default)
+    "bnl_notable": [(K, "    const bool table = nruns <= kRunCap;                                       // wave-uniform",
+                     "    const bool table = false;")],
+    # relaxed k_residual_rx: pair loop removed / staging gathers removed / whole staging removed (the decomposition in DESIGN.md section 4b)
+    "rx_nofluid": [(R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
+                    "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
+    "rx_nostage": [(R, "    const bool staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);",
+                    "    const bool staged = true;"),
+                   (R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
+                    "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
+}
+
+
+def main():
+    names = sys.argv[1:]
+    if not names or any(n not in PATCHES for n in names):
+        raise SystemExit("usage: removal_build.py %s" % " | ".join(sorted(PATCHES)))
+    os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
+    for name in names:
+        with tempfile.TemporaryDirectory() as tmp:
+            csrc = os.path.join(tmp, "cfd_taichi_amd", "csrc")
+            shutil.copytree(hip_build.CSRC, csrc)
+            shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+            for fname, old, new in PATCHES[name]:
+                path = os.path.join(csrc, fname)
+                text = open(path).read()
+                if text.count(old) != 1:
+                    raise SystemExit("patch %s: %r matches %d times in %s" % (name, old[:60], text.count(old), fname))
+                open(path, "w").write(text.replace(old, new))
+            out = os.path.join(ROOT, "ab", "libsph_%s.so" % name)
+            cmd = [hip_build.hipcc()] + hip_build.FLAGS + [os.path.join(csrc, s) for s in hip_build.SOURCES] + ["-o", out]
+            subprocess.run(cmd, check=True)
+            print(out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,5 @@
 """Two builds of the library advance the same scene in lock step and must stay bit-identical:  tools/soak_libs.py scene steps every libA.so libB.so
-(e.g. the default build against -DSPH_X_BNL_NOTABLE: k_build_nl's per-wave cell tables against the per-lane path, over a whole collapse)."""
+(e.g. the default build against ab/libsph_bnl_notable.so from tools/removal_build.py: k_build_nl's per-wave cell tables against the per-lane path, over a whole collapse)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
