@@ -165,7 +165,10 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
     restore()
     fence(sim)
     t0 = time.perf_counter()
-    stats = [sim.step_dfsph(1) for _ in range(args.steps)]
+    stats = []
+    for _ in range(args.steps):
+        st = sim.step_dfsph(1)
+        stats.append((st.n_div, st.n_dens))          # (the stats object is reused by the binding: copy the numbers)
     fence(sim)
     elapsed = time.perf_counter() - t0
     n = sim.n_fluid
@@ -176,7 +179,7 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
 
     out = {"arith": "SPH_ARITH_RELAXED (csrc/sph_relaxed_kernels.h: v_rsq_f32, FMAs, grad W as one scalar, per-step wall sums)", "active": active,
            "value": n * args.steps / elapsed / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
-           "n_dens_mean": sum(x.n_dens for x in stats) / len(stats), "n_div_mean": sum(x.n_div for x in stats) / len(stats),
+           "n_dens_mean": sum(x[1] for x in stats) / len(stats), "n_div_mean": sum(x[0] for x in stats) / len(stats),
            "exact_n_dens_mean": sum(x[1] for x in exact_stats) / len(exact_stats),
            "deviation_from_exact_after_the_timed_steps": {"pos": quant(sim.download(nat.F_POS), final_exact[0]), "vel": quant(sim.download(nat.F_VEL), final_exact[1]),
                                                           "norm": "per-particle |a - b| / max|b|; same start state (the exact handle's at the start of its timed window)"},
@@ -194,9 +197,19 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
         dom = max(sweeps, key=lambda k: sweeps[k][0])
         ms, cnt = prof[dom]
         avg_s = ms / cnt / 1e3
+        rx_names = {"dfsph_div_residual": "k_residual_rx<false>", "dfsph_dens_residual": "k_residual_rx<true>", "dfsph_warm_start": "k_correct_rx<0>",
+                    "dfsph_div_correct": "k_correct_rx<1>", "dfsph_dens_correct": "k_correct_rx<2>"}
+        traffic = None
+        try:
+            if scene_name == "dfsph_1m":
+                with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic_relaxed.json")) as f:
+                    traffic = json.load(f)["kernels"][rx_names[dom]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ALGO_BYTES[dom] * n / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ALGO_BYTES[dom] * n / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": cnt,
-                           "share_of_gpu_time": ms / tot if tot else None}
+                           "frac": ALGO_BYTES[dom] * n / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": "profiles/r03/pmc_traffic_relaxed.json (committed rocprofv3 --pmc passes with SPH_ARITH=relaxed; NOT measured in this run)" if traffic else None,
+                           "avg_launch_us": avg_s * 1e6, "launches": cnt, "share_of_gpu_time": ms / tot if tot else None}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps, "share": v[0] / tot}
                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     sim.close()
