@@ -92,6 +92,10 @@ SCENES.update({
                                        _CUBE, 0.6, [1.7, 0.6, 0.7], [0.0, 0.0, 90.0], 1000),
     "dfsph_rigid_2m": lambda: _with_solid(_scene("dfsph", 1e-3, [16.0, 12.0, 8.0], [5.0, 6.6, 7.6]),
                                           _CUBE, 3.3, [8.25, 2.97, 2.31], [0.0, 0.0, 90.0], 5000),
+    # the same scene with the body moved 0.5 m down the tank, clear of the water column (the reference's placement INTERSECTS the column: the
+    # density loop runs into its cap there): a coupled solve that converges, for a throughput datum that means something
+    "dfsph_rigid_2m_clear": lambda: _with_solid(_scene("dfsph", 1e-3, [16.0, 12.0, 8.0], [5.0, 6.6, 7.6]),
+                                                _CUBE, 3.3, [8.75, 2.97, 2.31], [0.0, 0.0, 90.0], 5000),
 })
 
 
