@@ -479,6 +479,8 @@ def main():
             state = (sim.download(nat.F_POS), sim.download(nat.F_VEL), warm, sim.scalar(nat.S_DELTA_TIME))
         fence(sim)
         stats = []
+        if world > 1:
+            sim.comm_stats(reset=True)               # transport requests of the timed steps only (config.rank0_comm)
         t0 = time.perf_counter()
         run(args.steps, stats)
         sim.synchronize()
@@ -499,6 +501,7 @@ def main():
 
     value = n_total * args.steps / elapsed / 1e6
     slab_info = sim.slab_info() if world > 1 else None
+    comm_stats_timed = sim.comm_stats() if world > 1 else None
 
     out = {
         "metric": "million particle-steps/sec (%s dam-break)" % solver_kind.upper(),
@@ -516,7 +519,12 @@ def main():
                               "note": "the pre-roll from rest (density loop at its minimum of 2 iterations for most of it); not the headline"}
     if slab_info is not None:
         out["config"]["rank0_slab"] = slab_info
-        out["config"]["rank0_comm"] = slab.comm.stats if slab.comm is not None else "native transport (no callbacks)"
+        cs = comm_stats_timed if comm_stats_timed is not None else sim.comm_stats()
+        steps_c = max(1, cs["steps"])
+        out["config"]["rank0_comm"] = {"per_step": {k: cs[k] / steps_c for k in cs if k != "steps"}, "steps": cs["steps"],
+                                       "transport": (slab.comm.stats if slab.comm is not None else "native RCCL (the library's own communicator, no callbacks)"),
+                                       "note": "requests of rank 0 during the timed steps: p2p_groups = send / recv pairs with the slab neighbours, bytes one way, "
+                                               "count_exchanges = host round trips; read against the cost model in DESIGN.md section 6"}
     if stats:
         nd = [s[0] for s in stats]; ns = [s[1] for s in stats]; ne = [s[2] for s in stats]
         out["config"].update({"n_div_mean": sum(nd) / len(nd), "n_dens_mean": sum(ns) / len(ns), "n_div_evals_mean": sum(ne) / len(ne)})

@@ -92,6 +92,10 @@ struct SphHandle {
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
     float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
+    // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
+    // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
+    // ordered on the stream, [5] all-reduces through the host, [6] steps
+    long long comm_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
     int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
@@ -792,6 +796,7 @@ int native_allreduce_stream(SphHandle *h, int n, int op);
 // all-reduce red_dev[0..n) over the slabs, ordered on the handle's stream
 int slab_allreduce_stream(SphHandle *h, int n, int op)
 {
+    h->comm_stat[4] += 1;
     if (h->native) return native_allreduce_stream(h, n, op);
     const SphComm &cm = h->comm;
     if (cm.on_host) {                                  // host transport: stage through the caller's host buffer
@@ -906,6 +911,7 @@ int native_allreduce_stream(SphHandle *h, int n, int op)
 // neighbour counts / host-side all-reduce through whichever transport the handle has
 int slab_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr)
 {
+    h->comm_stat[3] += 1;
     if (h->native) return native_exchange_counts(h, sl, sr, rl, rr);
     int rc = h->comm.exchange_counts(h->comm.user, sl, sr, rl, rr);
     return rc ? comm_fail(h, "exchange_counts", rc) : SPH_OK;
@@ -913,6 +919,7 @@ int slab_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int3
 
 int slab_allreduce_host(SphHandle *h, double *v, int n, int op)
 {
+    h->comm_stat[5] += 1;
     if (!h->native) {
         int rc = h->comm.allreduce(h->comm.user, v, n, op);
         return rc ? comm_fail(h, "allreduce", rc) : SPH_OK;
@@ -938,6 +945,7 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
         if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, h->stream));
     }
     if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
+    if (sl || sr || rl || rr) { h->comm_stat[0] += 1; h->comm_stat[1] += (long long)(sl + sr); h->comm_stat[2] += (long long)(rl + rr); }
     int rc;
     if (h->native) {
         if ((rc = native_exchange(h, sl, sr, rl, rr))) return rc;
@@ -1577,6 +1585,7 @@ int step_wcsph_once(SphHandle *h)
 {
     int rc;
     h->simulate_cnt += 1;                                   // solver_base.py:137
+    h->comm_stat[6] += 1;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     if ((rc = stage_density(h))) return rc;                 // wcsph_solver.py:34-35
     const Consts &c = h->c;
@@ -1874,6 +1883,7 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     int rc;
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;                                   // solver_base.py:137
+    h->comm_stat[6] += 1;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
     if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
     const bool host_loops = h->host_loops || (h->slab && !slab_async(h));
@@ -1906,6 +1916,7 @@ int step_pbf_once(SphHandle *h)
 {
     int rc;
     h->simulate_cnt += 1;                                   // solver_base.py:137
+    h->comm_stat[6] += 1;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     const Consts &c = h->c;
     const PbfConsts k = pbf_consts(h);
@@ -1969,6 +1980,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     int rc;
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;                                   // solver_base.py:137
+    h->comm_stat[6] += 1;
     if ((rc = require_async_slab(h))) return rc;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
     if ((rc = stage_density(h))) return rc;                 // compute_all_rho :239; P = (pos, rho)
@@ -2045,6 +2057,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     int rc;
     memset(st, 0, sizeof(*st));
     h->simulate_cnt += 1;
+    h->comm_stat[6] += 1;
     if ((rc = require_async_slab(h))) return rc;
     if ((rc = stage_sort_and_lists(h))) return rc;
     if ((rc = stage_density(h))) return rc;                 // predict_advection :38; P = (pos, rho)
@@ -2641,6 +2654,14 @@ int sph_get_stream(SphHandle *h, void **stream)
 {
     if (!h || !stream) return SPH_E_INVALID;
     *stream = (void *)h->stream;
+    return SPH_OK;
+}
+
+int sph_comm_stats(SphHandle *h, int64_t *out, int reset)
+{
+    if (!h || !out) return SPH_E_INVALID;
+    for (int k = 0; k < 8; ++k) out[k] = (int64_t)h->comm_stat[k];
+    if (reset) for (int k = 0; k < 8; ++k) h->comm_stat[k] = 0;
     return SPH_OK;
 }
 

@@ -278,6 +278,12 @@ int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t sl
 /* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity,
  * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = 0 */
 int sph_slab_info(SphHandle *h, int32_t *out8);
+/* What the halo transport was asked to do since the last reset (whichever transport drives it: native RCCL, callbacks over RCCL or gloo):
+ * out[0] point-to-point groups (a send / recv pair with each slab neighbour), out[1] bytes sent, out[2] bytes received, out[3] count
+ * exchanges (one host round trip each), out[4] all-reduces ordered on the handle's stream, out[5] all-reduces through the host,
+ * out[6] steps, out[7] 0.  bench.py reports them per step in config.rank0_comm so that a measured N > 1 line can be read against the
+ * cost model of DESIGN.md section 6. */
+int sph_comm_stats(SphHandle *h, int64_t *out8, int reset);
 /* local (device-order) access for slab handles: all resident particles, owned and ghost; ids < 0 mark ghosts (~id) */
 int sph_download_local(SphHandle *h, int field, float *host, size_t n_floats);
 int sph_download_ids(SphHandle *h, int32_t *host, size_t n);

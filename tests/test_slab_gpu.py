@@ -157,4 +157,7 @@ def test_bench_multi_rank_path_end_to_end(tmp_path, launcher):
     assert 0 < slab0["owned"] < 10000000 and slab0["ghosts"] > 50000 and slab0["x_lo"] == 0
     assert d["value"] > 0 and abs(d["value"] - 10.0 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["particles_on_rank"] == slab0["owned"] + slab0["ghosts"] or d["roofline"]["particles_on_rank"] > 0
+    comm = d["config"]["rank0_comm"]                         # transport requests per step of the timed window, whichever transport drove them
+    assert comm["steps"] == 3 and comm["per_step"]["p2p_groups"] >= 10 and comm["per_step"]["bytes_sent"] > 1e5
+    assert comm["per_step"]["allreduce_stream"] + comm["per_step"]["allreduce_host"] >= 3
     assert "cpu_baseline" not in d and "strong_scaling_base" not in d
