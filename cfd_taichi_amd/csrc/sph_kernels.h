@@ -949,8 +949,10 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
 // ======================================================================================
 // QUAD sweeps: 64 particles per workgroup, lane q = threadIdx.x & 3 of the quad serving particle blk * 64 + threadIdx.x / 4; every lane of a quad
 // carries the same accumulators, lane 0 writes the results (`owner`)
-#define SPH_SWEEP_PROLOGUE_M(QUAD)                           \
-    const int blk = xcd_block(blockIdx.x, gridDim.x);        \
+#define SPH_SWEEP_PROLOGUE_M(QUAD) SPH_SWEEP_PROLOGUE_B(QUAD, xcd_block(blockIdx.x, gridDim.x))
+// ... with the workgroup -> tile mapping chosen by the caller
+#define SPH_SWEEP_PROLOGUE_B(QUAD, BLK)                      \
+    const int blk = (BLK);                                   \
     const int q = (QUAD) ? (int)(threadIdx.x & 3) : 0;       \
     (void)q;                                                 \
     int i = (QUAD) ? blk * (kBlock / 4) + (int)(threadIdx.x >> 2) : blk * kBlock + (int)threadIdx.x; \
@@ -1206,6 +1208,33 @@ __device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs
     __syncthreads();
     return nst;
 }
+// ---- change propagation between the sweeps of the constant-density loop (round 3) -----------------------------------------------
+// rho* = max(rho + dt * sum, rho0) clamps at the rest density, and the reference's density sum has no self term, so in a collapsing
+// column ~99 % of the particles sit AT rho0 with stiffness k = 0: the loop (dfsph_solver.py:221-233) iterates for the floor layer and
+// a few compressed pockets (tools/zero_tiles.py: 0.5-1 % of the particles at dfsph_1m; 2-5 % lie within h of one, 5-10 % within 2h).
+//   D7 (k_correct<DENS>) of a tile whose staged set (own particles + halo) holds no k / rho != 0 adds only +-0 terms: the tile checks the
+//      staged k / rho FIRST (a 4-byte gather) and, if all are 0, leaves v* as it is.  Per 64-particle wave it reports whether any lane
+//      applied a nonzero correction: wave_dirty[i / 64].
+//   D6 (k_residual<DENS>) of a tile whose staged set lies in waves with wave_dirty == 0 would recompute, from unchanged v*, exactly what
+//      it wrote in the iteration before -- rho*, k / rho and its block partial are still in memory: it returns at once.  The waves that
+//      own a workgroup's staged set are read off its cell runs (a run is a cell: contiguous sorted indices, at most two waves).
+// The first D6 of a step computes everywhere (`force_all`).  Bit-identical to computing everything (SPH_TILE_SKIP=0;
+// tests/test_cell_order_gpu.py::test_density_loop_change_propagation_is_invisible), up to the sign of a zero velocity component
+// (v - (-0) = +0 where the skipped sweep keeps -0).  kr_split handles (single GPU, staged, no rigid entries).
+__device__ __forceinline__ bool stage_sources_flagged(const uint2 *__restrict__ stage_runs, int sw, int blk, const int *__restrict__ wave_flags)
+{
+    const int nruns = sw >> 16;
+    const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
+    int f = 0;
+    if (threadIdx.x < kBlock / 64) f = wave_flags[blk * (kBlock / 64) + threadIdx.x];      // the tile's own waves
+    for (int r = threadIdx.x; r < nruns; r += kBlock) {
+        const uint2 rn = runs[r];
+        const uint32_t first = rn.x, n = rn.y >> 16;
+        f |= wave_flags[first >> 6] | wave_flags[(first + n - 1u) >> 6];
+    }
+    return __syncthreads_or(f) != 0;
+}
+
 struct StageIdx { uint32_t j[kStageTrips][kStageBatch]; };
 // this thread's indices of all trips, then the barrier after which s_idx may be overwritten
 __device__ __forceinline__ StageIdx stage_take(const uint32_t *__restrict__ s_idx, int nst)
@@ -1270,6 +1299,45 @@ __device__ __forceinline__ bool stage_operand_ps_scaled(const Consts &c, float4 
     }
     __syncthreads();
     return true;
+}
+
+// The same with the scalars requested first and examined: returns 0 = not staged, 1 = staged, 2 = staged set holds no scalar != 0 (nothing
+// was copied; the correction sweep of the density loop has nothing to do, see stage_sources_flagged).  One more round trip than the
+// plain form for the workgroups that do have work (the positions are requested after the verdict).  (Asking the per-wave flags of the
+// residual sweep instead of the staged scalars themselves -- no expansion, no gather -- was measured: fewer tiles return, 30.5 -> 35.4 us.)
+template <bool SCALED>
+__device__ __forceinline__ int stage_operand_ps_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 1;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+    float sc[kStageTrips][kStageBatch];
+    int any = 0;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        if (t * kStageBatch * kBlock >= nst) break;
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) sc[t][u] = S[x.j[t][u]];                      // (clamped indices: duplicates of valid slots)
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) any |= sc[t][u] != 0.f;
+    }
+    if (!__syncthreads_or(any)) return 2;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+        float4 a[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[x.j[t][u]];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst)
+                s_A[base + u * kBlock] = SCALED ? make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, sc[t][u]) : make_float4(a[u].x, a[u].y, a[u].z, sc[t][u]);
+    }
+    __syncthreads();
+    return 1;
 }
 
 // two-operand variant: A staged in LDS, the global index of every staged element next to it (B is gathered from HBM/L2 through it)
@@ -1678,16 +1746,30 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
-                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho)
+                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
+                                                    int *__restrict__ wave_dirty)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
-    SPH_SWEEP_PROLOGUE_M(QUAD)
+    // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
+    // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
+    SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && !RIGID && c.kr_split;
-    const bool staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk)
-                                         : stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk));     // positions * 2^32
+    const bool track = MODE == CORR_DENS && split && wave_dirty != nullptr;       // change propagation in the density loop (stage_sources_flagged)
+    bool staged;
+    if (track) {
+        const int verdict = stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+        if (verdict == 2) {                                                        // every k / rho this tile can see is 0: v* stays
+            if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
+            return;
+        }
+        staged = verdict == 1;
+    } else {
+        staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk)
+                                  : stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk));     // positions * 2^32
+    }
     const float dt = ds->dt;
     const float rho_i = rho[ii];
     float k_i;
@@ -1748,6 +1830,11 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     };
     if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
     else for_nbrs_p(nlbp, kb, WP, wall);
+    if (track) {       // did any lane of this wave apply a correction?  (all sums +-0: v - (+-0) * dt leaves v)
+        const bool changed = live && (ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
+        const unsigned long long any = __ballot(changed);
+        if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
+    }
     if (!owner) return;
     float4 v = Vin[i];
     if (c.boundary_handle) {
@@ -1778,12 +1865,20 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
-                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
+                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
+                                                     const int *__restrict__ wave_dirty, int force_all)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE_M(QUAD)
+    const bool spread = DENS && STAGED && !RIGID && wave_dirty && !force_all;      // (see k_correct: round-robin tiles when most of them return at once)
+    if (spread) {                                                    // change propagation, see stage_sources_flagged
+        const int tb = (int)blockIdx.x, sw = stage_cnt[tb];
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tb, wave_dirty)) {             // rho*, k / rho and the block partial of the last iteration stand
+            return;
+        }
+    }
+    SPH_SWEEP_PROLOGUE_B(QUAD, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     const bool staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
     const float4 vi = V[ii];

@@ -92,6 +92,9 @@ struct SphHandle {
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
     float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
+    // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
+    int *wave_dirty = nullptr;                   // per 64-particle wave: did the last density correction change a velocity there?
+    bool opt_tile_skip = true, dens_first = true, tune_all = false;
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
     // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
     // ordered on the stream, [5] all-reduces through the host, [6] steps
@@ -708,6 +711,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_tile_skip) {
+                if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
+            }
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
         }
@@ -1621,6 +1627,8 @@ int check_overflow_all(SphHandle *h)
 }
 
 // ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
+// tiles of the density loop whose inputs did not change are not recomputed (single GPU, staged, no rigid entries)
+inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged && h->c.kr_split && !h->slab && !rigid_coupled(h); }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
@@ -1629,12 +1637,12 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, 1);
         return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, 1);
 }
 
 template <int MODE>
@@ -1642,28 +1650,32 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
+    int *wdirty = (MODE == CORR_DENS && tile_skip(h) && !h->tune_all) ? h->wave_dirty : nullptr;      // change propagation in the density loop
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
-                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho);
+                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty);
         return;
     }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
-                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho);
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
+    const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
+    const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
+    h->dens_first = false;
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, force_all);
         return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, force_all);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -1769,6 +1781,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     hipStream_t s = h->stream;
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
     hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
+    h->dens_first = true;
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
     // On a slab handle every sweep whose output the neighbours read is followed by the refresh of that field on the ghosts (enqueued,
     // not waited for, with a stream-ordered transport); gated sweeps still take part in the exchanges so that all slabs issue the same
@@ -1827,6 +1840,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
 int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
 {
     int rc;
+    h->dens_first = true;
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
     float err = 0.f, past = 0.f;
@@ -2311,6 +2325,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
@@ -2960,6 +2975,7 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
     if (!h->density_valid && (rc = stage_density(h))) return rc;
     const unsigned saved = h->sweep_lds;
     h->sweep_lds = lds_bytes;
+    h->tune_all = true;                    // repeated launches on one state: every tile computes (no change propagation)
     hipEvent_t a, b;
     HIP_TRY(h, hipEventCreate(&a));
     HIP_TRY(h, hipEventCreate(&b));
@@ -2989,6 +3005,7 @@ int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double 
     HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     h->sweep_lds = saved;
+    h->tune_all = false;
     if (which == 3) h->density_valid = false;
     *avg_us = (double)ms * 1000.0 / reps;
     return SPH_OK;

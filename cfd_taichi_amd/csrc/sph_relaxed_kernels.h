@@ -100,12 +100,20 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         const float *__restrict__ rho, const float *__restrict__ alpha,
                                                         const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
-                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
+                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
+                                                        const int *__restrict__ wave_dirty, int force_all)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
+    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
+    if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
+        const int tb = (int)blockIdx.x, sw = stage_cnt[tb];
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tb, wave_dirty)) {
+            return;
+        }
+    }
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(false)
+    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     (void)nlbp;
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     const bool staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
@@ -131,13 +139,13 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     float val = 0.f;
     int flag = 0;
     if (live) {
+        float kr;
         float sum = acc;
         if (c.boundary_handle && kb > 0 && !skip) {                               // :300 / :176
             const float4 gw = G[i];
             sum = __builtin_fmaf(__builtin_fmaf(vi.z, gw.z, __builtin_fmaf(vi.y, gw.y, vi.x * gw.x)), c.rx_rho0_m, acc);
         }
         const float rho_i = rho[i];
-        float kr;
         if (DENS) {
             val = rmax(__builtin_fmaf(ds->dt, sum, rho_i), c.rho0);               // :135 / :137
             flag = !(val == c.rho0);                                              // :139
@@ -161,14 +169,26 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
                                                        const float *__restrict__ alpha, const float *__restrict__ src,
                                                        float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                        const float4 *Vin, float4 *Vout, int gate,
-                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho)
+                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
+                                                       int *__restrict__ wave_dirty)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(false)
+    SPH_SWEEP_PROLOGUE_B(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     (void)nlbp;
-    const bool staged = stage_operand_ps(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+    const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
+    bool staged;
+    if (track) {
+        const int verdict = stage_operand_ps_checked<false>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+        if (verdict == 2) {
+            if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
+            return;
+        }
+        staged = verdict == 1;
+    } else {
+        staged = stage_operand_ps(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+    }
     const float dt = ds->dt;
     const float rho_i = rho[ii];
     float k_i;
@@ -198,14 +218,20 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     else        // a workgroup whose set did not fit: two global gathers per neighbour, masked tails
         walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) { o.a = P[j]; o.s = krho[j]; },
                              [&](const OperandPS &o, uint32_t j) { pair(make_float4(o.a.x, o.a.y, o.a.z, o.s), none, j); });
-    if (!live) return;
-    float4 v = Vin[i];
-    if (c.boundary_handle && kb > 0) {                                            // :322 / :310 / :187,191
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (c.boundary_handle && kb > 0 && live) {                                    // :322 / :310 / :187,191
         const float4 gw = G[i];
         const float kb_i = kr_i * c.rx_rho0_m;
-        ax = __builtin_fmaf(gw.x, kb_i, ax); ay = __builtin_fmaf(gw.y, kb_i, ay); az = __builtin_fmaf(gw.z, kb_i, az);
+        gx = gw.x * kb_i; gy = gw.y * kb_i; gz = gw.z * kb_i;
     }
-    v.x -= ax * dt; v.y -= ay * dt; v.z -= az * dt;                               // :324 / :312 / :189
+    if (track) {
+        const bool changed = live && (ax != 0.f || ay != 0.f || az != 0.f || gx != 0.f || gy != 0.f || gz != 0.f);
+        const unsigned long long any = __ballot(changed);
+        if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
+    }
+    if (!live) return;
+    float4 v = Vin[i];
+    v.x -= (ax + gx) * dt; v.y -= (ay + gy) * dt; v.z -= (az + gz) * dt;         // :324 / :312 / :189
     v.w = rho_i;
     Vout[i] = v;
     if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
