@@ -1220,7 +1220,8 @@ __device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs
 //      own a workgroup's staged set are read off its cell runs (a run is a cell: contiguous sorted indices, at most two waves).
 // The first D6 of a step computes everywhere (`force_all`).  Bit-identical to computing everything (SPH_TILE_SKIP=0;
 // tests/test_cell_order_gpu.py::test_density_loop_change_propagation_is_invisible), up to the sign of a zero velocity component
-// (v - (-0) = +0 where the skipped sweep keeps -0).  kr_split handles (single GPU, staged, no rigid entries).
+// (v - (-0) = +0 where the skipped sweep keeps -0).  Staged handles without rigid entries, slabs included: a wave that holds a ghost
+// counts as changed in every iteration (its owner may have moved its v*), so the tiles along a cut always recompute.
 __device__ __forceinline__ bool stage_sources_flagged(const uint2 *__restrict__ stage_runs, int sw, int blk, const int *__restrict__ wave_flags)
 {
     const int nruns = sw >> 16;
@@ -1275,6 +1276,35 @@ __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restric
     }
     __syncthreads();
     return true;
+}
+
+// stage_operand<SCALED> that also reports whether any staged element has .w != 0: 1 = staged, 2 = staged and every .w is 0 (the caller's
+// pair loop would add only +-0: see stage_sources_flagged), 0 = not staged.  For handles whose k / rho travels inside the (pos, k / rho)
+// float4 (slab handles, SPH_KR_SPLIT=0): the verdict comes with the copy, so a zero tile saves its pair loop, not its gathers.
+template <bool SCALED>
+__device__ __forceinline__ int stage_operand_w_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
+                                                       const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 2;                                 // a workgroup of ghosts only: nothing staged, nothing to add
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+    int any = 0;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+        float4 a[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) a[u] = A[x.j[t][u]];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) {
+                any |= a[u].w != 0.f;
+                s_A[base + u * kBlock] = SCALED ? make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, a[u].w) : a[u];
+            }
+    }
+    return __syncthreads_or(any) ? 1 : 2;
 }
 
 // kr_split handles: positions from the step's position array and the per-sweep scalar k / rho from its own 4-byte array (the sweeps
@@ -1757,10 +1787,11 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && !RIGID && c.kr_split;
-    const bool track = MODE == CORR_DENS && split && wave_dirty != nullptr;       // change propagation in the density loop (stage_sources_flagged)
+    const bool track = MODE == CORR_DENS && STAGED && !RIGID && wave_dirty != nullptr;   // change propagation in the density loop (stage_sources_flagged)
     bool staged;
     if (track) {
-        const int verdict = stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+        const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk)
+                                  : stage_operand_w_checked<true>(c, s_operand, P, stage_src, stage_cnt, blk);
         if (verdict == 2) {                                                        // every k / rho this tile can see is 0: v* stays
             if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
             return;
@@ -1831,7 +1862,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
     else for_nbrs_p(nlbp, kb, WP, wall);
     if (track) {       // did any lane of this wave apply a correction?  (all sums +-0: v - (+-0) * dt leaves v)
-        const bool changed = live && (ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
+        // (a ghost's v* is refreshed from its owner after this sweep: it may change behind this rank's back)
+        const bool changed = live && (ghost || ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
     }

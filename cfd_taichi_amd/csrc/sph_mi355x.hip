@@ -711,7 +711,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
-            if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_tile_skip) {
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
             }
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
@@ -1627,8 +1627,8 @@ int check_overflow_all(SphHandle *h)
 }
 
 // ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
-// tiles of the density loop whose inputs did not change are not recomputed (single GPU, staged, no rigid entries)
-inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged && h->c.kr_split && !h->slab && !rigid_coupled(h); }
+// tiles of the density loop whose inputs did not change are not recomputed (staged handles without rigid entries)
+inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged && !rigid_coupled(h); }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277

@@ -53,6 +53,8 @@ def main():
     rho = sim.gather(nat.F_RHO)
     result = None
     if rank == 0:
+        if os.environ.get("SLAB_REF_NOSKIP") == "1":      # the one-GPU reference computes every tile in every density iteration
+            os.environ["SPH_TILE_SKIP"] = "0"
         ref = nat.Simulation(nat.config_from_dict(cfg, device=device))
         ref_stats = []
         for _ in range(args.steps):
