@@ -1475,6 +1475,47 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
     __syncthreads();
     return true;
 }
+// The same with a look at a per-particle byte first: returns 0 = not staged, 1 = staged, 2 = no staged particle has its byte set (nothing was
+// copied).  The residual sweep of the density loop asks it with the bytes the last correction sweep wrote ("this particle's v* changed"):
+// the second, exact level of the change propagation (stage_sources_flagged is the first: per-wave flags, no expansion).
+template <bool SCALED>
+__device__ __forceinline__ int stage_operand_pv_checked(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
+                                                        const float4 *__restrict__ A, const float4 *__restrict__ B, const unsigned char *__restrict__ changed,
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 1;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+    int any = 0;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        if (t * kStageBatch * kBlock >= nst) break;
+        unsigned char f[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) f[u] = changed[x.j[t][u]];                     // (clamped indices: duplicates of valid slots)
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) any |= f[u];
+    }
+    if (!__syncthreads_or(any)) return 2;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+        float4 a[kStageBatch], b[kStageBatch];
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) {
+                const int e = base + u * kBlock;
+                s_A[e] = SCALED ? make_float4(a[u].x * 0x1p32f, a[u].y * 0x1p32f, a[u].z * 0x1p32f, b[u].x) : make_float4(a[u].x, a[u].y, a[u].z, b[u].x);
+                s_B[e] = make_float2(b[u].y, b[u].z);
+            }
+    }
+    __syncthreads();
+    return 1;
+}
 template <bool RIGID, bool SCALED = false, class Body>
 __device__ __forceinline__ void for_staged_nbrs_pv2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                     const float2 *__restrict__ s_B, const RigidView &rv, Body body)
@@ -1777,7 +1818,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                    int *__restrict__ wave_dirty)
+                                                    int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
@@ -1794,6 +1835,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                   : stage_operand_w_checked<true>(c, s_operand, P, stage_src, stage_cnt, blk);
         if (verdict == 2) {                                                        // every k / rho this tile can see is 0: v* stays
             if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
+            if (live) changed8[i] = 0;
             return;
         }
         staged = verdict == 1;
@@ -1866,6 +1908,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         const bool changed = live && (ghost || ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
+        if (live) changed8[i] = changed ? 1 : 0;
     }
     if (!owner) return;
     float4 v = Vin[i];
@@ -1898,7 +1941,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                     const int *__restrict__ wave_dirty, int force_all)
+                                                     const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
@@ -1912,7 +1955,14 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     }
     SPH_SWEEP_PROLOGUE_B(QUAD, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
-    const bool staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
+    bool staged;
+    if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
+        const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
+        if (verdict == 2) return;
+        staged = verdict == 1;
+    } else {
+        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
+    }
     const float4 vi = V[ii];
     float fa[1] = {0.f};
     float &acc = fa[0];

@@ -94,6 +94,7 @@ struct SphHandle {
     float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
     // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
     int *wave_dirty = nullptr;                   // per 64-particle wave: did the last density correction change a velocity there?
+    unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
     // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
@@ -713,6 +714,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
             if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
+                if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
             }
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
@@ -1637,12 +1639,12 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, 1);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1);
         return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, 1);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1);
 }
 
 template <int MODE>
@@ -1653,12 +1655,12 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     int *wdirty = (MODE == CORR_DENS && tile_skip(h) && !h->tune_all) ? h->wave_dirty : nullptr;      // change propagation in the density loop
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
-                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty);
+                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8);
         return;
     }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
-                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty);
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8);
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -1670,12 +1672,12 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     h->dens_first = false;
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, force_all);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all);
         return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, force_all);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all);
 }
 
 int launch_finalize(SphHandle *h, int mode)

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                        const int *__restrict__ wave_dirty, int force_all)
+                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -116,7 +116,14 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     (void)nlbp;
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
-    const bool staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
+    bool staged;
+    if (spread) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
+        const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
+        if (verdict == 2) return;
+        staged = verdict == 1;
+    } else {
+        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
+    }
     const float4 vi = V[ii];
     float acc = 0.f;
     const bool skip = !DENS && kf < 20;                                           // :258-261
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
                                                        float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                        const float4 *Vin, float4 *Vout, int gate,
                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                       int *__restrict__ wave_dirty)
+                                                       int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         const int verdict = stage_operand_ps_checked<false>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
         if (verdict == 2) {
             if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
+            if (live) changed8[i] = 0;
             return;
         }
         staged = verdict == 1;
@@ -228,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         const bool changed = live && (ax != 0.f || ay != 0.f || az != 0.f || gx != 0.f || gy != 0.f || gz != 0.f);
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
+        if (live) changed8[i] = changed ? 1 : 0;
     }
     if (!live) return;
     float4 v = Vin[i];
