@@ -95,6 +95,7 @@ struct SphHandle {
     // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
     int *wave_dirty = nullptr;                   // per 64-particle wave: did the last density correction change a velocity there?
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
+    int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
     // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
@@ -716,6 +717,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
             }
+            if (h->cfg.solver == SPH_SOLVER_PCISPH && !h->slab && h->opt_tile_skip)
+                if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
         }
@@ -2018,6 +2021,10 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
     auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
     if ((rc = ghosts_xyz(PP))) return rc;
+    // tiles without pressure skip update_press_force (k_pci_press): single-GPU staged handles without rigid entries
+    int *zero_press = (h->pci_zero_press && h->staged && !h->slab && !rg) ? h->pci_zero_press : nullptr;
+    if (zero_press)       // after k_pci_ext: press_force = 0 and pos_predict = the zero-pressure prediction everywhere
+        HIP_TRY(h, hipMemsetAsync(zero_press, 1, sizeof(int) * (size_t)h->nblocks, s));
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
         SPH_LAUNCH_RM0(k_pci_predict_rho, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
@@ -2032,7 +2039,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
                 SPH_LAUNCH_RM0(k_pci_press, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
-                               EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt);
+                               EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt, zero_press);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
             if ((rc = ghosts_xyz(PP))) return rc;

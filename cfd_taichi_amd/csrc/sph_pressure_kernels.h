@@ -352,6 +352,15 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
     PP[i] = make_float4(pp[0], pp[1], pp[2], 0.f);
 }
 
+// Tiles without pressure in the PCISPH pressure loop (round 3; the idea of the DFSPH density loop, sph_kernels.h: stage_sources_flagged).
+// press_iter = max(0, press_iter + delta * (rho_predict - rho0)) and the reference's density sum has no self term: early in a collapse the
+// pressure is 0 nearly everywhere (6 % of the particles of pcisph_1m carry one at step 60, 29 % at step 100: tools/pci_sparsity.py).
+// k_pci_press of a tile whose staged pressures are all 0 produces press_force = 0 and the zero-pressure prediction; if its outputs already
+// hold those (zero_press[tile]: set by k_pci_ext's values at the start of a step, kept by this sweep) it returns.  Bit-identical
+// (SPH_TILE_SKIP=0); single-GPU staged handles without rigid entries.  pcisph_1m steps 21-120: press sweep 68 -> 52 us, 137 -> 152
+// Mparticle-steps/s.  The same for predict_rho (skip when no staged predicted position was rewritten, the own pressures are and stay 0 and the
+// ping-pong destination already holds the zeros) was built and measured: at tile granularity the rewritten set dilates to everything,
+// no tile ever returned, and the check cost 3 us per launch -- not kept.
 // predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
 //   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
 template <bool RIGID, int SWEEP>
@@ -410,13 +419,25 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
                                                       const float4 *__restrict__ V, const float4 *__restrict__ EF,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ PF,
-                                                      float4 *__restrict__ PP, int gate, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                      float4 *__restrict__ PP, int gate, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt,
+                                                      int *__restrict__ zero_press)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    SPH_SWEEP_PROLOGUE_M(QUAD)
-    const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
+    const bool track = STAGED && !RIGID && zero_press != nullptr;          // tiles without pressure, see the note above k_pci_predict_rho
+    SPH_SWEEP_PROLOGUE_B(QUAD, track ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
+    bool staged, all_zero = false;
+    if (track) {
+        const int was_zero = zero_press[blk];                      // PF / PP of this tile hold the zero-pressure values (read before the barriers below)
+        const int verdict = stage_operand_w_checked<false>(c, s_operand, P, stage_src, stage_cnt, blk);
+        all_zero = verdict == 2;                                   // every pressure this tile can see is 0: every term below is +-0
+        if (all_zero && was_zero) return;                          // ... and its outputs already say so
+        if (threadIdx.x == 0) zero_press[blk] = all_zero ? 1 : 0;
+        staged = verdict != 0;
+    } else {
+        staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
+    }
     const float p_i = pi.w;
     constexpr float kRho0Sq = 1000000.0f;                    // self.rho_0 ** 2 (Python int)
     constexpr float kRcpRho0Sq = 1.0f / 1000000.0f;
@@ -438,12 +459,14 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
         fy += div_const(ps * g.y, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
         fz += div_const(ps * g.z, kRho0Sq, kRcpRho0Sq) * c.m * c.m;
     };
-    if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
+    // (all_zero: the sums would be +0 + (+-0 terms) = +0, the accumulators as they stand)
+    if (all_zero) {}
+    else if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
     else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float wa[3] = {0.f, 0.f, 0.f};
     float &bx = wa[0], &by = wa[1], &bz = wa[2];
-    if (c.boundary_handle) {
+    if (c.boundary_handle && !all_zero) {
         const float rho_i_2 = rho_own * rho_own;             // :221
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;

@@ -180,6 +180,30 @@ def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, 
         sim.close()
 
 
+@pytest.mark.parametrize("scene,steps,cap", [("breaking_dam_30k_pcisph", 40, "1664"), ("dfsph_tiny_wall_pcisph", 150, "1664"), ("breaking_dam_30k_pcisph", 45, "300")])
+def test_pcisph_change_propagation_is_invisible(scene, steps, cap, monkeypatch):
+    """The same idea in the PCISPH pressure loop (sph_pressure_kernels.h, k_pci_press): tiles whose staged pressures are all 0 and whose
+    outputs already hold the zero-pressure values skip update_press_force.  SPH_TILE_SKIP=0 computes everything: same state, pressures,
+    iteration counts and residuals."""
+    cfg = scenes.get(scene)
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    sims = []
+    for skip in ("1", "0"):
+        monkeypatch.setenv("SPH_TILE_SKIP", skip)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg)))
+    iters = []
+    for s_ in range(steps):
+        a, b = sims[0].step_pcisph(1), sims[1].step_pcisph(1)
+        assert (a.n_dens, a.dens_err) == (b.n_dens, b.dens_err), (scene, s_, a.n_dens, b.n_dens)
+        iters.append(a.n_dens)
+    for f in FIELDS + (nat.F_PRESS_ITER, nat.F_PRESS_FORCE, nat.F_POS_PREDICT):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
+    assert max(iters) >= 3
+    for sim in sims:
+        sim.close()
+
+
 @pytest.mark.parametrize("cap", ["1664", "200"])
 def test_lds_staging_with_a_rigid_body(cap, monkeypatch):
     """Tagged rigid entries stay global inside staged lists; the coupled run equals the unstaged one, body included."""
