@@ -2,10 +2,12 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
 from cfd_taichi_amd import _native as nat, scenes
-sim = nat.Simulation(nat.config_from_dict(scenes.get("pcisph_1m")))
+scene = sys.argv[1] if len(sys.argv) > 1 else "pcisph_1m"
+sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
+step = sim.step_pcisph if "pcisph" in scene else sim.step_iisph
 for target in (30, 60, 100):
     while sim.scalar(nat.S_SIMULATE_CNT) < target:
-        st = sim.step_pcisph(1)
+        st = step(1)
     pr = sim.download(nat.F_PRESS_ITER)
     pos = sim.download(nat.F_POS)
     ids, lpos = sim.download_local(nat.F_POS)
