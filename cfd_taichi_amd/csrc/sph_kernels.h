@@ -1221,7 +1221,8 @@ __device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs
 // The first D6 of a step computes everywhere (`force_all`).  Bit-identical to computing everything (SPH_TILE_SKIP=0;
 // tests/test_cell_order_gpu.py::test_density_loop_change_propagation_is_invisible), up to the sign of a zero velocity component
 // (v - (-0) = +0 where the skipped sweep keeps -0).  Staged handles without rigid entries, slabs included: a wave that holds a ghost
-// counts as changed in every iteration (its owner may have moved its v*), so the tiles along a cut always recompute.
+// counts as changed in every iteration (its owner may have moved its v*), so the tiles along a cut always recompute.  Rigid entries fit in:
+// the body's term of D7 is proportional to the particle's own k, and D6 sees the body at rest within a solver loop.
 __device__ __forceinline__ bool stage_sources_flagged(const uint2 *__restrict__ stage_runs, int sw, int blk, const int *__restrict__ wave_flags)
 {
     const int nruns = sw >> 16;
@@ -1828,7 +1829,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && !RIGID && c.kr_split;
-    const bool track = MODE == CORR_DENS && STAGED && !RIGID && wave_dirty != nullptr;   // change propagation in the density loop (stage_sources_flagged)
+    // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
+    const bool track = MODE == CORR_DENS && STAGED && wave_dirty != nullptr;
     bool staged;
     if (track) {
         const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk)
@@ -1946,7 +1948,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
-    const bool spread = DENS && STAGED && !RIGID && wave_dirty && !force_all;      // (see k_correct: round-robin tiles when most of them return at once)
+    // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
+    const bool spread = DENS && STAGED && wave_dirty && !force_all;
     if (spread) {                                                    // change propagation, see stage_sources_flagged
         const int tb = (int)blockIdx.x, sw = stage_cnt[tb];
         if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tb, wave_dirty)) {             // rho*, k / rho and the block partial of the last iteration stand

@@ -1632,8 +1632,8 @@ int check_overflow_all(SphHandle *h)
 }
 
 // ---- DFSPH launch helpers (buffer roles: see stage_density) --------------------------------------------------
-// tiles of the density loop whose inputs did not change are not recomputed (staged handles without rigid entries)
-inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged && !rigid_coupled(h); }
+// tiles of the density loop whose inputs did not change are not recomputed (staged dfsph handles)
+inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277

@@ -204,6 +204,33 @@ def test_pcisph_change_propagation_is_invisible(scene, steps, cap, monkeypatch):
         sim.close()
 
 
+def test_density_loop_change_propagation_with_a_rigid_body(monkeypatch):
+    """... and with rigid entries in the lists (the body's term of the correction is proportional to the particle's own stiffness, and the
+    body is at rest within a solver loop): coupled steps with and without SPH_TILE_SKIP, body included."""
+    cfg = scenes.get("dfsph_rigid_small")
+    rg = mesh.rigid_from_config(cfg)
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    sims = []
+    for skip in ("1", "0"):
+        monkeypatch.setenv("SPH_TILE_SKIP", skip)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg), rigid=rg))
+    n_dens = []
+    for s_ in range(120):
+        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
+        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), s_
+        n_dens.append(a.n_dens)
+        sims[0].rigid_step(); sims[1].rigid_step()
+    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f)), f
+    assert np.array_equal(sims[0].download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), sims[1].download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID))
+    ra, rb = sims[0].rigid_scalars(), sims[1].rigid_scalars()
+    for k in ("centroid", "omega", "vel"):
+        assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), k
+    assert max(n_dens) >= 3
+    for sim in sims:
+        sim.close()
+
+
 @pytest.mark.parametrize("cap", ["1664", "200"])
 def test_lds_staging_with_a_rigid_body(cap, monkeypatch):
     """Tagged rigid entries stay global inside staged lists; the coupled run equals the unstaged one, body included."""
