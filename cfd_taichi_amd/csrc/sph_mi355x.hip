@@ -95,7 +95,7 @@ struct SphHandle {
     // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
     int *wave_dirty = nullptr;                   // per 64-particle wave: did the last density correction change a velocity there?
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
-    int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press)
+    int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press); iisph: "d_ij holds zeros" (k_ii_dij)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
     // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
@@ -717,7 +717,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
             }
-            if (h->cfg.solver == SPH_SOLVER_PCISPH && !h->slab && h->opt_tile_skip)
+            if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
                 if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
@@ -2107,13 +2107,15 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
         SPH_LAUNCH_RM0(k_ii_rho_adv, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
                        DII, h->warm[h->wcur], h->rho_adv, h->aux, PB[0], rv, h->stage_src, h->stage_cnt);
     }
+    int *zero_dij = (h->pci_zero_press && h->staged && !h->slab) ? h->pci_zero_press : nullptr;      // tiles without pressure skip compute_all_d_ij (k_ii_dij)
+    if (zero_dij) HIP_TRY(h, hipMemsetAsync(zero_dij, 0, sizeof(int) * (size_t)h->nblocks, s));      // DIJ still holds last step's sums
     bool first = true;
     for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
                 SPH_LAUNCH_RM0(k_ii_dij, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
-                               DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt);
+                               DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt, zero_dij);
             }
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {

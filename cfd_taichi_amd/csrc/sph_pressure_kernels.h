@@ -129,6 +129,30 @@ __device__ __forceinline__ bool stage_operand_scalar(const Consts &c, float4 *__
     __syncthreads();
     return true;
 }
+// the same, reporting whether any staged A.w is != 0: 0 = not staged, 1 = staged, 2 = staged and every A.w is 0 (k_ii_dij: see there)
+__device__ __forceinline__ int stage_operand_scalar_checked(const Consts &c, float4 *__restrict__ s_A, float *__restrict__ s_S, const float4 *__restrict__ A,
+                                                            const float *__restrict__ S, const uint2 *__restrict__ stage_runs,
+                                                            const int *__restrict__ stage_cnt, int blk)
+{
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 2;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+    int any = 0;
+#pragma unroll
+    for (int t = 0; t < kStageTrips; ++t) {
+        const int base = threadIdx.x + t * kStageBatch * kBlock;
+        if (t * kStageBatch * kBlock >= nst) break;
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u)
+            if (base + u * kBlock < nst) {
+                const float4 a = A[x.j[t][u]];
+                any |= a.w != 0.f;
+                s_A[base + u * kBlock] = a; s_S[base + u * kBlock] = S[x.j[t][u]];
+            }
+    }
+    return __syncthreads_or(any) ? 1 : 2;
+}
 template <bool RIGID, class Body>
 __device__ __forceinline__ void for_staged_nbrs_ps2(const uint32_t *__restrict__ base, int cnt, const float4 *__restrict__ s_A,
                                                     const float *__restrict__ s_S, const RigidView &rv, Body body)
@@ -672,16 +696,30 @@ template <bool RIGID, int SWEEP>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                    const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv,
-                                                   const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                   const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, int *__restrict__ zero_dij)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(QUAD)
+    // Tiles without pressure (round 3, as in k_pci_press): d_ij = dt^2 sum_j (-m p_j / rho_j^2) grad W is 0 when every staged pressure is 0
+    // (9 % of the particles of iisph_1m carry one at step 60, 32 % at step 100); a tile whose DIJ already holds the zeros (zero_dij[tile],
+    // cleared at the start of a step) returns.  Rigid entries are not part of this sum (:319).  Bit-identical (SPH_TILE_SKIP=0).
+    const bool track = STAGED && zero_dij != nullptr;
+    SPH_SWEEP_PROLOGUE_B(QUAD, track ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
     (void)kb; (void)nlbp;
     float *s_rho = reinterpret_cast<float *>(s_operand + c.stage_cap);
-    const bool staged = STAGED && stage_operand_scalar(c, s_operand, s_rho, P, rho, stage_src, stage_cnt, blk);
+    bool staged, all_zero = false;
+    if (track) {
+        const int was_zero = zero_dij[blk];
+        const int verdict = stage_operand_scalar_checked(c, s_operand, s_rho, P, rho, stage_src, stage_cnt, blk);
+        all_zero = verdict == 2;
+        if (all_zero && was_zero) return;
+        if (threadIdx.x == 0) zero_dij[blk] = all_zero ? 1 : 0;
+        staged = verdict != 0;
+    } else {
+        staged = STAGED && stage_operand_scalar(c, s_operand, s_rho, P, rho, stage_src, stage_cnt, blk);
+    }
     float fa[3] = {0.f, 0.f, 0.f};
     float &sx = fa[0], &sy = fa[1], &sz = fa[2];
     auto pair = [&](const float4 pj, const float rho_j, const uint32_t j) {
@@ -693,7 +731,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
     };
-    if (QUAD) for_nbrs_ps_quad<RIGID>(nlp, kf, q, fa, P, rho, rv, pair);
+    if (all_zero) {}                                         // (the sums would be +0 + (+-0 terms) = +0)
+    else if (QUAD) for_nbrs_ps_quad<RIGID>(nlp, kf, q, fa, P, rho, rv, pair);
     else if (staged) for_staged_nbrs_ps2<RIGID>(nlp, kf, s_operand, s_rho, rv, pair);
     else for_nbrs_ps<RIGID>(nlp, kf, P, rho, rv, pair);
     if (!owner) return;

@@ -204,6 +204,27 @@ def test_pcisph_change_propagation_is_invisible(scene, steps, cap, monkeypatch):
         sim.close()
 
 
+@pytest.mark.parametrize("scene,steps", [("iisph_config_backup", 150), ("dfsph_tiny_wall_iisph", 150)])
+def test_iisph_tiles_without_pressure_are_invisible(scene, steps, monkeypatch):
+    """... and in IISPH's compute_all_d_ij (k_ii_dij): a tile whose staged pressures are all 0 and whose d_ij already hold the zeros returns."""
+    cfg = scenes.get(scene)
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    sims = []
+    for skip in ("1", "0"):
+        monkeypatch.setenv("SPH_TILE_SKIP", skip)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg)))
+    iters = []
+    for s_ in range(steps):
+        a, b = sims[0].step_iisph(1), sims[1].step_iisph(1)
+        assert (a.n_dens, a.dens_err) == (b.n_dens, b.dens_err), (scene, s_, a.n_dens, b.n_dens)
+        iters.append(a.n_dens)
+    for f in FIELDS + (nat.F_PRESS_ITER, nat.F_D_IJ, nat.F_PRESS_FORCE):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
+    assert max(iters) >= 3
+    for sim in sims:
+        sim.close()
+
+
 def test_density_loop_change_propagation_with_a_rigid_body(monkeypatch):
     """... and with rigid entries in the lists (the body's term of the correction is proportional to the particle's own stiffness, and the
     body is at rest within a solver loop): coupled steps with and without SPH_TILE_SKIP, body included."""
