@@ -180,6 +180,24 @@ def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, 
         sim.close()
 
 
+def test_host_driven_loops_with_change_propagation(monkeypatch):
+    """SPH_HOST_LOOPS=1 drives the DFSPH loops from the host as the reference does (one read-back per iteration); the change propagation
+    of the density loop rides along (the first compute_all_rho_adv of a step computes every tile in either variant): same bits."""
+    cfg = scenes.get("breaking_dam_30k_dfsph")
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    sims = []
+    for host in ("0", "1"):
+        monkeypatch.setenv("SPH_HOST_LOOPS", host)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg)))
+    for s_ in range(70):
+        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
+        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), s_
+    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f)), f
+    for sim in sims:
+        sim.close()
+
+
 @pytest.mark.parametrize("scene,steps,cap", [("breaking_dam_30k_pcisph", 40, "1664"), ("dfsph_tiny_wall_pcisph", 150, "1664"), ("breaking_dam_30k_pcisph", 45, "300")])
 def test_pcisph_change_propagation_is_invisible(scene, steps, cap, monkeypatch):
     """The same idea in the PCISPH pressure loop (sph_pressure_kernels.h, k_pci_press): tiles whose staged pressures are all 0 and whose
