@@ -15,6 +15,7 @@ F_POS, F_VEL, F_ACC, F_RHO, F_PRESSURE, F_ALPHA, F_WARM_K, F_RHO_ADV, F_RHO_DER 
 F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_NBR_COUNT, F_FORCE_EXT = range(9, 16)
 F_PRESS_ITER, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_A_II, F_D_IJ = range(16, 22)
 F_PBF_LAMBDA, F_PBF_DELTA_POS = 22, 23
+F_P_PAST = 24
 F_WALL_POS, F_WALL_VOL = 32, 33
 F_RIGID_POS, F_RIGID_VOL, F_RIGID_FORCE, F_RIGID_MASS, F_RIGID_VERT = 48, 49, 50, 51, 52
 _VEC_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_VISCOSITY, F_TENSION, F_PGRAD, F_BACC, F_FORCE_EXT, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT,

@@ -614,6 +614,7 @@ static real *field_ptr(Orc *o, int field, long *count, int *is_int)
     case ORC_F_D_IJ: *count = o->d_ij ? 3L * o->N : -1; return o->d_ij;
     case ORC_F_PBF_LAMBDA: *count = o->pbf_lambda ? o->N : -1; return o->pbf_lambda;
     case ORC_F_PBF_DELTA_POS: *count = o->pbf_dpos ? 3L * o->N : -1; return o->pbf_dpos;
+    case ORC_F_P_PAST: *count = o->p_past ? o->N : -1; return o->p_past;
     case ORC_F_WALL_POS: *count = 3L * o->Nb; return o->bpos;
     case ORC_F_WALL_VOL: *count = o->Nb; return o->bvol;
     case ORC_F_NBR_COUNT: *count = o->N; *is_int = 1; return NULL;

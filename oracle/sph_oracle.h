@@ -59,6 +59,7 @@ enum {
     ORC_F_PRESS_FORCE = 17,  /* pcisph press_force / iisph f_press */
     ORC_F_POS_PREDICT = 18, ORC_F_D_II = 19, ORC_F_A_II = 20, ORC_F_D_IJ = 21,
     ORC_F_PBF_LAMBDA = 22, ORC_F_PBF_DELTA_POS = 23,
+    ORC_F_P_PAST = 24,            /* iisph: last step's pressure (iisph_solver.py:209-210), what a hand-over has to carry */
     ORC_F_WALL_POS = 32, ORC_F_WALL_VOL = 33,
     ORC_F_RIGID_POS = 48, ORC_F_RIGID_VOL = 49, ORC_F_RIGID_FORCE = 50, ORC_F_RIGID_MASS = 51, ORC_F_RIGID_VERT = 52
 };

@@ -10,6 +10,8 @@ and both continue: bit-equal state, iteration counts and residuals.
   config 2  wcsph_250k       150 device steps, then 5 steps on both
   config 5  dfsph_rigid_2m   2 coupled steps from rest on both at full size (2 006 400 fluid + 123 k rigid samples)
   config 4  dfsph_10m        50 device steps, then 1 step on both           (oracle: about a minute)
+  config 3  dfsph_1m         150 device steps (late in the default line's window 71-170), then 2 steps on both
+  pcisph_1m / iisph_1m       40 and 120 device steps, then 2 steps on both (pcisph: pos, vel; iisph: pos, vel and last step's pressure)
 """
 import os
 import time
@@ -80,6 +82,47 @@ def test_dfsph_1m_steps_56_to_58_bit_exact():
     o = hand_over_dfsph(sim, cfg)
     counts = dfsph_steps_equal(sim, o, 3, "dfsph_1m @55")
     assert min(c[1] for c in counts) >= 8
+    sim.close(); o.close()
+
+
+def test_dfsph_1m_steps_151_to_152_bit_exact():
+    """Config 3 late in the window of bench.py's default line (steps 71-170): the column has hit the far wall, spray and ragged cells
+    everywhere, change propagation busy in the density loop."""
+    cfg = scenes.get("dfsph_1m")
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    pre = [sim.step_dfsph(1) for _ in range(150)]
+    assert all(s.lost == 0 and s.capped == 0 for s in pre)
+    o = hand_over_dfsph(sim, cfg)
+    dfsph_steps_equal(sim, o, 2, "dfsph_1m @150")
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("pre_steps", [40, 120])
+@pytest.mark.parametrize("scene,solver", [("pcisph_1m", "pcisph"), ("iisph_1m", "iisph")])
+def test_pressure_solvers_1m_mid_run_bit_exact(scene, solver, pre_steps):
+    """PCISPH / IISPH at 1 M away from rest (tests/test_fullsize_gpu.py meets the oracle in steps 1-2 only): 40 or 120 device steps (the
+    second inside the window 71-170 their bench lines time), hand-over, 2 steps on both.  pcisph carries positions and velocities (pressures restart at 0 every step, pcisph_solver.py:247-250), iisph
+    also last step's pressure (iisph_solver.py:68, 209-210)."""
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    g_step = sim.step_pcisph if solver == "pcisph" else sim.step_iisph
+    pre = [g_step(1) for _ in range(pre_steps)]
+    assert all(s.lost == 0 for s in pre)           # (pcisph at 1 M runs into the reference's cap of 80 iterations now and then: that is the reference)
+    o = orc.Oracle(cfg, solver=solver, num_threads=cores())
+    o_step = o.step_pcisph if solver == "pcisph" else o.step_iisph
+    o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
+    if solver == "iisph":
+        o.set(orc.F_P_PAST, sim.download(nat.F_PRESS_ITER))
+    for s in range(2):
+        t0 = time.time()
+        st = g_step(1)
+        o_step(1)
+        assert (st.n_dens, st.dens_err) == (o.last_stats.n_dens, o.last_stats.dens_err), (scene, s)
+        print("%s @%d: step +%d iterations %d, %.1f s" % (scene, pre_steps, s + 1, st.n_dens, time.time() - t0), flush=True)
+    label = "%s @%d: " % (scene, pre_steps)
+    same(sim.download(nat.F_PRESS_ITER), o.get(orc.F_PRESS_ITER), label + "pressure")
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), label + "pos")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), label + "vel")
     sim.close(); o.close()
 
 
