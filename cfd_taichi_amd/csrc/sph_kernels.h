@@ -996,6 +996,34 @@ __device__ __forceinline__ void for_nbrs_p_quad(const uint32_t *__restrict__ bas
     walk_list_quad<N, Operand1>(base, cnt, q, acc, [&](uint32_t j, Operand1 &o) { o.a = A[j]; }, [&](const Operand1 &o, uint32_t) { body(o.a); });
 }
 
+// ---- the wall terms of the DFSPH solver loops from a per-step cache ------------------------------------------------------------
+// Walls are static and the positions are frozen between the list build and the integrator, so grad W_ib of a (particle, wall
+// particle) pair is the same f32 triple in every sweep of a step: D1 (k_density<DFSPH>) evaluates it anyway and leaves
+// (grad W_ib, V_b) in wall_gc, laid out like the wall list it belongs to -- entry k of particle i at gc_index(i, k): a wave's
+// row is 1 KiB contiguous -- and D2-D7 read it back instead of gathering the wall particle and re-deriving the gradient (~65
+// instructions per pair in the exact arithmetic).  Same bits: the same function of the same inputs, evaluated once.
+__device__ __forceinline__ size_t gc_index(int i, int k, int pitch) { return ((size_t)(i >> 6) * pitch + k) * 64 + (size_t)(i & 63); }
+template <int DEPTH = 4, class Body>
+__device__ __forceinline__ void for_wall_cache(const float4 *__restrict__ base, int cnt, Body body)
+{
+    if (cnt <= 0) return;
+    // rows in groups of DEPTH, the next group requested before the bodies of this one run (each row is its own trip to HBM); the group past the
+    // end reads stale but mapped rows (the rest of the pitch, the next tile's first rows, the spare tile behind the last one)
+    float4 cur[DEPTH], nxt[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) cur[u] = base[(size_t)u * 64];
+    for (int k = 0; k < cnt; k += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) nxt[u] = base[(size_t)(k + DEPTH + u) * 64];
+        body(cur[0]);
+#pragma unroll
+        for (int u = 1; u < DEPTH; ++u)
+            if (k + u < cnt) body(cur[u]);
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) cur[u] = nxt[u];
+    }
+}
+
 // block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
 __device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
 {
@@ -1626,7 +1654,8 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
                                                     float *__restrict__ rho_out, float *__restrict__ aux_out,
                                                     float4 *__restrict__ Pout, float4 *Vout, RigidView rv,
                                                     const int *__restrict__ id, float *__restrict__ rho_orig,
-                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho)
+                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
+                                                    float4 *__restrict__ wall_gc)
 {
     constexpr bool STAGED = MODE == SWEEP_STAGED, QUAD = MODE == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
@@ -1654,6 +1683,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float wa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     float &rho_b = wa[0], &bx = wa[1], &by = wa[2], &bz = wa[3], &bsq = wa[4];
+    float4 *gcw = (DFSPH && !QUAD && wall_gc) ? wall_gc + gc_index(ii, 0, c.kbpitch) : nullptr;   // bodies run in list order: entry k goes to row k
     auto wall = [&](const float4 pj) {                       // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
@@ -1664,6 +1694,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
             float rx = cc * g.x, ry = cc * g.y, rz = cc * g.z;
             bx += rx; by += ry; bz += rz;
             bsq += (rx * rx + ry * ry) + rz * rz;
+            if (!QUAD && gcw) { *gcw = make_float4(g.x, g.y, g.z, pj.w); gcw += 64; }     // the solver loops' wall terms (for_wall_cache)
         }
     };
     if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
@@ -1819,7 +1850,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                    int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8)
+                                                    int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
@@ -1904,6 +1935,11 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         bx += s * g.x; by += s * g.y; bz += s * g.z;
     };
     if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
+    else if (wall_gc)
+        for_wall_cache(wall_gc + gc_index(ii, 0, c.kbpitch), kb, [&](const float4 gv) {       // (grad W_ib, V_b) as D1 left them
+            float s = gv.w * k_i / rho_i;
+            bx += s * gv.x; by += s * gv.y; bz += s * gv.z;
+        });
     else for_nbrs_p(nlbp, kb, WP, wall);
     if (track) {       // did any lane of this wave apply a correction?  (all sums +-0: v - (+-0) * dt leaves v)
         // (a ghost's v* is refreshed from its owner after this sweep: it may change behind this rank's back)
@@ -1943,7 +1979,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                     const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all)
+                                                     const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
+                                                     const float4 *__restrict__ wall_gc)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
@@ -2009,6 +2046,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
     };
     if (QUAD) for_nbrs_p_quad(nlbp, skip ? 0 : kb, q, wa, WP, wall);
+    else if (wall_gc)
+        for_wall_cache(wall_gc + gc_index(ii, 0, c.kbpitch), skip ? 0 : kb, [&](const float4 gv) {
+            accb += gv.w * dot3(vi.x, vi.y, vi.z, gv.x, gv.y, gv.z);
+        });
     else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);
     float val = 0.f;
     int flag = 0;

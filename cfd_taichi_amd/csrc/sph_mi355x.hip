@@ -92,6 +92,8 @@ struct SphHandle {
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
     float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
+    float4 *wall_gc = nullptr;                   // exact dfsph sweeps: (grad W_ib, V_b) per wall-list entry, written by D1 (for_wall_cache)
+    bool opt_wall_cache = true;                  // SPH_WALL_CACHE=0 at sph_create: D2-D7 walk the wall lists themselves (A/B, tests)
     // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
     int *wave_dirty = nullptr;                   // per 64-particle wave: did the last density correction change a velocity there?
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
@@ -614,6 +616,8 @@ inline size_t sweep_lds(const SphHandle *h, size_t bytes_per_staged) { return h-
 inline RigidView rigid_view_or_none(const SphHandle *h);
 
 inline bool is_dfsph(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH; }
+// (grad W_ib, V_b) of every wall-list entry, written by D1 and read by D2-D7 of the same step (for_wall_cache); nullptr: the sweeps walk the wall lists
+inline float4 *wall_cache(const SphHandle *h) { return h->wall_gc; }
 inline bool is_pressure_solver(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH; }
 // solvers with a per-particle scalar that must follow the particle through the sort: dfsph warm_start_k, iisph p_past
 inline bool carries_scalar(const SphHandle *h) { return h->cfg.solver == SPH_SOLVER_DFSPH || h->cfg.solver == SPH_SOLVER_IISPH; }
@@ -705,6 +709,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     // one spare 64-particle tile at the end: the software-pipelined walks read one row ahead
     if ((rc = dalloc(h, &h->nl, (n + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->nlb, (n + 64) * (size_t)c.kbpitch))) return rc;
+    // the wall terms of the solver loops from a per-step cache: 16 B per wall-list row (1 GiB per million particles at 64 rows, allocated like the list
+    // itself; only the rows of particles next to a wall are ever touched).  Not for quad sweeps (small scenes), not where the relaxed sweeps run.
+    const bool want_wall_cache = h->cfg.solver == SPH_SOLVER_DFSPH && c.boundary_handle && h->Nb > 0 && h->opt_wall_cache;
     {
         // LDS staging of the gather operands (plan in k_build_nl): DFSPH, PCISPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
         const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
@@ -722,6 +729,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
         }
+        if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad)
+            if ((rc = dalloc(h, &h->wall_gc, (n + 64) * (size_t)c.kbpitch))) return rc;
     }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
@@ -1565,12 +1574,12 @@ int stage_density(SphHandle *h)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
         SPH_LAUNCH_RM(k_density, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
+                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho, wall_cache(h));
     } else {
         ProfScope ps(h, K_W_DENSITY);
         SPH_LAUNCH_RM(k_density, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, (const float *)nullptr, h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho);
+                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho, (float4 *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
@@ -1647,7 +1656,8 @@ void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
+                  (const float4 *)wall_cache(h));
 }
 
 template <int MODE>
@@ -1663,7 +1673,8 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
-                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8);
+                  h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
+                  (const float4 *)wall_cache(h));
 }
 
 void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -1680,7 +1691,7 @@ void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_ad
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h));
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -2337,6 +2348,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
+    { const char *e = getenv("SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = getenv("SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }

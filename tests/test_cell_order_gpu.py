@@ -180,6 +180,36 @@ def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, 
         sim.close()
 
 
+@pytest.mark.parametrize("scene,steps,order,cap,quad", [("breaking_dam_30k_dfsph", 80, "morton", "1664", "1"), ("dfsph_small", 100, "morton", "300", "1"),
+                                                        ("dfsph_dam_x", 150, "morton", "1664", "1"), ("breaking_dam_30k_dfsph", 40, "linear", "1664", "0"),
+                                                        ("dfsph_rigid_small", 100, "morton", "1664", "1"), ("dfsph_rigid_small", 60, "linear", "1664", "0")])
+def test_wall_gradient_cache_is_invisible(scene, steps, order, cap, quad, monkeypatch):
+    """Round 3: D1 leaves (grad W_ib, V_b) of every wall-list entry in a per-step cache and the sweeps of the solver loops read it back
+    instead of gathering the wall particle and re-deriving the gradient (for_wall_cache, sph_kernels.h).  SPH_WALL_CACHE=0 makes them walk
+    the wall lists as before: same state, iteration counts and residuals -- staged sweeps, mixed staged / unstaged capacity, the plain
+    one-lane-per-particle sweeps in the reference's cell order, and with a rigid body in the lists."""
+    cfg = scenes.get(scene)
+    rg = mesh.rigid_from_config(cfg) if "rigid" in scene else None
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    monkeypatch.setenv("SPH_CELL_ORDER", order)
+    monkeypatch.setenv("SPH_QUAD", quad)
+    sims = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("SPH_WALL_CACHE", on)
+        sims.append(nat.Simulation(nat.config_from_dict(cfg), rigid=rg))
+    for s_ in range(steps):
+        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
+        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), (scene, s_)
+        if rg is not None:
+            assert np.array_equal(sims[0].download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), sims[1].download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)), s_
+            for sim in sims:
+                sim.rigid_step()
+    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K, nat.F_ALPHA):
+        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
+    for sim in sims:
+        sim.close()
+
+
 def test_host_driven_loops_with_change_propagation(monkeypatch):
     """SPH_HOST_LOOPS=1 drives the DFSPH loops from the host as the reference does (one read-back per iteration); the change propagation
     of the density loop rides along (the first compute_all_rho_adv of a step computes every tile in either variant): same bits."""

@@ -24,6 +24,7 @@ PATCHES = {
     "nofluid": [(K, "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);",
                  "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
     "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
+    "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
                   "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],
