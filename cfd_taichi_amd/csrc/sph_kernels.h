@@ -28,6 +28,20 @@ __device__ __forceinline__ int xcd_block(int orig, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// The sweeps of the DFSPH solver loops (k_correct, k_residual and their relaxed forms) on large grids: chunks of 32 consecutive tiles dealt
+// round-robin over the XCDs.  Neighbouring tiles still share an L2 (their halos overlap), and the XCDs finish together whatever the scene
+// looks like (under the contiguous eighths one XCD gets the floor layer with its wall terms, another one spray).  Measured at 1 M particles,
+// chunks of 16 / 32 / 64 / 128 tiles (profiles/r03/tune_xcd_chunk.log): residual 60.0 -> 59.2 us, correction 52.1 -> 50.9 us at 16-64, nothing
+// at 128; the list build loses 4 % under the same mapping and keeps the eighths.  Bijective for any grid size (tail: identity).
+__device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
+{
+    constexpr int C = 32;
+    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);
+    if (per < 4) return xcd_block(orig, nwg);
+    if (s >= per * C) return orig;
+    return ((s / C) * 8 + xcd) * C + s % C;
+}
+
 // Neighbour lists are stored per 64-particle wave tile, four rows interleaved per lane:
 //   entry (i, k) lives at ((i/64)*kmax + (k & ~3))*64 + (i%64)*4 + (k & 3)
 // so a lane fetches neighbours k..k+3 with ONE 16-byte load, a wave's load is 1 KiB contiguous, and
@@ -1857,7 +1871,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
-    SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && !RIGID && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
@@ -1993,7 +2007,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             return;
         }
     }
-    SPH_SWEEP_PROLOGUE_B(QUAD, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(QUAD, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")

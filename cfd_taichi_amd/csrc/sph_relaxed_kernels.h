@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
         }
     }
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
     (void)nlbp;
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_B(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
     bool staged;

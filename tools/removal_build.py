@@ -25,6 +25,11 @@ PATCHES = {
                  "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
     "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
     "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
+    # CORRECT variants (speed only): the chunk size of xcd_sweep_block (the product has 32)
+    "xcd_chunk16": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 16;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
+    "xcd_chunk64": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 64;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
+    "xcd_chunk128": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 128;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
+    "xcd_eighths": [(K, "    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;", "    if (per >= 0) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
                   "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],
