@@ -30,6 +30,18 @@ PATCHES = {
     "xcd_chunk64": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 64;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
     "xcd_chunk128": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 128;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
     "xcd_eighths": [(K, "    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;", "    if (per >= 0) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;")],
+    # exact k_residual: workgroups whose set did not fit the LDS capacity (1-2 % of them at 1 M) return at once: what do they cost the launch?
+    "nounstaged": [(K, "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n    }",
+                    "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
+    # a CORRECT variant with a side effect: every workgroup of the exact divergence-residual sweep leaves (begin, end, XCC id) of its life in a
+    # device array that sph_debug_timeline() copies out (tools/wg_timeline.py): how full is the chip over a launch, where is the tail?
+    "wg_timeline": [(K, "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// ======================================================================================\n// D5:",
+                     "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = xcc & 15; g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// ======================================================================================\n// D5:"),
+                    (K, "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) return;\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
+                     "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) return;\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
+                    (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
+                    ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
+                     "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
                   "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Life of every workgroup of one divergence-residual launch (ab/libsph_wg_timeline.so from tools/removal_build.py wg_timeline):
+how many workgroups are in flight over the launch, how long they live, per XCD when the last one ends.
+
+    python tools/removal_build.py wg_timeline && python tools/wg_timeline.py [scene] [advance_steps]"""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["SPH_LIB"] = os.path.join(ROOT, "ab", "libsph_wg_timeline.so")
+from cfd_taichi_amd import _native as nat, scenes  # noqa: E402
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "dfsph_1m"
+advance = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+sim = nat.Simulation(nat.config_from_dict(scenes.get(scene)))
+sim.step_dfsph(advance)
+sim.build_neighbors()
+for _ in range(3):
+    us = sim.tune_time(0, 0, 1)
+nwg = (sim.n_fluid + 255) // 256
+buf = np.zeros((nwg, 4), dtype=np.uint64)
+lib = nat.load()
+lib.sph_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.sph_debug_timeline(buf.ctypes.data, nwg) == 0
+t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 1].astype(np.int64); xcc = buf[:, 2].astype(np.int64); tile = buf[:, 3].astype(np.int64)
+base = t0.min()
+b, e = (t0 - base) / 100.0, (t1 - base) / 100.0          # wall_clock64: 100 MHz -> us
+life = e - b
+out = {"scene": scene, "step": advance + 1, "workgroups": int(nwg), "launch_us_events": us, "span_us": float(e.max()),
+       "life_us": {"mean": float(life.mean()), "p10": float(np.percentile(life, 10)), "p50": float(np.percentile(life, 50)),
+                   "p90": float(np.percentile(life, 90)), "p99": float(np.percentile(life, 99)), "max": float(life.max())},
+       "sum_life_over_span_x_slots": float(life.sum() / (e.max() * 1024)),
+       "per_xcd": {}}
+for x in sorted(set(xcc.tolist())):
+    m = xcc == x
+    out["per_xcd"][str(x)] = {"workgroups": int(m.sum()), "first_begin_us": float(b[m].min()), "last_end_us": float(e[m].max()), "sum_life_us": float(life[m].sum())}
+# in flight over time
+grid = np.arange(0, e.max(), 1.0)
+out["in_flight_every_us"] = [int(((b <= t) & (e > t)).sum()) for t in grid]
+# the slowest workgroups: who are they?
+slow = np.argsort(-life)[:12]
+out["slowest"] = [{"blockIdx": int(i), "tile": int(tile[i]), "xcd": int(xcc[i]), "begin_us": float(b[i]), "life_us": float(life[i])} for i in slow]
+print(json.dumps(out))
