@@ -189,7 +189,7 @@ __device__ __forceinline__ F3 grad_w(const Consts &c, float dx, float dy, float 
 
 // The same two functions for a pair taken from a neighbour list and evaluated at the positions the list was built from: list
 // membership is |x_ij| <= h exactly (r2_cut), so q = RN(r/h) <= 1 unless it is NaN, and NaN fails `1e-5 < q` as well: the gradient
-// needs two compares instead of four.  (PCISPH / IISPH sweeps at PREDICTED positions must use the general forms.)
+// needs two compares instead of four.  (The PCISPH sweeps at PREDICTED positions must use the general forms; IISPH never moves a particle inside a step and uses these.)
 __device__ __forceinline__ float cubic_w_in(const Consts &c, float r)
 {
     float q = div_by_h(c, r);

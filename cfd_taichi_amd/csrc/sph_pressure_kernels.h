@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const float sr = -pj.w * c.rho0 / (rho_i * rho_i);             // compute_d_ii :286
             ex += sr * g.x; ey += sr * g.y; ez += sr * g.z;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
             return;
         }
         ex += s_f * g.x; ey += s_f * g.y; ez += s_f * g.z;
-        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        float st = c.tens_c * cubic_w_in(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
         float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             float s = -pj.w / den;                           // compute_boundary_d_ii :292
             bx += s * g.x; by += s * g.y; bz += s * g.z;
         };
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;   // d_ii[i] - d_ji; gradW(-q) = -gradW(q)
         if (RIGID && (j & kRigidTag)) {
             const F3 w = rigid_velocity(rv, pj, dt, true);                             // compute_rho_adv :337-339
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             rb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                        // compute_rho_adv_boundary :349
             float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;
             ab += pj.w * dot3(ex, ey, ez, g.x, g.y, g.z);                              // compute_a_ii_boundary :322
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
         if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         const float a = c.neg_m * pj.w;                      // - m * p_iter[j]
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     auto pair = [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
         float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        F3 g = grad_w_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             sum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor :261
             return;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
             float r = norm3(dx, dy, dz);
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = grad_w_in(c, dx, dy, dz, r);
             bsum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor_boundary :240
         };
         if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
