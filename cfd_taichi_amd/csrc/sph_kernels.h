@@ -28,18 +28,14 @@ __device__ __forceinline__ int xcd_block(int orig, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-// The sweeps of the DFSPH solver loops (k_correct, k_residual and their relaxed forms) on large grids: chunks of 32 consecutive tiles dealt
-// round-robin over the XCDs.  Neighbouring tiles still share an L2 (their halos overlap), and the XCDs finish together whatever the scene
-// looks like (under the contiguous eighths one XCD gets the floor layer with its wall terms, another one spray).  Measured at 1 M particles,
-// chunks of 16 / 32 / 64 / 128 tiles (profiles/r03/tune_xcd_chunk.log): residual 60.0 -> 59.2 us, correction 52.1 -> 50.9 us at 16-64, nothing
-// at 128; the list build loses 4 % under the same mapping and keeps the eighths.  Bijective for any grid size (tail: identity).
+// The sweeps of the DFSPH solver loops (k_correct, k_residual and their relaxed forms).  Tried instead of the contiguous eighths: chunks of C
+// consecutive tiles dealt round-robin over the XCDs (the XCDs then finish together whatever the scene looks like).  At 1 M particles chunks of
+// 16-64 tiles were 1.5-2 % faster (residual 64.0 -> 62.5 us, correction 51.3 -> 50.2 us; 128: nothing; profiles/r03/tune_xcd_chunk*.log) but
+// moved 19 % more HBM bytes per launch (139 -> 166 MB: the halos of tiles on either side of a chunk boundary are fetched by two L2s) -- not kept.
+// tools/removal_build.py xcd_chunk32 rebuilds the variant.
 __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 {
-    constexpr int C = 32;
-    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);
-    if (per < 4) return xcd_block(orig, nwg);
-    if (s >= per * C) return orig;
-    return ((s / C) * 8 + xcd) * C + s % C;
+    return xcd_block(orig, nwg);
 }
 
 // Neighbour lists are stored per 64-particle wave tile, four rows interleaved per lane:

@@ -25,11 +25,16 @@ PATCHES = {
                  "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
     "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
     "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
-    # CORRECT variants (speed only): the chunk size of xcd_sweep_block (the product has 32)
-    "xcd_chunk16": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 16;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
-    "xcd_chunk64": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 64;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
-    "xcd_chunk128": [(K, "    constexpr int C = 32;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);", "    constexpr int C = 128;\n    const int xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);")],
-    "xcd_eighths": [(K, "    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;", "    if (per >= 0) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;")],
+    # CORRECT variants (speed only): the solver-loop sweeps take their tiles in chunks of C consecutive tiles dealt round-robin over the XCDs
+    # instead of one contiguous eighth per XCD (1.5-2 % faster at 16-64, 19 % more HBM traffic: not in the product)
+    "xcd_chunk16": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
+                    "    const int C = 16, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
+    "xcd_chunk32": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
+                    "    const int C = 32, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
+    "xcd_chunk64": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
+                    "    const int C = 64, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
+    "xcd_chunk128": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
+                    "    const int C = 128, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
     # exact k_residual: workgroups whose set did not fit the LDS capacity (1-2 % of them at 1 M) return at once: what do they cost the launch?
     "nounstaged": [(K, "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n    }",
                     "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
