@@ -27,7 +27,12 @@ buf = np.zeros((nwg, 4), dtype=np.uint64)
 lib = nat.load()
 lib.sph_debug_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.sph_debug_timeline(buf.ctypes.data, nwg) == 0
-t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 1].astype(np.int64); xcc = buf[:, 2].astype(np.int64); tile = buf[:, 3].astype(np.int64)
+t0 = buf[:, 0].astype(np.int64); t1 = buf[:, 1].astype(np.int64); tile = buf[:, 3].astype(np.int64)
+w2 = buf[:, 2]
+xcc = (w2 & np.uint64(0xff)).astype(np.int64)
+ph_staged = ((w2 >> np.uint64(8)) & np.uint64(0xffff)).astype(np.float64) / 100.0      # us after the workgroup's begin (thread 0; barriers added in front of the stamps)
+ph_pairs = ((w2 >> np.uint64(24)) & np.uint64(0xffff)).astype(np.float64) / 100.0
+ph_walls = ((w2 >> np.uint64(40)) & np.uint64(0xffff)).astype(np.float64) / 100.0
 base = t0.min()
 b, e = (t0 - base) / 100.0, (t1 - base) / 100.0          # wall_clock64: 100 MHz -> us
 life = e - b
@@ -35,6 +40,10 @@ out = {"scene": scene, "step": advance + 1, "workgroups": int(nwg), "launch_us_e
        "life_us": {"mean": float(life.mean()), "p10": float(np.percentile(life, 10)), "p50": float(np.percentile(life, 50)),
                    "p90": float(np.percentile(life, 90)), "p99": float(np.percentile(life, 99)), "max": float(life.max())},
        "sum_life_over_span_x_slots": float(life.sum() / (e.max() * 1024)),
+       "phases_us_mean": {"staging (begin -> operands in LDS)": float(ph_staged.mean()), "fluid pair loop (all four waves done)": float((ph_pairs - ph_staged).mean()),
+                          "wall terms": float((ph_walls - ph_pairs).mean()), "epilogue + block partial": float((life - ph_walls).mean())},
+       "phases_us_p90": {"staging": float(np.percentile(ph_staged, 90)), "pairs": float(np.percentile(ph_pairs - ph_staged, 90)), "walls": float(np.percentile(ph_walls - ph_pairs, 90)),
+                         "epilogue": float(np.percentile(life - ph_walls, 90))},
        "per_xcd": {}}
 for x in sorted(set(xcc.tolist())):
     m = xcc == x
