@@ -92,6 +92,7 @@ struct SphHandle {
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
     bool relaxed = false;                        // SphConfig.arith == SPH_ARITH_RELAXED (or SPH_ARITH=relaxed in the environment: tools)
     float4 *wall_grad = nullptr;                 // relaxed handles: per-step wall sums (k_rx_wall_grad)
+    float *wall_gsq = nullptr;                   //   ... and the walls' share of alpha's denominator
     float4 *wall_gc = nullptr;                   // exact dfsph sweeps: (grad W_ib, V_b) per wall-list entry, written by D1 (for_wall_cache)
     bool opt_wall_cache = true;                  // SPH_WALL_CACHE=0 at sph_create: D2-D7 walk the wall lists themselves (A/B, tests)
     // change propagation between the sweeps of the density loop (sph_kernels.h: stage_sources_flagged); SPH_TILE_SKIP=0 turns it off
@@ -727,7 +728,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
                 if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
-                if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
+                if ((rc = dalloc(h, &h->wall_grad, n)) || (rc = dalloc(h, &h->wall_gsq, n))) return rc;
         }
         if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad)
             if ((rc = dalloc(h, &h->wall_gc, (n + 64) * (size_t)c.kbpitch))) return rc;
@@ -1515,7 +1516,7 @@ int stage_sort_and_lists(SphHandle *h)
     }
     if (h->wall_grad && h->c.kr_split && h->c.boundary_handle && !rigid_coupled(h)) {     // use_relaxed: the wall sums of this step's positions
         ProfScope ps(h, K_BUILD_NL);
-        hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad);
+        hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad, h->wall_gsq);
     }
     HIP_TRY(h, hipGetLastError());
     if (h->staged && getenv("SPH_STAGE_DEBUG")) {
@@ -1546,6 +1547,9 @@ int check_overflow(SphHandle *h)
 
 PbfConsts pbf_consts(const SphHandle *h);
 
+// the tolerance-grade sweeps (sph_relaxed_kernels.h) run on this handle
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
+
 int stage_density(SphHandle *h)
 {
     const Consts &c = h->c;
@@ -1572,6 +1576,10 @@ int stage_density(SphHandle *h)
         // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
         // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
+        if (use_relaxed(h))
+            hipLaunchKernelGGL(k_density_rx, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->wall_grad, h->wall_gsq,
+                               h->nl, h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->V[h->vcur], h->stage_src, h->stage_cnt, h->krho);
+        else
         SPH_LAUNCH_RM(k_density, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
                       h->rho_orig, h->stage_src, h->stage_cnt, h->krho, wall_cache(h));
@@ -1644,7 +1652,6 @@ int check_overflow_all(SphHandle *h)
 // tiles of the density loop whose inputs did not change are not recomputed (staged dfsph handles)
 inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
-inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
 void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
@@ -1741,6 +1748,10 @@ int dfsph_ext_and_dt(SphHandle *h)
     int rc;
     {
         ProfScope ps(h, K_D_EXT);
+        if (use_relaxed(h))
+            hipLaunchKernelGGL(k_dfsph_ext_rx, grid_for(c.n), b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds,
+                               h->VA[0], h->pmax, h->stage_src, h->stage_cnt);
+        else
         SPH_LAUNCH_RM0(k_dfsph_ext, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
                        h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt);
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)

@@ -1,4 +1,5 @@
-// sph_relaxed_kernels.h -- tolerance-grade forms of the four DFSPH sweeps that dominate a step (SphConfig.arith = SPH_ARITH_RELAXED).
+// sph_relaxed_kernels.h -- tolerance-grade forms of the DFSPH pair sweeps (SphConfig.arith = SPH_ARITH_RELAXED): the four of the solver loops
+// that dominate a step (k_residual / k_correct) and the two per-step ones (density + alpha, external forces).
 //
 // The EXACT sweeps (sph_kernels.h) evaluate the reference's f32 expressions operation for operation -- a correctly rounded square root
 // and three correctly rounded divisions per pair, no contraction, sums in the single-thread order of the reference's cell lists -- so
@@ -74,22 +75,48 @@ __device__ __forceinline__ void rx_walk8(const uint32_t *__restrict__ base, int 
     }
 }
 
-// sum_B V_b m grad W(x_i - x_b): per fluid particle, once per step (walls are static, positions frozen between the grid rebuild and
-// the integrator).  D3 / D6 need v_i . G_i, D2 / D4 / D7 need (k_i / rho_i) (rho0 / m) G_i.
+// W / kw and m s / (h r) of one pair from its difference vector: the two scalars D1 and D5 need (rx_g is the second alone)
+struct RxWG { float w, g, r2; };
+__device__ __forceinline__ RxWG rx_wg(const Consts &c, float dx, float dy, float dz)
+{
+    RxWG o;
+    o.r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, 1e-30f)));
+    const float ri = __builtin_amdgcn_rsqf(o.r2);
+    const float q = (o.r2 * ri) * c.rh;
+    const float t = 1.0f - q, t2 = t * t;
+    const float w1 = __builtin_fmaf(6.0f * (q * q), q - 1.0f, 1.0f);          // 6 (q^3 - q^2) + 1          solver_base.py:76-88
+    const float w2 = 2.0f * (t2 * t);
+    const float g1 = __builtin_fmaf(q, c.rx_k1a, c.rx_k1b);
+    const float g2 = (t2 * ri) * c.rx_k2;
+    const bool inner = q <= 0.5f;
+    o.w = inner ? w1 : w2;
+    o.g = inner ? g1 : g2;
+    return o;
+}
+
+// The wall sums of a step, per fluid particle (walls are static, positions frozen between the grid rebuild and the integrator):
+//   G.xyz = sum_B V_b m grad W_ib     D3 / D6 need v_i . G_i, D2 / D4 / D7 (k_i / rho_i) (rho0 / m) G_i, D1 its square
+//   G.w   = sum_B V_b W_ib            D1: the walls' share of rho_i                        (solver_base.py:70-71)
+//   Gsq   = sum_B |V_b m grad W_ib|^2 D1: the walls' share of alpha's denominator          (dfsph_solver.py:82-89)
 __global__ __launch_bounds__(kBlock) void k_rx_wall_grad(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
-                                                         const uint32_t *__restrict__ nlb, const int *__restrict__ cnt, float4 *__restrict__ G)
+                                                         const uint32_t *__restrict__ nlb, const int *__restrict__ cnt, float4 *__restrict__ G,
+                                                         float *__restrict__ Gsq)
 {
     const uint32_t *nl = nullptr;
     SPH_SWEEP_PROLOGUE_M(false)
     (void)nlp; (void)kf;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f, ws = 0.f, sq = 0.f;
     auto wall = [&](const float4 pj) {
         const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        const float s = pj.w * rx_g(c, dx, dy, dz);
-        gx = __builtin_fmaf(s, dx, gx); gy = __builtin_fmaf(s, dy, gy); gz = __builtin_fmaf(s, dz, gz);
+        const RxWG k = rx_wg(c, dx, dy, dz);
+        const float s = pj.w * k.g;
+        const float tx = s * dx, ty = s * dy, tz = s * dz;
+        gx += tx; gy += ty; gz += tz;
+        sq = __builtin_fmaf(tz, tz, __builtin_fmaf(ty, ty, __builtin_fmaf(tx, tx, sq)));
+        ws = __builtin_fmaf(pj.w, k.w, ws);
     };
     for_nbrs_p(nlbp, kb, WP, wall);
-    if (live) G[i] = make_float4(gx, gy, gz, 0.f);
+    if (live) { G[i] = make_float4(gx, gy, gz, ws * c.kw); Gsq[i] = sq; }
 }
 
 // D3 / D6 (k_residual)                                           dfsph_solver.py:252-300, 124-176
@@ -245,6 +272,130 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     Vout[i] = v;
     if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
     if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
+}
+
+
+// D1 (k_density<DFSPH>): rho, alpha, k / rho of the warm start         solver_base.py:41-72, dfsph_solver.py:32-89, :333
+// The density needs the tail mask the gradient sweeps do without: the particle's own padding entry has W(0) = kw, not 0.
+__global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *__restrict__ P, const float4 *V, const float4 *__restrict__ G,
+                                                       const float *__restrict__ Gsq, const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
+                                                       const float *__restrict__ warm, const DevScalars *__restrict__ ds, float *__restrict__ rho_out,
+                                                       float *__restrict__ aux_out, float4 *Vout, const uint2 *__restrict__ stage_src,
+                                                       const int *__restrict__ stage_cnt, float *__restrict__ krho)
+{
+    extern __shared__ float4 s_operand[];
+    const uint32_t *nlb = nullptr;
+    SPH_SWEEP_PROLOGUE_M(false)
+    (void)nlbp;
+    const bool staged = stage_operand<false>(c, s_operand, P, stage_src, stage_cnt, blk);
+    float ws = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
+    auto pair = [&](const float4 pj, bool valid) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const RxWG k = rx_wg(c, dx, dy, dz);
+        ws += valid ? k.w : 0.f;                                                  // solver_base.py:62
+        const float rx = k.g * dx, ry = k.g * dy, rz = k.g * dz;                  // dfsph_solver.py:58,70 (m inside g)
+        sx += rx; sy += ry; sz += rz;
+        sq = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, __builtin_fmaf(rx, rx, sq)));     // :71
+    };
+    if (staged) {
+        if (kf > 0) {
+            uint4 jn = nl_load(nlp);
+            for (int kk = 0; kk < kf; kk += 8) {
+                const Nl16Group g = {{jn.x, jn.y, jn.z, jn.w}};
+                if (kk + 8 < kf) jn = nl_load(nlp + (size_t)((kk >> 3) + 1) * 256);
+                float4 a[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[2 * u] = s_operand[g.lo(u)]; a[2 * u + 1] = s_operand[g.hi(u)]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pair(a[u], kk + u < kf);
+            }
+        }
+    } else {
+        for_fluid_nbrs<false, false>(nlp, kf, P, nullptr, RigidView(), [&](const float4 pj, const float4, const uint32_t) { pair(pj, true); });
+    }
+    if (!live) return;
+    float rho_i = __builtin_fmaf(c.kw * c.m, ws, 0.001f);                         // rho starts at 0.001, solver_base.py:44
+    float den = (__builtin_fmaf(sz, sz, __builtin_fmaf(sy, sy, sx * sx))) + sq;   // dfsph_solver.py:47
+    if (c.boundary_handle) {
+        const float4 gw = kb > 0 ? G[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float gs = kb > 0 ? Gsq[i] : 0.f;
+        const float f = c.rx_rho0_m;                                              // V_b rho0 grad W = (rho0 / m) V_b m grad W
+        const float bx = gw.x * f, by = gw.y * f, bz = gw.z * f;
+        rho_i = __builtin_fmaf(gw.w, c.rho0, rho_i);                              // solver_base.py:49
+        den = (den + gs * (f * f)) + __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));    // :45
+    }
+    rho_out[i] = rho_i;
+    const float alpha = fabsf(den) < 1e-6f ? 0.0f : rho_i / den;                  // :48-51
+    aux_out[i] = alpha;
+    const float4 vi = V[i];
+    krho[i] = (warm[i] / ds->dt) / rho_i;                                         // :333
+    Vout[i] = make_float4(vi.x, vi.y, vi.z, rho_i);                               // velocity buffers carry rho in .w (read by D5)
+}
+
+// D5 (k_dfsph_ext): tension + viscosity + gravity, v*, max |v*|        solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
+// The particle's own padding entry contributes x_ij = 0 to the tension and shear = 0 to the viscosity: no tail mask.
+__global__ __launch_bounds__(kBlock) void k_dfsph_ext_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                         const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
+                                                         const DevScalars *__restrict__ ds, float4 *__restrict__ VAout, float *__restrict__ pmax,
+                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+{
+    extern __shared__ float4 s_operand[];
+    const uint32_t *nlb = nullptr;
+    SPH_SWEEP_PROLOGUE_M(false)
+    (void)kb; (void)nlbp;
+    uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);      // (vel, rho) is gathered from memory through the source list
+    const bool staged = stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
+    const float4 vi = V[ii];
+    const float rho_i = vi.w;
+    const float tk = c.tens_c * c.kw;
+    float wx = 0.f, wy = 0.f, wz = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+    auto pair = [&](const float4 pj, const float4 vj) {
+        const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+        const RxWG k = rx_wg(c, dx, dy, dz);
+        const float st = tk * k.w;                                                // solver_base.py:216
+        tx = __builtin_fmaf(st, dx, tx); ty = __builtin_fmaf(st, dy, ty); tz = __builtin_fmaf(st, dz, tz);
+        const float shear = __builtin_fmaf(vi.z - vj.z, dz, __builtin_fmaf(vi.y - vj.y, dy, (vi.x - vj.x) * dx));      // :183
+        const float nu = c.visc_num * __builtin_amdgcn_rcpf(rho_i + vj.w);        // :187
+        const float mp = (nu * shear) * __builtin_amdgcn_rcpf(k.r2 + c.visc_eps_h2);   // -pi_ij, :188
+        const float sv = shear < 0.f ? mp * k.g : 0.f;                            // :184, :189 (m inside g)
+        wx = __builtin_fmaf(sv, dx, wx); wy = __builtin_fmaf(sv, dy, wy); wz = __builtin_fmaf(sv, dz, wz);
+    };
+    if (staged) {
+        if (kf > 0) {
+            uint4 jn = nl_load(nlp);
+            for (int kk = 0; kk < kf; kk += 8) {
+                const Nl16Group g = {{jn.x, jn.y, jn.z, jn.w}};
+                if (kk + 8 < kf) jn = nl_load(nlp + (size_t)((kk >> 3) + 1) * 256);
+                float4 a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[2 * u] = s_operand[g.lo(u)]; a[2 * u + 1] = s_operand[g.hi(u)];
+                    b[2 * u] = V[s_src[g.lo(u)]]; b[2 * u + 1] = V[s_src[g.hi(u)]];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pair(a[u], b[u]);
+            }
+        }
+    } else {
+        for_fluid_nbrs<false, true>(nlp, kf, P, V, RigidView(), [&](const float4 pj, const float4 vj, const uint32_t) { pair(pj, vj); });
+    }
+    float vn = -INFINITY;
+    if (live) {
+        const float dt = ds->dt;
+        const float ten[3] = {tx * c.m, ty * c.m, tz * c.m};                      // :209
+        const float vis[3] = {wx * c.m, wy * c.m, wz * c.m};                      // :175
+        const float g[3] = {c.gravity * 0.0f, c.gravity * -1.0f, c.gravity * 0.0f};
+        const float v[3] = {vi.x, vi.y, vi.z};
+        float va[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float f = (g[a] + ten[a]) + vis[a];                             // dfsph_solver.py:96
+            va[a] = v[a] + dt * f / c.m;                                          // :102
+        }
+        VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
+        if (!ghost) vn = norm3(va[0], va[1], va[2]);                              // :103
+    }
+    block_partial_max(blk, vn, pmax);
 }
 
 }  // namespace sph

@@ -93,7 +93,7 @@ def test_relaxed_first_steps_within_1e5_of_the_oracle(scene):
             scene, s + 1, ep, max(rel(o.get(orc.F_POS), cp) for o in legal), qv[0], qv[1], lv[0], lv[1]))
         lp = max(rel(o.get(orc.F_POS), cp) for o in legal)
         assert ep <= max(1e-5, 2.0 * lp), (s, ep, lp)          # 1e-5 while the reference itself keeps it (4-6 steps), then the envelope
-        assert qv[0] <= 2.0 * lv[0] + 1e-6 and qv[1] <= 2.0 * lv[1] + 1e-6, (s, qv, lv)
+        assert qv[0] <= max(1e-5, 2.0 * lv[0]) and qv[1] <= max(1e-5, 2.0 * lv[1]), (s, qv, lv)      # north_star's 1e-5, or the envelope once it is wider
     rx.close(); canon.close()
     for o in legal:
         o.close()
