@@ -730,7 +730,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n)) || (rc = dalloc(h, &h->wall_gsq, n))) return rc;
         }
-        if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad)
+        // (up to 64 GiB of it, ~58 M particles at 64 rows: beyond that the sweeps walk the wall lists and the memory goes to the scene)
+        if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad && (n + 64) * (size_t)c.kbpitch * sizeof(float4) <= ((size_t)64 << 30))
             if ((rc = dalloc(h, &h->wall_gc, (n + 64) * (size_t)c.kbpitch))) return rc;
     }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
