@@ -1106,6 +1106,36 @@ __device__ __forceinline__ void fin_partial(const double *__restrict__ psum, con
         if (k < nparts) { v += psum[k]; m += pcnt[k]; }          // 0.0 + w0 = w0: the serial sum over the block's waves
     }
 }
+// the reduction itself, for a workgroup of kFinBlock threads: (sum, count) over the block partials end up in s_sum[0], s_cnt[0] (thread 0's view)
+__device__ __forceinline__ void fin_reduce(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, int group, int nparts,
+                                           double *__restrict__ s_sum, long long *__restrict__ s_cnt)
+{
+    double t = 0.0; int n = 0;
+    int k = threadIdx.x;
+    for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
+        double v[4]; int m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
+    }
+    {   // the rest, still as one batch of (predicated) loads
+        double v[4]; int m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
+    }
+    const double ws = wave_sum(t);
+    const int wn = wave_sum(n);
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_cnt[threadIdx.x >> 6] = wn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0.0; long long nn = 0;
+        for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_sum[w]; nn += s_cnt[w]; }
+        s_sum[0] = tt; s_cnt[0] = nn;
+    }
+}
 __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
                                                              int group = 1, int nparts = 0)
@@ -1114,33 +1144,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
     if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
     __shared__ double s_sum[kFinBlock / 64];
     __shared__ long long s_cnt[kFinBlock / 64];
-    if (phase != FINP_DECIDE) {
-        double t = 0.0; int n = 0;
-        int k = threadIdx.x;
-        for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
-            double v[4]; int m[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
-        }
-        {   // the rest, still as one batch of (predicated) loads
-            double v[4]; int m[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
-        }
-        const double ws = wave_sum(t);
-        const int wn = wave_sum(n);
-        if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_cnt[threadIdx.x >> 6] = wn; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tt = 0.0; long long nn = 0;
-            for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_sum[w]; nn += s_cnt[w]; }
-            s_sum[0] = tt; s_cnt[0] = nn;
-        }
-    }
+    if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);
     if (threadIdx.x != 0) return;
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
     if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }

@@ -1995,16 +1995,16 @@ int launch_pressure_finalize(SphHandle *h, int mode)
     if (h->slab) {
         {
             ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
+            hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
         int rc = slab_allreduce_stream(h, 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
+        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
         return SPH_OK;
     }
     ProfScope ps(h, K_FINALIZE);
-    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_ALL, (double *)nullptr, partial_group(h), partial_count(h));
     return SPH_OK;
 }
 

@@ -251,31 +251,14 @@ enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
 
 // phase / red: as k_finalize_mean (FINP_ALL on one GPU; FINP_REDUCE -> all-reduce over the slabs -> FINP_DECIDE when sharded)
 // group / nparts: as k_finalize_mean (quad sweeps write one partial per 64 particles; a block's partial is the in-order sum of its four)
-__global__ __launch_bounds__(kBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                              int group = 1, int nparts = 0)
+__global__ __launch_bounds__(kFinBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                                 DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                                 int group = 1, int nparts = 0)
 {
     if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
-    __shared__ double s_sum[kBlock];
-    __shared__ long long s_cnt[kBlock];
-    if (phase != FINP_DECIDE) {
-        double t = 0.0; long long n = 0;
-        int k = threadIdx.x;                       // same order as k_finalize_mean, eight loads in flight
-        for (; k + 7 * kBlock < nblocks; k += 8 * kBlock) {
-            double v[8]; int m[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) fin_partial(psum, pcnt, k + u * kBlock, nblocks, group, nparts, v[u], m[u]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { t += v[u]; n += m[u]; }
-        }
-        for (; k < nblocks; k += kBlock) { double v1; int m1; fin_partial(psum, pcnt, k, nblocks, group, nparts, v1, m1); t += v1; n += m1; }
-        s_sum[threadIdx.x] = t; s_cnt[threadIdx.x] = n;
-        __syncthreads();
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
-            if (threadIdx.x < off) { s_sum[threadIdx.x] += s_sum[threadIdx.x + off]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + off]; }
-            __syncthreads();
-        }
-    }
+    __shared__ double s_sum[kFinBlock / 64];
+    __shared__ long long s_cnt[kFinBlock / 64];
+    if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);      // the reduction of k_finalize_mean (one batch of loads, one barrier)
     if (threadIdx.x != 0) return;
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
     if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
