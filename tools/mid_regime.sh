@@ -1,3 +1,5 @@
+#!/bin/bash
+# null-result experiment of round 3 (see tools/README.md); output under gpurun_out/r03/
 set -e
 mkdir -p gpurun_out/r03/mid
 run() { # name workload envs...
