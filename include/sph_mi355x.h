@@ -63,7 +63,7 @@ typedef struct SphConfig {
     int32_t slab_capacity;      /* particles (owned + ghosts) a slab handle can hold; 0 = default (1.75 N / slab_count + 256k) */
     int32_t slab_rebalance_every; /* re-cut the slabs from the current particle distribution every M steps; 0 = static cuts */
     int32_t arith;              /* SPH_ARITH_EXACT (0, default): every f32 operation of the reference in its order, bit-equal to oracle/;
-                                   SPH_ARITH_RELAXED (1): the dominant dfsph sweeps of large single-GPU scenes may use approximate
+                                   SPH_ARITH_RELAXED (1): the dfsph pair sweeps of large single-GPU scenes may use approximate
                                    reciprocal square roots and FMA contraction (north_star's 1e-5 bar; see csrc/sph_relaxed_kernels.h).
                                    A permission: handles the relaxed sweeps do not cover run the exact ones. */
     int32_t reserved[4];
