@@ -51,6 +51,32 @@ PATCHES = {
                     (K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_walls = wall_clock64();\n    float val = 0.f;"),
                     ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
                      "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
+    # the same stamps in the relaxed divergence-residual sweep (tools/wg_timeline.py with SPH_ARITH=relaxed reads the same array)
+    "wg_timeline_rx": [(K, "constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip", "__device__ unsigned long long g_sub2[16384 * 4];\nconstexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip"),
+                       (K, "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    const int nst = w & 0xffff, nruns = w >> 16;",
+                        "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = w >> 16;"),
+                       (K, "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    __syncthreads();\n    return nst;",
+                        "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 1] = wall_clock64();\n    __syncthreads();\n    return nst;"),
+                       (R, "    const uint32_t *nlb = nullptr;\n    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))\n    (void)nlbp;\n    float2 *s_v2",
+                        "    const uint32_t *nlb = nullptr;\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 2] = wall_clock64();\n    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))\n    (void)nlbp;\n    float2 *s_v2"),
+                       ("sph_mi355x.hip", "int sph_set_scalar(", "int sph_debug_sub2(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_sub2), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_set_scalar("),
+                       (K, "// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle",
+                        "__device__ unsigned long long g_sub[16384 * 4];\n// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle"),
+                       (K, "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));\n    if (nst < 0) return false;\n    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n#pragma unroll\n    for (int t = 0; t < kStageTrips; ++t) {\n        const int base = threadIdx.x + t * kStageBatch * kBlock;\n        if (t * kStageBatch * kBlock >= nst) break;\n        float4 a[kStageBatch], b[kStageBatch];",
+                        "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));\n    const unsigned long long ts1 = wall_clock64();\n    if (nst < 0) return false;\n    if (nst == 0) return true;\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n    const unsigned long long ts2 = wall_clock64();\n    if (threadIdx.x == 0 && blockIdx.x < 16384) { g_sub[blockIdx.x * 4 + 0] = ts1; g_sub[blockIdx.x * 4 + 1] = ts2; }\n#pragma unroll\n    for (int t = 0; t < kStageTrips; ++t) {\n        const int base = threadIdx.x + t * kStageBatch * kBlock;\n        if (t * kStageBatch * kBlock >= nst) break;\n        float4 a[kStageBatch], b[kStageBatch];"),
+                       (K, "                s_B[e] = make_float2(b[u].y, b[u].z);\n            }\n    }\n    __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first",
+                        "                s_B[e] = make_float2(b[u].y, b[u].z);\n            }\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub[blockIdx.x * 4 + 2] = wall_clock64();\n    __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first"),
+                       ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
+                        "int sph_debug_sub(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_sub), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{"),
+                       (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
+                       ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
+                        "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{"),
+                       (R, "    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) return;\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
+                        "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) return;\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
+                       (R, "    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;"),
+                       (R, "    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    const unsigned long long t_walls = t_pairs;\n    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;"),
+                       (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// D2 / D4 / D7 (k_correct)",
+                        "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// D2 / D4 / D7 (k_correct)")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
                   "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],

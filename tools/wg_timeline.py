@@ -2,7 +2,8 @@
 """Life of every workgroup of one divergence-residual launch (ab/libsph_wg_timeline.so from tools/removal_build.py wg_timeline):
 how many workgroups are in flight over the launch, how long they live, per XCD when the last one ends.
 
-    python tools/removal_build.py wg_timeline && python tools/wg_timeline.py [scene] [advance_steps]"""
+    python tools/removal_build.py wg_timeline && python tools/wg_timeline.py [scene] [advance_steps]
+    python tools/removal_build.py wg_timeline_rx && SPH_ARITH=relaxed python tools/wg_timeline.py        (the relaxed sweep)"""
 import ctypes
 import json
 import os
@@ -12,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SPH_LIB"] = os.path.join(ROOT, "ab", "libsph_wg_timeline.so")
+os.environ["SPH_LIB"] = os.path.join(ROOT, "ab", "libsph_wg_timeline_rx.so" if os.environ.get("SPH_ARITH", "").startswith("r") else "libsph_wg_timeline.so")
 from cfd_taichi_amd import _native as nat, scenes  # noqa: E402
 
 scene = sys.argv[1] if len(sys.argv) > 1 else "dfsph_1m"
@@ -48,6 +49,22 @@ out = {"scene": scene, "step": advance + 1, "workgroups": int(nwg), "launch_us_e
 for x in sorted(set(xcc.tolist())):
     m = xcc == x
     out["per_xcd"][str(x)] = {"workgroups": int(m.sum()), "first_begin_us": float(b[m].min()), "last_end_us": float(e[m].max()), "sum_life_us": float(life[m].sum())}
+if hasattr(lib, "sph_debug_sub"):              # the relaxed build also stamps the sub-phases of the staging (thread 0's clock)
+    sub = np.zeros((nwg, 4), dtype=np.uint64)
+    lib.sph_debug_sub.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    if lib.sph_debug_sub(sub.ctypes.data, nwg) == 0:
+        ok = (sub[:, 0] >= buf[:, 0]) & (sub[:, 2] >= sub[:, 0]) & (sub[:, 2] <= buf[:, 1])          # staged workgroups of THIS launch
+        s1 = ((sub[:, 0].astype(np.int64) - t0) / 100.0)[ok]; s2 = ((sub[:, 1].astype(np.int64) - t0) / 100.0)[ok]; s3 = ((sub[:, 2].astype(np.int64) - t0) / 100.0)[ok]
+        out["staging_us_mean"] = {"workgroups": int(ok.sum()), "count + cell runs read, list expanded in LDS (barrier)": float(s1.mean()), "own indices taken (barrier)": float((s2 - s1).mean()),
+                                  "gathers returned, operands stored to LDS (thread 0)": float((s3 - s2).mean()), "last barrier (all threads' stores)": float((ph_staged[ok] - s3).mean())}
+if hasattr(lib, "sph_debug_sub2"):
+    sub2 = np.zeros((nwg, 4), dtype=np.uint64)
+    lib.sph_debug_sub2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    if lib.sph_debug_sub2(sub2.ctypes.data, nwg) == 0:
+        ok2 = (sub2[:, 2] >= buf[:, 0]) & (sub2[:, 0] >= sub2[:, 2]) & (sub2[:, 1] >= sub2[:, 0]) & (sub2[:, 1] <= buf[:, 1])
+        g = ((sub2[:, 2].astype(np.int64) - t0) / 100.0)[ok2]; a_ = ((sub2[:, 0].astype(np.int64) - t0) / 100.0)[ok2]; b_ = ((sub2[:, 1].astype(np.int64) - t0) / 100.0)[ok2]
+        out["staging_head_us_mean"] = {"workgroups": int(ok2.sum()), "gate read (control block)": float(g.mean()), "stage_cnt arrived": float((a_ - g).mean()),
+                                       "runs arrived, thread 0 expanded its run": float((b_ - a_).mean())}
 # in flight over time
 grid = np.arange(0, e.max(), 1.0)
 out["in_flight_every_us"] = [int(((b <= t) & (e > t)).sum()) for t in grid]
