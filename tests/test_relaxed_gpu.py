@@ -64,6 +64,26 @@ def test_relaxed_is_active_and_exact_is_not(scene):
         s.close()
 
 
+@pytest.mark.parametrize("scene,steps", [("dfsph_small", 40), ("dfsph_dam_x", 120), ("dfsph_tiny_clamp", 30), ("breaking_dam_30k_dfsph", 30)])
+def test_relaxed_density_and_alpha_per_particle(scene, steps):
+    """D1 in the relaxed arithmetic (k_density_rx: W and grad W from one v_rsq_f32, the walls' share from the per-step wall sums, a tail mask
+    for the particle's own padding entry) against the exact kernel on the SAME positions: rho and alpha of every particle within a few
+    ulp -- walls, clamp walls, ragged cells after `steps` steps.  (The first-steps test below sees D1 only through what the solver makes of it.)"""
+    cfg, ex = make(scene, nat.ARITH_EXACT)
+    _, rx = make(scene, nat.ARITH_RELAXED)
+    ex.step_dfsph(steps)
+    for f in (nat.F_POS, nat.F_VEL, nat.F_WARM_K):
+        rx.upload(f, ex.download(f))
+    ex.compute_density(); rx.compute_density()
+    assert rx.scalar(nat.S_ARITH_RELAXED) == 1.0
+    for f, tol in ((nat.F_RHO, 2e-6), (nat.F_ALPHA, 2e-5)):
+        a, b = rx.download(f).astype(np.float64), ex.download(f).astype(np.float64)
+        err = np.abs(a - b) / np.maximum(np.abs(b), 1e-30 if f == nat.F_RHO else float(np.abs(b).max()) * 1e-3)
+        print("%s after %d steps: field %d max rel err %.2e, median %.2e" % (scene, steps, f, err.max(), np.median(err)))
+        assert err.max() < tol, (scene, f, float(err.max()))
+    rx.close(); ex.close()
+
+
 @pytest.mark.parametrize("scene", ["dfsph_small", "dfsph_dam_x", "dfsph_tiny_clamp", "breaking_dam_30k_dfsph"])
 def test_relaxed_first_steps_within_1e5_of_the_oracle(scene):
     """Five steps from rest.  Positions: within 1e-5 (max norm) of the canonical oracle -- or within 2x what seeded legal executions of
