@@ -28,13 +28,18 @@ def cores():                  # the cgroup's share, not the host's CPU list (an 
     return n
 
 
-o = orc.Oracle(cfg, num_threads=cores())
+o = orc.Oracle(cfg, solver=solver, num_threads=cores())
 t0 = time.time()
 iters = []
 for s in range(1, steps + 1):
     if solver == "dfsph":
         st = sim.step_dfsph(1); o.step_dfsph(1, 100); so = o.last_stats
         assert (st.n_div, st.n_dens, st.div_err, st.dens_err, st.dt) == (so.n_div, so.n_dens, so.div_err, so.dens_err, so.dt), (s, st.n_div, so.n_div, st.n_dens, so.n_dens)
+        iters.append(st.n_dens)
+    elif solver in ("pcisph", "iisph"):
+        st = (sim.step_pcisph if solver == "pcisph" else sim.step_iisph)(1)
+        (o.step_pcisph if solver == "pcisph" else o.step_iisph)(1)
+        assert (st.n_dens, st.dens_err) == (o.last_stats.n_dens, o.last_stats.dens_err), (s, st.n_dens, o.last_stats.n_dens)
         iters.append(st.n_dens)
     else:
         sim.step_wcsph(1); o.step_wcsph(1)
