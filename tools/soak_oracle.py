@@ -9,14 +9,15 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cfd_taichi_amd import _native as nat, scenes  # noqa: E402
+from cfd_taichi_amd import _native as nat, mesh, scenes  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 scene, steps = sys.argv[1], int(sys.argv[2])
 check = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 cfg = scenes.get(scene)
 solver = cfg["solver"]["name"]
-sim = nat.Simulation(nat.config_from_dict(cfg))
+rg = mesh.rigid_from_config(cfg) if cfg.get("solid") else None       # a coupled body (rigid_solver.py): stepped on both sides
+sim = nat.Simulation(nat.config_from_dict(cfg), rigid=rg)
 def cores():                  # the cgroup's share, not the host's CPU list (an oversubscribed OpenMP team crawls)
     n = len(os.sched_getaffinity(0))
     try:
@@ -28,7 +29,7 @@ def cores():                  # the cgroup's share, not the host's CPU list (an 
     return n
 
 
-o = orc.Oracle(cfg, solver=solver, num_threads=cores())
+o = orc.Oracle(cfg, solver=solver, num_threads=cores(), rigid=rg)
 t0 = time.time()
 iters = []
 for s in range(1, steps + 1):
@@ -43,6 +44,13 @@ for s in range(1, steps + 1):
         iters.append(st.n_dens)
     else:
         sim.step_wcsph(1); o.step_wcsph(1)
+    if rg is not None:
+        fa, fb = sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), o.get(orc.F_RIGID_FORCE)
+        assert np.array_equal(fa, fb), "step %d: force on the body differs" % s
+        sim.rigid_step(); o.rigid_step()
+        ra, rb = sim.rigid_scalars(), o.rigid_scalars()
+        for k in ("centroid", "omega", "vel"):
+            assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), (s, k, ra[k], rb[k])
     if s % check == 0 or s == steps:
         for f, g in ((nat.F_POS, orc.F_POS), (nat.F_VEL, orc.F_VEL)):
             a, b = sim.download(f), o.get(g)
