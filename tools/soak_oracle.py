@@ -42,6 +42,8 @@ for s in range(1, steps + 1):
         (o.step_pcisph if solver == "pcisph" else o.step_iisph)(1)
         assert (st.n_dens, st.dens_err) == (o.last_stats.n_dens, o.last_stats.dens_err), (s, st.n_dens, o.last_stats.n_dens)
         iters.append(st.n_dens)
+    elif solver == "pbf":
+        sim.step_pbf(1); o.step_pbf(1)
     else:
         sim.step_wcsph(1); o.step_wcsph(1)
     if rg is not None:
