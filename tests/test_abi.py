@@ -119,3 +119,18 @@ def test_bench_launches_its_own_ranks_without_touching_the_gpu(monkeypatch):
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert ("torch" in sys.modules) == torch_loaded_before          # the parent did not import torch on the way
+
+
+def test_removal_build_patches_still_match_the_kernels():
+    """tools/removal_build.py builds its experiment variants from a patched COPY of csrc/ (the product kernels carry no experiment
+    switches); a patch is a text replacement that has to match the current source exactly -- checked here so that the recipes
+    behind the numbers DESIGN.md quotes do not rot when a kernel changes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("removal_build", os.path.join(ROOT, "tools", "removal_build.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    for name, patches in rb.PATCHES.items():
+        for fname, old, new, *want in patches:
+            text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", fname)).read()
+            assert text.count(old) == (want[0] if want else 1), (name, fname, old[:60])
+            assert old != new

@@ -78,16 +78,16 @@ PATCHES = {
                        (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// D2 / D4 / D7 (k_correct)",
                         "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// D2 / D4 / D7 (k_correct)")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
-    "nogather": [(K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }",
-                  "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }")],
+    "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
+                  "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;", 2)],
     # k_build_nl: every wave works its 27 cell entries out per lane (a CORRECT variant: tools/soak_libs.py holds it against the default)
     "bnl_notable": [(K, "    const bool table = nruns <= kRunCap;                                       // wave-uniform",
                      "    const bool table = false;")],
     # relaxed k_residual_rx: pair loop removed / staging gathers removed / whole staging removed (the decomposition in DESIGN.md section 4b)
     "rx_nofluid": [(R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
                     "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
-    "rx_nostage": [(R, "    const bool staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);",
-                    "    const bool staged = true;"),
+    "rx_nostage": [(R, "        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);\n    }\n    const float4 vi = V[ii];",
+                    "        staged = true;\n    }\n    const float4 vi = V[ii];"),
                    (R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
                     "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
 }
@@ -103,10 +103,10 @@ def main():
             csrc = os.path.join(tmp, "cfd_taichi_amd", "csrc")
             shutil.copytree(hip_build.CSRC, csrc)
             shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
-            for fname, old, new in PATCHES[name]:
+            for fname, old, new, *want in PATCHES[name]:          # (file, old, new[, matches expected: default 1])
                 path = os.path.join(csrc, fname)
                 text = open(path).read()
-                if text.count(old) != 1:
+                if text.count(old) != (want[0] if want else 1):
                     raise SystemExit("patch %s: %r matches %d times in %s" % (name, old[:60], text.count(old), fname))
                 open(path, "w").write(text.replace(old, new))
             out = os.path.join(ROOT, "ab", "libsph_%s.so" % name)
