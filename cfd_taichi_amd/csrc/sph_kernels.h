@@ -546,6 +546,11 @@ constexpr int kRunCap = 13;          // runs of equal cell per wave whose 27 cel
                                      // 13: the staged build's LDS stays under 20 KiB, eight workgroups per CU
 constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
 constexpr int kStageMaxCells = 640;
+// stage_cnt[blk] = staged particles | runs << 16 | kStageLists16 (-1: not staged).  kStageLists16: the fluid lists of this workgroup hold 16-bit
+// indices local to its staged set.  Without a rigid body that is every staged workgroup of an nl16 handle; with one, the workgroups whose
+// neighbourhood cells hold no rigid sample (tagged rigid entries need 32 bits) -- all but a thin shell around the body.
+constexpr int kStageLists16 = 1 << 30;
+__device__ __forceinline__ bool stage_lists16(const int *__restrict__ stage_cnt, int blk) { return (stage_cnt[blk] & (kStageLists16 | (int)0x80000000)) == kStageLists16; }
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
 // workgroups of a residual sweep resident per CU (4 x 39 KiB of the 160 KiB LDS), ~2 % of the workgroups at 1 M particles exceed it.
 __device__ __forceinline__ int stage_hash(int slot) { return (int)(((unsigned)slot * 2654435761u) >> 22); }
@@ -614,14 +619,16 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         }
         __syncthreads();
         // (2) local base of every cell of the set (table order), the ordered source list, the verdict
-        int own[kStageHash / kBlock], run = 0;
+        int own[kStageHash / kBlock], run = 0, rig = 0;
         const bool ok = s_ok != 0;
 #pragma unroll
         for (int q = 0; q < kStageHash / kBlock; ++q) {
             const int key = ok ? s_key[threadIdx.x * (kStageHash / kBlock) + q] : -1;
             own[q] = key >= 0 ? cell_start[key + 1] - cell_start[key] : 0;
             run += own[q];
+            if (RIGID && key >= 0) rig |= rv.rcell_start[key + 1] - rv.rcell_start[key];      // rigid samples in a cell this workgroup walks
         }
+        const bool near_body = RIGID && __syncthreads_or(rig) != 0;
         int nonempty = 0;
 #pragma unroll
         for (int q = 0; q < kStageHash / kBlock; ++q) nonempty += own[q] > 0 ? 1 : 0;
@@ -648,7 +655,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             }
             before += own[q];
         }
-        if (threadIdx.x == 0) { stage_cnt[blk] = staged ? (total | (nruns << 16)) : -1; s_ok = staged ? 1 : 0; }
+        if (threadIdx.x == 0) {
+            const bool l16 = staged && c.nl16 != 0 && !near_body;
+            stage_cnt[blk] = staged ? (total | (nruns << 16) | (l16 ? kStageLists16 : 0)) : -1;
+            s_ok = staged ? (l16 ? 3 : 1) : 0;
+        }
         __syncthreads();
     }
     constexpr int CHUNK = 4;
@@ -677,7 +688,8 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     if (table && rhead) { s_runc[wv][run][0] = cx; s_runc[wv][run][1] = cy; s_runc[wv][run][2] = cz; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    NlWriter wf{&s_stage[threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, staged && c.nl16 != 0, 0u, !staged && c.nl16 != 0};
+    const bool lists16 = STAGED && (s_ok & 2) != 0;           // (see kStageLists16)
+    NlWriter wf{&s_stage[threadIdx.x], nl + nl_index(i < c.n ? i : 0, 0, c.kpitch), 0, c.kmax, lists16, 0u, !lists16 && c.nl16 != 0};
     NlWriter ww{nullptr, nlb + nl_index(i < c.n ? i : 0, 0, c.kbpitch), 0, c.kbmax, false, 0u, false};
     int nq = 0;                       // get_neighbour_count with its rigid-entry quirk (RIGID only)
     uint32_t self_local = 0u;         // this particle's own index in the staged set (16-bit lists pad their last group with it)
@@ -1240,7 +1252,7 @@ __device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs
 {
     const int w = stage_cnt[blk];
     if (w < 0) return -1;                                   // uniform per workgroup
-    const int nst = w & 0xffff, nruns = w >> 16;
+    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;
     const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
     for (int r = threadIdx.x; r < nruns; r += kBlock) {
         const uint2 rn = runs[r];
@@ -1267,7 +1279,7 @@ __device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs
 // the body's term of D7 is proportional to the particle's own k, and D6 sees the body at rest within a solver loop.
 __device__ __forceinline__ bool stage_sources_flagged(const uint2 *__restrict__ stage_runs, int sw, int blk, const int *__restrict__ wave_flags)
 {
-    const int nruns = sw >> 16;
+    const int nruns = (sw >> 16) & 0x3fff;
     const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
     int f = 0;
     if (threadIdx.x < kBlock / 64) f = wave_flags[blk * (kBlock / 64) + threadIdx.x];      // the tile's own waves
@@ -1692,7 +1704,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
         }
     };
     if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
-    else if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair);
+    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs(nlp, kf, s_operand, pair);     // (a rigid build: no rigid cell near this tile)
     else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float wa[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1873,7 +1885,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
     SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
-    const bool split = STAGED && !RIGID && c.kr_split;
+    const bool split = STAGED && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
     const bool track = MODE == CORR_DENS && STAGED && wave_dirty != nullptr;
     bool staged;
@@ -1933,10 +1945,14 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     };
     struct OperandPS { float4 a; float s; };
     if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
-    else if (staged && !RIGID && c.nl16) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
+    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs(nlp, kf, s_operand, pair_scaled);
     else if (staged) for_staged_nbrs<RIGID, true>(nlp, kf, s_operand, rv, pair_scaled);
-    else if (split)          // a workgroup of a kr_split handle whose set did not fit: two global gathers per neighbour
-        walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) { o.a = P[j]; o.s = krho[j]; },
+    else if (split)          // a workgroup of a kr_split handle whose set did not fit: two global gathers per neighbour (a tagged entry: the rigid sample)
+        walk_list<OperandPS>(nlp, kf, [&](uint32_t j, OperandPS &o) {
+                                 const bool rg = RIGID && (j & kRigidTag);
+                                 const uint32_t idx = RIGID ? (j & ~kRigidTag) : j;
+                                 o.a = rg ? rv.RP[idx] : P[idx]; o.s = rg ? o.a.w : krho[idx];
+                             },
                              [&](const OperandPS &o, uint32_t j) { pair(make_float4(o.a.x, o.a.y, o.a.z, o.s), make_float4(0.f, 0.f, 0.f, 0.f), j); });
     else for_fluid_nbrs<RIGID, false>(nlp, kf, P, nullptr, rv, pair);
     float wa[3] = {0.f, 0.f, 0.f};
@@ -2048,7 +2064,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         }
     };
     if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, skip ? 0 : kf, q, fa, P, V, rv, pair);
-    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);
+    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);
     else if (staged) for_staged_nbrs_pv2<RIGID, true>(nlp, skip ? 0 : kf, s_operand, s_v2, rv, pair_scaled);
     else for_fluid_nbrs<RIGID, true>(nlp, skip ? 0 : kf, P, V, rv, pair);
     float wa[1] = {0.f};
@@ -2149,7 +2165,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
         }
     };
     if (QUAD) for_fluid_nbrs_quad<RIGID, true>(nlp, kf, q, fa, P, V, rv, pair);
-    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
+    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv(nlp, kf, s_operand, s_src, V, pair);
     else if (staged) for_staged_nbrs_pv<RIGID>(nlp, kf, s_operand, s_src, V, rv, pair);
     else for_fluid_nbrs<RIGID, true>(nlp, kf, P, V, rv, pair);
     float vn = -INFINITY;

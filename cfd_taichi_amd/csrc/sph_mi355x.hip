@@ -1436,10 +1436,11 @@ int stage_sort_and_lists(SphHandle *h)
         if ((rc = slab_exchange_particles(h))) return rc;
     }
     Consts &c = h->c;
-    // 16-bit local indices in the fluid lists of staged workgroups: the dfsph sweeps without rigid entries (tagged rigid entries need
-    // 32 bits; the pcisph / iisph sweeps keep the 32-bit walks).  SPH_NL16=0 at sph_create turns it off (A/B, tests/test_cell_order_gpu.py)
-    c.nl16 = (h->staged && is_dfsph(h) && !rigid_coupled(h) && h->opt_nl16) ? 1 : 0;
-    // k / rho in its own array: single-GPU dfsph handles with staged sweeps and no rigid entries (the ghost refresh of slab handles ships P.w)
+    // 16-bit local indices in the fluid lists of staged workgroups of the dfsph sweeps (the pcisph / iisph sweeps keep the 32-bit walks).  With a
+    // coupled body the list build decides per workgroup: tagged rigid entries need 32 bits, so the workgroups with a rigid sample in one of their
+    // neighbourhood cells keep 32-bit local indices (kStageLists16 in stage_cnt).  SPH_NL16=0 at sph_create turns it off (A/B, tests/test_cell_order_gpu.py)
+    c.nl16 = (h->staged && is_dfsph(h) && h->opt_nl16) ? 1 : 0;
+    // k / rho in its own array: single-GPU dfsph handles with staged sweeps (the ghost refresh of slab handles ships P.w)
     c.kr_split = (c.nl16 && !h->slab && h->opt_kr_split) ? 1 : 0;
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);

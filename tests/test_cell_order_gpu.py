@@ -153,6 +153,40 @@ def test_list_and_scalar_formats_are_invisible(cap, monkeypatch):
         sim.close()
 
 
+@pytest.mark.parametrize("scene,steps,cap", [("dfsph_rigid_small", 150, "1664"), ("dfsph_rigid_small", 80, "300"), ("dfsph_rigid_tilted", 60, "1664")])
+def test_list_and_scalar_formats_with_a_rigid_body(scene, steps, cap, monkeypatch):
+    """... and with a coupled body: the list build decides per workgroup -- 16-bit local indices where no cell of the workgroup's
+    neighbourhood holds a rigid sample, 32-bit local indices with tagged rigid entries in the shell around the body, 32-bit global ones
+    where the set did not fit (kStageLists16 in stage_cnt) -- and k / rho travels in its own array for all of them.  All on, the scalar
+    array off, both off: coupled steps, force on the body and body state included."""
+    cfg = scenes.get(scene)
+    rg = mesh.rigid_from_config(cfg)
+    monkeypatch.setenv("SPH_STAGE_CAP", cap)
+    sims = []
+    for nl16, split in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("SPH_NL16", nl16)
+        monkeypatch.setenv("SPH_KR_SPLIT", split)
+        sims.append(make(cfg, "morton", monkeypatch, rigid=rg))
+    for s_ in range(steps):
+        st = [sim.step_dfsph(1) for sim in sims]
+        for other in st[1:]:
+            assert (st[0].n_div, st[0].n_dens, st[0].div_err, st[0].dens_err, st[0].dt) == (other.n_div, other.n_dens, other.div_err, other.dens_err, other.dt), s_
+        ref = sims[0].download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)
+        assert all(np.array_equal(ref, sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID)) for sim in sims[1:]), s_
+        for sim in sims:
+            sim.rigid_step()
+    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K):
+        ref = sims[0].download(f)
+        assert all(np.array_equal(ref, sim.download(f)) for sim in sims[1:]), f
+    ra = sims[0].rigid_scalars()
+    for sim in sims[1:]:
+        rb = sim.rigid_scalars()
+        for k in ("centroid", "omega", "vel"):
+            assert np.array_equal(np.float32(ra[k]), np.float32(rb[k])), k
+    for sim in sims:
+        sim.close()
+
+
 @pytest.mark.parametrize("scene,steps,cap,arith", [("breaking_dam_30k_dfsph", 120, "1664", 0), ("dfsph_small", 150, "300", 0), ("dfsph_dam_x", 150, "1664", 0),
                                                    ("breaking_dam_30k_dfsph", 60, "1664", 1)])
 def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, monkeypatch):
