@@ -156,7 +156,8 @@ struct SphHandle {
     float4 *pos_orig = nullptr;   // fluid positions by original id   (get_neighbour_count quirk)
     float *rho_orig = nullptr;    // fluid densities by original id   (viscosity quirk)
     int *ncount = nullptr;        // ps.get_neighbour_count(i) with rigid entries
-    RigidReduce *rred = nullptr, *rred_host = nullptr;
+    RigidReduce *rred = nullptr, *rred_host = nullptr;      // kRigidParts partials on the device, combined into rred_host[0] (read_rigid_reduce)
+    float *rvmax_part = nullptr;
     std::vector<float> rvol_host, rmass_host;
     float centroid[3] = {0, 0, 0}, inertia_inv[9] = {0}, r_vel[3] = {0, 0, 0}, r_acc[3] = {0, 0, 0}, r_omega[3] = {0, 0, 0},
           r_alpha[3] = {0, 0, 0};
@@ -1258,14 +1259,15 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->pos_orig, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->rho_orig, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->ncount, (size_t)h->c.stride))) return rc;
-    if ((rc = dalloc(h, &h->rred, 1))) return rc;
+    if ((rc = dalloc(h, &h->rred, kRigidParts))) return rc;
+    if ((rc = dalloc(h, &h->rvmax_part, kRigidParts))) return rc;
     if ((rc = dalloc(h, &h->rnl, (nr + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->rcnt, nr))) return rc;
     const size_t stg_need = 3 * std::max(nr, (size_t)Nv);
     if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb))
         if ((rc = dalloc(h, &h->staging, stg_need))) return rc;      // the fluid arena's staging buffer is too small for this body
     if ((rc = dcommit(h))) return rc;
-    HIP_TRY(h, hipHostMalloc((void **)&h->rred_host, sizeof(RigidReduce), hipHostMallocDefault));
+    HIP_TRY(h, hipHostMalloc((void **)&h->rred_host, sizeof(RigidReduce) * (kRigidParts + 1), hipHostMallocDefault));
     std::vector<float4> rp4(nr);
     for (int i = 0; i < Nr; ++i) rp4[i] = make_float4(rpos[3 * (size_t)i], rpos[3 * (size_t)i + 1], rpos[3 * (size_t)i + 2], h->rvol_host[i]);
     HIP_TRY(h, hipMemcpyAsync(h->RPos, rp4.data(), sizeof(float4) * nr, hipMemcpyHostToDevice, h->stream));
@@ -1312,10 +1314,31 @@ RigidBodyState rigid_state(const SphHandle *h, const float vel[3], const float o
     return st;
 }
 
+inline dim3 rigid_parts_grid(const SphHandle *h) { return dim3((unsigned)std::max(1, std::min(kRigidParts, (h->Nr + kBlock - 1) / kBlock))); }
+
+// the partials of k_rigid_torque_force / k_rigid_collide (one per workgroup) combined in index order into rred_host[0]
 int read_rigid_reduce(SphHandle *h)
 {
-    HIP_TRY(h, hipMemcpyAsync(h->rred_host, h->rred, sizeof(RigidReduce), hipMemcpyDeviceToHost, h->stream));
+    const int np = (int)rigid_parts_grid(h).x;
+    RigidReduce *part = h->rred_host + 1;
+    HIP_TRY(h, hipMemcpyAsync(part, h->rred, sizeof(RigidReduce) * (size_t)np, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    RigidReduce r = part[0];
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = r.cnorm[a] & 1; hi[a] = (r.cnorm[a] >> 1) & 1; }
+    for (int k = 1; k < np; ++k) {
+        const RigidReduce &q = part[k];
+        for (int a = 0; a < 3; ++a) {
+            r.torque[a] += q.torque[a]; r.force[a] += q.force[a]; r.cp[a] += q.cp[a];
+            r.dmax[a] = fmaxf(r.dmax[a], q.dmax[a]); r.dmin[a] = fminf(r.dmin[a], q.dmin[a]);
+            lo[a] |= q.cnorm[a] & 1; hi[a] |= (q.cnorm[a] >> 1) & 1;
+        }
+        r.ccount += q.ccount;
+    }
+    // collision_norm[j]: -1 from the lower wall, +1 from the upper wall; if both fire in one step the later write wins in the reference
+    // (a race); here the upper wall wins, as in the oracle's particle loop order per axis
+    for (int a = 0; a < 3; ++a) r.cnorm[a] = hi[a] ? 1 : (lo[a] ? -1 : 0);
+    h->rred_host[0] = r;
     return SPH_OK;
 }
 
@@ -1339,7 +1362,7 @@ int rigid_step(SphHandle *h)
     const float dt = h->rs_dt;
     ProfScope ps(h, K_RIGID);
     // compute_attitude :118-128 (+ the force sum of kinematic :35-38: the forces do not change in between)
-    hipLaunchKernelGGL(k_rigid_torque_force, dim3(1), b, 0, s, h->Nr, h->RPos, h->rforce, rigid_state(h, nullptr, nullptr), h->rred);
+    hipLaunchKernelGGL(k_rigid_torque_force, rigid_parts_grid(h), b, 0, s, h->Nr, h->RPos, h->rforce, rigid_state(h, nullptr, nullptr), h->rred);
     if ((rc = read_rigid_reduce(h))) return rc;
     {
         const float torque[3] = {(float)h->rred_host->torque[0], (float)h->rred_host->torque[1], (float)h->rred_host->torque[2]};
@@ -1376,7 +1399,7 @@ int rigid_step(SphHandle *h)
             ori[a] = disp[a];
         }
     }
-    hipLaunchKernelGGL(k_rigid_collide, dim3(1), b, 0, s, h->Nr, h->RPos, rigid_state(h, vel, ori), h->rred);
+    hipLaunchKernelGGL(k_rigid_collide, rigid_parts_grid(h), b, 0, s, h->Nr, h->RPos, rigid_state(h, vel, ori), h->rred);
     if ((rc = read_rigid_reduce(h))) return rc;
     const RigidReduce &rr = *h->rred_host;
     for (int j = 0; j < 3; ++j) {
@@ -1760,7 +1783,8 @@ int dfsph_ext_and_dt(SphHandle *h)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
             for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];
             const float vn = sqrtf((h->r_vel[0] * h->r_vel[0] + h->r_vel[1] * h->r_vel[1]) + h->r_vel[2] * h->r_vel[2]);
-            hipLaunchKernelGGL(k_rigid_vmax, dim3(1), b, 0, s, h->Nr, h->RPos, st, vn, h->ds);
+            hipLaunchKernelGGL(k_rigid_vmax, rigid_parts_grid(h), b, 0, s, h->Nr, h->RPos, st, vn, h->ds, h->rvmax_part, 0);
+            hipLaunchKernelGGL(k_rigid_vmax, dim3(1), b, 0, s, h->Nr, h->RPos, st, vn, h->ds, h->rvmax_part, (int)rigid_parts_grid(h).x);
         }
     }
     const bool async = slab_async(h);

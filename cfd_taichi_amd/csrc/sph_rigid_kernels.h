@@ -129,13 +129,19 @@ __device__ __forceinline__ T block_sum_fixed(T v, T *sh)
     return r;
 }
 
-// torque = sum (x - c) x F, force = sum F   (compute_attitude :118-123, kinematic :35-38); one workgroup
+// The reductions over the body's sample particles run on kRigidParts workgroups (a body of config 5 has 123 k samples: one workgroup
+// walking all of them took 150-250 us per kernel, three kernels per step); workgroup b leaves its partial in out[b] and the host, which
+// reads the result back anyway, combines the partials in index order (sums in f64, maxima, flags): fixed order, no atomics.
+constexpr int kRigidParts = 64;
+
+// torque = sum (x - c) x F, force = sum F   (compute_attitude :118-123, kinematic :35-38)
 __global__ __launch_bounds__(kBlock) void k_rigid_torque_force(int nr, const float4 *__restrict__ RPos, const float *__restrict__ force,
                                                                RigidBodyState st, RigidReduce *__restrict__ out)
 {
     __shared__ double sh[kBlock];
     double t[3] = {0, 0, 0}, f[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < nr; i += kBlock) {
+    out += blockIdx.x;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nr; i += gridDim.x * kBlock) {
         const float4 p = RPos[i];
         float rx = p.x - st.c[0], ry = p.y - st.c[1], rz = p.z - st.c[2];
         float fx = force[3 * i], fy = force[3 * i + 1], fz = force[3 * i + 2];
@@ -172,10 +178,12 @@ __global__ __launch_bounds__(kBlock) void k_rigid_rotate(int n, float4 *__restri
     else { p3[3 * i] = ox; p3[3 * i + 1] = oy; p3[3 * i + 2] = oz; }
 }
 
-// wall test of kinematic (:53-76): extreme displacements per axis, collision normals, colliding-point sum; one workgroup
+// wall test of kinematic (:53-76): extreme displacements per axis, collision normals, colliding-point sum (partials per workgroup, see above;
+// cnorm of a partial: bit 0 = a lower-wall hit, bit 1 = an upper-wall hit on that axis)
 __global__ __launch_bounds__(kBlock) void k_rigid_collide(int nr, const float4 *__restrict__ RPos, RigidBodyState st,
                                                           RigidReduce *__restrict__ out)
 {
+    out += blockIdx.x;
     __shared__ double shd[kBlock];
     __shared__ float shf[kBlock];
     __shared__ int shi[kBlock];
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_rigid_collide(int nr, const float4 *
     int lo_hit[3] = {0, 0, 0}, hi_hit[3] = {0, 0, 0};
     double cp[3] = {0, 0, 0};
     int cc = 0;
-    for (int i = threadIdx.x; i < nr; i += kBlock) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nr; i += gridDim.x * kBlock) {
         const float4 p4 = RPos[i];
         const float p[3] = {p4.x, p4.y, p4.z};
         float rel[3] = {p[0] + st.ori[0] - st.c[0], p[1] + st.ori[1] - st.c[1], p[2] + st.ori[2] - st.c[2]};
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_rigid_collide(int nr, const float4 *
         // collision_norm[j]: -1 from the lower wall, +1 from the upper wall; if both fire in one step the later write wins
         // in the reference (a race); here the upper wall wins, as in the oracle's particle loop order per axis
         int lh = block_sum_fixed(lo_hit[a], shi), hh = block_sum_fixed(hi_hit[a], shi);
-        if (threadIdx.x == 0) out->cnorm[a] = hh > 0 ? 1 : (lh > 0 ? -1 : 0);
+        if (threadIdx.x == 0) out->cnorm[a] = (lh > 0 ? 1 : 0) | (hh > 0 ? 2 : 0);
         double s = block_sum_fixed(cp[a], shd);
         if (threadIdx.x == 0) out->cp[a] = s;
     }
@@ -242,13 +250,18 @@ __global__ __launch_bounds__(kBlock) void k_rigid_translate(int n, float4 *__res
     if (force_to_zero) { force_to_zero[3 * i] = 0.f; force_to_zero[3 * i + 1] = 0.f; force_to_zero[3 * i + 2] = 0.f; }
 }
 
-// max_rigid_vel = max_i ( |vel| + |omega x (x_i - c)| )         dfsph_solver.py:104-110; one workgroup
+// max_rigid_vel = max_i ( |vel| + |omega x (x_i - c)| )         dfsph_solver.py:104-110: partial maxima per workgroup in part[], the
+// second launch (one workgroup, nparts > 0) takes their maximum into ds->rigid_vmax
 __global__ __launch_bounds__(kBlock) void k_rigid_vmax(int nr, const float4 *__restrict__ RPos, RigidBodyState st, float vel_norm,
-                                                       DevScalars *__restrict__ ds)
+                                                       DevScalars *__restrict__ ds, float *__restrict__ part, int nparts)
 {
     __shared__ float shf[kBlock];
     float m = 0.0f;
-    for (int i = threadIdx.x; i < nr; i += kBlock) {
+    if (nparts > 0) {                      // second stage
+        for (int i = threadIdx.x; i < nparts; i += kBlock) m = fmaxf(m, part[i]);
+        nr = 0;
+    }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nr; i += gridDim.x * kBlock) {
         const float4 p = RPos[i];
         float rx = p.x - st.c[0], ry = p.y - st.c[1], rz = p.z - st.c[2];
         float cx = st.omega[1] * rz - st.omega[2] * ry, cy = st.omega[2] * rx - st.omega[0] * rz, cz = st.omega[0] * ry - st.omega[1] * rx;
@@ -260,7 +273,10 @@ __global__ __launch_bounds__(kBlock) void k_rigid_vmax(int nr, const float4 *__r
         if (threadIdx.x < off) shf[threadIdx.x] = fmaxf(shf[threadIdx.x], shf[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) ds->rigid_vmax = shf[0];
+    if (threadIdx.x == 0) {
+        if (nparts > 0) ds->rigid_vmax = shf[0];
+        else part[blockIdx.x] = shf[0];
+    }
 }
 
 }  // namespace sph
