@@ -21,8 +21,8 @@ from cfd_taichi_amd import build as hip_build  # noqa: E402
 K, R = "sph_kernels.h", "sph_relaxed_kernels.h"
 PATCHES = {
     # exact k_residual (sph_kernels.h): the fluid pair loop / the wall loop removed
-    "nofluid": [(K, "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);",
-                 "    else if (staged && !RIGID && c.nl16) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
+    "nofluid": [(K, "    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);",
+                 "    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
     "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
     "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
     # CORRECT variants (speed only): the solver-loop sweeps take their tiles in chunks of C consecutive tiles dealt round-robin over the XCDs
@@ -53,8 +53,8 @@ PATCHES = {
                      "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # the same stamps in the relaxed divergence-residual sweep (tools/wg_timeline.py with SPH_ARITH=relaxed reads the same array)
     "wg_timeline_rx": [(K, "constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip", "__device__ unsigned long long g_sub2[16384 * 4];\nconstexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip"),
-                       (K, "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    const int nst = w & 0xffff, nruns = w >> 16;",
-                        "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = w >> 16;"),
+                       (K, "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;",
+                        "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;"),
                        (K, "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    __syncthreads();\n    return nst;",
                         "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 1] = wall_clock64();\n    __syncthreads();\n    return nst;"),
                        (R, "    const uint32_t *nlb = nullptr;\n    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))\n    (void)nlbp;\n    float2 *s_v2",
