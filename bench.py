@@ -51,6 +51,9 @@ ALGO_BYTES = {
 }
 
 
+# kernels that skip tiles whose inputs did not change (change propagation in the dfsph density loop; zero-pressure tiles of pcisph / iisph)
+TILE_SKIPPING = ("dfsph_dens_residual", "dfsph_dens_correct", "pcisph_press_force", "iisph_d_ij")
+
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / device-buffer sharing across processes needs dmabuf IPC on this driver
 
 
@@ -66,6 +69,8 @@ def parse():
                     help="untimed steps before the warm-up (reported as config.preroll_steps and timed as early_phase)")
     ap.add_argument("--no-scaling-base", action="store_true", help="N=1: skip the dfsph_10m one-GPU point")
     ap.add_argument("--no-relaxed", action="store_true", help="N=1 dfsph: skip the tolerance-grade arithmetic leg (the `relaxed` object)")
+    ap.add_argument("--allow-overrides", action="store_true", default=os.environ.get("SPH_BENCH_ALLOW_OVERRIDES") == "1",
+                    help="print a line although development overrides (SPH_DEV=1 + SPH_* knobs) are in force; they are named in config.overrides")
     ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
                     help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
     return ap.parse_args()
@@ -193,7 +198,7 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
         prof = sim.profile()
         sim.profile_enable(False)
         tot = sum(ms for ms, _ in prof.values())
-        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0}
+        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0 and k not in TILE_SKIPPING}
         dom = max(sweeps, key=lambda k: sweeps[k][0])
         ms, cnt = prof[dom]
         avg_s = ms / cnt / 1e3
@@ -428,6 +433,12 @@ def main():
     group_for = (side if discipline == "native" else transport_group) if world > 1 else None
     sim, slab = make_sim(nat, scenes, scene_name, world, rank, local_rank, group_for, args.rebalance, discipline)
     n_total = sim.n_fluid
+    # development overrides (SPH_DEV=1 + SPH_* knobs, SPH_LIB) change what is measured: no line without naming them
+    overrides = sim.overrides()
+    if overrides and not args.allow_overrides:
+        raise SystemExit("[bench] development overrides are in force (%s): refusing to print a line; unset them or pass --allow-overrides "
+                         "(they are then named in config.overrides)" % ", ".join(overrides))
+    headline_arith = "relaxed" if sim.scalar(nat.S_ARITH_RELAXED) == 1.0 else "exact"
 
     has_rigid = bool(cfg.get("solid")) and world == 1
     rigid_active = has_rigid and bool(cfg["solid"].get("active", False))     # main.py:169-171: rs.step() only if ps.active_rigid[None] == 1
@@ -494,7 +505,7 @@ def main():
         return elapsed, early, stats, state
 
     run = make_run(sim, solver_kind, rigid_active)
-    want_relaxed = rank == 0 and world == 1 and solver_kind == "dfsph" and not has_rigid and not args.no_relaxed and os.environ.get("SPH_ARITH") is None
+    want_relaxed = rank == 0 and world == 1 and solver_kind == "dfsph" and not has_rigid and not args.no_relaxed and headline_arith == "exact"
     want_state = rank == 0 and world == 1 and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf") and (not args.no_cpu_baseline or want_relaxed)
     elapsed, early, stats, state = timed_window(sim, run, want_state)
     final_exact = (sim.download(nat.F_POS), sim.download(nat.F_VEL)) if want_relaxed else None
@@ -510,7 +521,7 @@ def main():
         # one series: N = 2, 4, 8 shard a FIXED workload (dfsph_10m); the N = 1 line carries that workload's one-GPU point as strong_scaling_base
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
-                   "grid": list(sim.grid), "preroll_steps": args.preroll,
+                   "grid": list(sim.grid), "preroll_steps": args.preroll, "arith": headline_arith, "overrides": overrides,
                    "timed_steps": "%d-%d" % (args.preroll + args.warmup + 1, args.preroll + args.warmup + args.steps),
                    "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s, cuts re-balanced every %d steps" % (world, transport, args.rebalance)},
     }
@@ -552,7 +563,10 @@ def main():
         sim.profile_enable(False)
         n_local = sim.slab_info()["owned"] + sim.slab_info()["ghosts"] if world > 1 else n_total
         tot = sum(ms for ms, _ in prof.values())
-        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0}
+        # kernels with change propagation return at once on the tiles whose inputs did not change: a launch does a
+        # fraction of the algorithmic work, so bytes x N / time is not a roofline fraction for them -- they are not priced and cannot be
+        # the dominant kernel of the roofline object (their times stay in kernel_breakdown_us)
+        sweeps = {k: v for k, v in prof.items() if ALGO_BYTES.get(k, 0) > 0 and k not in TILE_SKIPPING}
         dom = max(sweeps, key=lambda k: sweeps[k][0])
         ms, n = prof[dom]
         avg_s = ms / n / 1e3
@@ -566,7 +580,9 @@ def main():
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
                            "binding_limit": None,
-                           "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s)"}
+                           "not_priced": [k for k in prof if k in TILE_SKIPPING],
+                           "note": "priced on the HBM axis as north_star asks (algorithmic bytes / launch time / 8 TB/s); kernels in not_priced skip the tiles "
+                                   "whose inputs did not change, so a launch does a fraction of the algorithmic work: they are never the dominant kernel here"}
         mix = load_valu_mix(dom) if committed else None
         if mix:
             # stated only where an instruction mix of THIS kernel on THIS workload is committed, and computed from this run's launch time

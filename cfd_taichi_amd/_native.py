@@ -33,7 +33,7 @@ VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGI
 EXPORTS = [
     "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
-    "sph_get_scalar", "sph_set_scalar", "sph_synchronize", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
+    "sph_get_scalar", "sph_set_scalar", "sph_synchronize", "sph_overrides", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
     "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_comm_stats", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
@@ -136,9 +136,18 @@ class SphComm(ctypes.Structure):
 _lib = None
 
 
+def dev_mode():
+    """Development overrides (SPH_LIB here, the SPH_* knobs inside the library) take effect only with SPH_DEV=1."""
+    return os.environ.get("SPH_DEV") == "1"
+
+
 def library_path():
-    # SPH_LIB selects an alternative build of the same library (A/B experiments); default is the in-tree build
-    return os.environ.get("SPH_LIB") or _build.LIB
+    # SPH_LIB selects an alternative build of the same library (A/B experiments, tools); default is the in-tree build.
+    # It is a development override: without SPH_DEV=1 a set SPH_LIB is refused, never silently honoured or silently dropped.
+    alt = os.environ.get("SPH_LIB")
+    if alt and not dev_mode():
+        raise RuntimeError("SPH_LIB=%s is set but development overrides need SPH_DEV=1; the product loads %s only" % (alt, _build.LIB))
+    return alt or _build.LIB
 
 
 # the per-step path of include/sph_mi355x.h: what any implementation of the ABI exports (the device-specific entry points --
@@ -204,6 +213,8 @@ def load(build_if_missing=True):
     vp, ci = ctypes.c_void_p, ctypes.c_int
     _bind_core(lib)
     lib.sph_profile_reset.argtypes = [vp]
+    lib.sph_overrides.argtypes = [vp]
+    lib.sph_overrides.restype = ctypes.c_char_p
     lib.sph_profile_enable.argtypes = [vp, ci]
     lib.sph_profile_kernel_count.argtypes = []
     lib.sph_profile_kernel_name.argtypes = [ci]
@@ -421,6 +432,16 @@ class Simulation:
 
     def synchronize(self):
         self._check(self._lib.sph_synchronize(self._h))
+
+    def overrides(self):
+        """Development overrides in force on this handle, e.g. ['SPH_CELL_ORDER=morton'] (needs SPH_DEV=1 to take effect at all)."""
+        if not hasattr(self._lib, "sph_overrides"):
+            return []
+        txt = (self._lib.sph_overrides(self._h) or b"").decode()
+        out = [t for t in txt.split(";") if t]
+        if os.environ.get("SPH_LIB"):
+            out.append("SPH_LIB=" + os.environ["SPH_LIB"])
+        return out
 
     # ---- multi-GPU slab handles ----
     def set_comm(self, comm):

@@ -43,6 +43,29 @@ const char *kKernelNames[K_COUNT] = {
 
 thread_local std::string g_create_error;
 
+// Development overrides.  The SPH_* environment knobs (layout and arithmetic switches for A/B runs, tests and tools) take effect only
+// when SPH_DEV=1 is set as well; without it a set knob is ignored with one line on stderr.  Every override that did take effect is
+// recorded and reported by sph_overrides(), so that a measurement can name (or refuse) the switches it ran under.
+const char *dev_env(std::string *record, const char *name)
+{
+    const char *e = getenv(name);
+    if (!e) return nullptr;
+    const char *dev = getenv("SPH_DEV");
+    if (!(dev && dev[0] == '1' && dev[1] == 0)) {
+        static thread_local std::string warned;
+        if (warned.find(std::string(";") + name + ";") == std::string::npos) {
+            warned += std::string(";") + name + ";";
+            fprintf(stderr, "libsph_mi355x: %s is set but ignored (development overrides need SPH_DEV=1)\n", name);
+        }
+        return nullptr;
+    }
+    if (record && record->find(std::string(name) + "=") == std::string::npos) {
+        if (!record->empty()) *record += ";";
+        *record += std::string(name) + "=" + e;
+    }
+    return e;
+}
+
 }  // namespace
 
 struct SphHandle {
@@ -51,6 +74,7 @@ struct SphHandle {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    std::string overrides;       // development overrides in force on this handle (dev_env)
 
     int N = 0, Nb = 0, Nr = 0;
     int nblocks = 0;
@@ -389,7 +413,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         // in one XCD's L2 (measured, Mparticle-steps/s linear -> Morton: dfsph 1M 167 -> 203, 10M 162 -> 195, 250k 138 -> 148;
         // iisph 1M 37 -> 48; wcsph 1M 1348 -> 1423, 250k equal or 3% slower); scenes of tens of thousands of particles are launch-bound and
         // run 5-8% faster in the reference's own order.  SPH_CELL_ORDER=linear|morton forces one, SPH_CELL_TILE=4|8|16 the tile edge.
-        const char *e = getenv("SPH_CELL_ORDER"), *t = getenv("SPH_CELL_TILE");
+        const char *e = dev_env(&h->overrides, "SPH_CELL_ORDER"), *t = dev_env(&h->overrides, "SPH_CELL_TILE");
         const bool morton = e && !strcmp(e, "morton") ? true : e && !strcmp(e, "linear") ? false : h->N >= (cf.solver == SPH_SOLVER_WCSPH ? 1 << 19 : 1 << 17);
         c.order = morton ? CELL_ORDER_TILED : CELL_ORDER_LINEAR;
         const int edge = t ? atoi(t) : 4;
@@ -416,7 +440,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         // hash then sees a fraction of its inputs and the read latency of a sweep depends on where the allocator put the list
         // (measured: 833 vs 1090 cycles per request, sweeps 110 vs 145 us for identical handles).  An odd number of row groups
         // per tile walks the rows of consecutive tiles through all residues.
-        const char *e = getenv("SPH_NL_PITCH_PAD");
+        const char *e = dev_env(&h->overrides, "SPH_NL_PITCH_PAD");
         const int pad = e ? atoi(e) & ~3 : 4;
         // (every tile also keeps at least one spare group beyond kmax entries: the walks read one group ahead, NlWriter::flush)
         c.kpitch = c.kmax + (((c.kmax >> 2) & 1) ? 2 * pad : pad);
@@ -440,7 +464,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         // that its own initial condition degenerates (indices collide).  From 2^24 on the same expressions are evaluated in f64 -- the
         // continuation the formulas intend; below 2^24 the f32 path is kept bit for bit (SPH_LATTICE_F64=1 forces f64 everywhere: a test
         // checks that both agree there).
-        const char *force64 = getenv("SPH_LATTICE_F64");
+        const char *force64 = dev_env(&h->overrides, "SPH_LATTICE_F64");
         const int f32_limit = (force64 && force64[0] == '1') ? 0 : (1 << 24);
         for (int i = 0; i < N; ++i) {
             float x, z; int y;
@@ -473,7 +497,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         std::vector<int> col, cut;
         std::string why;
         if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why)) return fail(h, SPH_E_INVALID, "%s", why.c_str());
-        if (const char *e = getenv("SPH_SLAB_CUTS")) {       // debugging aid: comma-separated interior cuts, e.g. "9,18" for three slabs
+        if (const char *e = dev_env(&h->overrides, "SPH_SLAB_CUTS")) {       // debugging aid: comma-separated interior cuts, e.g. "9,18" for three slabs
             std::vector<int> forced{0};
             for (const char *q = e; *q;) { forced.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
             forced.push_back(c.gx);
@@ -651,7 +675,7 @@ int dcommit(SphHandle *h)
     h->arenas.push_back(base);
     for (size_t k = 0; k < h->plan.size(); ++k) *h->plan[k].first = base + off[k];
     HIP_TRY(h, hipMemsetAsync(base, 0, cur, h->stream));
-    if (getenv("SPH_ALLOC_DEBUG")) fprintf(stderr, "[alloc] handle %p: arena of %zu MiB at %p, %zu arrays\n", (void *)h, cur >> 20, (void *)base, h->plan.size());
+    if (dev_env(&h->overrides, "SPH_ALLOC_DEBUG")) fprintf(stderr, "[alloc] handle %p: arena of %zu MiB at %p, %zu arrays\n", (void *)h, cur >> 20, (void *)base, h->plan.size());
     h->plan.clear();
     return SPH_OK;
 }
@@ -716,7 +740,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     const bool want_wall_cache = h->cfg.solver == SPH_SOLVER_DFSPH && c.boundary_handle && h->Nb > 0 && h->opt_wall_cache;
     {
         // LDS staging of the gather operands (plan in k_build_nl): DFSPH, PCISPH and IISPH on the Morton curve; SPH_STAGE=0 turns it off, SPH_STAGE_CAP sets the capacity
-        const char *e = getenv("SPH_STAGE"), *cap = getenv("SPH_STAGE_CAP");
+        const char *e = dev_env(&h->overrides, "SPH_STAGE"), *cap = dev_env(&h->overrides, "SPH_STAGE_CAP");
         h->staged = c.order == CELL_ORDER_TILED && h->cfg.solver != SPH_SOLVER_WCSPH && h->cfg.solver != SPH_SOLVER_PBF && !(e && atoi(e) == 0);
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
@@ -1544,7 +1568,7 @@ int stage_sort_and_lists(SphHandle *h)
         hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad, h->wall_gsq);
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->staged && getenv("SPH_STAGE_DEBUG")) {
+    if (h->staged && dev_env(&h->overrides, "SPH_STAGE_DEBUG")) {
         std::vector<int> sc((size_t)h->nblocks);
         HIP_TRY(h, hipMemcpyAsync(sc.data(), h->stage_cnt, sizeof(int) * sc.size(), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -2380,16 +2404,16 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     SphHandle *h = new SphHandle();
     h->cfg = *cfg;
     h->device = cfg->device;
-    { const char *e = getenv("SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
-    { const char *e = getenv("SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
-    { const char *e = getenv("SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
-    { const char *e = getenv("SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
-    { const char *e = getenv("SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
-    { const char *e = getenv("SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
-    { const char *e = getenv("SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
-    { const char *e = getenv("SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
-    { const char *e = getenv("SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
-    { const char *e = getenv("SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
+    { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
+    { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
+    { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
+    { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
+    { const char *e = dev_env(&h->overrides, "SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
     int rc = SPH_OK;
     do {
         if (hipSetDevice(h->device) != hipSuccess) { rc = fail(h, SPH_E_HIP, "hipSetDevice(%d) failed", h->device); break; }
@@ -2672,7 +2696,7 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     memset(&h->comm, 0, sizeof(h->comm));
     h->comm.capacity = capacity_bytes;
     h->comm.stream_ordered = 1;
-    { const char *e = getenv("SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
     h->native = true;
     h->comm_set = true;
     return SPH_OK;
@@ -2720,7 +2744,7 @@ int sph_set_comm(SphHandle *h, const SphComm *comm)
         else h->red_dev = comm->reduce_buf;
     }
     if (comm->stream_ordered && comm->on_host) return fail(h, SPH_E_INVALID, "a stream-ordered transport needs device buffers (on_host = 0)");
-    { const char *e = getenv("SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
     h->comm_set = true;
     return SPH_OK;
 }
@@ -2986,6 +3010,8 @@ int sph_set_scalar(SphHandle *h, int which, double value)
         if (h->wcsph_graph[k]) { (void)hipGraphExecDestroy(h->wcsph_graph[k]); h->wcsph_graph[k] = nullptr; }
     return SPH_OK;
 }
+
+const char *sph_overrides(SphHandle *h) { return h ? h->overrides.c_str() : ""; }
 
 int sph_synchronize(SphHandle *h)
 {

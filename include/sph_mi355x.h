@@ -211,6 +211,10 @@ int sph_get_scalar(SphHandle *h, int which, double *out);
  * (pos, vel, warm_start_k, delta_time) can be moved into another handle, or into the oracle, completely. */
 int sph_set_scalar(SphHandle *h, int which, double value);
 int sph_synchronize(SphHandle *h);
+/* Development overrides in force on this handle: "NAME=value;NAME=value" (empty string: none).  The SPH_* environment knobs of the
+ * library (layout / arithmetic switches used by tests and tools for A/B runs) are read only when SPH_DEV=1 is set; every one that took
+ * effect is listed here, so a measurement can name the switches it ran under -- bench.py refuses to print a line otherwise. */
+const char *sph_overrides(SphHandle *h);
 
 /* Per-kernel timing with HIP events on the handle's stream (bench.py's roofline leg).
  * Enabling it records an event pair around every launch; totals are read back per kernel id. */

@@ -134,3 +134,22 @@ def test_removal_build_patches_still_match_the_kernels():
             text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", fname)).read()
             assert text.count(old) == (want[0] if want else 1), (name, fname, old[:60])
             assert old != new
+
+
+def test_development_overrides_need_sph_dev():
+    """SPH_LIB (which could load ANY .so as the product, the oracle's ABI library included) and the SPH_* knobs inside the
+    library are development overrides -- refused / ignored without SPH_DEV=1."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "SPH_DEV"}
+    env["SPH_LIB"] = os.path.join(ROOT, "oracle", "liborc_abi.so")
+    code = "import cfd_taichi_amd; from cfd_taichi_amd import _native; _native.load()"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "SPH_DEV=1" in r.stderr, r.stderr
+    env["SPH_DEV"] = "1"
+    env["SPH_LIB"] = os.path.join(ROOT, "cfd_taichi_amd", "libsph_mi355x.so")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # every knob of the library goes through the gate: no bare getenv("SPH_...") is left in the product sources
+    text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
+    assert re.findall(r'[^_a-z]getenv\("SPH_(?!DEV")', text) == []

@@ -126,3 +126,21 @@ def test_spray_and_clump(solver, morton, monkeypatch):
     assert sim.download(nat.F_NBR_COUNT).max() >= 39      # the clump is there
     step_both(sim, o, solver, 6)
     sim.close(); o.close()
+
+
+def test_environment_knobs_are_development_overrides(monkeypatch, capfd):
+    """Without SPH_DEV=1 a set SPH_* knob is ignored (one line on stderr), with it the handle reports it through sph_overrides."""
+    cfg = nat.config_from_dict(scenes.get("dfsph_small"))
+    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    monkeypatch.setenv("SPH_ARITH", "relaxed")
+    monkeypatch.delenv("SPH_DEV", raising=False)
+    sim = nat.Simulation(cfg)
+    assert sim.overrides() == [] and sim.scalar(nat.S_ARITH_RELAXED) == 0.0
+    sim.close()
+    assert "SPH_CELL_ORDER is set but ignored" in capfd.readouterr().err
+    monkeypatch.setenv("SPH_DEV", "1")
+    sim = nat.Simulation(cfg)
+    assert "SPH_CELL_ORDER=morton" in sim.overrides() and "SPH_ARITH=relaxed" in sim.overrides()
+    sim.step_dfsph(1)
+    assert sim.scalar(nat.S_ARITH_RELAXED) == 1.0
+    sim.close()

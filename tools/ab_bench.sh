@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # A/B two builds of libsph_mi355x.so on the same box, interleaved:  tools/ab_bench.sh libA.so libB.so [rounds]
 A=$1; B=$2; R=${3:-2}
 for r in $(seq 1 $R); do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # A/B of the cell storage order (Morton curve with tiles of 4/8/16 cells per axis, the reference's linear stride): whole steps, interleaved in one process.
 set -e
 L=cfd_taichi_amd/libsph_mi355x.so

@@ -3,6 +3,7 @@
 Every variant gets its own handle on the same scene; all advance in lock step (results are bit-identical across variants, so the
 state they time is the same), rounds of `AB_CHUNK` steps are timed in random order.  AB_SOLVER overrides the scene's solver."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import random
 import statistics
 import sys

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # Interleaved whole-step A/B of several library builds on the three bench scenes:  tools/ab_three.sh ab/libA.so ab/libB.so ...
 export SPH_BENCH_PREROLL=0
 for r in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 export SPH_BENCH_PREROLL=0
 for w in breaking_dam_30k_wcsph wcsph_250k; do python bench.py --workload $w --steps 1000 --warmup 200 --no-cpu-baseline 2>>gpurun_out/bench_stderr.log | python -c "
 import json,sys

@@ -1,5 +1,6 @@
 """Times the sort + neighbour-list build alone (HIP events) for one build of the library: tools/bnl_time.py [scene]."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # Runs the BASELINE.json configs that fit one GPU and the CPU baselines of BASELINE.md section 3 on a gpurun box.
 # Output: gpurun_out/measure_<name>.json
 set -o pipefail

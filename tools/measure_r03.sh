@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # Round-3 measurement set at the final kernels: every BASELINE config that fits one GPU (tools/measure_configs.sh) plus the round's extra scenes
 # (both arithmetics where it applies).  Output: gpurun_out/measure_*.json
 set -o pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # null-result experiment of round 3 (see tools/README.md); output under gpurun_out/r03/
 set -e
 mkdir -p gpurun_out/r03/mid

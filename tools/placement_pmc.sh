@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # PMC passes over tools/placement_pmc.py: which counter separates a fast handle from a slow one?
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

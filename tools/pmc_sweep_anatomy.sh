@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # SQ / LDS counters of the sweeps, separate --pmc passes over a short run; prints per-kernel means (tools/pmc_sweep_report.py) into
 # gpurun_out/anat_report[_TAG].txt and removes the (large) rocpd databases.  (A pass with the TA_* counters hung rocprofv3 on this pool: left out.)
 # Usage: [SPH_LIB=alt.so] [TAG=name] tools/pmc_sweep_anatomy.sh [bench args]       values are means per (launch, XCD x SE instance): x 32 = per launch

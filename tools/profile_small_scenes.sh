@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # rocprofv3 kernel stats of the small / coupled scenes: is any small kernel unexpectedly heavy?  (round 3: the single-workgroup rigid reductions were)
 R=$PWD; mkdir -p $R/gpurun_out/r03; cd /tmp; export TMPDIR=/tmp SPH_BENCH_PREROLL=0
 for wl in breaking_dam_30k_dfsph coupling_demo breaking_dam_30k_pcisph; do

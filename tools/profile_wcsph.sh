@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # rocprofv3 kernel stats of the two WCSPH configs (BASELINE configs 1 and 2):  bash tools/profile_wcsph.sh <tag>   -> gpurun_out/<tag>_stats_<workload>/
 tag=${1:-x}
 R=${GRAFT_REPO_ROOT:-$PWD}

@@ -9,6 +9,7 @@ Timing only: except `bnl_notable` the results of these builds are wrong on purpo
 (only the first build advances the scene; the others receive its state).  A patch is a list of (old, new) text replacements that must
 each match exactly once in the named file: a kernel that changed under a patch fails loudly instead of measuring something else."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import shutil
 import subprocess
 import sys

@@ -1,6 +1,7 @@
 """Two handles of one library that differ in ONE environment knob advance the same scene in lock step and must stay bit-identical:
     tools/soak_env.py scene steps every KNOB valueA valueB        (e.g. SPH_QUAD 1 0, SPH_BNL_SPLIT 9 0, SPH_STAGE 1 0)"""
 import os, sys, time
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfd_taichi_amd import _native as nat, scenes

@@ -3,6 +3,7 @@
     tools/soak_oracle.py scene steps [check]          SPH_CELL_ORDER=morton puts a small scene on the staged path (LDS staging, 16-bit lists,
                                                      change propagation, wall-gradient cache) that the large scenes run."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import sys
 import time
 

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # slabs with the large-scene path forced (Morton curve, LDS staging): small leaky scenes for thousands of steps, and the 1 M scene
 set -o pipefail
 run() { # scene world steps rebalance

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SPH_DEV=1 SPH_BENCH_ALLOW_OVERRIDES=1     # the SPH_* knobs below are development overrides (include/sph_mi355x.h: sph_overrides)
 # list build for small scenes: classic / three waves per 64 particles / nine, at several scene sizes:  tools/split_sweep.sh "scene bench-args" ...
 export SPH_BENCH_PREROLL=0
 for w in "$@"; do

@@ -1,5 +1,6 @@
 """Two settings of one environment knob give the same bits: tools/stage_check.py KNOB [scene steps ...]"""
 import os, sys
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from cfd_taichi_amd import _native as nat, scenes

@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 sys.path.insert(0, os.getcwd())
 from cfd_taichi_amd import _native as nat, scenes
 sim = nat.Simulation(nat.config_from_dict(scenes.get("dfsph_1m")))

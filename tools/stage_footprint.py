@@ -1,6 +1,7 @@
 """How many particles would a 256-particle workgroup have to stage (all particles of the 27-cell neighbourhoods of its own particles)?
 tools/stage_footprint.py scene steps  ->  distribution over workgroups, for the device order in use (SPH_CELL_ORDER)."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import sys
 
 import numpy as np

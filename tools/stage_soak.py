@@ -2,6 +2,7 @@
 Two handles (SPH_STAGE=1 / 0) advance in lock step; positions, velocities and the step statistics must stay bit-identical while the
 dam collapses (workgroups drift between staged and unstaged as the flow thins out)."""
 import os, sys, time
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfd_taichi_amd import _native as nat, scenes

@@ -4,6 +4,7 @@ Each build gets its own handle on the same scene advanced by the same steps; rou
 TUNE_COPY_STATE=1: only the first build advances the scene, the others receive its positions / velocities / warm_start_k (for
 removal-experiment builds whose results are wrong on purpose)."""
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import random
 import statistics
 import sys

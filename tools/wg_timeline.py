@@ -7,6 +7,7 @@ how many workgroups are in flight over the launch, how long they live, per XCD w
 import ctypes
 import json
 import os
+os.environ.setdefault("SPH_DEV", "1")     # tools run with development overrides enabled (sph_overrides reports them)
 import sys
 
 import numpy as np
