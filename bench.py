@@ -523,7 +523,9 @@ def main():
         "config": {"workload": scene_name, "solver": solver_kind, "particles": n_total, "wall_particles": sim.n_wall,
                    "grid": list(sim.grid), "preroll_steps": args.preroll, "arith": headline_arith, "overrides": overrides,
                    "timed_steps": "%d-%d" % (args.preroll + args.warmup + 1, args.preroll + args.warmup + args.steps),
-                   "parallelism": "1 GPU" if world == 1 else "%d x-slabs, 1 ghost cell layer, halo transport: %s, cuts re-balanced every %d steps" % (world, transport, args.rebalance)},
+                   "parallelism": "1 GPU" if world == 1 else "%d x-slabs, %s, halo transport: %s, cuts re-balanced every %d steps" % (
+                       world, "2 ghost cell columns per side (one halo refresh per dfsph solver iteration, edge tiles of the residual sweeps first)" if solver_kind == "dfsph"
+                       else "1 ghost cell column per side", transport, args.rebalance)},
     }
     if args.preroll > 0:
         out["early_phase"] = {"steps": "1-%d" % args.preroll, "value": n_total * args.preroll / early / 1e6, "ms_per_step": early / args.preroll * 1e3,

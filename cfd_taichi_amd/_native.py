@@ -61,7 +61,9 @@ class SphConfig(ctypes.Structure):
         ("slab_capacity", ctypes.c_int32),
         ("slab_rebalance_every", ctypes.c_int32),
         ("arith", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("slab_ghost_layers", ctypes.c_int32),
+        ("slab_overlap", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -113,6 +115,8 @@ EXCHANGE_COUNTS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_in
 EXCHANGE_BUFFERS_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.c_int32)
 ALLREDUCE_STREAM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32)
+EXCHANGE_COUNTS_N_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
 
 
 class SphComm(ctypes.Structure):
@@ -130,6 +134,7 @@ class SphComm(ctypes.Structure):
         ("stream_ordered", ctypes.c_int32),
         ("allreduce_stream", ALLREDUCE_STREAM_FN),
         ("reduce_buf", ctypes.c_void_p),
+        ("exchange_counts_n", EXCHANGE_COUNTS_N_FN),
     ]
 
 
@@ -245,7 +250,7 @@ class SphError(RuntimeError):
 
 
 def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0,
-                     slab_rank=0, slab_count=0, slab_capacity=0, slab_rebalance_every=0, arith=0):
+                     slab_rank=0, slab_count=0, slab_capacity=0, slab_rebalance_every=0, arith=0, slab_ghost_layers=0, slab_overlap=0):
     """Flatten a reference-style config dict (config/*.json schema) into SphConfig."""
     scene, sol, fluid = config["scene"], config["solver"], config["fluid"]
     name = solver_name or sol["name"]
@@ -269,6 +274,8 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.slab_rank, c.slab_count, c.slab_capacity = int(slab_rank), int(slab_count), int(slab_capacity)
     c.slab_rebalance_every = int(slab_rebalance_every)
     c.arith = int(arith)
+    c.slab_ghost_layers = int(slab_ghost_layers)
+    c.slab_overlap = int(slab_overlap)
     return c
 
 

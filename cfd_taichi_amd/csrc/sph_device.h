@@ -59,6 +59,10 @@ struct Consts {
     float rx_k1a, rx_k1b; // 3 m kg6 / h^2, -2 m kg6 / h^2
     float rx_k2;          // -m kg6 / h
     float rx_rho0_m;      // rho0 / m (wall sums carry m like the fluid sums)
+    // slab handles with two ghost columns per side (dfsph): ghosts of the INNER column (cell x == gw_left or gw_right; -1: none) have neighbour
+    // lists of their own and run D1 and the correction sweeps like owned particles (k_build_nl: "walker"), so that their v / v* never has to
+    // be refreshed inside a solver loop; ghost_walk = 1 on such handles
+    int gw_left, gw_right, ghost_walk;
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).

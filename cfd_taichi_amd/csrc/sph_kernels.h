@@ -38,6 +38,19 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
     return xcd_block(orig, nwg);
 }
 
+// Edge / interior split of a sweep (slab handles; the order comes from k_tile_order in sph_slab_kernels.h): phase 0 = every tile in one launch,
+// 1 = the edge tiles (tile_order[0 .. n_edge)), 2 = the interior ones; both split launches have the full grid, surplus workgroups leave at once.
+struct TilePhase { const int *order; int ntiles, phase; };
+__device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
+{
+    if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
+    const int ne = tp.order[tp.ntiles];
+    if (tp.phase == 1) return (int)blockIdx.x < ne ? tp.order[blockIdx.x] : -1;
+    const int ni = tp.ntiles - ne;
+    if ((int)blockIdx.x >= ni) return -1;
+    return tp.order[ne + (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ni))];
+}
+
 // Neighbour lists are stored per 64-particle wave tile, four rows interleaved per lane:
 //   entry (i, k) lives at ((i/64)*kmax + (k & ~3))*64 + (i%64)*4 + (k & 3)
 // so a lane fetches neighbours k..k+3 with ONE 16-byte load, a wave's load is 1 KiB contiguous, and
@@ -567,6 +580,9 @@ __device__ __forceinline__ int stage_lookup(const int *key, const int *base, int
     return 0;
 }
 
+// who owns neighbour lists: every owned particle (id >= 0), and on two-column slab handles the ghosts of the inner ghost column (Consts.gw_*)
+__device__ __forceinline__ bool list_walker(const Consts &c, int id, int cx) { return id >= 0 || (c.ghost_walk && (cx == c.gw_left || cx == c.gw_right)); }
+
 // (Candidates are requested four at a time: twelve per batch gain where there is less than a wave per SIMD -- 30 k particles: 54 -> 48 us --
 // and lose to the tests of candidates past the cell's end where issue is the limit -- 250 k: 68 -> 75 us; small scenes use k_build_nl_split.)
 template <bool RIGID, bool STAGED>
@@ -592,10 +608,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         for (int q = threadIdx.x; q < kStageHash; q += kBlock) s_key[q] = -1;
         if (threadIdx.x == 0) { s_ncell = 0; s_ok = 1; }
         __syncthreads();
-        if (i < c.n && id[i] >= 0) {
-            const float4 pi = P[i];
-            int cx, cy, cz, px, py, pz;
-            cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+        int hcx = 0, hcy = 0, hcz = 0;
+        if (i < c.n) cell_id_of(c, P[i].x, P[i].y, P[i].z, hcx, hcy, hcz);
+        if (i < c.n && list_walker(c, id[i], hcx)) {
+            const int cx = hcx, cy = hcy, cz = hcz;
+            int px, py, pz;
             // the first particle of every run of equal cell COORDINATES inserts the neighbourhood: particles that left the box share a
             // (wrapped or "outside") cell index with particles whose coordinates, and hence neighbour cells, differ
             bool head = threadIdx.x == 0 || id[i - 1] < 0;
@@ -671,13 +688,15 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     // now fills a table of (run, cell) entries with all lanes working (9 runs x 9 cells = 81 entries on 64 lanes) and every lane
     // reads its run's entry from LDS.  A wave with more runs than the table holds (sparse spray) works the entries out per lane.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool walker = i < c.n && id[i] >= 0;
-    if (i < c.n && !walker) cnt[i] = (int)0x80000000;     // ghost (multi-GPU): takes part as a neighbour only, owns no sums
     const float4 pi = P[i < c.n ? i : 0];
     const f32x2 pi_xy = {pi.x, pi.y};
     const unsigned cut_bits = __float_as_uint(c.r2_cut);
     int cx, cy, cz;
     cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+    const int my_raw_id = i < c.n ? id[i] : 0;
+    const bool walker = i < c.n && list_walker(c, my_raw_id, cx);
+    const int ghost_bit = my_raw_id < 0 ? (int)0x80000000 : 0;      // ghost (multi-GPU): owns no sums; without a list it takes part as a neighbour only
+    if (i < c.n && !walker) cnt[i] = (int)0x80000000;
     const int pcx = __shfl_up(cx, 1, 64), pcy = __shfl_up(cy, 1, 64), pcz = __shfl_up(cz, 1, 64);
     const bool pwalker = __shfl_up(walker ? 1 : 0, 1, 64) != 0;
     const bool rhead = walker && (lane == 0 || !pwalker || pcx != cx || pcy != cy || pcz != cz);
@@ -794,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         wf.flush(self_local);
         kf = wf.k; kb = ww.k;
         int kfc = kf < c.kmax ? kf : c.kmax, kbc = kb < c.kbmax ? kb : c.kbmax;
-        cnt[i] = kfc | (kbc << 16);
+        cnt[i] = kfc | (kbc << 16) | ghost_bit;
         if (RIGID) ncount[i] = nq;
     }
     note_list_lengths(c, kf, kb, ds);
@@ -853,13 +872,15 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
     const int blk = xcd_block(blockIdx.x, gridDim.x);
     const int i = blk * 64 + lane;
     if (i == 0 && plane == 0) ds->lost = cell_start[c.S + 1] - cell_start[c.S];   // size of the "outside the grid" bucket
-    const bool walker = i < c.n && id[i] >= 0;
-    if (i < c.n && !walker && plane == 0) cnt[i] = (int)0x80000000;               // ghost (multi-GPU)
     const float4 pi = P[i < c.n ? i : 0];
     const f32x2 pi_xy = {pi.x, pi.y};
     const unsigned cut_bits = __float_as_uint(c.r2_cut);
     int cx, cy, cz;
     cell_id_of(c, pi.x, pi.y, pi.z, cx, cy, cz);
+    const int my_raw_id = i < c.n ? id[i] : 0;
+    const bool walker = i < c.n && list_walker(c, my_raw_id, cx);
+    const int ghost_bit = my_raw_id < 0 ? (int)0x80000000 : 0;                    // ghost (multi-GPU), see k_build_nl
+    if (i < c.n && !walker && plane == 0) cnt[i] = (int)0x80000000;
     const int pcx = __shfl_up(cx, 1, 64), pcy = __shfl_up(cy, 1, 64), pcz = __shfl_up(cz, 1, 64);
     const bool pwalker = __shfl_up(walker ? 1 : 0, 1, 64) != 0;
     const bool rhead = walker && (lane == 0 || !pwalker || pcx != cx || pcy != cy || pcz != cz);
@@ -959,7 +980,7 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
     if (walker) walk(std::true_type{}, kf0, kb0);
     if (plane == 0) {
         if (walker) {
-            cnt[i] = (kft < c.kmax ? kft : c.kmax) | ((kbt < c.kbmax ? kbt : c.kbmax) << 16);
+            cnt[i] = (kft < c.kmax ? kft : c.kmax) | ((kbt < c.kbmax ? kbt : c.kbmax) << 16) | ghost_bit;
             if (RIGID) ncount[i] = nqt;
         }
         note_list_lengths(c, walker ? kft : 0, walker ? kbt : 0, ds);
@@ -973,7 +994,10 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
 // carries the same accumulators, lane 0 writes the results (`owner`)
 #define SPH_SWEEP_PROLOGUE_M(QUAD) SPH_SWEEP_PROLOGUE_B(QUAD, xcd_block(blockIdx.x, gridDim.x))
 // ... with the workgroup -> tile mapping chosen by the caller
-#define SPH_SWEEP_PROLOGUE_B(QUAD, BLK)                      \
+#define SPH_SWEEP_PROLOGUE_B(QUAD, BLK) SPH_SWEEP_PROLOGUE_G(QUAD, BLK, false)
+// GW ("ghosts walk"): on two-column slab handles the ghosts of the inner column have lists of their own (k_build_nl: list_walker); the sweeps
+// that must run on them -- D1 and the corrections D2 / D4 / D7 -- pass true, every other sweep sees a ghost's list as empty
+#define SPH_SWEEP_PROLOGUE_G(QUAD, BLK, GW)                  \
     const int blk = (BLK);                                   \
     const int q = (QUAD) ? (int)(threadIdx.x & 3) : 0;       \
     (void)q;                                                 \
@@ -983,9 +1007,9 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
     (void)owner;                                             \
     const int ii = live ? i : 0;                             \
     const int cw = live ? cnt[ii] : 0;                       \
-    const int kf = cw & 0xffff, kb = (cw >> 16) & 0x7fff;    \
     const bool ghost = cw < 0;                               \
     (void)ghost;                                             \
+    const int kf = (!(GW) && ghost) ? 0 : (cw & 0xffff), kb = (!(GW) && ghost) ? 0 : ((cw >> 16) & 0x7fff); \
     const float4 pi = P[ii];                                 \
     const uint32_t *nlp = nl + nl_index(ii, 0, c.kpitch);     \
     const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbpitch) : nullptr;
@@ -995,9 +1019,9 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
     const bool live = i < c.n;                               \
     const int ii = live ? i : 0;                             \
     const int cw = live ? cnt[ii] : 0;                       \
-    const int kf = cw & 0xffff, kb = (cw >> 16) & 0x7fff;    \
     const bool ghost = cw < 0;                               \
     (void)ghost;                                             \
+    const int kf = ghost ? 0 : (cw & 0xffff), kb = ghost ? 0 : ((cw >> 16) & 0x7fff); \
     const float4 pi = P[ii];                                 \
     const uint32_t *nlp = nl + nl_index(ii, 0, c.kpitch);     \
     const uint32_t *nlbp = nlb ? nlb + nl_index(ii, 0, c.kbpitch) : nullptr;
@@ -1286,7 +1310,7 @@ __device__ __forceinline__ bool stage_sources_flagged(const uint2 *__restrict__ 
     for (int r = threadIdx.x; r < nruns; r += kBlock) {
         const uint2 rn = runs[r];
         const uint32_t first = rn.x, n = rn.y >> 16;
-        f |= wave_flags[first >> 6] | wave_flags[(first + n - 1u) >> 6];
+        for (uint32_t w = first >> 6; w <= (first + n - 1u) >> 6; ++w) f |= wave_flags[w];      // (a run of > 65 particles spans three waves or more)
     }
     return __syncthreads_or(f) != 0;
 }
@@ -1685,7 +1709,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
 {
     constexpr bool STAGED = MODE == SWEEP_STAGED, QUAD = MODE == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    SPH_SWEEP_PROLOGUE_M(QUAD)
+    SPH_SWEEP_PROLOGUE_G(QUAD, xcd_block(blockIdx.x, gridDim.x), true)
     const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     float fa[5] = {0.001f, 0.f, 0.f, 0.f, 0.f};              // rho starts at 0.001, solver_base.py:44
     float &rho = fa[0], &sx = fa[1], &sy = fa[2], &sz = fa[3], &sq = fa[4];
@@ -1883,7 +1907,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
-    SPH_SWEEP_PROLOGUE_B(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_G(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x), true)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
@@ -1893,8 +1917,12 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk)
                                   : stage_operand_w_checked<true>(c, s_operand, P, stage_src, stage_cnt, blk);
         if (verdict == 2) {                                                        // every k / rho this tile can see is 0: v* stays
-            if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
-            if (live) changed8[i] = 0;
+            // (one-column slab handles: a ghost's v* is refreshed from its owner after this sweep and may change behind this rank's back,
+            // whatever this rank can see; on two-column handles the inner ghosts are corrected HERE, from the same inputs as on their owner)
+            const bool foreign = live && ghost && !c.ghost_walk;
+            const unsigned long long anyg = __ballot(foreign);
+            if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = anyg != 0ull ? 1 : 0;
+            if (live) changed8[i] = foreign ? 1 : 0;
             return;
         }
         staged = verdict == 1;
@@ -1972,8 +2000,9 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         });
     else for_nbrs_p(nlbp, kb, WP, wall);
     if (track) {       // did any lane of this wave apply a correction?  (all sums +-0: v - (+-0) * dt leaves v)
-        // (a ghost's v* is refreshed from its owner after this sweep: it may change behind this rank's back)
-        const bool changed = live && (ghost || ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
+        // (one-column slab handles: a ghost's v* is refreshed from its owner after this sweep, it may change behind this rank's back; two-column
+        // handles: the inner ghosts' corrections are computed here like everybody's, the outer ghosts' v* is never read)
+        const bool changed = live && ((ghost && !c.ghost_walk) || ax != 0.f || ay != 0.f || az != 0.f || bx != 0.f || by != 0.f || bz != 0.f);
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
@@ -2010,20 +2039,22 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                      const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
-                                                     const float4 *__restrict__ wall_gc)
+                                                     const float4 *__restrict__ wall_gc, TilePhase tp)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
+    const int tile = sweep_tile(tp, spread);
+    if (tile < 0) return;
     if (spread) {                                                    // change propagation, see stage_sources_flagged
-        const int tb = (int)blockIdx.x, sw = stage_cnt[tb];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tb, wave_dirty)) {             // rho*, k / rho and the block partial of the last iteration stand
+        const int sw = stage_cnt[tile];
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {           // rho*, k / rho and the block partial of the last iteration stand
             return;
         }
     }
-    SPH_SWEEP_PROLOGUE_B(QUAD, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(QUAD, tile)
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
@@ -2099,7 +2130,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             flag = val > 0.f && !ghost;                                                       // :275
             kr = (val * alpha[i] / ds->dt) / rho_i;                                           // :363,367
         }
-        if (owner) {
+        if (owner && !(ghost && c.ghost_walk)) {      // (two-column slab handles: a ghost's value and k / rho arrive with the halo, which may overlap this launch)
             out[i] = val;
             if (c.kr_split) krho[i] = kr;
             else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);

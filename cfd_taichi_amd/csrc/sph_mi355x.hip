@@ -140,7 +140,7 @@ struct SphHandle {
     // multi-GPU x-slab state (slab_count > 1)
     bool slab = false;
     int slab_rank = 0, nslab = 1;
-    SlabGeom geom = {0, 0, 0, 0};
+    SlabGeom geom = {0, 0, 0, 0, 1, 0, 0};
     int ncap = 0;                 // capacity (particles) of every per-particle array
     int n_owned = 0, n_ghost = 0, n_dead = 0;
     bool comm_set = false;
@@ -148,9 +148,17 @@ struct SphHandle {
     void *dsend[2] = {nullptr, nullptr}, *drecv[2] = {nullptr, nullptr};   // device-side message buffers
     bool own_dev_comm = false;
     int *dead = nullptr;
-    int *edge_off[4] = {nullptr, nullptr, nullptr, nullptr};    // 0 ghost-left, 1 send-left, 2 send-right, 3 ghost-right
+    // ordered edge lists, one per (side, direction): 0 ghost-left, 1 send-left, 2 send-right, 3 ghost-right.  With two ghost columns per side a
+    // list holds the column next to the cut first (edge_n[k][0] entries), then the second one (edge_n[k][1]); edge_off[2 k + l] are the per-cell
+    // offsets of column l of list k
+    int *edge_off[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int *edge_list[4] = {nullptr, nullptr, nullptr, nullptr};
-    int edge_count[4] = {0, 0, 0, 0};
+    int edge_n[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    bool cuts_moved = false;          // this step's re-balancing moved a cut: the particle exchange runs its two-round form
+    bool overlap = false;             // dfsph, two ghost columns: edge tiles of the residual sweeps first, halo on xstream under the interior tiles
+    hipStream_t xstream = nullptr;    // the halo's stream when overlap is on
+    hipEvent_t ev_edge = nullptr, ev_halo = nullptr;
+    int *tile_flag = nullptr, *tile_order = nullptr;
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
     // native transport (sph_rccl_attach): the library drives RCCL itself on its stream
@@ -230,14 +238,14 @@ hipEvent_t take_event(SphHandle *h)
 }
 
 struct ProfScope {
-    SphHandle *h; int kid; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(SphHandle *h_, int kid_) : h(h_), kid(kid_)
+    SphHandle *h; int kid; hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+    ProfScope(SphHandle *h_, int kid_, hipStream_t on = nullptr) : h(h_), kid(kid_), st(on ? on : h_->stream)
     {
-        if (h->profiling) { a = take_event(h); b = take_event(h); (void)hipEventRecord(a, h->stream); }
+        if (h->profiling) { a = take_event(h); b = take_event(h); (void)hipEventRecord(a, st); }
     }
     ~ProfScope()
     {
-        if (h->profiling) { (void)hipEventRecord(b, h->stream); h->ev_pending.push_back({a, b, kid}); }
+        if (h->profiling) { (void)hipEventRecord(b, st); h->ev_pending.push_back({a, b, kid}); }
     }
 };
 
@@ -245,6 +253,7 @@ void drain_profile(SphHandle *h)
 {
     if (h->ev_pending.empty()) return;
     (void)hipStreamSynchronize(h->stream);
+    if (h->xstream) (void)hipStreamSynchronize(h->xstream);
     for (auto &e : h->ev_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { h->prof_ms[e.kid] += ms; h->prof_n[e.kid] += 1; }
@@ -276,6 +285,9 @@ inline float host_cubic_w(float r, float h, float kw)
     return ret;
 }
 
+// Every slab is at least three columns wide: with two ghost columns per side the merged particle exchange needs ghost layers + 1 (a particle
+// that arrives from one neighbour must not land in the columns copied to the other, see k_classify_slab).
+constexpr int kMinSlabColumns = 3;
 // cut[k] = first column x with (particles in columns < x) >= k N / nslab
 void cuts_from_histogram(const std::vector<long long> &hist, long long N, int gx, int nslab, std::vector<int> &cut)
 {
@@ -303,8 +315,8 @@ void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, con
     cuts_from_histogram(hist, N, gx, nslab, cut);
     cut[0] = 0; cut[nslab] = gx;
     for (int k = 1; k < nslab; ++k) {
-        int lo = std::max(old_cut[k - 1] + 1, cut[k - 1] + 2);
-        int hi = std::min(old_cut[k + 1] - 1, gx - 2 * (nslab - k));
+        int lo = std::max(old_cut[k - 1] + 1, cut[k - 1] + kMinSlabColumns);
+        int hi = std::min(old_cut[k + 1] - 1, gx - kMinSlabColumns * (nslab - k));
         cut[k] = std::min(std::max(cut[k], lo), hi);
     }
 }
@@ -322,16 +334,28 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
         col[i] = cx;
         hist[cx]++;
     }
-    if (gx < 2 * nslab) {
+    if (gx < kMinSlabColumns * nslab) {
         char buf[160];
-        snprintf(buf, sizeof(buf), "%d slabs need at least %d cell columns along x, the grid has %d: too many slabs for this scene", nslab, 2 * nslab, gx);
+        snprintf(buf, sizeof(buf), "%d slabs need at least %d cell columns along x, the grid has %d: too many slabs for this scene", nslab, kMinSlabColumns * nslab, gx);
         why = buf;
         return false;
     }
     cuts_from_histogram(hist, N, gx, nslab, cut);
-    for (int k = 1; k < nslab; ++k)     // every slab at least 2 columns wide (edge column + one more), even where the fluid is narrow
-        cut[k] = std::min(std::max(cut[k], cut[k - 1] + 2), gx - 2 * (nslab - k));
+    for (int k = 1; k < nslab; ++k)     // every slab at least kMinSlabColumns wide, even where the fluid is narrow
+        cut[k] = std::min(std::max(cut[k], cut[k - 1] + kMinSlabColumns), gx - kMinSlabColumns * (nslab - k));
     return true;
+}
+
+// this rank's columns, its neighbours' far cuts and the ghost columns whose particles own lists, from h->cuts
+void set_slab_geometry(SphHandle *h)
+{
+    const std::vector<int> &cut = h->cuts;
+    const int r = h->slab_rank;
+    h->geom.x_lo = cut[r]; h->geom.x_hi = cut[r + 1];
+    h->geom.far_left = r > 0 ? cut[r - 1] : 0;
+    h->geom.far_right = r + 2 <= h->nslab ? cut[r + 2] : h->c.gx;
+    h->c.gw_left = (h->geom.layers == 2 && h->geom.has_left) ? h->geom.x_lo - 1 : -1;
+    h->c.gw_right = (h->geom.layers == 2 && h->geom.has_right) ? h->geom.x_hi : -1;
 }
 
 struct HostScene {
@@ -429,6 +453,7 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.boundary_handle = cf.boundary_handle ? 1 : 0;
     c.strict_cells = cf.slab_count > 1 ? 1 : 0;
     c.n = h->N;                                    // refined below for slab handles
+    c.gw_left = c.gw_right = -1; c.ghost_walk = 0;
     c.stride = (h->N + 63) / 64 * 64;
     c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
     c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64) + 3) & ~3;
@@ -505,8 +530,13 @@ int build_scene(SphHandle *h, HostScene &sc)
         }
         h->cuts = cut;
         h->rebalance_every = cf.slab_rebalance_every > 0 ? cf.slab_rebalance_every : 0;
-        h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
         h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
+        // two ghost columns per side by default for dfsph (one halo refresh per solver iteration, see step_dfsph_device_loops); the
+        // other solvers keep the one-column protocol
+        h->geom.layers = cf.slab_ghost_layers == 1 ? 1 : (cf.slab_ghost_layers == 2 || cf.solver == SPH_SOLVER_DFSPH) ? 2 : 1;
+        if (h->geom.layers == 2 && cf.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_INVALID, "slab_ghost_layers = 2 is the dfsph protocol");
+        c.ghost_walk = h->geom.layers == 2 ? 1 : 0;
+        set_slab_geometry(h);
         if (cf.solver == SPH_SOLVER_PCISPH) h->pci_fluid_pos = sc.fluid_pos;   // pre_compute looks at the whole lattice on every slab
         std::vector<float> own_pos; std::vector<int> own_id;
         for (int i = 0; i < N; ++i)
@@ -517,7 +547,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         sc.fluid_pos.swap(own_pos);
         h->init_ids.swap(own_id);
         h->n_owned = (int)h->init_ids.size();
-        long long cap = cf.slab_capacity > 0 ? cf.slab_capacity : (long long)(1.75 * N / h->nslab) + 262144;
+        long long cap = cf.slab_capacity > 0 ? cf.slab_capacity : (long long)((h->geom.layers == 2 ? 2.0 : 1.75) * N / h->nslab) + 262144;
         if (cap < h->n_owned) cap = h->n_owned;
         h->ncap = (int)std::min<long long>(cap, 0x7fffff00LL);
         c.n = h->n_owned;
@@ -752,11 +782,15 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             }
             if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
                 if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;
-            if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab)      // the relaxed sweeps' per-step wall sums (use_relaxed)
+            if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH)      // the relaxed sweeps' per-step wall sums (use_relaxed)
                 if ((rc = dalloc(h, &h->wall_grad, n)) || (rc = dalloc(h, &h->wall_gsq, n))) return rc;
         }
         // (up to 64 GiB of it, ~58 M particles at 64 rows: beyond that the sweeps walk the wall lists and the memory goes to the scene)
-        if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad && (n + 64) * (size_t)c.kbpitch * sizeof(float4) <= ((size_t)64 << 30))
+        // ... and never more than half of what is free on the device right now: the cache is an optimisation, the scene is not
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)1 << 62;
+        const size_t gc_bytes = (n + 64) * (size_t)c.kbpitch * sizeof(float4);
+        if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad && gc_bytes <= ((size_t)64 << 30) && gc_bytes <= free_b / 2)
             if ((rc = dalloc(h, &h->wall_gc, (n + 64) * (size_t)c.kbpitch))) return rc;
     }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
@@ -776,12 +810,21 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
     if (h->slab) {
         if ((rc = dalloc(h, &h->dead, n))) return rc;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k)
             if ((rc = dalloc(h, &h->edge_off[k], (size_t)c.gy * c.gz + 1))) return rc;
+        for (int k = 0; k < 4; ++k)
             if ((rc = dalloc(h, &h->edge_list[k], n))) return rc;
+        if ((rc = dalloc(h, &h->counters, kSlabCounters))) return rc;
+        HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * kSlabCounters, hipHostMallocDefault));
+        // edge / interior split of the residual sweeps (dfsph, two ghost columns): tile flags and the edge-first tile order
+        h->overlap = h->geom.layers == 2 && h->cfg.slab_overlap != 1;
+        if (h->overlap) {
+            if ((rc = dalloc(h, &h->tile_flag, (n + kBlock - 1) / kBlock + 1))) return rc;
+            if ((rc = dalloc(h, &h->tile_order, (n + kBlock - 1) / kBlock + 2))) return rc;
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_edge, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
         }
-        if ((rc = dalloc(h, &h->counters, 4))) return rc;
-        HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * 4, hipHostMallocDefault));
         if ((rc = dalloc(h, &h->col_hist, (size_t)c.gx))) return rc;
         HIP_TRY(h, hipHostMalloc((void **)&h->col_hist_host, sizeof(int) * (size_t)c.gx, hipHostMallocDefault));
     }
@@ -906,48 +949,52 @@ RcclApi &rccl()
     } while (0)
 
 // exchange_buffers of the native transport: one group of up to four point-to-point transfers, ordered on the handle's stream
-int native_exchange(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
+int native_exchange(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr)
 {
     RcclApi &n = rccl();
+    if (!stream) stream = h->stream;
     const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
     if (!((left >= 0 && (sl || rl)) || (right >= 0 && (sr || rr)))) return SPH_OK;
     NCCL_TRY(h, n.GroupStart());
     if (left >= 0) {
-        if (sl) NCCL_TRY(h, n.Send(h->dsend[0], sl, ncclChar, left, h->nccl, h->stream));
-        if (rl) NCCL_TRY(h, n.Recv(h->drecv[0], rl, ncclChar, left, h->nccl, h->stream));
+        if (sl) NCCL_TRY(h, n.Send(h->dsend[0], sl, ncclChar, left, h->nccl, stream));
+        if (rl) NCCL_TRY(h, n.Recv(h->drecv[0], rl, ncclChar, left, h->nccl, stream));
     }
     if (right >= 0) {
-        if (sr) NCCL_TRY(h, n.Send(h->dsend[1], sr, ncclChar, right, h->nccl, h->stream));
-        if (rr) NCCL_TRY(h, n.Recv(h->drecv[1], rr, ncclChar, right, h->nccl, h->stream));
+        if (sr) NCCL_TRY(h, n.Send(h->dsend[1], sr, ncclChar, right, h->nccl, stream));
+        if (rr) NCCL_TRY(h, n.Recv(h->drecv[1], rr, ncclChar, right, h->nccl, stream));
     }
     NCCL_TRY(h, n.GroupEnd());
     return SPH_OK;
 }
 
-// exchange_counts of the native transport: one int each way with each neighbour, then the host reads the two it received
-int native_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr)
+// exchange_counts of the native transport: n ints each way with each neighbour, then the host reads what it received
+constexpr int kCountInts = 8;
+int native_exchange_counts_n(SphHandle *h, int n, const int32_t *sl, const int32_t *sr, int32_t *rl, int32_t *rr)
 {
-    RcclApi &n = rccl();
+    RcclApi &api = rccl();
     const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
-    h->cnt_host[0] = sl; h->cnt_host[1] = sr; h->cnt_host[2] = 0; h->cnt_host[3] = 0;
-    HIP_TRY(h, hipMemcpyAsync(h->cnt_dev, h->cnt_host, sizeof(int) * 4, hipMemcpyHostToDevice, h->stream));
+    memset(h->cnt_host, 0, sizeof(int) * 4 * kCountInts);
+    for (int k = 0; k < n; ++k) { h->cnt_host[k] = sl[k]; h->cnt_host[kCountInts + k] = sr[k]; }
+    HIP_TRY(h, hipMemcpyAsync(h->cnt_dev, h->cnt_host, sizeof(int) * 4 * kCountInts, hipMemcpyHostToDevice, h->stream));
     if (left >= 0 || right >= 0) {
-        NCCL_TRY(h, n.GroupStart());
+        NCCL_TRY(h, api.GroupStart());
         if (left >= 0) {
-            NCCL_TRY(h, n.Send(h->cnt_dev + 0, 1, ncclInt32, left, h->nccl, h->stream));
-            NCCL_TRY(h, n.Recv(h->cnt_dev + 2, 1, ncclInt32, left, h->nccl, h->stream));
+            NCCL_TRY(h, api.Send(h->cnt_dev + 0, (size_t)n, ncclInt32, left, h->nccl, h->stream));
+            NCCL_TRY(h, api.Recv(h->cnt_dev + 2 * kCountInts, (size_t)n, ncclInt32, left, h->nccl, h->stream));
         }
         if (right >= 0) {
-            NCCL_TRY(h, n.Send(h->cnt_dev + 1, 1, ncclInt32, right, h->nccl, h->stream));
-            NCCL_TRY(h, n.Recv(h->cnt_dev + 3, 1, ncclInt32, right, h->nccl, h->stream));
+            NCCL_TRY(h, api.Send(h->cnt_dev + kCountInts, (size_t)n, ncclInt32, right, h->nccl, h->stream));
+            NCCL_TRY(h, api.Recv(h->cnt_dev + 3 * kCountInts, (size_t)n, ncclInt32, right, h->nccl, h->stream));
         }
-        NCCL_TRY(h, n.GroupEnd());
+        NCCL_TRY(h, api.GroupEnd());
     }
-    HIP_TRY(h, hipMemcpyAsync(h->cnt_host, h->cnt_dev, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->cnt_host, h->cnt_dev, sizeof(int) * 4 * kCountInts, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *rl = h->cnt_host[2]; *rr = h->cnt_host[3];
+    for (int k = 0; k < n; ++k) { rl[k] = h->cnt_host[2 * kCountInts + k]; rr[k] = h->cnt_host[3 * kCountInts + k]; }
     return SPH_OK;
 }
+int native_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr) { return native_exchange_counts_n(h, 1, &sl, &sr, rl, rr); }
 
 int native_allreduce_stream(SphHandle *h, int n, int op)
 {
@@ -956,12 +1003,24 @@ int native_allreduce_stream(SphHandle *h, int n, int op)
 }
 
 // neighbour counts / host-side all-reduce through whichever transport the handle has
-int slab_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr)
+// n ints to each neighbour, n from each (absent neighbour: zeros): one host round trip where the transport can (native RCCL, a SphComm with
+// exchange_counts_n), n of them through a plain exchange_counts
+int slab_exchange_counts_n(SphHandle *h, int n, const int32_t *sl, const int32_t *sr, int32_t *rl, int32_t *rr)
 {
-    h->comm_stat[3] += 1;
-    if (h->native) return native_exchange_counts(h, sl, sr, rl, rr);
-    int rc = h->comm.exchange_counts(h->comm.user, sl, sr, rl, rr);
-    return rc ? comm_fail(h, "exchange_counts", rc) : SPH_OK;
+    if (n > kCountInts) return fail(h, SPH_E_INVALID, "count exchange of %d ints", n);
+    for (int k = 0; k < n; ++k) rl[k] = rr[k] = 0;
+    if (h->native) { h->comm_stat[3] += 1; return native_exchange_counts_n(h, n, sl, sr, rl, rr); }
+    if (h->comm.exchange_counts_n) {
+        h->comm_stat[3] += 1;
+        int rc = h->comm.exchange_counts_n(h->comm.user, n, sl, sr, rl, rr);
+        return rc ? comm_fail(h, "exchange_counts_n", rc) : SPH_OK;
+    }
+    for (int k = 0; k < n; ++k) {
+        h->comm_stat[3] += 1;
+        int rc = h->comm.exchange_counts(h->comm.user, sl[k], sr[k], &rl[k], &rr[k]);
+        if (rc) return comm_fail(h, "exchange_counts", rc);
+    }
+    return SPH_OK;
 }
 
 int slab_allreduce_host(SphHandle *h, double *v, int n, int op)
@@ -982,34 +1041,39 @@ int slab_allreduce_host(SphHandle *h, double *v, int n, int op)
     return SPH_OK;
 }
 
-int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr)
+// `stream`: where the packed data was produced and the unpack will run (the handle's stream, or the halo stream of an overlapped refresh).
+// A stream-ordered CALLBACK transport enqueues on the handle's own stream whatever we say, so overlapped refreshes are only taken with the
+// native transport or a synchronous one (slab_can_overlap).
+int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     const SphComm &cm = h->comm;
     if (sl > cm.capacity || sr > cm.capacity || rl > cm.capacity || rr > cm.capacity)
         return fail(h, SPH_E_OVERFLOW, "halo message of %zu bytes exceeds the comm buffer capacity %zu", std::max(std::max(sl, sr), std::max(rl, rr)), cm.capacity);
     if (cm.on_host) {
-        if (sl) HIP_TRY(h, hipMemcpyAsync(cm.send_left, h->dsend[0], sl, hipMemcpyDeviceToHost, h->stream));
-        if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, h->stream));
+        if (sl) HIP_TRY(h, hipMemcpyAsync(cm.send_left, h->dsend[0], sl, hipMemcpyDeviceToHost, stream));
+        if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, stream));
     }
-    if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(h->stream));     // packed data complete before the transport reads it
+    if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(stream));     // packed data complete before the transport reads it
     if (sl || sr || rl || rr) { h->comm_stat[0] += 1; h->comm_stat[1] += (long long)(sl + sr); h->comm_stat[2] += (long long)(rl + rr); }
     int rc;
     if (h->native) {
-        if ((rc = native_exchange(h, sl, sr, rl, rr))) return rc;
+        if ((rc = native_exchange(h, sl, sr, rl, rr, stream))) return rc;
     } else {
         rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);      // stream-ordered transports enqueue behind the pack kernels instead
         if (rc) return comm_fail(h, "exchange_buffers", rc);
     }
     if (cm.on_host) {
-        if (rl) HIP_TRY(h, hipMemcpyAsync(h->drecv[0], cm.recv_left, rl, hipMemcpyHostToDevice, h->stream));
-        if (rr) HIP_TRY(h, hipMemcpyAsync(h->drecv[1], cm.recv_right, rr, hipMemcpyHostToDevice, h->stream));
+        if (rl) HIP_TRY(h, hipMemcpyAsync(h->drecv[0], cm.recv_left, rl, hipMemcpyHostToDevice, stream));
+        if (rr) HIP_TRY(h, hipMemcpyAsync(h->drecv[1], cm.recv_right, rr, hipMemcpyHostToDevice, stream));
     }
     return SPH_OK;
 }
+inline bool slab_can_overlap(const SphHandle *h) { return h->overlap && (h->native || !slab_stream_ordered(h)); }
 
 int read_counters(SphHandle *h)
 {
-    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof(int) * kSlabCounters, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SPH_OK;
 }
@@ -1038,16 +1102,27 @@ int slab_rebalance(SphHandle *h)
     for (int x = 0; x < c.gx; ++x) hist[x] = (long long)v[x];
     std::vector<int> cut;
     replan_slab_cuts(hist, c.gx, h->nslab, h->cuts, cut);
-    if (cut != h->cuts) {
+    h->cuts_moved = cut != h->cuts;
+    if (h->cuts_moved) {
         h->cuts = cut;
-        h->geom.x_lo = cut[h->slab_rank]; h->geom.x_hi = cut[h->slab_rank + 1];
+        set_slab_geometry(h);
         ++h->n_recuts;
     }
     return SPH_OK;
 }
 
-// Start of a step on a slab handle: migrate particles that left [x_lo, x_hi), then re-send both edge cell
-// columns as ghosts.  Old ghosts and leavers are only MARKED dead; the counting sort drops them.
+// Start of a step on a slab handle: particles that left [x_lo, x_hi) move to their new owner, last step's ghosts go, and the `layers`
+// columns next to each cut are copied to the neighbour as this step's ghosts.  Old ghosts and leavers are only MARKED dead; the counting
+// sort drops them.
+//   ordinary step   ONE message per neighbour carries migrants and ghost copies together (k_classify_slab, all three modes), after ONE
+//                   count exchange of five ints per side: records, ghost copies per column, and -- because a leaver that lands in one of
+//                   my ghost columns simply stays here as a ghost, the new owner does not send it back -- how many I kept per column, which
+//                   is how many of the receiver's arrivals belong to the columns it copies to me.  Two host round trips per step (the
+//                   counters read-back and the count exchange) where the two-round form takes four.
+//   re-cut step     two rounds (migrate, then ghost copies over what arrived): moved cuts can carry whole columns across a slab, so what
+//                   arrives from one side may belong to the columns copied to the other.
+// Afterwards edge_n[k][l] = particles of column l of ordered edge list k (0 ghost-left, 1 send-left, 2 send-right, 3 ghost-right), known on
+// both sides of a cut alike without looking at the sorted arrays.
 int slab_exchange_particles(SphHandle *h)
 {
     if (!h->comm_set) return fail(h, SPH_E_STATE, "slab handle needs sph_set_comm before stepping");
@@ -1056,67 +1131,76 @@ int slab_exchange_particles(SphHandle *h)
     const dim3 b(kBlock);
     float *warm = carries_scalar(h) ? h->warm[h->wcur] : nullptr;   // dfsph warm_start_k / iisph p_past travel with the particle
     const int cap_rec = (int)std::min<size_t>(h->comm.capacity / 32, 0x7fffffff);
-    const int n_prev = c.n;
-    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * 4, s));
-    {
-        ProfScope ps(h, K_SLAB);
-        hipLaunchKernelGGL(k_classify_migrate, grid_for(n_prev), b, 0, s, c, h->geom, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur],
-                           h->dead, (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters);
-    }
     int rc;
-    if ((rc = read_counters(h))) return rc;
-    const int mL = h->counters_host[0], mR = h->counters_host[1], ndead = h->counters_host[2];
-    if (mL > cap_rec || mR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d migrating particles exceed the comm buffer (%d records)", mL, mR, cap_rec);
-    int32_t rL = 0, rR = 0;
-    if ((rc = slab_exchange_counts(h, mL, mR, &rL, &rR))) return rc;
-    if ((long long)n_prev + rL + rR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by migration", h->ncap);
-    if ((rc = slab_xfer(h, 32 * (size_t)mL, 32 * (size_t)mR, 32 * (size_t)rL, 32 * (size_t)rR))) return rc;
-    {
-        ProfScope ps(h, K_SLAB);
-        if (rL) hipLaunchKernelGGL(k_append_records, grid_for(rL), b, 0, s, (const float4 *)h->drecv[0], rL, n_prev, 0, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
-        if (rR) hipLaunchKernelGGL(k_append_records, grid_for(rR), b, 0, s, (const float4 *)h->drecv[1], rR, n_prev + rL, 0, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
-    }
-    const int n_in = n_prev + rL + rR;
-    c.n = n_in;
-    HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * 2, s));
-    {
-        ProfScope ps(h, K_SLAB);
-        hipLaunchKernelGGL(k_classify_ghost, grid_for(n_in), b, 0, s, c, h->geom, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
-                           (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters);
-    }
-    if ((rc = read_counters(h))) return rc;
-    const int gL = h->counters_host[0], gR = h->counters_host[1];
-    if (gL > cap_rec || gR > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d ghost particles exceed the comm buffer (%d records)", gL, gR, cap_rec);
-    int32_t hL = 0, hR = 0;
-    if ((rc = slab_exchange_counts(h, gL, gR, &hL, &hR))) return rc;
-    if ((long long)n_in + hL + hR > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by ghosts", h->ncap);
-    if ((rc = slab_xfer(h, 32 * (size_t)gL, 32 * (size_t)gR, 32 * (size_t)hL, 32 * (size_t)hR))) return rc;
-    {
-        ProfScope ps(h, K_SLAB);
-        if (hL) hipLaunchKernelGGL(k_append_records, grid_for(hL), b, 0, s, (const float4 *)h->drecv[0], hL, n_in, 1, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
-        if (hR) hipLaunchKernelGGL(k_append_records, grid_for(hR), b, 0, s, (const float4 *)h->drecv[1], hR, n_in + hL, 1, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+    int n_res = c.n;                                   // resident slots, dead ones included
+    int ndead = 0;
+    int own_ghost[2][2] = {{0, 0}, {0, 0}}, own_kept[2][2] = {{0, 0}, {0, 0}};      // [side][column]: ghost copies I sent, leavers I kept as ghosts
+    int got_ghost[2][2] = {{0, 0}, {0, 0}}, got_kept[2][2] = {{0, 0}, {0, 0}};      // ... and what the neighbour on that side reported
+    auto round = [&](int mode) -> int {
+        HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * kSlabCounters, s));
+        {
+            ProfScope ps(h, K_SLAB);
+            hipLaunchKernelGGL(k_classify_slab, grid_for(n_res), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
+                               (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters, h->ds);
+        }
+        int r;
+        if ((r = read_counters(h))) return r;
+        const int *ct = h->counters_host;
+        if (ct[0] > cap_rec || ct[1] > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d particle records exceed the comm buffer (%d records)", ct[0], ct[1], cap_rec);
+        if (mode & kSlabMigrate) ndead = ct[2];
+        int32_t sl[5] = {ct[0], ct[3], ct[4], ct[5], ct[6]}, sr[5] = {ct[1], ct[7], ct[8], ct[9], ct[10]}, rl[5], rr[5];
+        if ((r = slab_exchange_counts_n(h, 5, sl, sr, rl, rr))) return r;
+        for (int l = 0; l < 2; ++l) {
+            own_ghost[0][l] += sl[1 + l]; own_kept[0][l] += sl[3 + l]; own_ghost[1][l] += sr[1 + l]; own_kept[1][l] += sr[3 + l];
+            got_ghost[0][l] += rl[1 + l]; got_kept[0][l] += rl[3 + l]; got_ghost[1][l] += rr[1 + l]; got_kept[1][l] += rr[3 + l];
+        }
+        if ((long long)n_res + rl[0] + rr[0] > h->ncap) return fail(h, SPH_E_OVERFLOW, "slab capacity %d exceeded by the particle exchange", h->ncap);
+        if ((r = slab_xfer(h, 32 * (size_t)sl[0], 32 * (size_t)sr[0], 32 * (size_t)rl[0], 32 * (size_t)rr[0]))) return r;
+        {
+            ProfScope ps(h, K_SLAB);
+            if (rl[0]) hipLaunchKernelGGL(k_append_records, grid_for(rl[0]), b, 0, s, (const float4 *)h->drecv[0], rl[0], n_res, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+            if (rr[0]) hipLaunchKernelGGL(k_append_records, grid_for(rr[0]), b, 0, s, (const float4 *)h->drecv[1], rr[0], n_res + rl[0], h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead);
+        }
+        // owned particles: migrants out, migrants in (a record is a migrant unless it is a ghost copy)
+        h->n_owned += -(sl[0] - sl[1] - sl[2]) - (sr[0] - sr[1] - sr[2]) + (rl[0] - rl[1] - rl[2]) + (rr[0] - rr[1] - rr[2]);
+        n_res += rl[0] + rr[0];
+        c.n = n_res;
+        return SPH_OK;
+    };
+    if (h->cuts_moved) {
+        if ((rc = round(kSlabMigrate))) return rc;
+        if ((rc = round(kSlabGhosts))) return rc;
+        h->cuts_moved = false;
+    } else {
+        if ((rc = round(kSlabMigrate | kSlabGhosts | kSlabKeep))) return rc;
     }
     HIP_TRY(h, hipGetLastError());
-    c.n = n_in + hL + hR;                     // the sort runs over everything resident, dead slots included
-    h->n_dead = ndead;
-    h->n_owned = h->n_owned - mL - mR + rL + rR;
-    h->n_ghost = hL + hR;
-    h->edge_count[0] = hL; h->edge_count[1] = gL; h->edge_count[2] = gR; h->edge_count[3] = hR;
+    h->n_dead = ndead;                        // the sort runs over everything resident, dead slots included
+    for (int l = 0; l < 2; ++l) {
+        h->edge_n[0][l] = got_ghost[0][l] + own_kept[0][l];      // ghost-left column l: the left neighbour's copies + my leavers that stayed as ghosts
+        h->edge_n[1][l] = own_ghost[0][l] + got_kept[0][l];      // send-left column l: my copies + arrivals the left neighbour kept as ghosts
+        h->edge_n[2][l] = own_ghost[1][l] + got_kept[1][l];
+        h->edge_n[3][l] = got_ghost[1][l] + own_kept[1][l];
+    }
+    h->n_ghost = h->edge_n[0][0] + h->edge_n[0][1] + h->edge_n[3][0] + h->edge_n[3][1];
     return SPH_OK;
 }
 
-// refresh one field of the ghosts after the sweep that produced it (mode: see k_pack_field)
-int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho)
+// refresh one field of the ghosts after the sweep that produced it (mode: see k_pack_field).  cols: how many of the ghost columns per side
+// (1 = the column next to the cut only; the lists hold it first).
+int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho, int cols = 2)
 {
     hipStream_t s = h->stream;
     const dim3 b(kBlock);
     const size_t fl = mode == 0 ? 1 : (mode == 1 ? 3 : 2);      // modes 2 and 3: two floats
-    const int nsl = h->edge_count[1], nsr = h->edge_count[2], nrl = h->edge_count[0], nrr = h->edge_count[3];
+    auto cnt = [&](int k) { return h->edge_n[k][0] + (cols >= 2 && h->geom.layers >= 2 ? h->edge_n[k][1] : 0); };
+    const int nsl = cnt(1), nsr = cnt(2), nrl = cnt(0), nrr = cnt(3);
+    float *S = h->c.kr_split ? h->krho : nullptr;               // where the per-sweep scalar k / rho lives (else P.w)
     {
         ProfScope ps(h, K_SLAB);
         if (nsl + nsr)
             hipLaunchKernelGGL(k_pack_field, grid_for(nsl + nsr), b, 0, s, h->edge_list[1], nsl, (float *)h->dsend[0], h->edge_list[2], nsr,
-                               (float *)h->dsend[1], mode, P, V);
+                               (float *)h->dsend[1], mode, P, V, S);
     }
     int rc = slab_xfer(h, 4 * fl * nsl, 4 * fl * nsr, 4 * fl * nrl, 4 * fl * nrr);
     if (rc) return rc;
@@ -1124,9 +1208,41 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
         ProfScope ps(h, K_SLAB);
         if (nrl + nrr)
             hipLaunchKernelGGL(k_unpack_field, grid_for(nrl + nrr), b, 0, s, h->edge_list[0], nrl, (const float *)h->drecv[0], h->edge_list[3], nrr,
-                               (const float *)h->drecv[1], mode, P, V, rho);
+                               (const float *)h->drecv[1], mode, P, V, rho, S);
     }
     HIP_TRY(h, hipGetLastError());
+    return SPH_OK;
+}
+
+// The one halo refresh of a dfsph solver iteration on a two-column slab handle: the residual sweep's value (rho_derivative / rho_adv) for
+// the inner ghost column, the owner's k / rho for the outer one -- 4 bytes per ghost (k_pack_resid / k_unpack_resid).  With `overlap` the
+// caller has run the EDGE tiles of the sweep only: the pack waits for them (ev_edge) on the halo's own stream, and whoever reads the ghosts
+// next waits for ev_halo -- the interior tiles of the sweep run under the transfer.
+int slab_exchange_resid(SphHandle *h, bool dens, float *val, bool overlap)
+{
+    hipStream_t s = overlap ? h->xstream : h->stream;
+    const dim3 b(kBlock);
+    const int nsl = h->edge_n[1][0] + h->edge_n[1][1], nsr = h->edge_n[2][0] + h->edge_n[2][1];
+    const int nrl = h->edge_n[0][0] + h->edge_n[0][1], nrr = h->edge_n[3][0] + h->edge_n[3][1];
+    float *S = h->c.kr_split ? h->krho : nullptr;
+    float4 *P = h->P[1 - h->pcur];
+    if (overlap) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_edge, 0));
+    {
+        ProfScope ps(h, K_SLAB, s);
+        if (nsl + nsr)
+            hipLaunchKernelGGL(k_pack_resid, grid_for(nsl + nsr), b, 0, s, h->edge_list[1], nsl, h->edge_n[1][0], (float *)h->dsend[0], h->edge_list[2], nsr,
+                               h->edge_n[2][0], (float *)h->dsend[1], val, P, S);
+    }
+    int rc = slab_xfer(h, 4 * (size_t)nsl, 4 * (size_t)nsr, 4 * (size_t)nrl, 4 * (size_t)nrr, s);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, K_SLAB, s);
+        if (nrl + nrr)
+            hipLaunchKernelGGL(k_unpack_resid, grid_for(nrl + nrr), b, 0, s, h->c, h->edge_list[0], nrl, h->edge_n[0][0], (const float *)h->drecv[0], h->edge_list[3], nrr,
+                               h->edge_n[3][0], (const float *)h->drecv[1], dens ? 1 : 0, h->aux, h->rho, h->ds, val, P, S);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (overlap) HIP_TRY(h, hipEventRecord(h->ev_halo, s));
     return SPH_OK;
 }
 
@@ -1487,8 +1603,8 @@ int stage_sort_and_lists(SphHandle *h)
     // coupled body the list build decides per workgroup: tagged rigid entries need 32 bits, so the workgroups with a rigid sample in one of their
     // neighbourhood cells keep 32-bit local indices (kStageLists16 in stage_cnt).  SPH_NL16=0 at sph_create turns it off (A/B, tests/test_cell_order_gpu.py)
     c.nl16 = (h->staged && is_dfsph(h) && h->opt_nl16) ? 1 : 0;
-    // k / rho in its own array: single-GPU dfsph handles with staged sweeps (the ghost refresh of slab handles ships P.w)
-    c.kr_split = (c.nl16 && !h->slab && h->opt_kr_split) ? 1 : 0;
+    // k / rho in its own array: dfsph handles with staged sweeps (on slab handles the ghost refreshes write it)
+    c.kr_split = (c.nl16 && h->opt_kr_split) ? 1 : 0;
     hipStream_t s = h->stream;
     dim3 g = grid_for(c.n);
     const dim3 b(kBlock);
@@ -1530,12 +1646,31 @@ int stage_sort_and_lists(SphHandle *h)
     if (h->slab) {
         HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * (size_t)c.n, s));
         ProfScope ps(h, K_SLAB);
-        const int layer[4] = {h->geom.has_left ? h->geom.x_lo - 1 : -1, h->geom.has_left ? h->geom.x_lo : -1,
-                              h->geom.has_right ? h->geom.x_hi - 1 : -1, h->geom.has_right ? h->geom.x_hi : -1};
+        // ordered edge lists: list k, column l (0 = next to the cut): ghost-left x_lo - 1 - l, send-left x_lo + l, send-right x_hi - 1 - l, ghost-right x_hi + l
+        const SlabGeom &sg = h->geom;
         for (int k = 0; k < 4; ++k) {
-            if (layer[k] < 0) continue;
-            hipLaunchKernelGGL(k_layer_offsets, dim3(1), b, 0, s, c, h->cell_start, layer[k], h->edge_off[k]);
-            hipLaunchKernelGGL(k_layer_list, grid_for(c.gy * c.gz), b, 0, s, c, h->cell_start, layer[k], h->edge_off[k], h->edge_list[k]);
+            if (!(k < 2 ? sg.has_left : sg.has_right)) continue;
+            for (int l = 0; l < sg.layers; ++l) {
+                const int col = k == 0 ? sg.x_lo - 1 - l : k == 1 ? sg.x_lo + l : k == 2 ? sg.x_hi - 1 - l : sg.x_hi + l;
+                hipLaunchKernelGGL(k_layer_offsets, dim3(1), b, 0, s, c, h->cell_start, col, h->edge_off[2 * k + l]);
+                hipLaunchKernelGGL(k_layer_list, grid_for(c.gy * c.gz), b, 0, s, c, h->cell_start, col, h->edge_off[2 * k + l],
+                                   h->edge_list[k] + (l ? h->edge_n[k][0] : 0));
+            }
+        }
+        if (dev_env(&h->overrides, "SPH_SLAB_CHECK")) {       // the host's bookkeeping of the column populations against the sorted arrays
+            for (int k = 0; k < 4; ++k)
+                for (int l = 0; l < sg.layers; ++l) {
+                    if (!(k < 2 ? sg.has_left : sg.has_right)) continue;
+                    int tot = -1;
+                    HIP_TRY(h, hipMemcpyAsync(&tot, h->edge_off[2 * k + l] + (size_t)c.gy * c.gz, sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIP_TRY(h, hipStreamSynchronize(s));
+                    if (tot != h->edge_n[k][l])
+                        return fail(h, SPH_E_STATE, "slab %d step %d: edge list %d column %d holds %d particles, the exchange counted %d", h->slab_rank, h->simulate_cnt, k, l, tot, h->edge_n[k][l]);
+                }
+        }
+        if (h->overlap) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
+            hipLaunchKernelGGL(k_tile_flags, g, b, 0, s, c, h->geom, h->P[h->pcur], h->tile_flag);
+            hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
     }
     if (rigid_coupled(h) && (rc = stage_sort_rigid(h))) return rc;
@@ -1597,7 +1732,7 @@ int check_overflow(SphHandle *h)
 PbfConsts pbf_consts(const SphHandle *h);
 
 // the tolerance-grade sweeps (sph_relaxed_kernels.h) run on this handle
-inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && !h->slab && h->wall_grad; }
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && h->wall_grad; }
 
 int stage_density(SphHandle *h)
 {
@@ -1640,7 +1775,12 @@ int stage_density(SphHandle *h)
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->slab) {   // ghosts need (k/rho, rho) resp. (rho, p/rho^2) from their owners
+    if (h->slab && dfsph && h->geom.layers == 2) {
+        // two ghost columns: the inner one computed rho, alpha and its warm-start k / rho itself (same inputs, same order as on its owner); the
+        // outer one is only ever read as a neighbour of the warm start: k / rho
+        int rc = slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr);
+        if (rc) return rc;
+    } else if (h->slab) {   // ghosts need (k/rho, rho) resp. (rho, p/rho^2) from their owners
         const bool ps = is_pressure_solver(h);            // their sweeps read rho[] of the neighbours: mode 3 fills it from P.w
         int rc = slab_exchange_field(h, ps ? 3 : 2, dfsph ? h->P[1 - h->pcur] : h->P[h->pcur], h->V[h->vcur], (dfsph || ps) ? h->rho : nullptr);
         if (rc) return rc;
@@ -1701,19 +1841,21 @@ int check_overflow_all(SphHandle *h)
 // tiles of the density loop whose inputs did not change are not recomputed (staged dfsph handles)
 inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
-void launch_div_residual(SphHandle *h, int gate)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+inline TilePhase tile_phase(const SphHandle *h, int phase) { return TilePhase{h->tile_order, h->nblocks, phase}; }
+void launch_div_residual(SphHandle *h, int gate, int phase = 0)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
+    const TilePhase tp = tile_phase(h, phase);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tp);
         return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
-                  (const float4 *)wall_cache(h));
+                  (const float4 *)wall_cache(h), tp);
 }
 
 template <int MODE>
@@ -1733,21 +1875,22 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
                   (const float4 *)wall_cache(h));
 }
 
-void launch_dens_residual(SphHandle *h, int gate)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
+void launch_dens_residual(SphHandle *h, int gate, int phase = 0)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
+    const TilePhase tp = tile_phase(h, phase);
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
-    h->dens_first = false;
+    if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tp);
         return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h));
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -1817,7 +1960,7 @@ int dfsph_ext_and_dt(SphHandle *h)
         hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, async ? h->red_dev : (double *)nullptr);
     }
     if (h->slab) {
-        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
+        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr, 1))) return rc;     // v* of the column next to the cut (all the density residual reads)
         if (async) {
             if ((rc = slab_allreduce_stream(h, 1, 1))) return rc;          // max |v*| over all slabs, stays on the device
         } else {
@@ -1863,20 +2006,37 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     // On a slab handle every sweep whose output the neighbours read is followed by the refresh of that field on the ghosts (enqueued,
     // not waited for, with a stream-ordered transport); gated sweeps still take part in the exchanges so that all slabs issue the same
     // sequence of transfers (they re-send unchanged values).
-    auto ghosts_v = [&](float4 *V) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
-    auto ghosts_k = [&]() -> int { return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK; };
+    // Two ghost columns (slab_ghost_layers = 2, the dfsph default): the inner ghost column runs the correction sweeps itself -- its neighbours
+    // are all resident, its inputs are the owner's, so are its results -- and a solver iteration needs ONE refresh, the residual's
+    // (slab_exchange_resid); with slab_can_overlap the residual sweep runs its edge tiles first and its interior tiles under that transfer.
+    const bool two = h->slab && h->geom.layers == 2;
+    const bool ovl = two && slab_can_overlap(h);
+    auto ghosts_v = [&](float4 *V) -> int { return (h->slab && !two) ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
+    // a residual sweep and the refresh of what it produced on the ghosts
+    auto residual = [&](bool dens, int gate) -> int {
+        int r = SPH_OK;
+        if (ovl) {
+            if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1);
+            HIP_TRY(h, hipEventRecord(h->ev_edge, s));
+            if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2);       // enqueued before the host turns to the transfer
+            if ((r = slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, true))) return r;
+            HIP_TRY(h, hipStreamWaitEvent(s, h->ev_halo, 0));                                       // the next sweep reads the ghosts
+            return SPH_OK;
+        }
+        if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate);
+        if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
+        return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
+    };
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
-    launch_div_residual(h, GATE_NONE);                                               // :398
-    if ((rc = ghosts_k())) return rc;
+    if ((rc = residual(false, GATE_NONE))) return rc;                                // :398
     if ((rc = launch_finalize(h, FIN_DIV_FIRST))) return rc;
     // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
     // and the host does not need the outcome before the density loop's first read-back
     for (int done = 0; done < 15; ++done) {
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
-        launch_div_residual(h, GATE_DIV);                                                 // :408
-        if ((rc = ghosts_k())) return rc;
+        if ((rc = residual(false, GATE_DIV))) return rc;                                  // :408
         if ((rc = launch_finalize(h, FIN_DIV_LOOP))) return rc;
     }
     if ((rc = dfsph_ext_and_dt(h))) return rc;
@@ -1884,8 +2044,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     bool first = true;
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
-            launch_dens_residual(h, GATE_DENS);                                      // :227
-            if ((rc = ghosts_k())) return rc;
+            if ((rc = residual(true, GATE_DENS))) return rc;                         // :227
             if ((rc = launch_finalize(h, FIN_DENS))) return rc;
             launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
@@ -1918,13 +2077,19 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
 {
     int rc;
     h->dens_first = true;
+    const bool two = h->slab && h->geom.layers == 2;       // (see step_dfsph_device_loops)
+    auto ghosts_v = [&](float4 *V) -> int { return (h->slab && !two) ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
+    auto ghosts_k = [&](bool dens) -> int {
+        if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
+        return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
+    };
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
-    if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
+    if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
     float err = 0.f, past = 0.f;
     auto residual = [&](float *out) -> int {
         launch_div_residual(h, GATE_NONE);
         int r;
-        if (h->slab && (r = slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr))) return r;
+        if ((r = ghosts_k(false))) return r;
         return reduce_mean_host(h, 0.0f, out);
     };
     if ((rc = residual(&err))) return rc;                                            // :398
@@ -1937,7 +2102,7 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
     int iter_cnt = 0;
     while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {                  // :400
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
-        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->V[h->vcur], nullptr))) return rc;
+        if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         past = err;
         if ((rc = residual(&err))) return rc;                                        // :408
         st->n_div_evals += 1;
@@ -1953,12 +2118,12 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
     while (it < 2 || rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {                         // :225
         if (it >= cap) { st->capped = 1; break; }
         launch_dens_residual(h, GATE_NONE);
-        if (h->slab && (rc = slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr))) return rc;
+        if ((rc = ghosts_k(true))) return rc;
         float avg;
         if ((rc = reduce_mean_host(h, 1000.0f, &avg))) return rc;
         launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_NONE);
         if (rigid_coupled(h)) launch_rigid_force(h, GATE_NONE);
-        if (h->slab && (rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr))) return rc;
+        if ((rc = ghosts_v(h->VA[0]))) return rc;
         rho_avg = (double)avg;
         it += 1;
     }
@@ -2483,6 +2648,9 @@ void sph_destroy(SphHandle *h)
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
+    if (h->ev_edge) (void)hipEventDestroy(h->ev_edge);
+    if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
+    if (h->xstream) { (void)hipStreamSynchronize(h->xstream); (void)hipStreamDestroy(h->xstream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2643,11 +2811,11 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts)
 
 int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts)
 {
-    if (!column_histogram || !old_cuts || !new_cuts || grid_x < 2 || slab_count < 1 || grid_x < 2 * slab_count)
+    if (!column_histogram || !old_cuts || !new_cuts || grid_x < 2 || slab_count < 1 || grid_x < kMinSlabColumns * slab_count)
         return fail(nullptr, SPH_E_INVALID, "bad argument");
     for (int k = 0; k < slab_count; ++k)
-        if (old_cuts[k + 1] < old_cuts[k] + 2 || old_cuts[0] != 0 || old_cuts[slab_count] != grid_x)
-            return fail(nullptr, SPH_E_INVALID, "old cuts must start at 0, end at grid_x and leave every slab >= 2 columns");
+        if (old_cuts[k + 1] < old_cuts[k] + kMinSlabColumns || old_cuts[0] != 0 || old_cuts[slab_count] != grid_x)
+            return fail(nullptr, SPH_E_INVALID, "old cuts must start at 0, end at grid_x and leave every slab >= %d columns", kMinSlabColumns);
     std::vector<long long> hist(column_histogram, column_histogram + grid_x);
     std::vector<int> oldc(old_cuts, old_cuts + slab_count + 1), cut;
     replan_slab_cuts(hist, grid_x, slab_count, oldc, cut);
@@ -2691,8 +2859,8 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * (size_t)h->red_cap));
     h->own_red = true;
     HIP_TRY(h, hipHostMalloc((void **)&h->red_host, sizeof(double) * (size_t)h->red_cap, hipHostMallocDefault));
-    HIP_TRY(h, hipMalloc((void **)&h->cnt_dev, sizeof(int) * 4));
-    HIP_TRY(h, hipHostMalloc((void **)&h->cnt_host, sizeof(int) * 4, hipHostMallocDefault));
+    HIP_TRY(h, hipMalloc((void **)&h->cnt_dev, sizeof(int) * 4 * kCountInts));
+    HIP_TRY(h, hipHostMalloc((void **)&h->cnt_host, sizeof(int) * 4 * kCountInts, hipHostMallocDefault));
     memset(&h->comm, 0, sizeof(h->comm));
     h->comm.capacity = capacity_bytes;
     h->comm.stream_ordered = 1;

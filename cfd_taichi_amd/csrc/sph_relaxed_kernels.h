@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_rx_wall_grad(Consts c, const float4 
                                                          float *__restrict__ Gsq)
 {
     const uint32_t *nl = nullptr;
-    SPH_SWEEP_PROLOGUE_M(false)
+    SPH_SWEEP_PROLOGUE_G(false, xcd_block(blockIdx.x, gridDim.x), true)
     (void)nlp; (void)kf;
     float gx = 0.f, gy = 0.f, gz = 0.f, ws = 0.f, sq = 0.f;
     auto wall = [&](const float4 pj) {
@@ -128,19 +128,21 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         const DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all)
+                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
+    const int tile = sweep_tile(tp, spread);
+    if (tile < 0) return;
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
-        const int tb = (int)blockIdx.x, sw = stage_cnt[tb];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tb, wave_dirty)) {
+        const int sw = stage_cnt[tile];
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {
             return;
         }
     }
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_B(false, tile)
     (void)nlbp;
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
@@ -182,15 +184,17 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
         const float rho_i = rho[i];
         if (DENS) {
             val = rmax(__builtin_fmaf(ds->dt, sum, rho_i), c.rho0);               // :135 / :137
-            flag = !(val == c.rho0);                                              // :139
+            flag = !(val == c.rho0) && !ghost;                                    // :139
             kr = ((val - c.rho0) * alpha[i] / ds->dt2) / rho_i;                   // :199,203
         } else {
             val = skip ? 0.f : rmax(sum, 0.0f);                                   // :267 / :269
-            flag = val > 0.f;                                                     // :275
+            flag = val > 0.f && !ghost;                                           // :275
             kr = (val * alpha[i] / ds->dt) / rho_i;                               // :363,367
         }
-        out[i] = val;
-        krho[i] = kr;
+        if (!(ghost && c.ghost_walk)) {       // (two-column slab handles: a ghost's value and k / rho arrive with the halo)
+            out[i] = val;
+            krho[i] = kr;
+        }
     }
     block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
@@ -209,15 +213,17 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_B(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))
+    SPH_SWEEP_PROLOGUE_G(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x), true)
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
     bool staged;
     if (track) {
         const int verdict = stage_operand_ps_checked<false>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
         if (verdict == 2) {
-            if (threadIdx.x < kBlock / 64) wave_dirty[blk * (kBlock / 64) + threadIdx.x] = 0;
-            if (live) changed8[i] = 0;
+            const bool foreign = live && ghost && !c.ghost_walk;           // (see k_correct in sph_kernels.h)
+            const unsigned long long anyg = __ballot(foreign);
+            if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = anyg != 0ull ? 1 : 0;
+            if (live) changed8[i] = foreign ? 1 : 0;
             return;
         }
         staged = verdict == 1;
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         gx = gw.x * kb_i; gy = gw.y * kb_i; gz = gw.z * kb_i;
     }
     if (track) {
-        const bool changed = live && (ax != 0.f || ay != 0.f || az != 0.f || gx != 0.f || gy != 0.f || gz != 0.f);
+        const bool changed = live && ((ghost && !c.ghost_walk) || ax != 0.f || ay != 0.f || az != 0.f || gx != 0.f || gy != 0.f || gz != 0.f);
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *_
 {
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(false)
+    SPH_SWEEP_PROLOGUE_G(false, xcd_block(blockIdx.x, gridDim.x), true)
     (void)nlbp;
     const bool staged = stage_operand<false>(c, s_operand, P, stage_src, stage_cnt, blk);
     float ws = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;

@@ -15,6 +15,8 @@ __device__ __forceinline__ int id_key(int id) { return id < 0 ? ~id : id; }
 struct SlabGeom {
     int x_lo, x_hi;        // owned cell columns [x_lo, x_hi)
     int has_left, has_right;
+    int layers;            // ghost cell columns per side (1, or 2: see the two-column protocol in sph_mi355x.hip)
+    int far_left, far_right;   // the neighbours' far cuts: columns [far_left, x_lo) belong to the left neighbour, [x_hi, far_right) to the right one
 };
 
 __device__ __forceinline__ void write_record(float4 *__restrict__ buf, int slot, float4 p, float4 v, float warm, int id)
@@ -63,77 +65,96 @@ __device__ __forceinline__ int wave_alloc(int *__restrict__ counter, bool want)
     return want ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
 }
 
-// (1) previous ghosts die; owned particles that left the slab are packed for the neighbour and die here.
-__global__ __launch_bounds__(kBlock) void k_classify_migrate(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
-                                                             const float *__restrict__ warm, const int *__restrict__ id,
-                                                             int *__restrict__ dead, float4 *__restrict__ send_left,
-                                                             float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
+// lanes that want to be counted, one atomicAdd per wave
+__device__ __forceinline__ void wave_count(int *__restrict__ counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m != 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(counter, __popcll(m));
+}
+
+// The particle exchange at the start of a step.  Device counters (kSlabCounters ints):
+//   [0] records for the left neighbour, [1] for the right one, [2] slots that die here,
+//   [3 + 4 side + l]      ghost copies of my send column l + 1 on that side (side 0 = left, 1 = right; l = 0 is the column next to the cut),
+//   [3 + 4 side + 2 + l]  leavers to that side that I KEEP as ghosts of my ghost column l + 1 there.
+// mode bits: kSlabMigrate -- last step's ghosts die, owned particles that left [x_lo, x_hi) are packed for the neighbour (id >= 0 on the wire);
+//            kSlabGhosts  -- owned particles of the `layers` columns next to a cut are copied to that neighbour (~id on the wire);
+//            kSlabKeep    -- a leaver that lands in one of my ghost columns stays resident as a ghost (id := ~id) instead of dying: the
+//                            new owner would send it straight back.
+// All three together are ONE message per neighbour (the merged exchange of ordinary steps: a particle moves a fraction of a cell per step,
+// and slabs are at least layers + 1 columns wide, so nothing a neighbour sends me can land in the columns I copy to the OTHER neighbour).
+// A step that moved the cuts runs two rounds instead -- kSlabMigrate alone, then kSlabGhosts over what arrived -- because a re-cut can
+// move whole columns across a slab.  A leaver of a merged step that lands beyond the neighbour's own slab breaks the assumption: it
+// raises overflow bit 2 and the step fails loudly on every rank (check_overflow_all).
+constexpr int kSlabCounters = 16;
+enum { kSlabMigrate = 1, kSlabGhosts = 2, kSlabKeep = 4 };
+__global__ __launch_bounds__(kBlock) void k_classify_slab(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                          const float *__restrict__ warm, int *__restrict__ id, int *__restrict__ dead,
+                                                          float4 *__restrict__ send_left, float4 *__restrict__ send_right, int cap_records,
+                                                          int *__restrict__ counters, DevScalars *__restrict__ ds)
 {
     const int s = blockIdx.x * kBlock + threadIdx.x;
     const bool in = s < c.n;
+    const bool migrate = (mode & kSlabMigrate) != 0, ghosts = (mode & kSlabGhosts) != 0, keep = (mode & kSlabKeep) != 0;
     const int pid = in ? id[s] : 0;
+    const bool skip = in && !migrate && dead[s] != 0;        // second round: slots the first round killed
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool go_left = false, go_right = false;
-    if (in && pid >= 0) {
-        p = P[s];
-        const int cx = (int)floorf(p.x / c.h);
-        go_left = g.has_left && cx < g.x_lo;
-        go_right = !go_left && g.has_right && cx >= g.x_hi;
+    bool go_left = false, go_right = false, dies = false;
+    int gl = 0, gr = 0, kl = 0, kr = 0;                      // ghost copy for the left / right neighbour, kept as my ghost on the left / right: column 1 or 2 (0: no)
+    if (in && !skip) {
+        if (pid < 0) {
+            dies = migrate;                                  // last step's ghost
+        } else {
+            p = P[s];
+            // "is an edge particle" must be decided by the cell the sort bins the particle into (the ordered edge lists enumerate CELL LISTS):
+            // the reference's 1-D index, ParticleSystem.py:486-494; a particle outside the grid sits in no cell of a slab handle (strict_cells)
+            int cx, cy, cz;
+            const int cid = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+            const int col = cid < c.C ? cid % c.gx : -1;
+            if (migrate) {
+                go_left = g.has_left && cx < g.x_lo;
+                go_right = !go_left && g.has_right && cx >= g.x_hi;
+            }
+            if (go_left || go_right) {
+                if (keep && col >= 0) {
+                    if (go_left && col >= g.x_lo - g.layers && col < g.x_lo) kl = g.x_lo - col;
+                    if (go_right && col >= g.x_hi && col < g.x_hi + g.layers) kr = col - g.x_hi + 1;
+                    // merged exchange only: a leaver must land inside the neighbour's slab, clear of the columns it copies to ITS other neighbour
+                    if ((go_left && cx < g.far_left + g.layers && g.far_left > 0) || (go_right && cx >= g.far_right - g.layers && g.far_right < c.gx)) atomicOr(&ds->overflow, 4);
+                }
+                dies = kl == 0 && kr == 0;
+            } else if (ghosts && col >= 0) {
+                if (g.has_left && col >= g.x_lo && col < g.x_lo + g.layers) gl = col - g.x_lo + 1;
+                if (g.has_right && col < g.x_hi && col >= g.x_hi - g.layers) gr = g.x_hi - col;
+            }
+        }
     }
-    const bool dies = in && (pid < 0 || go_left || go_right);       // last step's ghosts, and owned particles that left the slab
-    const int sl = wave_alloc(&counters[0], go_left);
-    const int sr = wave_alloc(&counters[1], go_right);
-    (void)wave_alloc(&counters[2], dies);
-    if (go_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, pid);
-    if (go_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, pid);
-    if (in) dead[s] = dies ? 1 : 0;
+    const bool to_left = go_left || gl != 0, to_right = go_right || gr != 0;
+    const int sl = wave_alloc(&counters[0], to_left);
+    const int sr = wave_alloc(&counters[1], to_right);
+    wave_count(&counters[2], dies);
+    wave_count(&counters[3], gl == 1); wave_count(&counters[4], gl == 2); wave_count(&counters[5], kl == 1); wave_count(&counters[6], kl == 2);
+    wave_count(&counters[7], gr == 1); wave_count(&counters[8], gr == 2); wave_count(&counters[9], kr == 1); wave_count(&counters[10], kr == 2);
+    if (to_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, go_left ? pid : ~pid);
+    if (to_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, go_right ? pid : ~pid);
+    if (in && migrate) {
+        dead[s] = dies ? 1 : 0;
+        if (kl != 0 || kr != 0) id[s] = ~pid;
+    }
 }
 
-// (2)/(4) received records are appended behind the resident particles
-__global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restrict__ buf, int count, int base, int as_ghost,
+// received records are appended behind the resident particles; the sign of the id on the wire says owned (migrant) or ghost
+__global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restrict__ buf, int count, int base,
                                                            float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ warm,
                                                            int *__restrict__ id, int *__restrict__ dead)
 {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= count) return;
     float4 a = buf[2 * (size_t)r], b = buf[2 * (size_t)r + 1];
-    int pid = __float_as_int(b.w);
     P[base + r] = make_float4(a.x, a.y, a.z, 0.f);
     V[base + r] = make_float4(a.w, b.x, b.y, 0.f);
     if (warm) warm[base + r] = b.z;
-    id[base + r] = as_ghost ? ~pid : pid;
+    id[base + r] = __float_as_int(b.w);
     dead[base + r] = 0;
-}
-
-// (3) owned particles in the two edge cell columns are copied to the neighbours as ghosts
-__global__ __launch_bounds__(kBlock) void k_classify_ghost(Consts c, SlabGeom g, const float4 *__restrict__ P, const float4 *__restrict__ V,
-                                                           const float *__restrict__ warm, const int *__restrict__ id,
-                                                           const int *__restrict__ dead, float4 *__restrict__ send_left,
-                                                           float4 *__restrict__ send_right, int cap_records, int *__restrict__ counters)
-{
-    const int s = blockIdx.x * kBlock + threadIdx.x;
-    bool to_left = false, to_right = false;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    int pid = 0;
-    if (s < c.n && !dead[s]) {
-        pid = id[s];
-        if (pid >= 0) {
-            p = P[s];
-            // The ordered edge lists (k_layer_list) enumerate the CELL LISTS of the edge columns, so "is an edge particle" must be
-            // decided by the cell the sort bins the particle into -- the reference's 1-D index (ParticleSystem.py:486-494, guarded only
-            // by 0 <= id <= C at :393): a particle that slipped through a wall in y or z still has a valid 1-D index (it wraps into a
-            // neighbouring row of the same column) and is a member of that cell; one whose index is out of range sits in no cell.
-            int cx, cy, cz;
-            const int cid = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
-            const int col = cid < c.C ? cid % c.gx : -1;
-            to_left = g.has_left && col == g.x_lo;
-            to_right = g.has_right && col == g.x_hi - 1;
-        }
-    }
-    const int sl = wave_alloc(&counters[0], to_left);
-    const int sr = wave_alloc(&counters[1], to_right);
-    if (to_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, pid);
-    if (to_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, pid);
 }
 
 // Ordered list of the sorted slots that live in cell column `layer_cx`: cells ascending (y, then z), slots
@@ -170,6 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_offsets(Consts c, const int *_
     if (threadIdx.x == 0) off[ncol] = carry_s;
 }
 
+// (a side's two columns share one list: the second column's entries start at list + count of the first)
 __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__restrict__ cell_start, int layer_cx, const int *__restrict__ off,
                                                        int *__restrict__ list)
 {
@@ -182,12 +204,12 @@ __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__re
     for (int s = a; s < b; ++s) list[o + (s - a)] = s;
 }
 
-// ghost field refresh: mode 0 = P.w (1 float), 1 = V.xyz (3 floats), 2 = (P.w, V.w) (2 floats; rho[] := V.w, dfsph),
-// 3 = (P.w, V.w) with rho[] := P.w (pcisph / iisph: P.w carries rho).  One launch serves both sides:
-// threads [0, count_a) work on side a (left), threads [count_a, count_a + count_b) on side b (right).
+// ghost field refresh: mode 0 = the per-sweep scalar k / rho (1 float), 1 = V.xyz (3 floats), 2 = (scalar, V.w) (2 floats; rho[] := V.w, dfsph),
+// 3 = (P.w, V.w) with rho[] := P.w (pcisph / iisph: P.w carries rho).  The scalar is S[s] on kr_split handles (S = krho), else P[s].w.
+// One launch serves both sides: threads [0, count_a) work on side a (left), threads [count_a, count_a + count_b) on side b (right).
 __global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ list_a, int count_a, float *__restrict__ out_a,
                                                        const int *__restrict__ list_b, int count_b, float *__restrict__ out_b, int mode,
-                                                       const float4 *__restrict__ P, const float4 *__restrict__ V)
+                                                       const float4 *__restrict__ P, const float4 *__restrict__ V, const float *__restrict__ S)
 {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= count_a + count_b) return;
@@ -195,14 +217,14 @@ __global__ __launch_bounds__(kBlock) void k_pack_field(const int *__restrict__ l
     if (b) r -= count_a;
     const int s = (b ? list_b : list_a)[r];
     float *out = b ? out_b : out_a;
-    if (mode == 0) out[r] = P[s].w;
+    if (mode == 0) out[r] = S ? S[s] : P[s].w;
     else if (mode == 1) { float4 v = V[s]; out[3 * (size_t)r] = v.x; out[3 * (size_t)r + 1] = v.y; out[3 * (size_t)r + 2] = v.z; }
-    else { out[2 * (size_t)r] = P[s].w; out[2 * (size_t)r + 1] = V[s].w; }
+    else { out[2 * (size_t)r] = S ? S[s] : P[s].w; out[2 * (size_t)r + 1] = V[s].w; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__ list_a, int count_a, const float *__restrict__ in_a,
                                                          const int *__restrict__ list_b, int count_b, const float *__restrict__ in_b, int mode,
-                                                         float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ rho)
+                                                         float4 *__restrict__ P, float4 *__restrict__ V, float *__restrict__ rho, float *__restrict__ S)
 {
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= count_a + count_b) return;
@@ -210,15 +232,93 @@ __global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__
     if (b) r -= count_a;
     const int s = (b ? list_b : list_a)[r];
     const float *in = b ? in_b : in_a;
-    if (mode == 0) P[s].w = in[r];
+    if (mode == 0) { if (S) S[s] = in[r]; else P[s].w = in[r]; }
     else if (mode == 1) { V[s].x = in[3 * (size_t)r]; V[s].y = in[3 * (size_t)r + 1]; V[s].z = in[3 * (size_t)r + 2]; }
     else {
         const float aa = in[2 * (size_t)r];
         const float bb = in[2 * (size_t)r + 1];
-        P[s].w = aa;
+        if (S) S[s] = aa; else P[s].w = aa;
         V[s].w = bb;
         if (rho) rho[s] = mode == 3 ? aa : bb;    // dfsph: V.w carries rho; the correction sweeps rewrite it from rho[]
     }
+}
+
+// The residual refresh of the two-column protocol (dfsph): one float per ghost.  The first n1 entries of a side's list are its INNER column,
+// whose particles run the correction sweeps themselves and need the residual value (rho_derivative / rho_adv: `val`) -- their k / rho is
+// re-derived on arrival with the very expression of k_residual, from the alpha and rho the ghost computed itself in D1; the entries behind them
+// are the OUTER column, read only as neighbours: they get the owner's k / rho.
+__global__ __launch_bounds__(kBlock) void k_pack_resid(const int *__restrict__ list_a, int count_a, int n1_a, float *__restrict__ out_a,
+                                                       const int *__restrict__ list_b, int count_b, int n1_b, float *__restrict__ out_b,
+                                                       const float *__restrict__ val, const float4 *__restrict__ P, const float *__restrict__ S)
+{
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count_a + count_b) return;
+    const bool b = r >= count_a;
+    if (b) r -= count_a;
+    const int s = (b ? list_b : list_a)[r];
+    (b ? out_b : out_a)[r] = r < (b ? n1_b : n1_a) ? val[s] : (S ? S[s] : P[s].w);
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_resid(Consts c, const int *__restrict__ list_a, int count_a, int n1_a, const float *__restrict__ in_a,
+                                                         const int *__restrict__ list_b, int count_b, int n1_b, const float *__restrict__ in_b,
+                                                         int dens, const float *__restrict__ alpha, const float *__restrict__ rho, const DevScalars *__restrict__ ds,
+                                                         float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S)
+{
+    int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= count_a + count_b) return;
+    const bool b = r >= count_a;
+    if (b) r -= count_a;
+    const int s = (b ? list_b : list_a)[r];
+    const float x = (b ? in_b : in_a)[r];
+    float kr = x;
+    if (r < (b ? n1_b : n1_a)) {
+        val[s] = x;
+        if (dens) kr = ((x - c.rho0) * alpha[s] / ds->dt2) / rho[s];           // dfsph_solver.py:199,203 as k_residual writes it
+        else kr = (x * alpha[s] / ds->dt) / rho[s];                            // :363,367
+    }
+    if (S) S[s] = kr; else P[s].w = kr;
+}
+
+// Edge / interior split of the residual sweeps (slab handles, dfsph): a tile is an EDGE tile if one of its particles lies in a column that
+// takes part in the halo of this step -- a ghost column or a column copied to a neighbour.  tile_order lists the edge tiles first (ascending),
+// then the interior ones (ascending); tile_order[ntiles] = number of edge tiles.  The edge launch of a sweep works on [0, n_edge), its results
+// are packed and sent while the interior launch works on the rest.
+__global__ __launch_bounds__(kBlock) void k_tile_flags(Consts c, SlabGeom g, const float4 *__restrict__ P, int *__restrict__ flag)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    int e = 0;
+    if (i < c.n) {
+        const int cx = (int)floorf(P[i].x / c.h);
+        e = (g.has_left && cx < g.x_lo + g.layers) || (g.has_right && cx >= g.x_hi - g.layers);
+    }
+    e = __syncthreads_or(e);
+    if (threadIdx.x == 0) flag[blockIdx.x] = e ? 1 : 0;
+}
+__global__ __launch_bounds__(kBlock) void k_tile_order(const int *__restrict__ flag, int ntiles, int *__restrict__ order)
+{
+    // one workgroup: exclusive scan of the flags in chunks of 256 with a carry
+    __shared__ int wsum[kBlock / 64];
+    __shared__ int carry_s, total_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {          // pass 0 counts the edge tiles, pass 1 places both kinds
+        if (pass == 1) { if (threadIdx.x == 0) { total_s = carry_s; carry_s = 0; } __syncthreads(); }
+        for (int base = 0; base < ntiles; base += kBlock) {
+            const int t = base + threadIdx.x;
+            const int v = t < ntiles ? flag[t] : 0;
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+            const int inc = wave_inclusive_scan(v);
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            int woff = 0;
+            for (int q = 0; q < w; ++q) woff += wsum[q];
+            const int before = carry_s + woff + inc - v;         // edge tiles in front of t
+            if (pass == 1 && t < ntiles) order[v ? before : total_s + (t - before)] = t;
+            __syncthreads();
+            if (threadIdx.x == kBlock - 1) carry_s = before + v;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) order[ntiles] = total_s;
 }
 
 __global__ __launch_bounds__(kBlock) void k_unsort_ids(int n, const int *__restrict__ id, int *__restrict__ out)

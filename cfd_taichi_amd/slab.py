@@ -59,12 +59,14 @@ class TorchComm:
         self._cb_buffers = nat.EXCHANGE_BUFFERS_FN(self._exchange_buffers)
         self._cb_allreduce = nat.ALLREDUCE_FN(self._allreduce)
         self._cb_allreduce_stream = nat.ALLREDUCE_STREAM_FN(self._allreduce_stream)
+        self._cb_counts_n = nat.EXCHANGE_COUNTS_N_FN(self._exchange_counts_n)
         self.struct = nat.SphComm()
         self.struct.user = None
         self.struct.exchange_counts = self._cb_counts
         self.struct.exchange_buffers = self._cb_buffers
         self.struct.allreduce = self._cb_allreduce
         self.struct.allreduce_stream = self._cb_allreduce_stream
+        self.struct.exchange_counts_n = self._cb_counts_n
         self.struct.reduce_buf = self.reduce_t.data_ptr()
         self.struct.stream_ordered = 1 if self.stream_ordered else 0
         for k, t in self.bufs.items():
@@ -82,6 +84,18 @@ class TorchComm:
         allc = allc.cpu().view(self.world, 2)
         recv_left = int(allc[self.left, 1]) if self.left is not None else 0
         recv_right = int(allc[self.right, 0]) if self.right is not None else 0
+        return recv_left, recv_right
+
+    def exchange_counts_n(self, send_left, send_right):
+        """n ints to each neighbour in ONE round trip; returns (recv_left, recv_right) lists (zeros where there is no neighbour)."""
+        torch, dist = self.torch, self.dist
+        n = len(send_left)
+        mine = torch.tensor(list(send_left) + list(send_right), dtype=torch.int32, device=self.device)
+        allc = torch.empty(2 * n * self.world, dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        allc = allc.cpu().view(self.world, 2, n)
+        recv_left = [int(v) for v in allc[self.left, 1]] if self.left is not None else [0] * n
+        recv_right = [int(v) for v in allc[self.right, 0]] if self.right is not None else [0] * n
         return recv_left, recv_right
 
     def _p2p_ops(self, sl, sr, rl, rr):
@@ -155,6 +169,14 @@ class TorchComm:
             self.stats["exchange_counts"] += 1
             rl, rr = self.exchange_counts(send_left, send_right)
             recv_left[0], recv_right[0] = rl, rr
+        return self._guard(run)
+
+    def _exchange_counts_n(self, user, n, send_left, send_right, recv_left, recv_right):
+        def run():
+            self.stats["exchange_counts"] += 1
+            rl, rr = self.exchange_counts_n([send_left[k] for k in range(n)], [send_right[k] for k in range(n)])
+            for k in range(n):
+                recv_left[k], recv_right[k] = rl[k], rr[k]
         return self._guard(run)
 
     def _exchange_buffers(self, user, sl, sr, rl, rr):

@@ -66,7 +66,12 @@ typedef struct SphConfig {
                                    SPH_ARITH_RELAXED (1): the dfsph pair sweeps of large single-GPU scenes may use approximate
                                    reciprocal square roots and FMA contraction (north_star's 1e-5 bar; see csrc/sph_relaxed_kernels.h).
                                    A permission: handles the relaxed sweeps do not cover run the exact ones. */
-    int32_t reserved[4];
+    int32_t slab_ghost_layers;  /* slab handles: ghost cell columns per side.  0 = default: 2 for dfsph (the correction sweeps run on the inner
+                                   ghost column too, so a solver iteration needs ONE halo refresh -- the residual's -- instead of two), 1 for
+                                   the other solvers; 1 forces the one-column protocol.  Results do not depend on it. */
+    int32_t slab_overlap;       /* slab handles, dfsph: 0 = default (on): the residual sweeps run their edge tiles first and the interior tiles
+                                   while the halo of the edge results travels on a second stream; 1 = off (everything on one stream) */
+    int32_t reserved[2];
 } SphConfig;
 
 #define SPH_ARITH_EXACT 0
@@ -260,6 +265,9 @@ typedef struct SphComm {
     /* optional: in-place all-reduce of the first n doubles of reduce_buf (op 0 = sum, 1 = max), ordered like exchange_buffers */
     int (*allreduce_stream)(void *user, int32_t n, int32_t op);
     double *reduce_buf;         /* >= 4 doubles: device memory with on_host = 0, host memory (the library stages) with on_host = 1 */
+    /* optional: exchange_counts with n (<= 8) ints per neighbour in one round trip -- the particle exchange of a step sends
+     * (records, ghosts per column, migrants the sender keeps as ghosts per column) in ONE message; NULL: the library calls exchange_counts n times */
+    int (*exchange_counts_n)(void *user, int32_t n, const int32_t *send_left, const int32_t *send_right, int32_t *recv_left, int32_t *recv_right);
 } SphComm;
 
 int sph_set_comm(SphHandle *h, const SphComm *comm);

@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--rebalance", type=int, default=0)
+    ap.add_argument("--layers", type=int, default=0, help="SphConfig.slab_ghost_layers (0 = the solver's default)")
+    ap.add_argument("--overlap", type=int, default=0, help="SphConfig.slab_overlap (0 = default on, 1 = off)")
+    ap.add_argument("--arith", type=int, default=0, help="SphConfig.arith on the slabs AND on the one-GPU reference")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import torch
@@ -35,7 +38,8 @@ def main():
     from cfd_taichi_amd import scenes
     from cfd_taichi_amd.slab import SlabSimulation
     cfg = json.load(open(args.scene)) if os.path.exists(args.scene) else scenes.get(args.scene)
-    sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance)
+    sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance, slab_ghost_layers=args.layers, slab_overlap=args.overlap,
+                         arith=args.arith)
     dfsph = sim.solver != "wcsph"      # every solver but wcsph reports per-step statistics
     stats = []
     owned_max = 0
@@ -55,7 +59,7 @@ def main():
     if rank == 0:
         if os.environ.get("SLAB_REF_NOSKIP") == "1":      # the one-GPU reference computes every tile in every density iteration
             os.environ["SPH_TILE_SKIP"] = "0"
-        ref = nat.Simulation(nat.config_from_dict(cfg, device=device))
+        ref = nat.Simulation(nat.config_from_dict(cfg, device=device, arith=args.arith))
         ref_stats = []
         for _ in range(args.steps):
             if dfsph:
@@ -72,7 +76,7 @@ def main():
             "pos_equal": bool(np.array_equal(pos, rp)), "vel_equal": bool(np.array_equal(vel, rv)), "rho_equal": bool(np.array_equal(rho, rr)),
             "pos_rel_err": rel(pos, rp), "vel_rel_err": rel(vel, rv),
             "stats_equal": stats == ref_stats, "stats_last": stats[-1] if stats else None, "ref_stats_last": ref_stats[-1] if ref_stats else None,
-            "comm": sim.comm.stats,
+            "comm": sim.comm.stats, "lib_comm": sim.sim.comm_stats(), "relaxed": [sim.sim.scalar(nat.S_ARITH_RELAXED), ref.scalar(nat.S_ARITH_RELAXED)],
         }
         with open(args.out, "w") as f:
             json.dump(result, f)

@@ -34,11 +34,11 @@ def test_struct_layouts(tmp_path):
     probes = [("sizeof(SphConfig)", ctypes.sizeof(_native.SphConfig)), ("sizeof(SphStepStats)", ctypes.sizeof(_native.SphStepStats)),
               ("sizeof(SphSizes)", ctypes.sizeof(_native.SphSizes)), ("sizeof(SphRigid)", ctypes.sizeof(_native.SphRigid)),
               ("sizeof(SphComm)", ctypes.sizeof(_native.SphComm))]
-    for struct, cls, fields in (("SphConfig", _native.SphConfig, ["boundary_handle", "max_density_iters", "slab_rebalance_every", "arith", "reserved"]),
+    for struct, cls, fields in (("SphConfig", _native.SphConfig, ["boundary_handle", "max_density_iters", "slab_rebalance_every", "arith", "slab_ghost_layers", "slab_overlap", "reserved"]),
                                 ("SphStepStats", _native.SphStepStats, ["capped", "div_first_err", "dt", "lost"]),
                                 ("SphRigid", _native.SphRigid, ["points", "vertices", "rho_0", "pos_offset", "attitude_offset", "active"]),
                                 ("SphComm", _native.SphComm, ["exchange_counts", "exchange_buffers", "allreduce", "send_left", "recv_right", "capacity", "on_host",
-                                                              "stream_ordered", "allreduce_stream", "reduce_buf"])):
+                                                              "stream_ordered", "allreduce_stream", "reduce_buf", "exchange_counts_n"])):
         for f in fields:
             probes.append(("offsetof(%s, %s)" % (struct, f), getattr(cls, f).offset))
     src = tmp_path / "sz.c"

@@ -51,6 +51,15 @@ def _worker(rank, world, port, results):
     a, b = ctypes.c_int32(), ctypes.c_int32()
     ok &= comm._exchange_counts(None, 7, 9, ctypes.pointer(a), ctypes.pointer(b)) == 0
     ok &= a.value == (9 if rank > 0 else 0) and b.value == (7 if rank < world - 1 else 0)
+    # the merged particle exchange's count message: n ints per neighbour in one round trip
+    nl, nr = comm.exchange_counts_n([rank, 10 + rank, 20 + rank], [100 + rank, 110 + rank, 120 + rank])
+    ok &= nl == ([100 + rank - 1, 110 + rank - 1, 120 + rank - 1] if rank > 0 else [0, 0, 0])
+    ok &= nr == ([rank + 1, 10 + rank + 1, 20 + rank + 1] if rank < world - 1 else [0, 0, 0])
+    sl5, sr5 = (ctypes.c_int32 * 5)(*[rank + k for k in range(5)]), (ctypes.c_int32 * 5)(*[50 + rank + k for k in range(5)])
+    rl5, rr5 = (ctypes.c_int32 * 5)(), (ctypes.c_int32 * 5)()
+    ok &= comm._exchange_counts_n(None, 5, sl5, sr5, rl5, rr5) == 0
+    ok &= list(rl5) == ([50 + rank - 1 + k for k in range(5)] if rank > 0 else [0] * 5)
+    ok &= list(rr5) == ([rank + 1 + k for k in range(5)] if rank < world - 1 else [0] * 5)
     vals = (ctypes.c_double * 2)(1.0, float(rank))
     ok &= comm._allreduce(None, vals, 2, 0) == 0 and vals[0] == float(world)
     # the in-place reduce buffer of the device-side loop control (host transport: the library stages reduce_buf itself)
@@ -83,17 +92,17 @@ def test_slab_planner_partitions_the_lattice():
     cfg = nat.config_from_dict(scenes.get("dfsph_1m"))
     for world in (2, 4, 8):
         cuts, counts = nat.plan_slabs(cfg, world)
-        assert cuts[0] == 0 and cuts[-1] == 161 and all(b - a >= 2 for a, b in zip(cuts, cuts[1:]))
+        assert cuts[0] == 0 and cuts[-1] == 161 and all(b - a >= 3 for a, b in zip(cuts, cuts[1:]))
         assert sum(counts) == 1000000
         assert max(counts) <= 1.25 * 1000000 / world      # cell-column granularity: 10k particles per column
     with pytest.raises(nat.SphError):
-        nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_small")), 9)    # 16 cell columns cannot hold 9 slabs of >= 2 columns
+        nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_small")), 6)    # 16 cell columns cannot hold 6 slabs of >= 3 columns
     cuts, counts = nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_dam_x")), 3)   # fluid narrower than 3 equal-count slabs: widths clamp
-    assert cuts == [0, 3, 5, 21] and sum(counts) == 960 and min(counts) > 0
+    assert cuts == [0, 3, 6, 21] and sum(counts) == 960
 
 
 def test_replan_rule_properties():
-    """sph_replan_slabs (host-only): equal-count cuts of a column histogram, never narrower than 2 columns, and every cut
+    """sph_replan_slabs (host-only): equal-count cuts of a column histogram, never narrower than 3 columns (ghost layers + 1), and every cut
     stays strictly between its old neighbours so that migration only ever talks to the adjacent slab."""
     rng = np.random.default_rng(5)
     gx = 41
@@ -107,14 +116,14 @@ def test_replan_rule_properties():
             new = nat.replan_slabs(hist, old)
             assert new[0] == 0 and new[-1] == gx
             for k in range(nslab):
-                assert new[k + 1] >= new[k] + 2
+                assert new[k + 1] >= new[k] + 3
             for k in range(1, nslab):
                 assert old[k - 1] < new[k] < old[k + 1]
             old = new
     # a fixed distribution is reached after a few re-plans and then stays put (idempotence)
     hist = np.zeros(gx, dtype=np.int64)
     hist[20:36] = 1000
-    cuts = [0, 2, 4, 6, gx]
+    cuts = [0, 3, 6, 9, gx]
     for _ in range(40):
         cuts = nat.replan_slabs(hist, cuts)
     assert cuts == nat.replan_slabs(hist, cuts)

@@ -19,12 +19,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_slabs(tmp_path, scene, world, steps, rebalance=0, legacy=False, env_extra=None):
-    out = tmp_path / ("slab_%s_%d_%d_%d.json" % (os.path.basename(scene), world, rebalance, legacy))
+def run_slabs(tmp_path, scene, world, steps, rebalance=0, legacy=False, env_extra=None, layers=0, overlap=0, arith=0):
+    out = tmp_path / ("slab_%s_%d_%d_%d_%d%d%d.json" % (os.path.basename(scene), world, rebalance, legacy, layers, overlap, arith))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "slab_worker.py"), "--scene", scene, "--steps", str(steps),
-           "--backend", "gloo", "--rebalance", str(rebalance), "--out", str(out)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_SLAB_LEGACY="1" if legacy else "0")
+           "--backend", "gloo", "--rebalance", str(rebalance), "--layers", str(layers), "--overlap", str(overlap), "--arith", str(arith), "--out", str(out)]
+    # SPH_SLAB_CHECK: every step, the host's bookkeeping of the edge-column populations is compared with the sorted arrays
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_SLAB_LEGACY="1" if legacy else "0", SPH_SLAB_CHECK="1")
     env.update(env_extra or {})
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -80,6 +81,42 @@ def test_particles_that_leak_through_walls_near_a_cut(tmp_path, scene, world, st
     assert r["slabs"][0]["recuts"] >= 5
 
 
+@pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap", [
+    ("dfsph_small", 3, 25, 0, 1, 0), ("dfsph_small", 2, 25, 0, 2, 1), ("dfsph_dam_x", 3, 200, 7, 1, 0), ("dfsph_dam_x", 3, 200, 7, 2, 1),
+    ("breaking_dam_30k_dfsph", 4, 12, 3, 2, 0), ("breaking_dam_30k_dfsph", 2, 12, 0, 1, 0)])
+def test_ghost_column_protocols_agree(tmp_path, scene, world, steps, rebalance, layers, overlap):
+    """VERDICT r3 next #1a-c.  dfsph on slabs, every combination of the halo protocol against one GPU, bit for bit (state, iteration counts, residuals):
+    one ghost column (two refreshes per solver iteration: v after a correction, k / rho after a residual) or two (the inner ghost column runs
+    the corrections itself: ONE refresh per iteration, 4 bytes per ghost), the residual sweeps in one launch or split into edge tiles + interior
+    tiles with the halo of the edge results on its own stream; ordinary steps exchange particles in ONE message per neighbour (migrants + ghost
+    copies after one count exchange), steps that move the cuts in two rounds.  The worker runs with SPH_SLAB_CHECK=1."""
+    r = run_slabs(tmp_path, scene, world, steps, rebalance=rebalance, layers=layers, overlap=overlap, env_extra={"SPH_CELL_ORDER": "morton"})
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], r
+    assert r["stats_equal"], (r["stats_last"], r["ref_stats_last"])
+    assert sum(s["owned"] for s in r["slabs"]) == r["n"]
+    lc, n_steps = r["lib_comm"], r["lib_comm"]["steps"]
+    recuts = r["slabs"][0]["recuts"]
+    assert n_steps == steps
+    # host round trips of the particle exchange: one count exchange per ordinary step, two when the cuts moved
+    assert lc["count_exchanges"] == steps + recuts, (lc, recuts)
+    if layers == 2:
+        # per step: particle message + k / rho after D1 + (1 + 15 enqueued) divergence residuals + v* after D5 + one per density residual;
+        # the one-column protocol sends a velocity refresh on top of every residual's
+        dens_launches = lc["p2p_groups"] - recuts - steps * (1 + 1 + 16 + 1)
+        assert 2 * steps <= dens_launches <= 102 * steps, lc
+        assert lc["allreduce_stream"] == steps * (16 + 1) + dens_launches, lc
+
+
+@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_small", 2, 12, 0), ("breaking_dam_30k_dfsph", 3, 40, 9)])
+def test_relaxed_arithmetic_on_slabs(tmp_path, scene, world, steps, rebalance):
+    """VERDICT r3 next #1d: SphConfig.arith = SPH_ARITH_RELAXED on slab handles (k / rho in its own array there too, the per-step wall sums for the
+    inner ghost column as well).  Every sum runs in the same order on every decomposition, so the sharded relaxed run equals the one-GPU relaxed
+    run bit for bit; that the relaxed kernels really ran on both is checked through SPH_S_ARITH_RELAXED."""
+    r = run_slabs(tmp_path, scene, world, steps, rebalance=rebalance, arith=1, env_extra={"SPH_CELL_ORDER": "morton"})
+    assert r["relaxed"] == [1.0, 1.0], r["relaxed"]
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "stats_last", "ref_stats_last")}
+
+
 def test_legacy_host_loops_on_slabs(tmp_path):
     """SPH_SLAB_LEGACY=1: the host-driven loops (one read-back + host all-reduce per residual) stay available and agree."""
     r = run_slabs(tmp_path, "dfsph_small", 2, 12, legacy=True)
@@ -101,7 +138,8 @@ def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_re
     static = run_slabs(tmp_path, scene, world, steps, rebalance=0)
     assert static["pos_equal"]
     spread = lambda res: max(s["owned"] for s in res["slabs"]) - min(s["owned"] for s in res["slabs"])   # noqa: E731
-    assert spread(r) <= spread(static), (r["slabs"], static["slabs"])
+    # (every slab keeps >= 3 columns -- ghost layers + 1 -- which on these 21-column scenes leaves the re-cut little room: allow a few particles)
+    assert spread(r) <= spread(static) + 8, (r["slabs"], static["slabs"])
 
 
 def test_stream_ordered_transport_plumbing_on_rccl():
