@@ -28,14 +28,14 @@ PATCHES = {
     "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
     # CORRECT variants (speed only): the solver-loop sweeps take their tiles in chunks of C consecutive tiles dealt round-robin over the XCDs
     # instead of one contiguous eighth per XCD (1.5-2 % faster at 16-64, 19 % more HBM traffic: not in the product)
-    "xcd_chunk16": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
-                    "    const int C = 16, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
-    "xcd_chunk32": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
-                    "    const int C = 32, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
-    "xcd_chunk64": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
-                    "    const int C = 64, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
-    "xcd_chunk128": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Neighbour lists",
-                    "    const int C = 128, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Neighbour lists")],
+    "xcd_chunk16": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Edge / interior split of a sweep",
+                    "    const int C = 16, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Edge / interior split of a sweep")],
+    "xcd_chunk32": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Edge / interior split of a sweep",
+                    "    const int C = 32, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Edge / interior split of a sweep")],
+    "xcd_chunk64": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Edge / interior split of a sweep",
+                    "    const int C = 64, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Edge / interior split of a sweep")],
+    "xcd_chunk128": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Edge / interior split of a sweep",
+                    "    const int C = 128, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Edge / interior split of a sweep")],
     # exact k_residual: workgroups whose set did not fit the LDS capacity (1-2 % of them at 1 M) return at once: what do they cost the launch?
     "nounstaged": [(K, "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n    }",
                     "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
@@ -58,8 +58,8 @@ PATCHES = {
                         "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;"),
                        (K, "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    __syncthreads();\n    return nst;",
                         "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 1] = wall_clock64();\n    __syncthreads();\n    return nst;"),
-                       (R, "    const uint32_t *nlb = nullptr;\n    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))\n    (void)nlbp;\n    float2 *s_v2",
-                        "    const uint32_t *nlb = nullptr;\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 2] = wall_clock64();\n    SPH_SWEEP_PROLOGUE_B(false, spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x))\n    (void)nlbp;\n    float2 *s_v2"),
+                       (R, "    const uint32_t *nlb = nullptr;\n    SPH_SWEEP_PROLOGUE_B(false, tile)\n    (void)nlbp;\n    float2 *s_v2",
+                        "    const uint32_t *nlb = nullptr;\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 2] = wall_clock64();\n    SPH_SWEEP_PROLOGUE_B(false, tile)\n    (void)nlbp;\n    float2 *s_v2"),
                        ("sph_mi355x.hip", "int sph_set_scalar(", "int sph_debug_sub2(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_sub2), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_set_scalar("),
                        (K, "// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle",
                         "__device__ unsigned long long g_sub[16384 * 4];\n// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle"),
