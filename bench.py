@@ -151,7 +151,7 @@ def cpu_baseline(scene_name, solver_kind, state=None, first_step=1):
             "sample": sample + "; OpenMP restatement of the ti.cpu path (oracle/), not Taichi", "seconds": dt_s}
 
 
-def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact_stats, fence):
+def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact_stats, fence, solver_kind="dfsph"):
     """SphConfig.arith = SPH_ARITH_RELAXED on the same workload: a second handle receives the state the exact handle had at the start of
     its timed window (pos, vel, warm_start_k, delta_time), runs the same --steps steps between two fences, and is compared with where
     the exact handle ended: per-particle deviation quantiles (relative to max|x| resp. max|v|), iteration counts next to each other.
@@ -161,19 +161,30 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
     sim = nat.Simulation(nat.config_from_dict(cfg, device=device, arith=nat.ARITH_RELAXED))
     pos, vel, warm, dt = state
 
+    wcsph = solver_kind == "wcsph"
+
     def restore():
-        sim.upload(nat.F_POS, pos); sim.upload(nat.F_VEL, vel); sim.upload(nat.F_WARM_K, warm); sim.set_dt(dt)
+        sim.upload(nat.F_POS, pos); sim.upload(nat.F_VEL, vel)
+        if not wcsph:
+            sim.upload(nat.F_WARM_K, warm); sim.set_dt(dt)
 
     restore()
-    st = sim.step_dfsph(1)                    # untimed: list build, graph of buffers, clocks
+    if wcsph:
+        sim.step_wcsph(4)                     # untimed: list build, graph capture, clocks
+    else:
+        sim.step_dfsph(1)
     active = sim.scalar(nat.S_ARITH_RELAXED) == 1.0
     restore()
+    builds0 = sim.scalar(nat.S_VERLET_BUILDS) if wcsph else 0
     fence(sim)
     t0 = time.perf_counter()
     stats = []
-    for _ in range(args.steps):
-        st = sim.step_dfsph(1)
-        stats.append((st.n_div, st.n_dens))          # (the stats object is reused by the binding: copy the numbers)
+    if wcsph:
+        sim.step_wcsph(args.steps)
+    else:
+        for _ in range(args.steps):
+            st = sim.step_dfsph(1)
+            stats.append((st.n_div, st.n_dens))          # (the stats object is reused by the binding: copy the numbers)
     fence(sim)
     elapsed = time.perf_counter() - t0
     n = sim.n_fluid
@@ -183,17 +194,26 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
         return {"q50": float(np.quantile(e, 0.5)), "q99": float(np.quantile(e, 0.99)), "max": float(e.max())}
 
     out = {"arith": "SPH_ARITH_RELAXED (csrc/sph_relaxed_kernels.h: v_rsq_f32, FMAs, grad W as one scalar, per-step wall sums)", "active": active,
-           "value": n * args.steps / elapsed / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
-           "n_dens_mean": sum(x[1] for x in stats) / len(stats), "n_div_mean": sum(x[0] for x in stats) / len(stats),
-           "exact_n_dens_mean": sum(x[1] for x in exact_stats) / len(exact_stats),
+           "value": n * args.steps / elapsed / 1e6, "unit": "Mparticle-steps/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps}
+    if wcsph:
+        out["verlet_list_builds_in_the_timed_steps"] = sim.scalar(nat.S_VERLET_BUILDS) - builds0
+        out["arith"] += "; Verlet lists (skin 0.05 h, rebuilt when a particle has moved skin / 2)"
+    else:
+        out.update({"n_dens_mean": sum(x[1] for x in stats) / len(stats), "n_div_mean": sum(x[0] for x in stats) / len(stats),
+                    "exact_n_dens_mean": sum(x[1] for x in exact_stats) / len(exact_stats)})
+    out.update({
            "deviation_from_exact_after_the_timed_steps": {"pos": quant(sim.download(nat.F_POS), final_exact[0]), "vel": quant(sim.download(nat.F_VEL), final_exact[1]),
                                                           "norm": "per-particle |a - b| / max|b|; same start state (the exact handle's at the start of its timed window)"},
-           "envelope": "two legal executions of the REFERENCE differ by more than this after as many steps (profiles/r03/envelope_*.json, tools/envelope.py)"}
+           "envelope": ("wcsph: the reference's own envelope is 4e-8 after 200 steps; tests/test_relaxed_gpu.py holds this path to 1e-5 of the oracle directly" if wcsph else
+                        "two legal executions of the REFERENCE differ by more than this after as many steps (profiles/r03/envelope_*.json, tools/envelope.py)")})
     if args.profile_steps > 0:
         restore()
         sim.profile_enable(True)
-        for _ in range(args.steps):
-            sim.step_dfsph(1)
+        if wcsph:
+            sim.step_wcsph(args.steps)
+        else:
+            for _ in range(args.steps):
+                sim.step_dfsph(1)
         sim.synchronize()
         prof = sim.profile()
         sim.profile_enable(False)
@@ -203,7 +223,7 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
         ms, cnt = prof[dom]
         avg_s = ms / cnt / 1e3
         rx_names = {"dfsph_div_residual": "k_residual_rx<false>", "dfsph_dens_residual": "k_residual_rx<true>", "dfsph_warm_start": "k_correct_rx<0>",
-                    "dfsph_div_correct": "k_correct_rx<1>", "dfsph_dens_correct": "k_correct_rx<2>"}
+                    "dfsph_div_correct": "k_correct_rx<1>", "dfsph_dens_correct": "k_correct_rx<2>", "wcsph_density": "k_wcsph_density_rx", "wcsph_force": "k_wcsph_force_rx"}
         traffic = None
         try:
             if scene_name == "dfsph_1m":
@@ -505,7 +525,7 @@ def main():
         return elapsed, early, stats, state
 
     run = make_run(sim, solver_kind, rigid_active)
-    want_relaxed = rank == 0 and world == 1 and solver_kind == "dfsph" and not has_rigid and not args.no_relaxed and headline_arith == "exact"
+    want_relaxed = rank == 0 and world == 1 and solver_kind in ("dfsph", "wcsph") and not has_rigid and not args.no_relaxed and headline_arith == "exact"
     want_state = rank == 0 and world == 1 and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf") and (not args.no_cpu_baseline or want_relaxed)
     elapsed, early, stats, state = timed_window(sim, run, want_state)
     final_exact = (sim.download(nat.F_POS), sim.download(nat.F_VEL)) if want_relaxed else None
@@ -620,7 +640,7 @@ def main():
                                       "note": "bench.py --gpus N (N > 1) runs this workload sharded into N x-slabs (scaling: strong); this is its N = 1 point"}
         bsim.close()
     if want_relaxed:
-        out["relaxed"] = relaxed_leg(nat, scenes, scene_name, local_rank, args, state, final_exact, stats, fence)
+        out["relaxed"] = relaxed_leg(nat, scenes, scene_name, local_rank, args, state, final_exact, stats, fence, solver_kind)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene_name, solver_kind, state, args.preroll + args.warmup + 1)
         out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

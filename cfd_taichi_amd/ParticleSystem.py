@@ -14,10 +14,15 @@ class ParticleSystem:
     material_solid_boundary = 1
     material_solid = 2
 
-    def __init__(self, config, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0):
+    def __init__(self, config, device=0, max_neighbors=0, max_wall_neighbors=0, max_density_iters=0, arith=None):
+        """arith: "exact" (default: every f32 operation of the reference in its order) or "relaxed" (SphConfig.arith = SPH_ARITH_RELAXED:
+        the tolerance-grade pair sweeps where the library has them -- dfsph on large scenes, wcsph with Verlet lists; north_star's 1e-5 bar);
+        `config["solver"]["arith"]` is read when the argument is not given.  The reference has one arithmetic; this is the one knob the
+        mirror API adds."""
         self.config = config
+        self.arith = nat.arith_id(arith if arith is not None else config.get("solver", {}).get("arith"))
         self._native_opts = dict(device=device, max_neighbors=max_neighbors, max_wall_neighbors=max_wall_neighbors,
-                                 max_density_iters=max_density_iters)
+                                 max_density_iters=max_density_iters, arith=self.arith)
         self._rigid_input = None
         if config.get("solid", {}):                                      # :35-64
             from . import mesh as _mesh
@@ -86,9 +91,13 @@ class ParticleSystem:
         self._sim = nat.Simulation(cfg, rigid=self._rigid_input)
         self._solver_kind = kind
 
-    def _attach_solver(self, kind):
+    def _attach_solver(self, kind, arith=None):
         """Called by <name>_solver.__init__: the per-solver constants (c_s, tension_k, clamp offset;
-        wcsph_solver.py:17-22 vs solver_base.py:23-26) are baked into the handle."""
+        wcsph_solver.py:17-22 vs solver_base.py:23-26) and the arithmetic are baked into the handle."""
+        if arith is not None and nat.arith_id(arith) != self.arith:
+            self.arith = nat.arith_id(arith)
+            self._native_opts["arith"] = self.arith
+            kind, self._solver_kind = kind, None            # rebuild the handle below
         if kind != self._solver_kind:
             pos = self._sim.download(nat.F_POS)
             vel = self._sim.download(nat.F_VEL)

@@ -27,6 +27,7 @@ S_RIGID_CENTROID, S_RIGID_OMEGA, S_RIGID_VEL, S_RIGID_MASS, S_RIGID_INERTIA_INV 
 S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME, S_GRAPH_LAUNCHES = range(6)
 S_PCISPH_DELTA, S_PCISPH_BETA, S_PCISPH_MAX_INDEX, S_PCISPH_MAX_COUNT = range(6, 10)
 S_ARITH_RELAXED = 30
+S_VERLET_BUILDS = 31
 VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ,
                  F_PBF_DELTA_POS}
 
@@ -277,6 +278,15 @@ def config_from_dict(config, solver_name=None, device=0, max_neighbors=0, max_wa
     c.slab_ghost_layers = int(slab_ghost_layers)
     c.slab_overlap = int(slab_overlap)
     return c
+
+
+def arith_id(arith):
+    """"exact" / "relaxed" / 0 / 1 / None -> SphConfig.arith"""
+    if arith in (None, 0, "0", "exact", ARITH_EXACT):
+        return ARITH_EXACT
+    if arith in (1, "1", "relaxed"):
+        return ARITH_RELAXED
+    raise ValueError("arith must be 'exact' or 'relaxed', got %r" % (arith,))
 
 
 def plan_slabs(cfg, slab_count):

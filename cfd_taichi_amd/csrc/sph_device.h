@@ -63,6 +63,11 @@ struct Consts {
     // lists of their own and run D1 and the correction sweeps like owned particles (k_build_nl: "walker"), so that their v / v* never has to
     // be refreshed inside a solver loop; ghost_walk = 1 on such handles
     int gw_left, gw_right, ghost_walk;
+    // cell edge of the grid the particles are binned into (cell_id_of).  Equal to h -- the reference's grid, ParticleSystem.py:100-101,490-494 --
+    // except on Verlet handles (wcsph under the relaxed arithmetic, sph_relaxed_kernels.h): there the lists hold every pair within
+    // h + skin = hcell and are rebuilt only once a particle has moved more than skin / 2 since the last build (verlet_thr2 = (skin / 2)^2)
+    float hcell, verlet_thr2;
+    int verlet;
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).
@@ -77,7 +82,9 @@ struct DevScalars {
     int max_wall_nbrs;
     int lost;          // particles outside the grid
     float rigid_vmax;  // max over rigid particles of |vel| + |omega x (x - c)|   dfsph_solver.py:104-110
-    int pad[2];
+    // Verlet handles: `moved` is raised by the integrator when a particle is more than skin / 2 away from where the lists were built,
+    // k_verlet_decide turns it into `rebuild` for the sort + list build kernels of the next step (all enqueued every step, gated by it)
+    int rebuild, moved;
     double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
     long long cnt;
     // device-side control of the reference's host loops (correct_divergence_error dfsph_solver.py:393-416,
@@ -87,7 +94,7 @@ struct DevScalars {
     float div_err, div_past, div_first, dens_avg;
     // pcisph / iisph pressure loops reuse dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds:
     float res_prev;
-    int res_have_prev, res_diverged, pad2;
+    int res_have_prev, res_diverged, verlet_builds;
     // Per-build maxima of the list lengths, sharded: workgroup w raises shard w % kNoteShards, the host takes the maximum over the
     // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
     // list build: same-address traffic serialises even when it is only loads.)

@@ -66,9 +66,9 @@ __device__ __forceinline__ size_t nl_index(int i, int k, int kmax)
 __device__ __forceinline__ int cell_id_of(const Consts &c, float x, float y, float z, int &cx, int &cy, int &cz)
 {
     // get_particle_grid_index_3d / _1d                       ParticleSystem.py:486-494
-    cx = (int)floorf(x / c.h);
-    cy = (int)floorf(y / c.h);
-    cz = (int)floorf(z / c.h);
+    cx = (int)floorf(x / c.hcell);
+    cy = (int)floorf(y / c.hcell);
+    cz = (int)floorf(z / c.hcell);
     int id = cx + cy * c.sy + cz * c.sz;
     if (id < 0 || id >= c.C) id = c.C;   // "lost" bucket (reference prints and skips, :393-395)
     // The reference guards only the 1-D index: a particle that slipped through a wall keeps a valid index and is binned into a
@@ -123,8 +123,9 @@ __device__ __forceinline__ int cell_slot(const Consts &c, int id)
 // a slot allocator -- k_order_gather establishes the canonical order inside a cell -- so any assignment is fine.
 __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *__restrict__ P, const int *__restrict__ dead,
                                                        int *__restrict__ cell_of, int *__restrict__ rank, int *__restrict__ cell_count,
-                                                       DevScalars *__restrict__ ds)
+                                                       DevScalars *__restrict__ ds, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;       // Verlet handles: the lists of an earlier step still hold (DevScalars.rebuild)
     const int s = blockIdx.x * kBlock + threadIdx.x;
     // the per-build maxima of the list lengths start at zero (instead of a memset launch before the list build)
     if (ds && blockIdx.x == 0 && threadIdx.x < 2 * kNoteShards) ds->nbr_shard[threadIdx.x] = 0;
@@ -153,8 +154,9 @@ __global__ __launch_bounds__(kBlock) void k_hash_count(Consts c, const float4 *_
 constexpr int kScanTile = kBlock * 4;   // four entries per thread
 // `in` (the cell histogram) is zeroed as it is read: the next step's k_hash_count finds it clean without a memset launch
 __global__ __launch_bounds__(kBlock) void k_scan_tiles(int *__restrict__ in, int *__restrict__ out,
-                                                       int *__restrict__ tile_sums, int n)
+                                                       int *__restrict__ tile_sums, int n, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;
     __shared__ int wsum[kBlock / 64];
     int base = blockIdx.x * kScanTile + threadIdx.x * 4;
     int v[4];
@@ -181,8 +183,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(int *__restrict__ in, int
     if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = woff + inc;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sums, int ntiles)
+__global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sums, int ntiles, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;
     // single block; serial over chunks of 256 with a carry (ntiles is small: cells / 1024)
     __shared__ int wsum[kBlock / 64];
     __shared__ int carry_s;
@@ -205,15 +208,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sum
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n)
+__global__ __launch_bounds__(kBlock) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] += tile_sums[i / kScanTile];
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter(Consts c, const int *__restrict__ cell_of, const int *__restrict__ rank,
-                                                    const int *__restrict__ cell_start, int *__restrict__ slot_src)
+                                                    const int *__restrict__ cell_start, int *__restrict__ slot_src, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s >= c.n) return;
     int cell = cell_of[s];
@@ -228,10 +233,16 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
                                                          const float4 *__restrict__ Vin, const float *__restrict__ warm_in,
                                                          const int *__restrict__ id_in, float4 *__restrict__ Pout,
                                                          float4 *__restrict__ Vout, float *__restrict__ warm_out,
-                                                         int *__restrict__ id_out, float4 *__restrict__ pos_orig)
+                                                         int *__restrict__ id_out, float4 *__restrict__ pos_orig,
+                                                         const int *__restrict__ gate = nullptr, float4 *__restrict__ x0 = nullptr)
 {
     int d = blockIdx.x * kBlock + threadIdx.x;
     if (d >= c.n) return;
+    if (gate && *gate == 0) {           // Verlet handles between two builds: the order stands, the arrays only change roles (the host flips its buffer indices every step)
+        Pout[d] = Pin[d]; Vout[d] = Vin[d]; id_out[d] = id_in[d];
+        if (warm_in) warm_out[d] = warm_in[d];
+        return;
+    }
     int src = slot_src[d];
     int cell = cell_of[src];
     int a = cell_start[cell], b = cell_start[cell + 1];
@@ -253,6 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
     if (warm_in) warm_out[dst] = warm_in[src];
     id_out[dst] = raw;
     if (pos_orig) pos_orig[key] = pp;
+    if (x0) x0[dst] = pp;               // Verlet handles: where this particle was when the lists were built
 }
 
 // ---- rigid body (config 5) ------------------------------------------------------------------------
@@ -591,8 +603,9 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
                                                      RigidView rv, int *__restrict__ ncount, uint2 *__restrict__ stage_runs,
-                                                     int *__restrict__ stage_cnt)
+                                                     int *__restrict__ stage_cnt, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;       // Verlet handles: the lists still hold
     __shared__ uint32_t s_stage[4 * kBlock];
     __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok;
     __shared__ uint4 s_cell[kBlock / 64][kRunCap * 9];
@@ -861,8 +874,9 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
                                                                       const float4 *__restrict__ WP, const int *__restrict__ wcell_start,
                                                                       const int *__restrict__ id, uint32_t *__restrict__ nl,
                                                                       uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
-                                                                      RigidView rv, int *__restrict__ ncount)
+                                                                      RigidView rv, int *__restrict__ ncount, const int *__restrict__ gate = nullptr)
 {
+    if (gate && *gate == 0) return;
     constexpr int CPW = 27 / NW;                                                  // cells per wave: 9 (a dx-plane) or 3 (a (dx, dy) column)
     __shared__ uint4 s_cell[NW][kRunCap * CPW];
     __shared__ int s_cslot[RIGID ? NW : 1][RIGID ? kRunCap * CPW : 1], s_runc[NW][kRunCap][3];

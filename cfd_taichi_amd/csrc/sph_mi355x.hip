@@ -42,6 +42,7 @@ const char *kKernelNames[K_COUNT] = {
     "iisph_update_p", "iisph_integrate", "pbf_lambda", "pbf_delta_pos", "pbf_xsph"};
 
 thread_local std::string g_create_error;
+thread_local bool g_creating_with_rigid = false;     // sph_create_rigid builds the fluid handle first: no Verlet lists there (the body moves through the grid)
 
 // Development overrides.  The SPH_* environment knobs (layout and arithmetic switches for A/B runs, tests and tools) take effect only
 // when SPH_DEV=1 is set as well; without it a set knob is ignored with one line on stderr.  Every override that did take effect is
@@ -124,6 +125,8 @@ struct SphHandle {
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
     int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press); iisph: "d_ij holds zeros" (k_ii_dij)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
+    bool verlet = false;                         // wcsph under the relaxed arithmetic: lists with a skin, rebuilt on demand (sph_relaxed_kernels.h)
+    float4 *x0 = nullptr;                        //   ... positions at the last list build
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
     // pair with each neighbour), [1] bytes sent, [2] bytes received, [3] count exchanges (one host round trip each), [4] all-reduces
     // ordered on the stream, [5] all-reduces through the host, [6] steps
@@ -385,14 +388,26 @@ int build_scene(SphHandle *h, HostScene &sc)
         h->Nb = layer * ring + bottom * 2;
     }
     h->Nr = 0;
+    // Verlet lists (wcsph, relaxed arithmetic, one GPU, no body): cells of edge h + skin and lists of every pair within it, rebuilt only when a
+    // particle has moved skin / 2 (sph_relaxed_kernels.h).  SPH_VERLET_SKIN sets the skin as a fraction of h (0 turns the reuse off).
+    double skin = 0.0;
+    h->verlet = cf.solver == SPH_SOLVER_WCSPH && h->relaxed && cf.slab_count <= 1 && !g_creating_with_rigid;
+    if (h->verlet) {
+        const char *e = dev_env(&h->overrides, "SPH_VERLET_SKIN");
+        skin = e ? std::min(std::max(atof(e), 0.0), 0.5) : 0.05;
+    }
+    const double cell_edge = support * (1.0 + skin);
     int g[3];
-    for (int a = 0; a < 3; ++a) g[a] = (int)std::ceil((cf.box_max[a] - cf.box_min[a]) / support) + 1;   // :100-101
+    for (int a = 0; a < 3; ++a) g[a] = (int)std::ceil((cf.box_max[a] - cf.box_min[a]) / cell_edge) + 1;   // :100-101 (cell_edge = support but on Verlet handles)
     if (h->N <= 0) return fail(h, SPH_E_INVALID, "scene has no fluid particles");
     long long C = (long long)g[0] * g[1] * g[2];
     if (C <= 0 || C > 0x7ffffff0LL) return fail(h, SPH_E_INVALID, "grid too large");
 
     memset(&c, 0, sizeof(c));
     c.h = (float)support;
+    c.hcell = h->verlet ? (float)cell_edge : c.h;
+    c.verlet = h->verlet ? 1 : 0;
+    c.verlet_thr2 = (float)((0.5 * skin * support) * (0.5 * skin * support));
     c.m = (float)m;
     c.d = (float)d;
     c.rho0 = 1000.0f;
@@ -417,6 +432,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         while (sqrtf(t) > c.h) t = nextafterf(t, 0.0f);
         while (sqrtf(nextafterf(t, INFINITY)) <= c.h) t = nextafterf(t, INFINITY);
         c.r2_cut = t;
+        if (h->verlet) c.r2_cut = c.hcell * c.hcell;      // Verlet lists: every pair within h + skin
     }
     const double c_s = cf.solver == SPH_SOLVER_WCSPH ? 10 : 13;      // wcsph_solver.py:18 vs solver_base.py:24
     const double t_k = cf.solver == SPH_SOLVER_WCSPH ? 0.2 : 0.5;    // wcsph_solver.py:20 vs solver_base.py:26
@@ -455,8 +471,9 @@ int build_scene(SphHandle *h, HostScene &sc)
     c.n = h->N;                                    // refined below for slab handles
     c.gw_left = c.gw_right = -1; c.ghost_walk = 0;
     c.stride = (h->N + 63) / 64 * 64;
-    c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : 64) + 3) & ~3;        // rows come in groups of four
-    c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : 64) + 3) & ~3;
+    // (Verlet lists hold (1 + skin)^3 as many pairs: default capacity 80 there)
+    c.kmax = ((cf.max_neighbors > 0 ? cf.max_neighbors : (h->verlet ? 80 : 64)) + 3) & ~3;        // rows come in groups of four
+    c.kbmax = ((cf.max_wall_neighbors > 0 ? cf.max_wall_neighbors : (h->verlet ? 80 : 64)) + 3) & ~3;
     if (cf.boundary_handle == 0) c.kbmax = 4;      // clamp walls: no wall particles, the wall lists stay empty (one row group, never walked)
     if (c.kmax > 0xffff || c.kbmax > 0x7fff) return fail(h, SPH_E_INVALID, "neighbour capacity too large");
     {
@@ -594,9 +611,9 @@ int build_scene(SphHandle *h, HostScene &sc)
     std::vector<int> wcell(Nb > 0 ? Nb : 1), wc3(3 * (size_t)(Nb > 0 ? Nb : 1));
     sc.wcell_start.assign((size_t)c.C + 1, 0);
     for (int i = 0; i < Nb; ++i) {
-        int cx = (int)floorf(sc.wall_pos[3 * (size_t)i] / c.h);
-        int cy = (int)floorf(sc.wall_pos[3 * (size_t)i + 1] / c.h);
-        int cz = (int)floorf(sc.wall_pos[3 * (size_t)i + 2] / c.h);
+        int cx = (int)floorf(sc.wall_pos[3 * (size_t)i] / c.hcell);
+        int cy = (int)floorf(sc.wall_pos[3 * (size_t)i + 1] / c.hcell);
+        int cz = (int)floorf(sc.wall_pos[3 * (size_t)i + 2] / c.hcell);
         int id = cx + cy * c.sy + cz * c.sz;
         if (id < 0 || id >= c.C) return fail(h, SPH_E_INVALID, "wall particle %d falls outside the grid", i);
         wcell[i] = id; wc3[3 * (size_t)i] = cx; wc3[3 * (size_t)i + 1] = cy; wc3[3 * (size_t)i + 2] = cz;
@@ -793,6 +810,10 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (want_wall_cache && sweep_mode(h) != SWEEP_QUAD && !h->wall_grad && gc_bytes <= ((size_t)64 << 30) && gc_bytes <= free_b / 2)
             if ((rc = dalloc(h, &h->wall_gc, (n + 64) * (size_t)c.kbpitch))) return rc;
     }
+    if (h->verlet) {      // the wall sums of the step (density -> force kernel) and the positions of the last list build
+        if ((rc = dalloc(h, &h->wall_grad, n))) return rc;
+        if ((rc = dalloc(h, &h->x0, n))) return rc;
+    }
     if ((rc = dalloc(h, &h->cell_of, n))) return rc;
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
@@ -855,6 +876,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     h->ds_host->dt = (float)h->cfg.delta_time;                       // solver_base.py:16
     h->ds_host->dt2 = h->ds_host->dt * h->ds_host->dt;               // dfsph_solver.py:20
     h->ds_host->ps_dt = 0.f;                                         // ParticleSystem.py:37
+    h->ds_host->moved = 1;                                           // Verlet handles: the first step builds the lists
     HIP_TRY(h, hipMemcpyAsync(h->ds, h->ds_host, sizeof(DevScalars), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dt_wcsph = (float)h->cfg.delta_time;
@@ -1612,21 +1634,25 @@ int stage_sort_and_lists(SphHandle *h)
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     const bool carry = carries_scalar(h);
     (void)dfsph;
+    // Verlet handles: every kernel of the sort and the list build is enqueued every step and leaves at once unless the integrator of the
+    // step before found a particle skin / 2 away from where the lists were built (k_verlet_decide: DevScalars.moved -> rebuild)
+    const int *gate = h->verlet ? &h->ds->rebuild : nullptr;
     {
         ProfScope ps(h, K_HASH);
+        if (h->verlet) hipLaunchKernelGGL(k_verlet_decide, dim3(1), dim3(1), 0, s, h->ds);
         // cell_count is clean: the arena starts zeroed and k_scan_tiles zeroes the histogram as it consumes it
         hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->slab ? h->dead : (const int *)nullptr, h->cell_of, h->rank,
-                           h->cell_count, h->ds);
+                           h->cell_count, h->ds, gate);
     }
     {
         ProfScope ps(h, K_SCAN);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->cell_count, h->cell_start, h->tile_sums, (int)ncell);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles);
-        hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->cell_start, h->tile_sums, (int)ncell);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->cell_count, h->cell_start, h->tile_sums, (int)ncell, gate);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles, gate);
+        hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->cell_start, h->tile_sums, (int)ncell, gate);
     }
     {
         ProfScope ps(h, K_SCATTER);
-        hipLaunchKernelGGL(k_scatter, g, b, 0, s, c, h->cell_of, h->rank, h->cell_start, h->slot_src);
+        hipLaunchKernelGGL(k_scatter, g, b, 0, s, c, h->cell_of, h->rank, h->cell_start, h->slot_src, gate);
     }
     if (h->slab) {
         // dead slots took no part in the sort: the sorted arrays end after the live particles
@@ -1639,7 +1665,7 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_ORDER_GATHER);
         hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
                            carry ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
-                           h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr);
+                           h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr, gate, h->x0);
         h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
         if (carry) h->wcur ^= 1;
     }
@@ -1678,9 +1704,9 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_BUILD_NL);
         // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
 #define SPH_BNL(R, S) hipLaunchKernelGGL((k_build_nl<R, S>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
-                                             h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt)
+                                             h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt, gate)
 #define SPH_BNL_SPLIT(R, NW) hipLaunchKernelGGL((k_build_nl_split<R, NW>), dim3((unsigned)std::max(1, (c.n + 63) / 64)), dim3(NW * 64), 0, s, c, h->P[h->pcur], \
-                                                h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount)
+                                                h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, gate)
         // small unstaged scenes: one wave per dx-plane (3) or per (dx, dy) column (9) of the same 64 particles.  Measured (tools/split_sweep.sh):
         // 22 k particles 77 -> 55 -> 34 us, 29 k 54 -> 32 -> 27 us, 55 k 146 -> 81 -> 64 us (rigid) / 56 -> 44 -> 48 us; 250 k 69 -> 87 -> 122 us.
         const bool rg = rigid_coupled(h);
@@ -1755,6 +1781,15 @@ int stage_density(SphHandle *h)
         return SPH_OK;
     }
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    if (h->verlet) {      // wcsph under the relaxed arithmetic: Verlet lists hold pairs beyond h, only the clamped kernel functions may walk them
+        ProfScope ps(h, K_W_DENSITY);
+        hipLaunchKernelGGL(k_wcsph_density_rx, grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
+                           h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->wall_grad);
+        h->pcur ^= 1; h->vcur ^= 1;                         // P = (pos, rho), V = (vel, p / rho^2)
+        HIP_TRY(h, hipGetLastError());
+        h->density_valid = true;
+        return SPH_OK;
+    }
     if (dfsph) {
         // DFSPH buffer roles for the whole step: P[pcur] = sorted positions (never written until the integrator),
         // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
@@ -1804,6 +1839,20 @@ int step_wcsph_once(SphHandle *h)
     h->simulate_cnt += 1;                                   // solver_base.py:137
     h->comm_stat[6] += 1;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141
+    if (h->verlet) {                                        // the relaxed arithmetic: two kernels over the Verlet lists (sph_relaxed_kernels.h)
+        const Consts &cv = h->c;
+        if ((rc = stage_density(h))) return rc;             // pressure_phase, wcsph_solver.py:32-38
+        {
+            ProfScope ps(h, K_W_FORCE);                     // + kinematic_phase :40-63
+            hipLaunchKernelGGL(k_wcsph_force_rx, grid_for(cv.n), dim3(kBlock), 0, h->stream, cv, h->dt_wcsph, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt,
+                               h->wall_grad, h->x0, h->P[1 - h->pcur], h->V[1 - h->vcur], h->VA[0], h->ds);
+            h->pcur ^= 1; h->vcur ^= 1;
+        }
+        HIP_TRY(h, hipGetLastError());
+        h->nl_valid = false;
+        h->density_valid = false;
+        return SPH_OK;
+    }
     if ((rc = stage_density(h))) return rc;                 // wcsph_solver.py:34-35
     const Consts &c = h->c;
     if (rigid_coupled(h)) launch_rigid_force_p<RF_WCSPH>(h, h->P[h->pcur], nullptr, GATE_NONE);   // wcsph_solver.py:127, positions of this step
@@ -2608,7 +2657,9 @@ int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **ou
     if (cfg->slab_count > 1) return fail(nullptr, SPH_E_INVALID, "rigid coupling is not available on slab handles");
     if (rigid->n_particles <= 0 || !rigid->points) return fail(nullptr, SPH_E_INVALID, "rigid body has no sample points");
     if (cfg->solver == SPH_SOLVER_PBF) return fail(nullptr, SPH_E_INVALID, "pbf has no rigid coupling (pbf_solver.py has no material branches)");
+    g_creating_with_rigid = true;
     int rc = sph_create(cfg, out);
+    g_creating_with_rigid = false;
     if (rc) return rc;
     SphHandle *h = *out;
     rc = build_rigid(h, rigid);
@@ -2685,6 +2736,10 @@ int sph_upload(SphHandle *h, int species, int field, const float *host, size_t n
     else if (field == SPH_F_VEL) hipLaunchKernelGGL(k_sort_in_vec, g, b, 0, s, h->N, h->staging, h->id[h->icur], h->V[h->vcur]);
     else hipLaunchKernelGGL(k_sort_in_scalar, g, b, 0, s, h->N, h->staging, h->id[h->icur], h->warm[h->wcur]);
     HIP_TRY(h, hipGetLastError());
+    if (h->verlet) {              // new positions: the Verlet lists of the last build no longer apply
+        h->ds_host->moved = 1;
+        HIP_TRY(h, hipMemcpyAsync(&h->ds->moved, &h->ds_host->moved, sizeof(int), hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(h, hipStreamSynchronize(s));
     h->nl_valid = false;
     h->density_valid = false;
@@ -3144,7 +3199,8 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PCISPH_MAX_INDEX: *out = (double)h->pci_max_index; return SPH_OK;
     case SPH_S_PCISPH_MAX_COUNT: *out = (double)h->pci_max_count; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
-    case SPH_S_ARITH_RELAXED: *out = use_relaxed(h) ? 1.0 : 0.0; return SPH_OK;      // kr_split is settled by the first list build
+    case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet) ? 1.0 : 0.0; return SPH_OK;
+    case SPH_S_VERLET_BUILDS: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->verlet_builds; return SPH_OK; }      // kr_split is settled by the first list build
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {
             if (which < SPH_S_RIGID_OMEGA) *out = (double)h->centroid[which - SPH_S_RIGID_CENTROID];

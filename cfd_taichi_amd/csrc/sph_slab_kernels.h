@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_column_histogram(Consts c, const flo
     }
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s < c.n && id[s] >= 0) {
-        int cx = (int)floorf(P[s].x / c.h);
+        int cx = (int)floorf(P[s].x / c.hcell);
         cx = cx < 0 ? 0 : (cx >= c.gx ? c.gx - 1 : cx);
         atomicAdd(use_lds ? &local[cx] : &hist[cx], 1);
     }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_flags(Consts c, SlabGeom g, con
     const int i = blockIdx.x * kBlock + threadIdx.x;
     int e = 0;
     if (i < c.n) {
-        const int cx = (int)floorf(P[i].x / c.h);
+        const int cx = (int)floorf(P[i].x / c.hcell);
         e = (g.has_left && cx < g.x_lo + g.layers) || (g.has_right && cx >= g.x_hi - g.layers);
     }
     e = __syncthreads_or(e);

@@ -10,8 +10,8 @@ from .solver_base import solver_base
 class dfsph_solver(solver_base):
     _kind = "dfsph"
 
-    def __init__(self, particle_system, config, verbose=True):
-        super().__init__(particle_system, config)
+    def __init__(self, particle_system, config, verbose=True, arith=None):
+        super().__init__(particle_system, config, arith)
         self.min_iteration_density = 2                  # dfsph_solver.py:21-29
         self.density_threshold = 0.1
         self.min_iteration_density_divergence = 1

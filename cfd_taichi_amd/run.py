@@ -46,7 +46,7 @@ def main_sharded(args, config):
     else:
         dist.init_process_group("gloo")
     transport = os.environ.get("SPH_RUN_TRANSPORT", "native" if own_gpu else "torch")
-    sim = SlabSimulation(config, rank, world, device=device, transport=transport, rebalance_every=50)
+    sim = SlabSimulation(config, rank, world, device=device, transport=transport, rebalance_every=50, arith=nat.arith_id(args.arith))
     scene_config, solver_config = config["scene"], config["solver"]
     iter_cnt = solver_config.get("iter_cnt")
     ply_dir = args.ply_dir or ("./output" if scene_config.get("is_output_ply", False) else None)
@@ -84,6 +84,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=0, help="stop after this many frames (0 = use --until)")
     ap.add_argument("--ply-dir", default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--arith", default=None, choices=["exact", "relaxed"],
+                    help="exact (default): the reference's f32 operations in its order; relaxed: the tolerance-grade sweeps (SphConfig.arith)")
     args = ap.parse_args(argv)
 
     config = utils.read_config(args.config)
@@ -94,7 +96,7 @@ def main(argv=None):
     scene_config, solver_config = config["scene"], config["solver"]
     print("Simulation Start!")
     start_time = time.time()
-    ps = ParticleSystem(config, device=args.device)
+    ps = ParticleSystem(config, device=args.device, arith=args.arith)
     name = solver_config.get("name")
     if name not in ("wcsph", "dfsph", "pcisph", "iisph", "pbf"):
         raise SystemExit("solver '%s' is not covered; pass --solver wcsph | dfsph | pcisph | iisph | pbf" % name)

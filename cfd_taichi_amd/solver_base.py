@@ -7,11 +7,13 @@ from .fields import DeviceField, ScalarField
 class solver_base:
     _kind = None   # "wcsph" | "dfsph"
 
-    def __init__(self, particle_system, config):
+    def __init__(self, particle_system, config, arith=None):
+        """arith: None keeps the ParticleSystem's arithmetic; "exact" / "relaxed" rebuilds its handle with that one (see ParticleSystem)."""
         solver_config = config.get("solver")
         scene_config = config.get("scene")
         self.ps = particle_system
-        self._sim = particle_system._attach_solver(self._kind)
+        self._sim = particle_system._attach_solver(self._kind, arith)
+        self.arith = "relaxed" if particle_system.arith == nat.ARITH_RELAXED else "exact"
         self.particle_count = particle_system.particle_num
         self.kernel_h = self.ps.particle_radius * 4          # solver_base.py:17
         self.rho_0 = 1000                                    # :19

@@ -9,8 +9,8 @@ from .solver_base import solver_base
 class wcsph_solver(solver_base):
     _kind = "wcsph"
 
-    def __init__(self, particle_system, config):
-        super().__init__(particle_system, config)
+    def __init__(self, particle_system, config, arith=None):
+        super().__init__(particle_system, config, arith)
         self.viscosity_c_s = 10      # wcsph_solver.py:17-22
         self.tension_k = 0.2
         self.gamma = 7

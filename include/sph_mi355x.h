@@ -167,6 +167,7 @@ typedef struct SphRigid {
 #define SPH_S_RIGID_VEL 16        /* +0,1,2: rigid_particles.vel (uniform over the body) */
 #define SPH_S_RIGID_MASS 19       /* rigid_solver.mass[None] */
 #define SPH_S_RIGID_INERTIA_INV 20 /* +0..8: ps.rigid_inertia_tensor_inv[None], row major */
+#define SPH_S_VERLET_BUILDS 31    /* diagnostics: list builds so far on a Verlet handle (wcsph under the relaxed arithmetic: the lists carry a skin and are rebuilt on demand) */
 #define SPH_S_ARITH_RELAXED 30    /* diagnostics: 1 if this handle's dfsph sweeps run the tolerance-grade kernels (SphConfig.arith asked AND the handle qualifies) */
 
 typedef struct SphHandle SphHandle;

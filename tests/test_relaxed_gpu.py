@@ -176,3 +176,113 @@ def test_relaxed_dfsph_1m_20_steps_from_the_timed_phase():
     print("dfsph_1m, 20 steps from step 55: (n_dens exact, relaxed) %s; pos q50/q99/q999 %.2e %.2e %.2e; vel %.2e %.2e %.2e" % ((diffs,) + tuple(qp) + tuple(qv)))
     assert qp[0] <= 1e-5 and qp[1] <= 1e-4
     ex.close(); rx.close()
+
+
+# ---- WCSPH under the relaxed arithmetic: Verlet lists, two kernels per step --------------------------------------------
+# WCSPH is the solver whose own nondeterminism envelope is tiny (4e-8 after 200 steps), so here north_star's bar --
+# positions and velocities within 1e-5 (max norm) of the reference after N steps -- is tested DIRECTLY against the oracle.
+
+def wcsph_pair(scene):
+    cfg = scenes.get(scene)
+    rx = nat.Simulation(nat.config_from_dict(cfg, arith=nat.ARITH_RELAXED))
+    return cfg, rx
+
+
+@pytest.mark.parametrize("scene,steps", [("breaking_dam_30k_wcsph", 200), ("wcsph_small", 400), ("wcsph_tiny_wall", 300), ("wcsph_tiny_clamp", 300),
+                                         ("wcsph_dam_x", 1500)])
+def test_relaxed_wcsph_within_1e5_of_the_oracle(scene, steps):
+    """Config 1 (29 k particles) 200 steps from rest, and smaller scenes far longer (wcsph_dam_x: the column collapses and runs along the box,
+    the lists are rebuilt many times): max-norm deviation from the canonical oracle <= 1e-5 in positions AND velocities at several points
+    of the run -- or, where a seeded LEGAL execution of the oracle (racy cell-list order: what the reference does to itself) is further than
+    that from the canonical one, within 3x of the larger of two of them: a column of a few hundred particles pressed against a wall by the stiff Tait equation is
+    not as well conditioned as the free dam.  The run must really have reused lists (fewer builds than steps)."""
+    cfg, rx = wcsph_pair(scene)
+    o = orc.Oracle(cfg, num_threads=8)
+    legal = []
+    for seed in (7, 19):
+        lo = orc.Oracle(cfg, num_threads=8)
+        lo.set_schedule(seed, 1)
+        legal.append(lo)
+    marks = sorted({max(1, steps // 4), steps // 2, steps})
+    done = 0
+    for m in marks:
+        rx.step_wcsph(m - done); o.step_wcsph(m - done)
+        for lo in legal:
+            lo.step_wcsph(m - done)
+        done = m
+        ep, ev = rel(rx.download(nat.F_POS), o.get(orc.F_POS)), rel(rx.download(nat.F_VEL), o.get(orc.F_VEL))
+        lp = max(rel(lo.get(orc.F_POS), o.get(orc.F_POS)) for lo in legal)
+        lv = max(rel(lo.get(orc.F_VEL), o.get(orc.F_VEL)) for lo in legal)
+        print("%s step %d: pos max-norm %.2e vel max-norm %.2e (legal schedules of the reference: %.2e %.2e)" % (scene, m, ep, ev, lp, lv))
+        assert ep <= max(1e-5, 3.0 * lp) and ev <= max(1e-5, 3.0 * lv), (scene, m, ep, ev, lp, lv)
+        if scene == "breaking_dam_30k_wcsph":
+            assert ep <= 1e-5 and ev <= 1e-5          # BASELINE config 1: north_star's bar as stated
+    assert rx.scalar(nat.S_ARITH_RELAXED) == 1.0
+    builds = rx.scalar(nat.S_VERLET_BUILDS)
+    print("%s: %d list builds in %d steps" % (scene, builds, steps))
+    assert 1 <= builds < steps
+    rx.close(); o.close()
+    for lo in legal:
+        lo.close()
+
+
+def test_relaxed_wcsph_250k_steps_151_to_155():
+    """Config 2 in the phase its bench line times: 150 exact steps on the device, then the state goes to a relaxed handle and to the oracle,
+    both run steps 151-155; <= 1e-5 max norm after each."""
+    cfg = scenes.get("wcsph_250k")
+    ex = nat.Simulation(nat.config_from_dict(cfg))
+    ex.step_wcsph(150)
+    pos, vel = ex.download(nat.F_POS), ex.download(nat.F_VEL)
+    ex.close()
+    rx = nat.Simulation(nat.config_from_dict(cfg, arith=nat.ARITH_RELAXED))
+    rx.upload(nat.F_POS, pos); rx.upload(nat.F_VEL, vel)
+    o = orc.Oracle(cfg, num_threads=16)
+    o.set(orc.F_POS, pos); o.set(orc.F_VEL, vel)
+    for s in range(5):
+        rx.step_wcsph(1); o.step_wcsph(1)
+        ep, ev = rel(rx.download(nat.F_POS), o.get(orc.F_POS)), rel(rx.download(nat.F_VEL), o.get(orc.F_VEL))
+        print("wcsph_250k step %d: pos max-norm %.2e vel max-norm %.2e" % (151 + s, ep, ev))
+        assert ep <= 1e-5 and ev <= 1e-5, (s, ep, ev)
+    assert rx.scalar(nat.S_ARITH_RELAXED) == 1.0
+    rx.close(); o.close()
+
+
+def test_relaxed_wcsph_list_reuse_is_only_a_schedule():
+    """SPH_VERLET_SKIN=0 rebuilds the lists every step (a zero skin: any motion counts as moved): the same relaxed kernels on canonical
+    lists.  The reused-list run stays within 1e-6 of it over 300 steps -- what changes between two builds is the ORDER of the sums and which
+    pairs beyond h are visited (they contribute exactly 0)."""
+    cfg = scenes.get("wcsph_small")
+    a = nat.Simulation(nat.config_from_dict(cfg, arith=nat.ARITH_RELAXED))
+    os.environ["SPH_VERLET_SKIN"] = "0"
+    try:
+        b = nat.Simulation(nat.config_from_dict(cfg, arith=nat.ARITH_RELAXED))
+    finally:
+        os.environ.pop("SPH_VERLET_SKIN", None)
+    a.step_wcsph(300); b.step_wcsph(300)
+    print("builds", a.scalar(nat.S_VERLET_BUILDS), b.scalar(nat.S_VERLET_BUILDS), rel(a.download(nat.F_POS), b.download(nat.F_POS)), rel(a.download(nat.F_VEL), b.download(nat.F_VEL)))
+    assert b.scalar(nat.S_VERLET_BUILDS) == 300 and a.scalar(nat.S_VERLET_BUILDS) < 150
+    assert rel(a.download(nat.F_POS), b.download(nat.F_POS)) <= 1e-6 and rel(a.download(nat.F_VEL), b.download(nat.F_VEL)) <= 1e-5
+    a.close(); b.close()
+
+
+def test_arith_through_the_mirror_api(capsys):
+    """ParticleSystem(config, arith=...), <name>_solver(ps, config, arith=...) and run.py --arith reach SphConfig.arith (VERDICT r3 missing #3)."""
+    from cfd_taichi_amd import ParticleSystem, wcsph_solver
+    cfg = scenes.get("wcsph_tiny_wall")
+    ps = ParticleSystem(cfg, arith="relaxed")
+    sol = wcsph_solver(ps, cfg)
+    sol.step(3)
+    assert sol.arith == "relaxed" and sol._sim.scalar(nat.S_ARITH_RELAXED) == 1.0
+    ps2 = ParticleSystem(cfg)
+    sol2 = wcsph_solver(ps2, cfg)
+    sol2.step(3)
+    assert sol2.arith == "exact" and sol2._sim.scalar(nat.S_ARITH_RELAXED) == 0.0
+    sol3 = wcsph_solver(ParticleSystem(cfg), cfg, arith="relaxed")          # the solver may ask for it too: the handle is rebuilt
+    sol3.step(3)
+    assert sol3.arith == "relaxed" and sol3._sim.scalar(nat.S_ARITH_RELAXED) == 1.0
+    assert rel(sol3.ps.fluid_particles.pos.to_numpy(), sol2.ps.fluid_particles.pos.to_numpy()) <= 1e-6
+    cfg4 = scenes.get("wcsph_tiny_wall")
+    cfg4["solver"]["arith"] = "relaxed"                                      # ... or the config
+    assert ParticleSystem(cfg4).arith == nat.ARITH_RELAXED
+    with pytest.raises(ValueError):
+        ParticleSystem(cfg, arith="fast")
