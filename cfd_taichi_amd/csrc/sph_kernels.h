@@ -1085,7 +1085,18 @@ __device__ __forceinline__ void for_wall_cache(const float4 *__restrict__ base, 
 }
 
 // block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
-__device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
+// `through`: the partial is stored write-through at agent scope (sc1) -- the fused finalize (fin_fused) reads it from another XCD inside the same launch
+__device__ __forceinline__ void store_partial(double *__restrict__ psum, int *__restrict__ pcnt, int e, double t, int n, bool through)
+{
+    if (through) {
+        __hip_atomic_store(&psum[e], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&pcnt[e], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        psum[e] = t;
+        pcnt[e] = n;
+    }
+}
+__device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt, bool through = false)
 {
     __shared__ double s_sum[kBlock / 64];
     __shared__ int s_cnt[kBlock / 64];
@@ -1097,15 +1108,14 @@ __device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, 
     if (threadIdx.x == 0) {
         double t = 0.0; int n = 0;
         for (int k = 0; k < kBlock / 64; ++k) { t += s_sum[k]; n += s_cnt[k]; }
-        psum[blk] = t;
-        pcnt[blk] = n;
+        store_partial(psum, pcnt, blk, t, n, through);
     }
 }
 // QUAD sweeps: a workgroup holds 64 particles, one per quad -- exactly one WAVE of a one-lane-per-particle workgroup.  Its partial is
 // that wave's butterfly: the owners' values go through LDS into particle order and wave 0 reduces them with the same tree.
 // psum / pcnt then hold one entry per 64 particles; k_finalize_mean (group = 4) first adds four consecutive entries in order, which is
 // the serial sum over the four waves of the 256-particle block above: same bits.
-__device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int flag, bool owner_lane, double *__restrict__ psum, int *__restrict__ pcnt)
+__device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int flag, bool owner_lane, double *__restrict__ psum, int *__restrict__ pcnt, bool through = false)
 {
     __shared__ double s_v[kBlock / 4];
     __shared__ int s_f[kBlock / 4];
@@ -1114,7 +1124,7 @@ __device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int f
     if (threadIdx.x < 64) {
         const double ws = wave_sum(s_v[threadIdx.x]);
         const int wc = wave_sum(s_f[threadIdx.x]);
-        if (threadIdx.x == 0) { psum[blk] = ws; pcnt[blk] = wc; }
+        if (threadIdx.x == 0) store_partial(psum, pcnt, blk, ws, wc, through);
     }
 }
 
@@ -1146,36 +1156,55 @@ enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
 constexpr int kFinBlock = 1024;
 // group = 4: psum / pcnt hold one entry per 64 particles (QUAD sweeps, block_partial_mean_quad); `nblocks` still counts blocks of 256 particles and
 // `nparts` the entries: a block's partial is the in-order sum of its (up to) four entries.
+// THROUGH: the partials are read with agent-scope (sc1) loads -- inside the launch that produced them (fin_fused)
+template <bool THROUGH>
+__device__ __forceinline__ void load_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, double &v, int &m)
+{
+    if (THROUGH) {
+        v = __hip_atomic_load(&psum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = __hip_atomic_load(&pcnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        v = psum[e]; m = pcnt[e];
+    }
+}
+template <bool THROUGH = false>
 __device__ __forceinline__ void fin_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, int nblocks, int group, int nparts, double &v, int &m)
 {
     v = 0.0; m = 0;
     if (e >= nblocks) return;
-    if (group == 1) { v = psum[e]; m = pcnt[e]; return; }
+    if (group == 1) { load_partial<THROUGH>(psum, pcnt, e, v, m); return; }
     for (int u = 0; u < group; ++u) {
         const int k = e * group + u;
-        if (k < nparts) { v += psum[k]; m += pcnt[k]; }          // 0.0 + w0 = w0: the serial sum over the block's waves
+        if (k < nparts) { double pv; int pm; load_partial<THROUGH>(psum, pcnt, k, pv, pm); v += pv; m += pm; }          // 0.0 + w0 = w0: the serial sum over the block's waves
     }
 }
-// the reduction itself, for a workgroup of kFinBlock threads: (sum, count) over the block partials end up in s_sum[0], s_cnt[0] (thread 0's view)
-__device__ __forceinline__ void fin_reduce(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, int group, int nparts,
-                                           double *__restrict__ s_sum, long long *__restrict__ s_cnt)
+// what "virtual thread" vt of a kFinBlock-thread workgroup adds up: the partials vt, vt + kFinBlock, ... in ascending order
+template <bool THROUGH>
+__device__ __forceinline__ void fin_thread_sum(const double *__restrict__ psum, const int *__restrict__ pcnt, int vt, int nblocks, int group, int nparts, double &t, int &n)
 {
-    double t = 0.0; int n = 0;
-    int k = threadIdx.x;
+    t = 0.0; n = 0;
+    int k = vt;
     for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
         double v[4]; int m[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+        for (int u = 0; u < 4; ++u) fin_partial<THROUGH>(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
     }
     {   // the rest, still as one batch of (predicated) loads
         double v[4]; int m[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+        for (int u = 0; u < 4; ++u) fin_partial<THROUGH>(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
     }
+}
+// the reduction itself, for a workgroup of kFinBlock threads: (sum, count) over the block partials end up in s_sum[0], s_cnt[0] (thread 0's view)
+__device__ __forceinline__ void fin_reduce(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, int group, int nparts,
+                                           double *__restrict__ s_sum, long long *__restrict__ s_cnt)
+{
+    double t; int n;
+    fin_thread_sum<false>(psum, pcnt, threadIdx.x, nblocks, group, nparts, t, n);
     const double ws = wave_sum(t);
     const int wn = wave_sum(n);
     if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_cnt[threadIdx.x >> 6] = wn; }
@@ -1186,23 +1215,13 @@ __device__ __forceinline__ void fin_reduce(const double *__restrict__ psum, cons
         s_sum[0] = tt; s_cnt[0] = nn;
     }
 }
-__global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                             int group = 1, int nparts = 0)
+// the reference's host logic, evaluated where the data is (same f64 compares as the Python host code); one thread
+__device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode, double sum, long long cnt)
 {
-    if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
-    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
-    __shared__ double s_sum[kFinBlock / 64];
-    __shared__ long long s_cnt[kFinBlock / 64];
-    if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);
-    if (threadIdx.x != 0) return;
-    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
-    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
-    ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
+    ds->sum = sum; ds->cnt = cnt;
     if (mode == FIN_PLAIN) return;
-    // the reference's host logic, evaluated where the data is (same f64 compares as the Python host code)
     if (mode == FIN_DIV_FIRST || mode == FIN_DIV_LOOP) {
-        const float err = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // dfsph_solver.py:278-279
+        const float err = cnt > 0 ? (float)(sum / (double)cnt) : 0.0f;   // dfsph_solver.py:278-279
         int it = ds->div_it;
         int active;
         if (mode == FIN_DIV_FIRST) {                                     // :398-399
@@ -1218,7 +1237,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
         ds->div_it = it;
         ds->div_active = active;
     } else {
-        const float avg = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 1000.0f;  // :148-149
+        const float avg = cnt > 0 ? (float)(sum / (double)cnt) : 1000.0f;  // :148-149
         ds->dens_avg = avg;
         ds->dens_d7_active = 1;                                          // iter_all_vel_adv of this iteration runs (:229)
         const int it = ds->dens_it + 1;                                  // :231
@@ -1228,6 +1247,81 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
         ds->dens_active = active;
     }
 }
+__global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                             int group = 1, int nparts = 0)
+{
+    if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
+    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
+    __shared__ double s_sum[kFinBlock / 64];
+    __shared__ long long s_cnt[kFinBlock / 64];
+    if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);
+    if (threadIdx.x != 0) return;
+    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
+    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
+    fin_decide(ds, mode, s_sum[0], s_cnt[0]);
+}
+
+// ---- the finalize fused into the sweep that produced the partials (VERDICT r3 next #5b) --------------------------------------------------
+// Between two sweeps of a solver loop sat a single-workgroup launch (k_finalize_mean: 4.2 us at 1 M particles, 4.7 us of a 22 us iteration at
+// 30 k).  Three earlier fusions lost to the agent-scope RELEASE fence they needed (it writes back the XCD's whole L2).  This one has no fence:
+//   * the lane that stores a workgroup's partial stores it write-through (sc1: store_partial), waits for the store (s_waitcnt vmcnt(0)) and
+//     takes a ticket with an agent-scope atomic add that returns -- on one of kFinShards counters, each on a cache line of its own (thousands
+//     of workgroups on ONE word serialise at ~12 ns each); the workgroup whose add completes a shard adds to a second-level counter, and the
+//     one whose add completes THAT is the last workgroup of the launch: every partial was in memory before the add it follows;
+//   * the last workgroup reads all partials with sc1 loads (they bypass the non-coherent L2) in k_finalize_mean's own order -- its 256 threads
+//     play four "virtual threads" of the 1024-thread tree each -- and takes the decision; it zeroes the tickets for the next launch.
+// MEASURED (round 4, profiles/r04/null/fin_fuse_ab.txt): bit-identical in every lock-step case, and slower than the launch it replaces -- config 1
+// dfsph 44.9 -> 42.4 Mparticle-steps/s, dfsph_1m 330.9 -> 321.5: the chain store-ack, ticket, second-level ticket, sc1 loads is four dependent
+// trips to the memory side (~1.5-2 us each) where a kernel boundary costs ~4.3 us.  Off by default (SPH_FIN_FUSE=1 turns it on: tests, A/B).
+// No workgroup ever waits for another: nothing can hang.  Workgroups that skip their tile (change propagation) take a ticket all the same;
+// their partial of an earlier launch is in memory.  Valid hand-off form: MI355X_MICROARCH.md "Inter-workgroup visibility", first table row.
+constexpr int kFinShards = 64, kFinTicketStride = 32;          // (32 ints = 128 B per shard counter)
+constexpr int kFinTicketInts = (kFinShards + 1) * kFinTicketStride;
+struct FinFuse { int *ticket; int mode, group, nparts, nblocks; };      // ticket == nullptr: the separate k_finalize_mean launch follows
+__device__ __forceinline__ void fin_fused(const FinFuse &ff, const double *__restrict__ psum, const int *__restrict__ pcnt, DevScalars *__restrict__ ds)
+{
+    __shared__ int s_last;
+    __shared__ double s_fsum[kFinBlock / 64];
+    __shared__ long long s_fcnt[kFinBlock / 64];
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial store (if any) has reached memory
+        int last = 0;
+        const int shard = (int)(blockIdx.x & (kFinShards - 1));
+        const int expect = ((int)gridDim.x + kFinShards - 1 - shard) / kFinShards;
+        const int old = __hip_atomic_fetch_add(&ff.ticket[shard * kFinTicketStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == expect - 1) {
+            const int nsh = (int)gridDim.x < kFinShards ? (int)gridDim.x : kFinShards;
+            const int old2 = __hip_atomic_fetch_add(&ff.ticket[kFinShards * kFinTicketStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old2 == nsh - 1 ? 1 : 0;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last workgroup of the launch: k_finalize_mean's tree with kBlock threads
+#pragma unroll
+    for (int j = 0; j < kFinBlock / kBlock; ++j) {
+        double t; int n;
+        fin_thread_sum<true>(psum, pcnt, (int)threadIdx.x + j * kBlock, ff.nblocks, ff.group, ff.nparts, t, n);
+        const double ws = wave_sum(t);
+        const int wn = wave_sum(n);
+        if ((threadIdx.x & 63) == 0) { s_fsum[(threadIdx.x >> 6) + j * (kBlock / 64)] = ws; s_fcnt[(threadIdx.x >> 6) + j * (kBlock / 64)] = wn; }
+    }
+    if (threadIdx.x <= kFinShards) __hip_atomic_store(&ff.ticket[threadIdx.x * kFinTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tt = 0.0; long long nn = 0;
+        for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_fsum[w]; nn += s_fcnt[w]; }
+        fin_decide(ds, ff.mode, tt, nn);
+    }
+}
+// a fused launch whose gate is closed: what k_finalize_mean does for an iteration the loop does not run
+__device__ __forceinline__ void fin_fused_closed(const FinFuse &ff, DevScalars *__restrict__ ds)
+{
+    if (ff.ticket && ff.mode == FIN_DENS && blockIdx.x == 0 && threadIdx.x == 0) ds->dens_d7_active = 0;
+}
+
 
 __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 {
@@ -2048,16 +2142,16 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                      const float *__restrict__ rho, const float *__restrict__ alpha,
-                                                     const DevScalars *__restrict__ ds, float *__restrict__ out,
+                                                     DevScalars *__restrict__ ds, float *__restrict__ out,
                                                      float4 *__restrict__ Pout, double *__restrict__ psum, int *__restrict__ pcnt,
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                      const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
-                                                     const float4 *__restrict__ wall_gc, TilePhase tp)
+                                                     const float4 *__restrict__ wall_gc, TilePhase tp, FinFuse ff)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) return;
+    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); return; }
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
     const int tile = sweep_tile(tp, spread);
@@ -2065,6 +2159,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     if (spread) {                                                    // change propagation, see stage_sources_flagged
         const int sw = stage_cnt[tile];
         if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {           // rho*, k / rho and the block partial of the last iteration stand
+            if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
             return;
         }
     }
@@ -2073,7 +2168,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
         const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) return;
+        if (verdict == 2) { if (ff.ticket) fin_fused(ff, psum, pcnt, ds); return; }
         staged = verdict == 1;
     } else {
         staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
@@ -2150,8 +2245,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
         }
     }
-    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
-    else block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt, ff.ticket != nullptr);
+    else block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);
+    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
 }
 
 // ======================================================================================

@@ -125,6 +125,10 @@ struct SphHandle {
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
     int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press); iisph: "d_ij holds zeros" (k_ii_dij)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
+    // dfsph: tickets of the finalize fused into the residual sweeps (sph_kernels.h: fin_fused).  Bit-identical, and SLOWER than the separate
+    // single-workgroup launch at every size measured (round 4: 0.945x at 30 k particles, 0.97x at 1 M): off unless SPH_FIN_FUSE=1 (A/B, tests)
+    int *fin_ticket = nullptr;
+    bool opt_fin_fuse = false;
     bool verlet = false;                         // wcsph under the relaxed arithmetic: lists with a skin, rebuilt on demand (sph_relaxed_kernels.h)
     float4 *x0 = nullptr;                        //   ... positions at the last list build
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
@@ -826,6 +830,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
     const size_t nblocks_cap = (n + 63) / 64;    // quad sweeps: one partial per 64 particles; others one per 256 (a few KB either way, and no second predicate to keep in step with sweep_mode)
+    if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_fin_fuse)
+        if ((rc = dalloc(h, &h->fin_ticket, kFinTicketInts))) return rc;
     if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
@@ -1891,20 +1897,27 @@ int check_overflow_all(SphHandle *h)
 inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline TilePhase tile_phase(const SphHandle *h, int phase) { return TilePhase{h->tile_order, h->nblocks, phase}; }
-void launch_div_residual(SphHandle *h, int gate, int phase = 0)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+// fin_mode >= 0: the loop decision k_finalize_mean would take after this sweep is taken by the sweep's last workgroup (fin_fused)
+inline bool fin_fusable(const SphHandle *h) { return h->fin_ticket != nullptr; }
+inline FinFuse fin_fuse(const SphHandle *h, int fin_mode)
+{
+    return FinFuse{(fin_mode >= 0 && fin_fusable(h)) ? h->fin_ticket : nullptr, fin_mode, partial_group(h), partial_count(h), h->nblocks};
+}
+void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
     const TilePhase tp = tile_phase(h, phase);
+    const FinFuse ff = fin_fuse(h, fin_mode);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tp);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tp, ff);
         return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
-                  (const float4 *)wall_cache(h), tp);
+                  (const float4 *)wall_cache(h), tp, ff);
 }
 
 template <int MODE>
@@ -1924,22 +1937,23 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
                   (const float4 *)wall_cache(h));
 }
 
-void launch_dens_residual(SphHandle *h, int gate, int phase = 0)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
+void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
     const TilePhase tp = tile_phase(h, phase);
+    const FinFuse ff = fin_fuse(h, fin_mode);
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tp);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tp, ff);
         return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, ff);
 }
 
 int launch_finalize(SphHandle *h, int mode)
@@ -2062,7 +2076,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const bool ovl = two && slab_can_overlap(h);
     auto ghosts_v = [&](float4 *V) -> int { return (h->slab && !two) ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
     // a residual sweep and the refresh of what it produced on the ghosts
-    auto residual = [&](bool dens, int gate) -> int {
+    auto residual_sweep = [&](bool dens, int gate) -> int {
         int r = SPH_OK;
         if (ovl) {
             if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1);
@@ -2076,25 +2090,33 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
         return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
     };
+    // ... followed by the loop decision: taken by the sweep's own last workgroup on one GPU (fin_fused), by k_finalize_mean around the
+    // all-reduce on slabs
+    auto residual = [&](bool dens, int gate, int fin_mode) -> int {
+        int r = SPH_OK;
+        if (!h->slab && fin_fusable(h)) {
+            if (dens) launch_dens_residual(h, gate, 0, fin_mode); else launch_div_residual(h, gate, 0, fin_mode);
+            return SPH_OK;
+        }
+        if ((r = residual_sweep(dens, gate))) return r;
+        return launch_finalize(h, fin_mode);
+    };
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
-    if ((rc = residual(false, GATE_NONE))) return rc;                                // :398
-    if ((rc = launch_finalize(h, FIN_DIV_FIRST))) return rc;
+    if ((rc = residual(false, GATE_NONE, FIN_DIV_FIRST))) return rc;                 // :398
     // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
     // and the host does not need the outcome before the density loop's first read-back
     for (int done = 0; done < 15; ++done) {
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
-        if ((rc = residual(false, GATE_DIV))) return rc;                                  // :408
-        if ((rc = launch_finalize(h, FIN_DIV_LOOP))) return rc;
+        if ((rc = residual(false, GATE_DIV, FIN_DIV_LOOP))) return rc;                    // :408
     }
     if ((rc = dfsph_ext_and_dt(h))) return rc;
     // ---- correct_density_error, :221-233: first chunk = last step's iteration count (it changes slowly), then two at a time ----
     bool first = true;
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
-            if ((rc = residual(true, GATE_DENS))) return rc;                         // :227
-            if ((rc = launch_finalize(h, FIN_DENS))) return rc;
+            if ((rc = residual(true, GATE_DENS, FIN_DENS))) return rc;               // :227
             launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
             if ((rc = ghosts_v(h->VA[0]))) return rc;
@@ -2624,6 +2646,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_FIN_FUSE"); h->opt_fin_fuse = e && atoi(e) == 1; }
     { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }

@@ -125,19 +125,20 @@ template <bool DENS>
 __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                         const float4 *__restrict__ G, const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                         const float *__restrict__ rho, const float *__restrict__ alpha,
-                                                        const DevScalars *__restrict__ ds, float *__restrict__ out,
+                                                        DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp)
+                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp, FinFuse ff)
 {
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) return;
+    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); return; }
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
         const int sw = stage_cnt[tile];
         if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {
+            if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
             return;
         }
     }
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     bool staged;
     if (spread) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
         const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) return;
+        if (verdict == 2) { if (ff.ticket) fin_fused(ff, psum, pcnt, ds); return; }
         staged = verdict == 1;
     } else {
         staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
             krho[i] = kr;
         }
     }
-    block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);
+    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
 }
 
 // D2 / D4 / D7 (k_correct)                                       dfsph_solver.py:314-355, 302-312 + 357-391, 178-219

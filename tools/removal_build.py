@@ -87,6 +87,10 @@ PATCHES = {
     # relaxed k_residual_rx: pair loop removed / staging gathers removed / whole staging removed (the decomposition in DESIGN.md section 4b)
     "rx_nofluid": [(R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
                     "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
+    # relaxed sweeps with HALF the index stream (every second 16-byte group of a list is not loaded, the walk reuses the group before it: same
+    # LDS gathers, same arithmetic, half the list bytes from HBM): what a 2x more compact list encoding could buy at most
+    "rx_halflist": [(R, "        if (kk + 8 < cnt) jn = nl_load(base + (size_t)((kk >> 3) + 1) * 256);\n        pair8(g);",
+                     "        if (kk + 8 < cnt && ((kk >> 3) & 1)) jn = nl_load(base + (size_t)((kk >> 3) + 1) * 256);\n        pair8(g);")],
     "rx_nostage": [(R, "        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);\n    }\n    const float4 vi = V[ii];",
                     "        staged = true;\n    }\n    const float4 vi = V[ii];"),
                    (R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
