@@ -40,10 +40,16 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 
 // Edge / interior split of a sweep (slab handles; the order comes from k_tile_order in sph_slab_kernels.h): phase 0 = every tile in one launch,
 // 1 = the edge tiles (tile_order[0 .. n_edge)), 2 = the interior ones; both split launches have the full grid, surplus workgroups leave at once.
+// phase 3 (one GPU): every tile in one launch, each XCD's contiguous eighth taken heavy tiles first (k_tile_perm): order[] is a permutation
+// WITHIN the eighths, so every XCD keeps its brick of the domain and its L2 working set, and the tiles that live longest -- floor and wall tiles:
+// 19.5 us against a mean of 12.1 at 1 M particles -- start first instead of wherever their index falls, so that the tail of a launch is made
+// of ordinary tiles (profiles/r03/wg_timeline_div_residual.json: a sixth of every sweep was its drain).  MEASURED (round 4): no effect -- the drain
+// of a launch is one workgroup lifetime whatever tiles come last; off by default (SPH_TILE_LPT=<wall weight>), see profiles/r04/null/tile_lpt_ab.txt.
 struct TilePhase { const int *order; int ntiles, phase; };
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
 {
     if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
+    if (tp.phase == 3) return spread ? (int)blockIdx.x : tp.order[xcd_sweep_block(blockIdx.x, gridDim.x)];
     const int ne = tp.order[tp.ntiles];
     if (tp.phase == 1) return (int)blockIdx.x < ne ? tp.order[blockIdx.x] : -1;
     const int ni = tp.ntiles - ne;
@@ -998,6 +1004,55 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
             if (RIGID) ncount[i] = nqt;
         }
         note_list_lengths(c, walker ? kft : 0, walker ? kbt : 0, ds);
+    }
+}
+
+// ---- heavy tiles first (TilePhase phase 3) -------------------------------------------------------------------------------------
+// cost of a tile = the list entries its 256 particles walk (fluid + wall), known once k_build_nl has run
+__global__ __launch_bounds__(kBlock) void k_tile_cost(Consts c, const int *__restrict__ cnt, int *__restrict__ cost, int wall_weight)
+{
+    __shared__ int s_w[kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    int v = 0;
+    if (i < c.n) { const int cw = cnt[i]; v = cw < 0 ? 0 : (cw & 0xffff) + wall_weight * ((cw >> 16) & 0x7fff); }
+    const int ws = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; ++k) t += s_w[k]; cost[blockIdx.x] = t; }
+}
+// one workgroup per XCD eighth [start, start + len) of the tiles (the partition xcd_block makes): a stable partition, the tiles whose cost exceeds
+// 1.2 x the eighth's mean first, the others behind them, both in their original (spatial) order
+__global__ __launch_bounds__(kBlock) void k_tile_perm(const int *__restrict__ cost, int ntiles, int *__restrict__ perm)
+{
+    __shared__ int wsum[kBlock / 64];
+    __shared__ long long s_tot;
+    __shared__ int carry_s, heavy_s;
+    const int q = ntiles >> 3, r = ntiles & 7, x = (int)blockIdx.x;
+    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, len = q + (x < r ? 1 : 0);
+    if (threadIdx.x == 0) { s_tot = 0; carry_s = 0; }
+    __syncthreads();
+    long long mine = 0;
+    for (int k = threadIdx.x; k < len; k += kBlock) mine += cost[start + k];
+    atomicAdd((unsigned long long *)&s_tot, (unsigned long long)mine);
+    __syncthreads();
+    const long long tot = s_tot;
+    for (int pass = 0; pass < 2; ++pass) {          // pass 0 counts the heavy tiles, pass 1 places both kinds
+        if (pass == 1) { if (threadIdx.x == 0) { heavy_s = carry_s; carry_s = 0; } __syncthreads(); }
+        for (int base = 0; base < len; base += kBlock) {
+            const int k = base + (int)threadIdx.x;
+            const int hv = (k < len && (long long)cost[start + k] * 5 * len > tot * 6) ? 1 : 0;
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+            const int inc = wave_inclusive_scan(hv);
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            int woff = 0;
+            for (int u = 0; u < w; ++u) woff += wsum[u];
+            const int before = carry_s + woff + inc - hv;
+            if (pass == 1 && k < len) perm[start + (hv ? before : heavy_s + (k - before))] = start + k;
+            __syncthreads();
+            if (threadIdx.x == kBlock - 1) carry_s = before + hv;
+            __syncthreads();
+        }
     }
 }
 
@@ -2008,14 +2063,15 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                    int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc)
+                                                    int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc,
+                                                    TilePhase tp)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
-    SPH_SWEEP_PROLOGUE_G(QUAD, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x), true)
+    SPH_SWEEP_PROLOGUE_G(QUAD, sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr), true)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i

@@ -129,6 +129,11 @@ struct SphHandle {
     // single-workgroup launch at every size measured (round 4: 0.945x at 30 k particles, 0.97x at 1 M): off unless SPH_FIN_FUSE=1 (A/B, tests)
     int *fin_ticket = nullptr;
     bool opt_fin_fuse = false;
+    // staged dfsph sweeps on one GPU: each XCD's eighth of the tiles heavy tiles first (sph_kernels.h: TilePhase phase 3, k_tile_perm).  Bit-identical and
+    // WITHOUT effect on the sweeps at any weighting of the wall entries (round 4, profiles/r04/null/tile_lpt_ab.txt): off unless SPH_TILE_LPT=<wall weight>
+    int *tile_cost = nullptr, *tile_perm = nullptr;
+    bool opt_tile_lpt = false;
+    int tile_wall_weight = 1;
     bool verlet = false;                         // wcsph under the relaxed arithmetic: lists with a skin, rebuilt on demand (sph_relaxed_kernels.h)
     float4 *x0 = nullptr;                        //   ... positions at the last list build
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
@@ -797,6 +802,10 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_tile_lpt) {
+                if ((rc = dalloc(h, &h->tile_cost, (n + kBlock - 1) / kBlock + 8))) return rc;
+                if ((rc = dalloc(h, &h->tile_perm, (n + kBlock - 1) / kBlock + 8))) return rc;
+            }
             if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
@@ -1726,6 +1735,11 @@ int stage_sort_and_lists(SphHandle *h)
 #undef SPH_BNL
 #undef SPH_BNL_SPLIT
     }
+    if (h->tile_perm && h->nblocks >= 64) {      // heavy tiles first within each XCD's eighth, for the sweeps of this step (TilePhase phase 3)
+        ProfScope ps(h, K_BUILD_NL);
+        hipLaunchKernelGGL(k_tile_cost, dim3(h->nblocks), b, 0, s, c, h->cnt, h->tile_cost, h->tile_wall_weight);
+        hipLaunchKernelGGL(k_tile_perm, dim3(8), b, 0, s, h->tile_cost, h->nblocks, h->tile_perm);
+    }
     if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
         ProfScope ps(h, K_RIGID);
         hipLaunchKernelGGL(k_build_rnl, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->P[h->pcur], h->cell_start, h->rnl, h->rcnt, h->ds);
@@ -1896,7 +1910,11 @@ int check_overflow_all(SphHandle *h)
 // tiles of the density loop whose inputs did not change are not recomputed (staged dfsph handles)
 inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
-inline TilePhase tile_phase(const SphHandle *h, int phase) { return TilePhase{h->tile_order, h->nblocks, phase}; }
+inline TilePhase tile_phase(const SphHandle *h, int phase)
+{
+    if (phase == 0 && h->tile_perm && h->nblocks >= 64) return TilePhase{h->tile_perm, h->nblocks, 3};      // one GPU, staged: heavy tiles first within each XCD's eighth
+    return TilePhase{h->tile_order, h->nblocks, phase};
+}
 // fin_mode >= 0: the loop decision k_finalize_mean would take after this sweep is taken by the sweep's last workgroup (fin_fused)
 inline bool fin_fusable(const SphHandle *h) { return h->fin_ticket != nullptr; }
 inline FinFuse fin_fuse(const SphHandle *h, int fin_mode)
@@ -1928,13 +1946,13 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     int *wdirty = (MODE == CORR_DENS && tile_skip(h) && !h->tune_all) ? h->wave_dirty : nullptr;      // change propagation in the density loop
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
-                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8);
+                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, tile_phase(h, 0));
         return;
     }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                  (const float4 *)wall_cache(h));
+                  (const float4 *)wall_cache(h), tile_phase(h, 0));
 }
 
 void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -2647,6 +2665,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_FIN_FUSE"); h->opt_fin_fuse = e && atoi(e) == 1; }
+    { const char *e = dev_env(&h->overrides, "SPH_TILE_LPT"); h->opt_tile_lpt = e && atoi(e) > 0; if (h->opt_tile_lpt) h->tile_wall_weight = atoi(e); }
     { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }

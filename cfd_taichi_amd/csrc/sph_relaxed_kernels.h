@@ -210,12 +210,12 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
                                                        float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                        const float4 *Vin, float4 *Vout, int gate,
                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                       int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8)
+                                                       int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, TilePhase tp)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_G(false, (MODE == CORR_DENS && wave_dirty != nullptr) ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x), true)
+    SPH_SWEEP_PROLOGUE_G(false, sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr), true)
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
     bool staged;
