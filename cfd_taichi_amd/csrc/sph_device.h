@@ -82,8 +82,8 @@ struct DevScalars {
     int max_wall_nbrs;
     int lost;          // particles outside the grid
     float rigid_vmax;  // max over rigid particles of |vel| + |omega x (x - c)|   dfsph_solver.py:104-110
-    // Verlet handles: `moved` is raised by the integrator when a particle is more than skin / 2 away from where the lists were built,
-    // k_verlet_decide turns it into `rebuild` for the sort + list build kernels of the next step (all enqueued every step, gated by it)
+    // Verlet handles: `moved` is raised by the integrator when a particle is more than skin / 2 away from where the lists were built; the sort +
+    // list build kernels of the next step (all enqueued every step) run only if it is set, the density kernel behind them takes it down
     int rebuild, moved;
     double sum;        // last (sum, count) reduction: the host forms mean = sum / cnt (after an all-reduce when sharded)
     long long cnt;

@@ -214,11 +214,27 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(int *__restrict__ tile_sum
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n, const int *__restrict__ gate = nullptr)
+// fold != 0: tile_sums still holds the RAW per-tile totals (k_scan_sums was not launched: grids of up to kScanFoldTiles tiles) and every
+// workgroup adds up the totals of the tiles in front of its own -- a few hundred L2-resident ints against a dependent launch (~3 us)
+constexpr int kScanFoldTiles = 1024;
+__global__ __launch_bounds__(kBlock) void k_scan_add(int *__restrict__ out, const int *__restrict__ tile_sums, int n, const int *__restrict__ gate = nullptr, int fold = 0)
 {
     if (gate && *gate == 0) return;
     int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] += tile_sums[i / kScanTile];
+    if (!fold) {
+        if (i < n) out[i] += tile_sums[i / kScanTile];
+        return;
+    }
+    __shared__ int s_w[kBlock / 64];
+    const int tile = (int)(blockIdx.x * kBlock) / kScanTile;          // (kScanTile is a multiple of kBlock: a workgroup lies in one tile)
+    int v = 0;
+    for (int t = threadIdx.x; t < tile; t += kBlock) v += tile_sums[t];
+    const int ws = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < kBlock / 64; ++k) before += s_w[k];
+    if (i < n) out[i] += before;
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter(Consts c, const int *__restrict__ cell_of, const int *__restrict__ rank,

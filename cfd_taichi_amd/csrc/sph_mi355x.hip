@@ -1651,10 +1651,9 @@ int stage_sort_and_lists(SphHandle *h)
     (void)dfsph;
     // Verlet handles: every kernel of the sort and the list build is enqueued every step and leaves at once unless the integrator of the
     // step before found a particle skin / 2 away from where the lists were built (k_verlet_decide: DevScalars.moved -> rebuild)
-    const int *gate = h->verlet ? &h->ds->rebuild : nullptr;
+    const int *gate = h->verlet ? &h->ds->moved : nullptr;
     {
         ProfScope ps(h, K_HASH);
-        if (h->verlet) hipLaunchKernelGGL(k_verlet_decide, dim3(1), dim3(1), 0, s, h->ds);
         // cell_count is clean: the arena starts zeroed and k_scan_tiles zeroes the histogram as it consumes it
         hipLaunchKernelGGL(k_hash_count, g, b, 0, s, c, h->P[h->pcur], h->slab ? h->dead : (const int *)nullptr, h->cell_of, h->rank,
                            h->cell_count, h->ds, gate);
@@ -1662,8 +1661,9 @@ int stage_sort_and_lists(SphHandle *h)
     {
         ProfScope ps(h, K_SCAN);
         hipLaunchKernelGGL(k_scan_tiles, dim3(h->ntiles), b, 0, s, h->cell_count, h->cell_start, h->tile_sums, (int)ncell, gate);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles, gate);
-        hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->cell_start, h->tile_sums, (int)ncell, gate);
+        const int fold = h->ntiles <= kScanFoldTiles ? 1 : 0;
+        if (!fold) hipLaunchKernelGGL(k_scan_sums, dim3(1), b, 0, s, h->tile_sums, h->ntiles, gate);
+        hipLaunchKernelGGL(k_scan_add, grid_for((int)ncell), b, 0, s, h->cell_start, h->tile_sums, (int)ncell, gate, fold);
     }
     {
         ProfScope ps(h, K_SCATTER);
@@ -1804,7 +1804,7 @@ int stage_density(SphHandle *h)
     if (h->verlet) {      // wcsph under the relaxed arithmetic: Verlet lists hold pairs beyond h, only the clamped kernel functions may walk them
         ProfScope ps(h, K_W_DENSITY);
         hipLaunchKernelGGL(k_wcsph_density_rx, grid_for(c.n), dim3(kBlock), 0, s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt,
-                           h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->wall_grad);
+                           h->rho, h->aux, h->P[1 - h->pcur], h->V[1 - h->vcur], h->wall_grad, h->ds, 1);
         h->pcur ^= 1; h->vcur ^= 1;                         // P = (pos, rho), V = (vel, p / rho^2)
         HIP_TRY(h, hipGetLastError());
         h->density_valid = true;

@@ -413,9 +413,9 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext_rx(Consts c, const float4 
 //   * VERLET LISTS: the lists hold every pair within h + skin (cells of edge h + skin, Consts.hcell) and are rebuilt -- sort included -- only
 //     when a particle has moved more than skin / 2 since the last build.  The kernel functions are clamped at q = 1, where W and grad W
 //     vanish continuously, so a listed pair beyond h contributes exactly 0 and a pair that comes within h between two builds is already listed
-//     (both moved < skin / 2).  The integrator raises DevScalars.moved, k_verlet_decide turns it into DevScalars.rebuild for the next step's
-//     sort and list-build kernels, which are enqueued every step and leave at their first instruction otherwise: the step stays a fixed
-//     launch sequence (hipGraph replay) without any host decision.  At 250 k particles the list build was 44 % of the exact step.
+//     (both moved < skin / 2).  The integrator raises DevScalars.moved; the next step's sort and list-build kernels, enqueued every step, read
+//     it at their first instruction and leave unless it is set (the density kernel, which runs after them, takes it down again): the step stays
+//     a fixed launch sequence (hipGraph replay) without any host decision.  At 250 k particles the list build was 44 % of the exact step.
 //   * the wall sums (sum_b V_b W, sum_b V_b m grad W) are taken once per step, by the density kernel, and handed to the force kernel.
 // Summation order between two builds is the order of the last build, not the canonical one: a different legal execution of the reference,
 // whose own envelope for wcsph is 4e-8 after 200 steps; tests/test_relaxed_gpu.py holds this path to 1e-5 of the oracle.
@@ -437,13 +437,6 @@ __device__ __forceinline__ RxWG rx_wg_clamped(const Consts &c, float dx, float d
     return o;
 }
 
-__global__ void k_verlet_decide(DevScalars *__restrict__ ds)
-{
-    const int r = ds->moved != 0 ? 1 : 0;
-    ds->rebuild = r;
-    ds->moved = 0;
-    ds->verlet_builds += r;
-}
 
 // W1: rho, p, p / rho^2 and the wall sums of the step          solver_base.py:41-72, wcsph_solver.py:66-90
 //   writes Pout = (pos, rho), Vout = (vel, p / rho^2), rho[], pressure[], G = sum_b V_b m grad W_ib
@@ -451,8 +444,10 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_density_rx(Consts c, const flo
                                                              const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                              const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
                                                              float *__restrict__ rho_out, float *__restrict__ p_out, float4 *__restrict__ Pout,
-                                                             float4 *__restrict__ Vout, float4 *__restrict__ G)
+                                                             float4 *__restrict__ Vout, float4 *__restrict__ G, DevScalars *__restrict__ ds, int count_build)
 {
+    // every gated kernel of this step has read DevScalars.moved by now (stream order): take it down for the integrator of this step
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ds->moved != 0) { ds->moved = 0; if (count_build) ds->verlet_builds += 1; }
     SPH_SWEEP_PROLOGUE_M(false)
     float ws = 0.f;
     for_fluid_nbrs<false, false>(nlp, kf, P, nullptr, RigidView(), [&](const float4 pj, const float4, const uint32_t) {
