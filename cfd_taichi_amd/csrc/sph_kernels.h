@@ -1023,6 +1023,15 @@ __global__ __launch_bounds__(NW * 64) void k_build_nl_split(Consts c, const floa
     }
 }
 
+// Relaxed arithmetic with a coupled rigid body (round 4): the tolerance-grade sweeps cover the workgroups whose lists are 16-bit (no rigid sample in any
+// cell of their neighbourhood: all but a thin shell around the body, kStageLists16), the exact RIGID sweeps the rest -- two launches per sweep over the
+// two halves of one tile order (k_tile_order in sph_slab_kernels.h: flagged tiles first).  flag[t] = 1: tile t keeps the exact kernels.
+__global__ __launch_bounds__(kBlock) void k_tile_flags_exact(const int *__restrict__ stage_cnt, int ntiles, int *__restrict__ flag)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < ntiles) flag[t] = stage_lists16(stage_cnt, t) ? 0 : 1;
+}
+
 // ---- heavy tiles first (TilePhase phase 3) -------------------------------------------------------------------------------------
 // cost of a tile = the list entries its 256 particles walk (fluid + wall), known once k_build_nl has run
 __global__ __launch_bounds__(kBlock) void k_tile_cost(Consts c, const int *__restrict__ cnt, int *__restrict__ cost, int wall_weight)
@@ -1884,11 +1893,13 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
                                                     float4 *__restrict__ Pout, float4 *Vout, RigidView rv,
                                                     const int *__restrict__ id, float *__restrict__ rho_orig,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                    float4 *__restrict__ wall_gc)
+                                                    float4 *__restrict__ wall_gc, TilePhase tp = TilePhase{nullptr, 0, 0})
 {
     constexpr bool STAGED = MODE == SWEEP_STAGED, QUAD = MODE == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
-    SPH_SWEEP_PROLOGUE_G(QUAD, xcd_block(blockIdx.x, gridDim.x), true)
+    const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_G(QUAD, tile, true)
     const bool staged = STAGED && stage_operand(c, s_operand, P, stage_src, stage_cnt, blk);
     float fa[5] = {0.001f, 0.f, 0.f, 0.f, 0.f};              // rho starts at 0.001, solver_base.py:44
     float &rho = fa[0], &sx = fa[1], &sy = fa[2], &sz = fa[3], &sq = fa[4];
@@ -2087,7 +2098,9 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
-    SPH_SWEEP_PROLOGUE_G(QUAD, sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr), true)
+    const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_G(QUAD, tile, true)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
@@ -2331,12 +2344,14 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
                                                       float *__restrict__ pmax, RigidView rv,
-                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, TilePhase tp = TilePhase{nullptr, 0, 0})
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(QUAD)
+    const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_B(QUAD, tile)
     (void)kb; (void)nlbp;
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);      // (vel, rho) needs 16 B: gathered from memory
     const bool staged = STAGED && stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);

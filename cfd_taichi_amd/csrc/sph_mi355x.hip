@@ -1335,6 +1335,12 @@ RigidView rigid_view(const SphHandle *h)
 inline bool rigid_coupled(const SphHandle *h) { return h->rigid && h->rigid_active && h->cfg.fs_couple; }
 inline RigidView rigid_view_or_none(const SphHandle *h) { return rigid_coupled(h) ? rigid_view(h) : RigidView(); }
 
+// the tolerance-grade sweeps (sph_relaxed_kernels.h) run on this handle
+// (with a coupled body -- rx_split -- they cover the workgroups with 16-bit lists, i.e. without a rigid sample in reach, and the exact RIGID sweeps the thin
+// shell around the body: two launches per sweep over the two halves of tile_order)
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && h->wall_grad && (!rigid_coupled(h) || h->tile_order); }
+inline bool rx_split(const SphHandle *h) { return use_relaxed(h) && rigid_coupled(h); }
+
 // init_rigid_particles_pos + init_rigid_particles_data (ParticleSystem.py:198-223, 249-295), once, on the host
 int build_rigid(SphHandle *h, const SphRigid *rg)
 {
@@ -1440,6 +1446,10 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->rvmax_part, kRigidParts))) return rc;
     if ((rc = dalloc(h, &h->rnl, (nr + 64) * (size_t)c.kpitch))) return rc;
     if ((rc = dalloc(h, &h->rcnt, nr))) return rc;
+    if (h->relaxed && h->staged && !h->tile_order) {       // relaxed arithmetic next to a body: the tile order of the exact / relaxed split (rx_split)
+        if ((rc = dalloc(h, &h->tile_flag, (size_t)(h->c.stride + kBlock - 1) / kBlock + 1))) return rc;
+        if ((rc = dalloc(h, &h->tile_order, (size_t)(h->c.stride + kBlock - 1) / kBlock + 2))) return rc;
+    }
     const size_t stg_need = 3 * std::max(nr, (size_t)Nv);
     if (stg_need > 3 * std::max((size_t)h->c.stride, (size_t)h->Nb))
         if ((rc = dalloc(h, &h->staging, stg_need))) return rc;      // the fluid arena's staging buffer is too small for this body
@@ -1735,6 +1745,11 @@ int stage_sort_and_lists(SphHandle *h)
 #undef SPH_BNL
 #undef SPH_BNL_SPLIT
     }
+    if (rx_split(h)) {       // tiles with a rigid sample in reach (32-bit lists) first: the exact RIGID sweeps take them, the relaxed sweeps the rest
+        ProfScope ps(h, K_BUILD_NL);
+        hipLaunchKernelGGL(k_tile_flags_exact, grid_for(h->nblocks), b, 0, s, h->stage_cnt, h->nblocks, h->tile_flag);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
+    }
     if (h->tile_perm && h->nblocks >= 64) {      // heavy tiles first within each XCD's eighth, for the sweeps of this step (TilePhase phase 3)
         ProfScope ps(h, K_BUILD_NL);
         hipLaunchKernelGGL(k_tile_cost, dim3(h->nblocks), b, 0, s, c, h->cnt, h->tile_cost, h->tile_wall_weight);
@@ -1744,7 +1759,7 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_RIGID);
         hipLaunchKernelGGL(k_build_rnl, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->P[h->pcur], h->cell_start, h->rnl, h->rcnt, h->ds);
     }
-    if (h->wall_grad && h->c.kr_split && h->c.boundary_handle && !rigid_coupled(h)) {     // use_relaxed: the wall sums of this step's positions
+    if (h->wall_grad && h->c.kr_split && h->c.boundary_handle && use_relaxed(h)) {     // the wall sums of this step's positions
         ProfScope ps(h, K_BUILD_NL);
         hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad, h->wall_gsq);
     }
@@ -1777,8 +1792,6 @@ int check_overflow(SphHandle *h)
 
 PbfConsts pbf_consts(const SphHandle *h);
 
-// the tolerance-grade sweeps (sph_relaxed_kernels.h) run on this handle
-inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && !rigid_coupled(h) && h->wall_grad; }
 
 int stage_density(SphHandle *h)
 {
@@ -1815,13 +1828,15 @@ int stage_density(SphHandle *h)
         // P[1-pcur] = (pos, k/rho) scratch rewritten by D1/D3/D6, V[vcur] and VA[0] updated in place (a thread only ever
         // writes its own element and no sweep reads the array it writes from its neighbours)
         ProfScope ps(h, K_D_DENSITY_ALPHA);
+        const bool split = rx_split(h);
         if (use_relaxed(h))
             hipLaunchKernelGGL(k_density_rx, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->wall_grad, h->wall_gsq,
-                               h->nl, h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->V[h->vcur], h->stage_src, h->stage_cnt, h->krho);
-        else
+                               h->nl, h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->V[h->vcur], h->stage_src, h->stage_cnt, h->krho,
+                               split ? TilePhase{h->tile_order, h->nblocks, 2} : TilePhase{nullptr, 0, 0}, h->id[h->icur], split ? h->rho_orig : (float *)nullptr);
+        if (!use_relaxed(h) || split)
         SPH_LAUNCH_RM(k_density, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
-                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho, wall_cache(h));
+                      h->rho_orig, h->stage_src, h->stage_cnt, h->krho, wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : TilePhase{nullptr, 0, 0});
     } else {
         ProfScope ps(h, K_W_DENSITY);
         SPH_LAUNCH_RM(k_density, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
@@ -1925,12 +1940,14 @@ void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
-    const TilePhase tp = tile_phase(h, phase);
-    const FinFuse ff = fin_fuse(h, fin_mode);
+    const bool split = rx_split(h);
+    const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
+    const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
     if (use_relaxed(h)) {
+        const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tp, ff);
-        return;
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff);
+        if (!split) return;
     }
     SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
@@ -1944,30 +1961,34 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     const Consts &c = h->c;
     ProfScope ps(h, kid);
     int *wdirty = (MODE == CORR_DENS && tile_skip(h) && !h->tune_all) ? h->wave_dirty : nullptr;      // change propagation in the density loop
+    const bool split = rx_split(h);
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
-                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, tile_phase(h, 0));
-        return;
+                           h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
+                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tile_phase(h, 0));
+        if (!split) return;
     }
     SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                  (const float4 *)wall_cache(h), tile_phase(h, 0));
+                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0));
 }
 
 void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DENS_RESIDUAL);
-    const TilePhase tp = tile_phase(h, phase);
-    const FinFuse ff = fin_fuse(h, fin_mode);
+    const bool split = rx_split(h);
+    const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
+    const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
+        const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tp, ff);
-        return;
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr, ff);
+        if (!split) return;
     }
     SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
@@ -2021,12 +2042,13 @@ int dfsph_ext_and_dt(SphHandle *h)
     int rc;
     {
         ProfScope ps(h, K_D_EXT);
+        const bool split = rx_split(h);
         if (use_relaxed(h))
             hipLaunchKernelGGL(k_dfsph_ext_rx, grid_for(c.n), b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds,
-                               h->VA[0], h->pmax, h->stage_src, h->stage_cnt);
-        else
+                               h->VA[0], h->pmax, h->stage_src, h->stage_cnt, split ? TilePhase{h->tile_order, h->nblocks, 2} : TilePhase{nullptr, 0, 0});
+        if (!use_relaxed(h) || split)
         SPH_LAUNCH_RM0(k_dfsph_ext, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
-                       h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt);
+                       h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt, split ? TilePhase{h->tile_order, h->nblocks, 1} : TilePhase{nullptr, 0, 0});
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
             for (int a = 0; a < 3; ++a) st.omega[a] = h->r_omega[a];

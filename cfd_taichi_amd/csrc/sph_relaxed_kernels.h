@@ -215,7 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_G(false, sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr), true)
+    const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_G(false, tile, true)
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
     bool staged;
@@ -289,11 +291,14 @@ __global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *_
                                                        const float *__restrict__ Gsq, const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                        const float *__restrict__ warm, const DevScalars *__restrict__ ds, float *__restrict__ rho_out,
                                                        float *__restrict__ aux_out, float4 *Vout, const uint2 *__restrict__ stage_src,
-                                                       const int *__restrict__ stage_cnt, float *__restrict__ krho)
+                                                       const int *__restrict__ stage_cnt, float *__restrict__ krho, TilePhase tp,
+                                                       const int *__restrict__ id, float *__restrict__ rho_orig)
 {
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_G(false, xcd_block(blockIdx.x, gridDim.x), true)
+    const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_G(false, tile, true)
     (void)nlbp;
     const bool staged = stage_operand<false>(c, s_operand, P, stage_src, stage_cnt, blk);
     float ws = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, sq = 0.f;
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *_
         den = (den + gs * (f * f)) + __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));    // :45
     }
     rho_out[i] = rho_i;
+    if (rho_orig) rho_orig[id[i]] = rho_i;                                        // (a coupled body's viscosity reads rho by ORIGINAL id, solver_base.py:198-199)
     const float alpha = fabsf(den) < 1e-6f ? 0.0f : rho_i / den;                  // :48-51
     aux_out[i] = alpha;
     const float4 vi = V[i];
@@ -345,11 +351,13 @@ __global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *_
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                          const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                          const DevScalars *__restrict__ ds, float4 *__restrict__ VAout, float *__restrict__ pmax,
-                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
+                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, TilePhase tp)
 {
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
-    SPH_SWEEP_PROLOGUE_M(false)
+    const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
+    if (tile < 0) return;
+    SPH_SWEEP_PROLOGUE_B(false, tile)
     (void)kb; (void)nlbp;
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);      // (vel, rho) is gathered from memory through the source list
     const bool staged = stage_operand_src(c, s_operand, s_src, P, stage_src, stage_cnt, blk);
