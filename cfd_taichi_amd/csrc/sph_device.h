@@ -292,6 +292,48 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
     return (ax * bx + ay * by) + az * bz;
 }
 
+// ---- kernel functions by arithmetic (round 4): the pcisph / iisph sweeps pick them through a template argument -----------------------------
+// KF<false>: the reference's operations in its order (the functions above).  KF<true> (SphConfig.arith = SPH_ARITH_RELAXED): the distance from
+// one v_rsq_f32, W as a clamped polynomial with FMAs (q > 1 gives 0: the pcisph sweeps evaluate list pairs at PREDICTED positions), grad W as
+// one scalar times the difference vector with v_rcp_f32 in place of the three correctly rounded divisions, no 1e-5 gate (r^2 is floored, a
+// coincident pair contributes 0).  Same signatures, so a sweep body is written once.
+template <bool RX> struct KF;
+template <> struct KF<false> {
+    static __device__ __forceinline__ float norm3(float x, float y, float z) { return ::sph::norm3(x, y, z); }
+    static __device__ __forceinline__ float w(const Consts &c, float r) { return cubic_w(c, r); }
+    static __device__ __forceinline__ float w_in(const Consts &c, float r) { return cubic_w_in(c, r); }
+    static __device__ __forceinline__ F3 grad(const Consts &c, float dx, float dy, float dz, float r) { return grad_w(c, dx, dy, dz, r); }
+    static __device__ __forceinline__ F3 grad_in(const Consts &c, float dx, float dy, float dz, float r) { return grad_w_in(c, dx, dy, dz, r); }
+};
+template <> struct KF<true> {
+    static __device__ __forceinline__ float norm3(float x, float y, float z)
+    {
+        const float r2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, __builtin_fmaf(x, x, 1e-30f)));
+        return r2 * __builtin_amdgcn_rsqf(r2);
+    }
+    static __device__ __forceinline__ float w(const Consts &c, float r)
+    {
+        const float q = r * c.rh;
+        const float t = rmax(1.0f - q, 0.0f);
+        const float w1 = __builtin_fmaf(6.0f * (q * q), q - 1.0f, 1.0f);          // solver_base.py:76-88
+        const float w2 = 2.0f * ((t * t) * t);
+        return c.kw * (q <= 0.5f ? w1 : w2);
+    }
+    static __device__ __forceinline__ float w_in(const Consts &c, float r) { return w(c, r); }
+    static __device__ __forceinline__ F3 grad(const Consts &c, float dx, float dy, float dz, float r)
+    {
+        const float q = r * c.rh;
+        const float t = rmax(1.0f - q, 0.0f);
+        const float s1 = (c.kg6 * q) * __builtin_fmaf(3.0f, q, -2.0f);            // solver_base.py:90-103 (with the reference's factor 6)
+        const float s2 = c.neg_kg6 * (t * t);
+        const float g = (q <= 0.5f ? s1 : s2) * __builtin_amdgcn_rcpf(__builtin_fmaxf(c.h * r, 1e-30f));
+        F3 o;
+        o.x = g * dx; o.y = g * dy; o.z = g * dz;
+        return o;
+    }
+    static __device__ __forceinline__ F3 grad_in(const Consts &c, float dx, float dy, float dz, float r) { return grad(c, dx, dy, dz, r); }
+};
+
 // wcsph_solver.py:86-90, x**7 by squaring
 __device__ __forceinline__ float tait_pressure(float rho)
 {

@@ -683,6 +683,14 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if ((mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<false, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                            \
         else hipLaunchKernelGGL((K<false, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                                   \
     } while (0)
+// the pcisph / iisph sweeps: the same with the kernel functions of the relaxed arithmetic (KF<true>, sph_device.h) where the handle asks for it --
+// plain and staged sweeps without a coupled body
+#define SPH_LAUNCH_RMX0(K, rg, mode, rx, n, lds, s, ...)                                                                                 \
+    do {                                                                                                                                 \
+        if ((rx) && !(rg) && (mode) == SWEEP_STAGED) hipLaunchKernelGGL((K<false, SWEEP_STAGED, true>), grid_for(n), dim3(kBlock), lds, s, __VA_ARGS__); \
+        else if ((rx) && !(rg) && (mode) == SWEEP_PLAIN) hipLaunchKernelGGL((K<false, SWEEP_PLAIN, true>), grid_for(n), dim3(kBlock), lds, s, __VA_ARGS__); \
+        else SPH_LAUNCH_RM0(K, rg, mode, n, lds, s, __VA_ARGS__);                                                                         \
+    } while (0)
 constexpr int kQuadBelow = 65536;          // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
 constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_split with nine / three waves per 64 particles up to these sizes (unstaged handles)
 // dynamic LDS of a staged sweep: bytes per staged particle x capacity (else the occupancy-experiment knob)
@@ -1340,6 +1348,13 @@ inline RigidView rigid_view_or_none(const SphHandle *h) { return rigid_coupled(h
 // shell around the body: two launches per sweep over the two halves of tile_order)
 inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && h->wall_grad && (!rigid_coupled(h) || h->tile_order); }
 inline bool rx_split(const SphHandle *h) { return use_relaxed(h) && rigid_coupled(h); }
+// pcisph / iisph under the relaxed arithmetic: the sweeps take KF<true> (sph_device.h); plain and staged sweeps, no coupled body (the quad sweeps of
+// small scenes and the RIGID instantiations stay exact)
+inline bool relaxed_pressure(const SphHandle *h)
+{
+    return h->relaxed && (h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !rigid_coupled(h) &&
+           (h->staged || !(!h->slab && h->opt_quad && h->c.n <= h->quad_below));
+}
 
 // init_rigid_particles_pos + init_rigid_particles_data (ParticleSystem.py:198-223, 249-295), once, on the host
 int build_rigid(SphHandle *h, const SphRigid *rg)
@@ -2362,7 +2377,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_P_EXT);                           // compute_ext_force, reset(), first predict_vel_pos
-        SPH_LAUNCH_RM0(k_pci_ext, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF,
+        SPH_LAUNCH_RMX0(k_pci_ext, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, EF, PF,
                        PB[0], PP, rv, h->stage_src, h->stage_cnt);
     }
     // sharded: the ghosts' predicted positions / pressures come from their owners after the sweep that produced them
@@ -2375,7 +2390,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         HIP_TRY(h, hipMemsetAsync(zero_press, 1, sizeof(int) * (size_t)h->nblocks, s));
     auto predict_rho = [&](int k, int gate) {               // the k-th predict_rho + residual: reads press from PB[k&1]
         ProfScope ps(h, K_P_PREDICT_RHO);
-        SPH_LAUNCH_RM0(k_pci_predict_rho, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
+        SPH_LAUNCH_RMX0(k_pci_predict_rho, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->pci_delta, PP, h->WP, h->nl, h->nlb, h->cnt, h->ds, PB[k & 1],
                        PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv, h->stage_src, h->stage_cnt);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
@@ -2386,7 +2401,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_P_PRESS);                 // iter_press (already in PB[k&1]), update_press_force, predict_vel_pos
-                SPH_LAUNCH_RM0(k_pci_press, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
+                SPH_LAUNCH_RMX0(k_pci_press, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4)), s, c, dt, PB[k & 1], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->V[h->vcur],
                                EF, h->ds, PF, PP, GATE_DENS, rv, h->stage_src, h->stage_cnt, zero_press);
             }
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
@@ -2443,7 +2458,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     hipLaunchKernelGGL(k_pressure_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     {
         ProfScope ps(h, K_I_ADVECT);                        // :43-56
-        SPH_LAUNCH_RM0(k_ii_advect, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+        SPH_LAUNCH_RMX0(k_ii_advect, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                        h->cnt, VA, DII, rv, h->stage_src, h->stage_cnt);
     }
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
@@ -2452,7 +2467,7 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
     if ((rc = ghosts_xyz(DII))) return rc;
     {
         ProfScope ps(h, K_I_RHO_ADV);                       // :58-82; a_ii lives in aux, p_past in the carried scalar
-        SPH_LAUNCH_RM0(k_ii_rho_adv, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
+        SPH_LAUNCH_RMX0(k_ii_rho_adv, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), s, c, dt, h->P[h->pcur], VA, h->WP, h->nl, h->nlb, h->cnt,
                        DII, h->warm[h->wcur], h->rho_adv, h->aux, PB[0], rv, h->stage_src, h->stage_cnt);
     }
     int *zero_dij = (h->pci_zero_press && h->staged && !h->slab) ? h->pci_zero_press : nullptr;      // tiles without pressure skip compute_all_d_ij (k_ii_dij)
@@ -2462,13 +2477,13 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
             {
                 ProfScope ps(h, K_I_DIJ);                   // compute_all_d_ij :91
-                SPH_LAUNCH_RM0(k_ii_dij, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
+                SPH_LAUNCH_RMX0(k_ii_dij, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, dt, PB[(k - 1) & 1], h->rho, h->nl, h->cnt, h->ds,
                                DIJ, GATE_DENS, rv, h->stage_src, h->stage_cnt, zero_dij);
             }
             if ((rc = ghosts_xyz(DIJ))) return rc;
             {
                 ProfScope ps(h, K_I_UPDATE_P);              // update_p :93 + compute_residual :97
-                SPH_LAUNCH_RM0(k_ii_update_p, rg, sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
+                SPH_LAUNCH_RMX0(k_ii_update_p, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
                                h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
             if ((rc = ghosts_w(PB[k & 1]))) return rc;
@@ -3263,7 +3278,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PCISPH_MAX_INDEX: *out = (double)h->pci_max_index; return SPH_OK;
     case SPH_S_PCISPH_MAX_COUNT: *out = (double)h->pci_max_count; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
-    case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet) ? 1.0 : 0.0; return SPH_OK;
+    case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet || relaxed_pressure(h)) ? 1.0 : 0.0; return SPH_OK;
     case SPH_S_VERLET_BUILDS: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->verlet_builds; return SPH_OK; }      // kr_split is settled by the first list build
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {

@@ -301,13 +301,14 @@ __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 // ======================================================================================
 // compute_ext_force (:237-244: tension, viscosity, gravity) + reset() (:247-250) + the first predict_vel_pos (:73-89)
 //   reads P = (pos, rho), V = (vel, -)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                     const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                     float4 *__restrict__ EF, float4 *__restrict__ PF, float4 *__restrict__ PB0,
                                                     float4 *__restrict__ PP, RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE_M(QUAD)
@@ -321,14 +322,14 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
     float &tx = fa[3], &ty = fa[4], &tz = fa[5];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
+        float r = K::norm3(dx, dy, dz);
         if (RIGID && (j & kRigidTag)) { rigid_viscosity(c, rv, vi, rho_i, pj, j, dx, dy, dz, r, wx, wy, wz); return; }
-        float st = c.tens_c * cubic_w(c, r);                 // solver_base.py:216
+        float st = c.tens_c * K::w(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
         float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
         if (shear < 0.f) {
-            F3 g = grad_w(c, dx, dy, dz, r);
+            F3 g = K::grad(c, dx, dy, dz, r);
             float q2 = r * r;
             float nu = c.visc_num / (rho_i + pj.w);          // :187
             float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_ext(Consts c, float dt, const fl
 // no tile ever returned, and the check cost 3 us per launch -- not kept.
 // predict_rho (:91-103) + compute_residual partials (:126-138) + the iter_press this particle would see next (:105-109).
 //   P here is PP = predicted positions: the neighbour SET is the list (current positions), the kernel argument is not.
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delta, const float4 *__restrict__ P,
                                                             const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                             const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
                                                             const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE_M(QUAD)
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
     float &rp = fa[0];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;   // rigid entries: the body where it is now (:159-161)
-        if (RIGID && (j & kRigidTag)) rp += cubic_w(c, norm3(dx, dy, dz)) * pj.w * c.rho0;
-        else rp += cubic_w(c, norm3(dx, dy, dz)) * c.m;      // :155-156
+        if (RIGID && (j & kRigidTag)) rp += K::w(c, K::norm3(dx, dy, dz)) * pj.w * c.rho0;
+        else rp += K::w(c, K::norm3(dx, dy, dz)) * c.m;      // :155-156
     };
     if (QUAD) for_fluid_nbrs_quad<RIGID, false>(nlp, kf, q, fa, P, nullptr, rv, pair);
     else if (staged) for_staged_nbrs<RIGID>(nlp, kf, s_operand, rv, pair);
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
     float &rb = wa[0];
     auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        rb += cubic_w(c, norm3(dx, dy, dz)) * pj.w;          // :167-168
+        rb += K::w(c, K::norm3(dx, dy, dz)) * pj.w;          // :167-168
     };
     if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);
     else for_nbrs_p(nlbp, kb, WP, wall);
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_rho(Consts c, float delt
 }
 
 // update_press_force (:111-124, :192-224) + predict_vel_pos (:73-89).   P here is PB = (pos, press_iter)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                       const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                       const int *__restrict__ cnt, const float *__restrict__ rho,
@@ -430,6 +432,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
                                                       int *__restrict__ zero_press)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const bool track = STAGED && !RIGID && zero_press != nullptr;          // tiles without pressure, see the note above k_pci_predict_rho
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
     const Recip rden = recip_prepare(rho_own * rho_own);     // rho_i ** 2, the divisor of every rigid term (:208)
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const float a = pj.w * c.rho0 * p_i;                                  // :208
             fx += div_shared(a * g.x, rden) * c.m; fy += div_shared(a * g.y, rden) * c.m; fz += div_shared(a * g.z, rden) * c.m;   // :210
@@ -477,8 +480,8 @@ __global__ __launch_bounds__(kBlock) void k_pci_press(Consts c, float dt, const 
         const float rho_i_2 = rho_own * rho_own;             // :221
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            float r = norm3(dx, dy, dz);
-            F3 g = grad_w(c, dx, dy, dz, r);
+            float r = K::norm3(dx, dy, dz);
+            F3 g = K::grad(c, dx, dy, dz, r);
             float s = pj.w * p_i / rho_i_2;                  // :223
             bx -= s * g.x; by -= s * g.y; bz -= s * g.z;
         };
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_integrate(Consts c, float dt, co
 // IISPH
 // ======================================================================================
 // predict_advection, first half (:43-56): tension, viscosity, f_adv, v_adv, d_ii.   P = (pos, rho), V = (vel, -)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                       const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -541,6 +544,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE_M(QUAD)
     uint32_t *s_src = reinterpret_cast<uint32_t *>(s_operand + c.stage_cap);
@@ -554,8 +558,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
     float &ex = fa[6], &ey = fa[7], &ez = fa[8];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const float sr = -pj.w * c.rho0 / (rho_i * rho_i);             // compute_d_ii :286
             ex += sr * g.x; ey += sr * g.y; ez += sr * g.z;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
             return;
         }
         ex += s_f * g.x; ey += s_f * g.y; ez += s_f * g.z;
-        float st = c.tens_c * cubic_w_in(c, r);                 // solver_base.py:216
+        float st = c.tens_c * K::w_in(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
         float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
@@ -584,8 +588,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
         const float den = rho_i * rho_i;
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            float r = norm3(dx, dy, dz);
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            float r = K::norm3(dx, dy, dz);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             float s = -pj.w / den;                           // compute_boundary_d_ii :292
             bx += s * g.x; by += s * g.y; bz += s * g.z;
         };
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_advect(Consts c, float dt, const 
 }
 
 // predict_advection, second half (:58-82): rho_adv, p_iter = 0.5 p_past, a_ii.   P = (pos, rho), V = VA = (v_adv, -)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                        const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                        const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -623,6 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
                                                        RigidView rv, const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     SPH_SWEEP_PROLOGUE_M(QUAD)
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
@@ -634,8 +639,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
     float &ra = fa[0], &aii = fa[1];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;   // d_ii[i] - d_ji; gradW(-q) = -gradW(q)
         if (RIGID && (j & kRigidTag)) {
             const F3 w = rigid_velocity(rv, pj, dt, true);                             // compute_rho_adv :337-339
@@ -654,8 +659,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
     if (c.boundary_handle) {
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            float r = norm3(dx, dy, dz);
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            float r = K::norm3(dx, dy, dz);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             rb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                        // compute_rho_adv_boundary :349
             float ex = di.x - cji * -g.x, ey = di.y - cji * -g.y, ez = di.z - cji * -g.z;
             ab += pj.w * dot3(ex, ey, ez, g.x, g.y, g.z);                              // compute_a_ii_boundary :322
@@ -675,13 +680,14 @@ __global__ __launch_bounds__(kBlock) void k_ii_rho_adv(Consts c, float dt, const
 }
 
 // compute_all_d_ij (:130-135, :324-327).   P here is PB = (pos, p_iter)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const float4 *__restrict__ P, const float *__restrict__ rho,
                                                    const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                    const DevScalars *__restrict__ ds, float4 *__restrict__ DIJ, int gate, RigidView rv,
                                                    const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, int *__restrict__ zero_dij)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
@@ -708,8 +714,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
     auto pair = [&](const float4 pj, const float rho_j, const uint32_t j) {
         if (RIGID && (j & kRigidTag)) return;                // compute_d_ij: fluid neighbours only (:319)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         const float a = c.neg_m * pj.w;                      // - m * p_iter[j]
         const Recip den = recip_prepare(rho_j * rho_j);
         sx += div_shared(a * g.x, den); sy += div_shared(a * g.y, den); sz += div_shared(a * g.z, den);   // :327
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_dij(Consts c, float dt, const flo
 }
 
 // update_p (:137-157) + compute_residual partials (:110-121).   P = PBin = (pos, p_iter); writes PBout = (pos, new p_iter)
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, const float4 *__restrict__ P, const float4 *__restrict__ DII,
                                                         const float4 *__restrict__ DIJ, const float4 *__restrict__ WP,
                                                         const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
@@ -734,6 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the handle's arithmetic (sph_device.h)
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
     SPH_SWEEP_PROLOGUE_M(QUAD)
@@ -758,8 +765,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     float &sum = fa[0];
     auto pair = [&](const float4 pj, const float4 dj, const float4 ej, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             sum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor :261
             return;
@@ -778,8 +785,8 @@ __global__ __launch_bounds__(kBlock) void k_ii_update_p(Consts c, float dt, cons
     if (c.boundary_handle) {
         auto wall = [&](const float4 pj) {
             float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            float r = norm3(dx, dy, dz);
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            float r = K::norm3(dx, dy, dz);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             bsum += dot3(a.x, a.y, a.z, g.x, g.y, g.z) * pj.w * c.rho0;   // sum_factor_boundary :240
         };
         if (QUAD) for_nbrs_p_quad(nlbp, kb, q, wa, WP, wall);

@@ -340,3 +340,44 @@ def test_relaxed_next_to_a_rigid_body(scene, steps, monkeypatch):
     for sim in (rx, ex):
         sim.close()
     o.close(); legal.close()
+
+
+# ---- PCISPH / IISPH under the relaxed arithmetic (round 4: the sweeps take the kernel functions KF<true>, sph_device.h) --------------------------
+
+@pytest.mark.parametrize("scene,steps,morton", [("breaking_dam_30k_pcisph", 12, True), ("breaking_dam_30k_iisph", 40, True), ("dfsph_tiny_wall_pcisph", 60, False),
+                                                ("dfsph_tiny_wall_iisph", 60, False), ("iisph_config_backup", 60, True), ("pcisph_config_backup", 40, True)])
+def test_relaxed_pressure_solvers_stay_inside_the_reference_envelope(scene, steps, morton, monkeypatch):
+    """SPH_ARITH_RELAXED on pcisph / iisph handles: staged sweeps (Morton curve) and the plain one-lane sweeps (SPH_QUAD=0 for the small scenes).
+    Against the canonical oracle next to two seeded legal executions of the oracle: positions and velocities within max(1e-5, 3x the legal
+    schedules' own deviation) at several points of the run, the pressure loop's iteration count within 2 (or 10 %) of the oracle's."""
+    cfg = scenes.get(scene)
+    if morton:
+        monkeypatch.setenv("SPH_CELL_ORDER", "morton")
+    else:
+        monkeypatch.setenv("SPH_QUAD", "0")
+    rx = nat.Simulation(nat.config_from_dict(cfg, arith=nat.ARITH_RELAXED))
+    o = orc.Oracle(cfg, num_threads=8)
+    legal = []
+    for seed in (7, 19):
+        lo = orc.Oracle(cfg, num_threads=8)
+        lo.set_schedule(seed, 1)
+        legal.append(lo)
+    pci = cfg["solver"]["name"] == "pcisph"
+    marks = sorted({max(1, steps // 4), steps // 2, steps})
+    for s in range(steps):
+        st = rx.step(1)
+        (o.step_pcisph if pci else o.step_iisph)(1)
+        for lo in legal:
+            (lo.step_pcisph if pci else lo.step_iisph)(1)
+        assert rx.scalar(nat.S_ARITH_RELAXED) == 1.0
+        no = o.last_stats.n_dens
+        assert abs(st.n_dens - no) <= max(2, no // 10), (s, st.n_dens, no)
+        if s + 1 in marks:
+            ep, ev = rel(rx.download(nat.F_POS), o.get(orc.F_POS)), rel(rx.download(nat.F_VEL), o.get(orc.F_VEL))
+            lp = max(rel(lo.get(orc.F_POS), o.get(orc.F_POS)) for lo in legal)
+            lv = max(rel(lo.get(orc.F_VEL), o.get(orc.F_VEL)) for lo in legal)
+            print("%s step %d: pos max-norm %.2e vel max-norm %.2e (legal schedules of the reference: %.2e %.2e), %d / %d pressure iterations" % (scene, s + 1, ep, ev, lp, lv, st.n_dens, no))
+            assert ep <= max(1e-5, 3.0 * lp) and ev <= max(1e-5, 3.0 * lv), (scene, s + 1, ep, ev, lp, lv)
+    rx.close(); o.close()
+    for lo in legal:
+        lo.close()
