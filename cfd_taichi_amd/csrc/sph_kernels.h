@@ -1884,7 +1884,7 @@ __device__ __forceinline__ void for_staged16_nbrs_pv2(const uint32_t *__restrict
     });
 }
 
-template <bool DFSPH, bool RIGID, int MODE>
+template <bool DFSPH, bool RIGID, int MODE, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__restrict__ P, const float4 *V,
                                                     const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                     const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -1896,6 +1896,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
                                                     float4 *__restrict__ wall_gc, TilePhase tp = TilePhase{nullptr, 0, 0})
 {
     constexpr bool STAGED = MODE == SWEEP_STAGED, QUAD = MODE == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
     const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
     if (tile < 0) return;
@@ -1905,12 +1906,12 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     float &rho = fa[0], &sx = fa[1], &sy = fa[2], &sz = fa[3], &sq = fa[4];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
+        float r = K::norm3(dx, dy, dz);
         const bool rg = RIGID && (j & kRigidTag);
-        if (rg) rho += pj.w * cubic_w_in(c, r) * c.rho0;        // solver_base.py:65  (V_j * W * rho_0)
-        else rho += c.m * cubic_w_in(c, r);                     // solver_base.py:62
+        if (rg) rho += pj.w * K::w_in(c, r) * c.rho0;        // solver_base.py:65  (V_j * W * rho_0)
+        else rho += c.m * K::w_in(c, r);                     // solver_base.py:62
         if (DFSPH) {
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             const float cm = rg ? pj.w * c.rho0 : c.m;       // dfsph_solver.py:62,75 / :58,70
             float rx = cm * g.x, ry = cm * g.y, rz = cm * g.z;
             sx += rx; sy += ry; sz += rz;
@@ -1926,10 +1927,10 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     float4 *gcw = (DFSPH && !QUAD && wall_gc) ? wall_gc + gc_index(ii, 0, c.kbpitch) : nullptr;   // bodies run in list order: entry k goes to row k
     auto wall = [&](const float4 pj) {                       // pj = (x, y, z, V_b)
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        rho_b += pj.w * cubic_w_in(c, r);                       // solver_base.py:70-71
+        float r = K::norm3(dx, dy, dz);
+        rho_b += pj.w * K::w_in(c, r);                       // solver_base.py:70-71
         if (DFSPH) {
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             float cc = pj.w * c.rho0;                        // dfsph_solver.py:82,88
             float rx = cc * g.x, ry = cc * g.y, rz = cc * g.z;
             bx += rx; by += ry; bz += rz;
@@ -2082,7 +2083,7 @@ __global__ __launch_bounds__(kBlock) void k_wcsph_force(Consts c, float dt, cons
 // ======================================================================================
 enum { CORR_WARM = 0, CORR_DIV = 1, CORR_DENS = 2 };
 
-template <int MODE, bool RIGID, int SWEEP>
+template <int MODE, bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ WP,
                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
@@ -2094,6 +2095,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     TilePhase tp)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
@@ -2134,8 +2136,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     float &ax = fa[0], &ay = fa[1], &az = fa[2];
     auto pair = [&](const float4 pj, const float4, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             float s = pj.w * c.rho0 * k_i / rho_i;                                // :345 / :377 / :211  (no 1e-5 gate)
             ax += s * g.x; ay += s * g.y; az += s * g.z;
@@ -2180,8 +2182,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     float &bx = wa[0], &by = wa[1], &bz = wa[2];
     auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219
         bx += s * g.x; by += s * g.y; bz += s * g.z;
     };
@@ -2222,7 +2224,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
 //   D6 (dfsph_solver.py:124-176): rho*_i = max(rho_i + dt (same sums with v*), rho0)
 // Writes Pout.w = k/rho for the correction sweep that follows and the block partials of the mean.
 // ======================================================================================
-template <bool DENS, bool RIGID, int SWEEP>
+template <bool DENS, bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                      const float4 *__restrict__ WP, const uint32_t *__restrict__ nl,
                                                      const uint32_t *__restrict__ nlb, const int *__restrict__ cnt,
@@ -2235,6 +2237,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      const float4 *__restrict__ wall_gc, TilePhase tp, FinFuse ff)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); return; }
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
@@ -2266,8 +2269,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     const float dt_r = RIGID ? ds->dt : 0.f;
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         if (RIGID && (j & kRigidTag)) {
             const F3 w = rigid_velocity(rv, pj, dt_r, DENS);                      // :292-293 / :168-169
             acc += pj.w * c.rho0 * dot3(vi.x - w.x, vi.y - w.y, vi.z - w.z, g.x, g.y, g.z);   // :294 / :170
@@ -2296,8 +2299,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     float &accb = wa[0];
     auto wall = [&](const float4 pj) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
-        F3 g = grad_w_in(c, dx, dy, dz, r);
+        float r = K::norm3(dx, dy, dz);
+        F3 g = K::grad_in(c, dx, dy, dz, r);
         accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);                     // :300 / :176
     };
     if (QUAD) for_nbrs_p_quad(nlbp, skip ? 0 : kb, q, wa, WP, wall);
@@ -2339,7 +2342,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
 // D5: tension + viscosity + external force + v* and max |v*|
 //     solver_base.py:170-217, dfsph_solver.py:91-103.   V = (vel, rho)
 // ======================================================================================
-template <bool RIGID, int SWEEP>
+template <bool RIGID, int SWEEP, bool RX = false>
 __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                       const uint32_t *__restrict__ nl, const int *__restrict__ cnt,
                                                       const DevScalars *__restrict__ ds, float4 *__restrict__ VAout,
@@ -2347,6 +2350,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
                                                       const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, TilePhase tp = TilePhase{nullptr, 0, 0})
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
+    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
     const uint32_t *nlb = nullptr;
     const int tile = tp.phase == 0 ? xcd_block(blockIdx.x, gridDim.x) : sweep_tile(tp, false);
@@ -2362,7 +2366,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
     float &tx = fa[3], &ty = fa[4], &tz = fa[5];
     auto pair = [&](const float4 pj, const float4 vj, const uint32_t j) {
         float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-        float r = norm3(dx, dy, dz);
+        float r = K::norm3(dx, dy, dz);
         if (RIGID && (j & kRigidTag)) {
             // solver_base.py:190-201: no tension from rigid neighbours; viscosity against the body velocity, with
             // rho[particle_j.index] = the FLUID density at the rigid particle's local index (quirk, :198-199)
@@ -2370,7 +2374,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             float shear = dot3(vx, vy, vz, dx, dy, dz);
             const int jl = rv.rid[j & ~kRigidTag];
             if (shear < 0.f && jl < rv.n_fluid) {
-                F3 g = grad_w_in(c, dx, dy, dz, r);
+                F3 g = K::grad_in(c, dx, dy, dz, r);
                 float q2 = r * r;
                 float nu = c.visc_num / (rho_i + rv.rho_orig[jl]);
                 float pi_ = -nu * shear / (q2 + c.visc_eps_h2);
@@ -2379,12 +2383,12 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             }
             return;
         }
-        float st = c.tens_c * cubic_w_in(c, r);                 // solver_base.py:216
+        float st = c.tens_c * K::w_in(c, r);                 // solver_base.py:216
         tx += st * dx; ty += st * dy; tz += st * dz;
         float vx = vi.x - vj.x, vy = vi.y - vj.y, vz = vi.z - vj.z;
         float shear = dot3(vx, vy, vz, dx, dy, dz);          // :183
         if (shear < 0.f) {
-            F3 g = grad_w_in(c, dx, dy, dz, r);
+            F3 g = K::grad_in(c, dx, dy, dz, r);
             float q2 = r * r;
             float nu = c.visc_num / (rho_i + vj.w);          // :187
             float pi_ = -nu * shear / (q2 + c.visc_eps_h2);  // :188
@@ -2410,7 +2414,7 @@ __global__ __launch_bounds__(kBlock) void k_dfsph_ext(Consts c, const float4 *__
             va[a] = v[a] + dt * f / c.m;                     // :102
         }
         if (owner) VAout[i] = make_float4(va[0], va[1], va[2], rho_i);
-        if (!ghost) vn = norm3(va[0], va[1], va[2]);         // :103
+        if (!ghost) vn = K::norm3(va[0], va[1], va[2]);         // :103
     }
     block_partial_max(blk, vn, pmax);
 }

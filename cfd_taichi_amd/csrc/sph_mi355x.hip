@@ -683,6 +683,21 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if ((mode) == SWEEP_QUAD) hipLaunchKernelGGL((K<false, SWEEP_QUAD>), g_, b_, 0, s, __VA_ARGS__);                            \
         else hipLaunchKernelGGL((K<false, SWEEP_PLAIN>), g_, b_, lds, s, __VA_ARGS__);                                                   \
     } while (0)
+// the dfsph sweeps of UNSTAGED handles under the relaxed arithmetic (relaxed_unstaged): plain and quad sweeps with KF<true> (sph_device.h)
+#define SPH_LAUNCH_RMX(K, T0, rg, mode, rx, n, lds, s, ...)                                                                              \
+    do {                                                                                                                                 \
+        if ((rx) && !(rg) && (mode) == SWEEP_QUAD)                                                                                       \
+            hipLaunchKernelGGL((K<T0, false, SWEEP_QUAD, true>), dim3((unsigned)std::max(1, ((n) + 63) / 64)), dim3(kBlock), 0, s, __VA_ARGS__); \
+        else if ((rx) && !(rg) && (mode) == SWEEP_PLAIN) hipLaunchKernelGGL((K<T0, false, SWEEP_PLAIN, true>), grid_for(n), dim3(kBlock), lds, s, __VA_ARGS__); \
+        else SPH_LAUNCH_RM(K, T0, rg, mode, n, lds, s, __VA_ARGS__);                                                                      \
+    } while (0)
+#define SPH_LAUNCH_RMXQ0(K, rg, mode, rx, n, lds, s, ...)                                                                                \
+    do {                                                                                                                                 \
+        if ((rx) && !(rg) && (mode) == SWEEP_QUAD)                                                                                       \
+            hipLaunchKernelGGL((K<false, SWEEP_QUAD, true>), dim3((unsigned)std::max(1, ((n) + 63) / 64)), dim3(kBlock), 0, s, __VA_ARGS__); \
+        else if ((rx) && !(rg) && (mode) == SWEEP_PLAIN) hipLaunchKernelGGL((K<false, SWEEP_PLAIN, true>), grid_for(n), dim3(kBlock), lds, s, __VA_ARGS__); \
+        else SPH_LAUNCH_RM0(K, rg, mode, n, lds, s, __VA_ARGS__);                                                                         \
+    } while (0)
 // the pcisph / iisph sweeps: the same with the kernel functions of the relaxed arithmetic (KF<true>, sph_device.h) where the handle asks for it --
 // plain and staged sweeps without a coupled body
 #define SPH_LAUNCH_RMX0(K, rg, mode, rx, n, lds, s, ...)                                                                                 \
@@ -1348,6 +1363,9 @@ inline RigidView rigid_view_or_none(const SphHandle *h) { return rigid_coupled(h
 // shell around the body: two launches per sweep over the two halves of tile_order)
 inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && h->wall_grad && (!rigid_coupled(h) || h->tile_order); }
 inline bool rx_split(const SphHandle *h) { return use_relaxed(h) && rigid_coupled(h); }
+// dfsph handles the tolerance-grade kernels of sph_relaxed_kernels.h do not cover because their sweeps are not staged (scenes below 131 k particles in
+// the reference's cell order: plain and quad sweeps): the exact sweeps with the kernel functions KF<true> -- same lists, same order of the sums
+inline bool relaxed_unstaged(const SphHandle *h) { return h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH && !h->staged && !rigid_coupled(h); }
 // pcisph / iisph under the relaxed arithmetic: the sweeps take KF<true> (sph_device.h); plain and staged sweeps, no coupled body (the quad sweeps of
 // small scenes and the RIGID instantiations stay exact)
 inline bool relaxed_pressure(const SphHandle *h)
@@ -1849,7 +1867,7 @@ int stage_density(SphHandle *h)
                                h->nl, h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->V[h->vcur], h->stage_src, h->stage_cnt, h->krho,
                                split ? TilePhase{h->tile_order, h->nblocks, 2} : TilePhase{nullptr, 0, 0}, h->id[h->icur], split ? h->rho_orig : (float *)nullptr);
         if (!use_relaxed(h) || split)
-        SPH_LAUNCH_RM(k_density, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
+        SPH_LAUNCH_RMX(k_density, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4)), s, c, h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb,
                       h->cnt, h->warm[h->wcur], h->ds, h->rho, h->aux, h->P[1 - h->pcur], h->V[h->vcur], rigid_view_or_none(h), h->id[h->icur],
                       h->rho_orig, h->stage_src, h->stage_cnt, h->krho, wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : TilePhase{nullptr, 0, 0});
     } else {
@@ -1964,7 +1982,7 @@ void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff);
         if (!split) return;
     }
-    SPH_LAUNCH_RM(k_residual, false, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
                   (const float4 *)wall_cache(h), tp, ff);
@@ -1983,7 +2001,7 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
                            split ? TilePhase{h->tile_order, h->nblocks, 2} : tile_phase(h, 0));
         if (!split) return;
     }
-    SPH_LAUNCH_RM(k_correct, MODE, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
+    SPH_LAUNCH_RMX(k_correct, MODE, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
                   (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0));
@@ -2005,7 +2023,7 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = 
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr, ff);
         if (!split) return;
     }
-    SPH_LAUNCH_RM(k_residual, true, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, ff);
 }
@@ -2062,7 +2080,7 @@ int dfsph_ext_and_dt(SphHandle *h)
             hipLaunchKernelGGL(k_dfsph_ext_rx, grid_for(c.n), b, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl, h->cnt, h->ds,
                                h->VA[0], h->pmax, h->stage_src, h->stage_cnt, split ? TilePhase{h->tile_order, h->nblocks, 2} : TilePhase{nullptr, 0, 0});
         if (!use_relaxed(h) || split)
-        SPH_LAUNCH_RM0(k_dfsph_ext, rigid_coupled(h), sweep_mode(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
+        SPH_LAUNCH_RMXQ0(k_dfsph_ext, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t)), s, c, h->P[h->pcur], h->V[h->vcur], h->nl,
                        h->cnt, h->ds, h->VA[0], h->pmax, rigid_view_or_none(h), h->stage_src, h->stage_cnt, split ? TilePhase{h->tile_order, h->nblocks, 1} : TilePhase{nullptr, 0, 0});
         if (h->rigid) {   // max_rigid_vel, :104-110 (loops over the rigid particles whether or not the body is active)
             RigidBodyState st = rigid_state(h, nullptr, nullptr);
@@ -3278,7 +3296,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PCISPH_MAX_INDEX: *out = (double)h->pci_max_index; return SPH_OK;
     case SPH_S_PCISPH_MAX_COUNT: *out = (double)h->pci_max_count; return SPH_OK;
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
-    case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet || relaxed_pressure(h)) ? 1.0 : 0.0; return SPH_OK;
+    case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet || relaxed_pressure(h) || relaxed_unstaged(h)) ? 1.0 : 0.0; return SPH_OK;
     case SPH_S_VERLET_BUILDS: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->verlet_builds; return SPH_OK; }      // kr_split is settled by the first list build
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {
