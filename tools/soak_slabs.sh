@@ -8,7 +8,7 @@ r=json.load(open("gpurun_out/soak_$1_$2.json"))
 print({k:r[k] for k in ("pos_equal","vel_equal","rho_equal","stats_equal","pos_rel_err")}, [(s["owned"],s["x_lo"],s["x_hi"],s["recuts"]) for s in r["slabs"]])
 PY
 }
-export HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2
+export HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2 SPH_DEV=1 SPH_SLAB_CHECK=1     # (the host's edge-column bookkeeping is checked against the sorted arrays every step)
 run dfsph_dam_x 3 2500 7
 run dfsph_dam_x 4 1500 5
 run wcsph_dam_x 3 8000 11
