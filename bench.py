@@ -458,7 +458,8 @@ def main():
     if overrides and not args.allow_overrides:
         raise SystemExit("[bench] development overrides are in force (%s): refusing to print a line; unset them or pass --allow-overrides "
                          "(they are then named in config.overrides)" % ", ".join(overrides))
-    sim.build_neighbors()          # (which sweeps run is settled by the first list build: k / rho array, 16-bit lists)
+    if world == 1:
+        sim.build_neighbors()      # (which sweeps run is settled by the first list build: k / rho array, 16-bit lists)
     headline_arith = "relaxed" if sim.scalar(nat.S_ARITH_RELAXED) == 1.0 else "exact"
 
     has_rigid = bool(cfg.get("solid")) and world == 1
