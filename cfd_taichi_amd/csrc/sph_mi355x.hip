@@ -1817,6 +1817,9 @@ int check_overflow(SphHandle *h)
         (void)hipMemsetAsync(&h->ds->overflow, 0, sizeof(int), h->stream);
         if (h->ds_host->overflow & 2)
             return fail(h, SPH_E_OVERFLOW, "internal: a cell was missing from a workgroup's staging plan (run with SPH_STAGE=0 and report)");
+        if (h->ds_host->overflow & 4)
+            return fail(h, SPH_E_OVERFLOW, "a particle crossed a whole slab in one step (it left its slab and landed beyond the neighbour's): the one-message particle "
+                                           "exchange assumes a fraction of a cell per step -- lower delta_time or use fewer, wider slabs");
         return fail(h, SPH_E_OVERFLOW, "neighbour list overflow: %d fluid / %d wall neighbours, capacity %d / %d (raise max_neighbors)",
                     h->ds_host->max_nbrs, h->ds_host->max_wall_nbrs, h->c.kmax, h->c.kbmax);
     }
@@ -1949,7 +1952,7 @@ int check_overflow_all(SphHandle *h)
         double v[1] = {(double)ovf};
         int rc = slab_allreduce_host(h, v, 1, 1);
         if (rc) return rc;
-        if (v[0] > 0.0 && !ovf) return fail(h, SPH_E_OVERFLOW, "neighbour list overflow on another slab");
+        if (v[0] > 0.0 && !ovf) return fail(h, SPH_E_OVERFLOW, "list overflow or exchange failure on another slab (flags %d)", (int)v[0]);
     }
     return check_overflow(h);
 }
