@@ -485,7 +485,7 @@ class Simulation:
         out = (ctypes.c_int32 * 8)()
         self._check(self._lib.sph_slab_info(self._h, out))
         return {"owned": out[0], "ghosts": out[1], "x_lo": out[2], "x_hi": out[3], "capacity": out[4], "recuts": out[5],
-                "rebalance_every": out[6]}
+                "rebalance_every": out[6], "ghost_columns": out[7] & 15, "halo_overlapped": bool(out[7] & 16), "allreduce_hidden": bool(out[7] & 32)}
 
     def comm_stats(self, reset=False):
         """Transport requests since the last reset: {p2p_groups, bytes_sent, bytes_received, count_exchanges, allreduce_stream, allreduce_host, steps}."""

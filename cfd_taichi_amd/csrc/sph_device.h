@@ -95,6 +95,11 @@ struct DevScalars {
     // pcisph / iisph pressure loops reuse dens_active / dens_it / dens_cap / dens_capped / dens_avg; iisph_solver.py:97-100 adds:
     float res_prev;
     int res_have_prev, res_diverged, verlet_builds;
+    // Slab handles that hide the residual's all-reduce behind the next correction sweep (step_dfsph_device_loops: "speculation"): the decision of
+    // evaluation e is also kept in gate_hist[e & 1], so that a sweep enqueued BEHIND the reduction of evaluation e can still read the decision of
+    // e - 1 without racing the kernel that takes e; stop_at = the evaluation whose decision closed the divergence loop (the correction sweep that ran
+    // ahead of it is undone by the next residual launch)
+    int gate_hist[2], stop_at, pad3;
     // Per-build maxima of the list lengths, sharded: workgroup w raises shard w % kNoteShards, the host takes the maximum over the
     // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
     // list build: same-address traffic serialises even when it is only loads.)
@@ -102,9 +107,10 @@ struct DevScalars {
 };
 constexpr int kNoteShards = 64;
 
-enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3 };
+enum { GATE_NONE = 0, GATE_DIV = 1, GATE_DENS = 2, GATE_DENS_D7 = 3, GATE_HIST0 = 16, GATE_HIST1 = 17 };
 __device__ __forceinline__ bool gate_closed(const DevScalars *ds, int gate)
 {
+    if (gate >= GATE_HIST0) return ds->gate_hist[gate - GATE_HIST0] == 0;
     if (gate == GATE_DIV) return ds->div_active == 0;
     if (gate == GATE_DENS) return ds->dens_active == 0;
     if (gate == GATE_DENS_D7) return ds->dens_d7_active == 0;

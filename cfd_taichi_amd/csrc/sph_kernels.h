@@ -46,6 +46,17 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 // of ordinary tiles (profiles/r03/wg_timeline_div_residual.json: a sixth of every sweep was its drain).  MEASURED (round 4): no effect -- the drain
 // of a launch is one workgroup lifetime whatever tiles come last; off by default (SPH_TILE_LPT=<wall weight>), see profiles/r04/null/tile_lpt_ab.txt.
 struct TilePhase { const int *order; int ntiles, phase; };
+// Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_mi355x.hip: step_dfsph_device_loops): the correction of
+// evaluation e runs before decision e is known and leaves the velocities and warm_start_k it overwrote in SpecSave; if decision e closed the loop
+// (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
+struct SpecSave { float4 *v; float *w; };
+struct SpecUndo { float4 *v_dst; const float4 *v_src; float *w_dst; const float *w_src; int eval; };
+__device__ __forceinline__ void spec_undo(const Consts &c, const SpecUndo &un, const DevScalars *__restrict__ ds, const TilePhase &tp)
+{
+    if (!un.v_dst || tp.phase == 2 || ds->stop_at != un.eval) return;          // (a split sweep: its first launch undoes)
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (i < c.n) { un.v_dst[i] = un.v_src[i]; un.w_dst[i] = un.w_src[i]; }
+}
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
 {
     if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
@@ -1327,19 +1338,29 @@ __device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode
         ds->dens_active = active;
     }
 }
+// hist >= 0: this is evaluation number `hist` of its loop; the decision also goes to gate_hist[hist & 1] (see DevScalars)
 __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                              DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                             int group = 1, int nparts = 0)
+                                                             int group = 1, int nparts = 0, int hist = -1)
 {
-    if (mode == FIN_DIV_LOOP && ds->div_active == 0) return;
-    if (mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0 && phase != FINP_REDUCE) ds->dens_d7_active = 0; return; }
+    if (mode == FIN_DIV_LOOP && ds->div_active == 0) { if (hist >= 0 && threadIdx.x == 0 && phase != FINP_REDUCE) ds->gate_hist[hist & 1] = 0; return; }
+    if (mode == FIN_DENS && ds->dens_active == 0) {
+        if (threadIdx.x == 0 && phase != FINP_REDUCE) { ds->dens_d7_active = 0; if (hist >= 0) ds->gate_hist[hist & 1] = 0; }
+        return;
+    }
     __shared__ double s_sum[kFinBlock / 64];
     __shared__ long long s_cnt[kFinBlock / 64];
     if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);
     if (threadIdx.x != 0) return;
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
     if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
+    const int was = (mode == FIN_DENS) ? ds->dens_active : ds->div_active;
     fin_decide(ds, mode, s_sum[0], s_cnt[0]);
+    if (hist >= 0) {
+        const int now = (mode == FIN_DENS) ? ds->dens_active : ds->div_active;
+        ds->gate_hist[hist & 1] = now;
+        if (mode != FIN_DENS && was != 0 && now == 0) ds->stop_at = hist;
+    }
 }
 
 // ---- the finalize fused into the sweep that produced the partials (VERDICT r3 next #5b) --------------------------------------------------
@@ -1408,6 +1429,7 @@ __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
     ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0;
     ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
     ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
+    ds->gate_hist[0] = 1; ds->gate_hist[1] = 1; ds->stop_at = -1;
 }
 
 // max |v*| over the block partials                              dfsph_solver.py:100-103
@@ -1440,6 +1462,7 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
     ds->dt = dt;
     ds->dt2 = dt * dt;                                            // :118
     ds->ps_dt = dt;                                               // :119
+    ds->gate_hist[0] = 1; ds->gate_hist[1] = 1;                   // (between the two solver loops: the density loop's decisions start afresh)
 }
 
 // ======================================================================================
@@ -2092,7 +2115,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
                                                     int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc,
-                                                    TilePhase tp)
+                                                    TilePhase tp, SpecSave sv = SpecSave{nullptr, nullptr})
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
@@ -2204,6 +2227,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     }
     if (!owner) return;
     float4 v = Vin[i];
+    if (MODE == CORR_DIV && sv.v) { sv.v[i] = v; sv.w[i] = warm[i]; }             // this sweep runs AHEAD of the loop decision: what the undo restores
     if (c.boundary_handle) {
         // :322 / :310 ; for D7 :187 then :191 -- same association: (a + b*rho0) * dt
         v.x -= (ax + bx * c.rho0) * dt;
@@ -2234,12 +2258,12 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                      const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
-                                                     const float4 *__restrict__ wall_gc, TilePhase tp, FinFuse ff)
+                                                     const float4 *__restrict__ wall_gc, TilePhase tp, FinFuse ff, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); return; }
+    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
     const int tile = sweep_tile(tp, spread);

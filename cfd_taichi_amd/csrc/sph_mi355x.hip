@@ -170,6 +170,10 @@ struct SphHandle {
     bool overlap = false;             // dfsph, two ghost columns: edge tiles of the residual sweeps first, halo on xstream under the interior tiles
     hipStream_t xstream = nullptr;    // the halo's stream when overlap is on
     hipEvent_t ev_edge = nullptr, ev_halo = nullptr;
+    // ... and the residual's all-reduce + loop decision on a third stream, under the next correction sweep (slab_can_overlap; step_dfsph_device_loops)
+    hipStream_t rstream = nullptr;
+    hipEvent_t ev_red = nullptr, ev_dec = nullptr;
+    float4 *spec_v = nullptr; float *spec_w = nullptr;      // what a divergence correction that ran ahead of its loop decision overwrote (SpecSave / SpecUndo)
     int *tile_flag = nullptr, *tile_order = nullptr;
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
@@ -266,6 +270,7 @@ void drain_profile(SphHandle *h)
     if (h->ev_pending.empty()) return;
     (void)hipStreamSynchronize(h->stream);
     if (h->xstream) (void)hipStreamSynchronize(h->xstream);
+    if (h->rstream) (void)hipStreamSynchronize(h->rstream);
     for (auto &e : h->ev_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { h->prof_ms[e.kid] += ms; h->prof_n[e.kid] += 1; }
@@ -883,6 +888,11 @@ int alloc_device(SphHandle *h, const HostScene &sc)
             HIP_TRY(h, hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
             HIP_TRY(h, hipEventCreateWithFlags(&h->ev_edge, hipEventDisableTiming));
             HIP_TRY(h, hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
+            if ((rc = dalloc(h, &h->spec_v, n))) return rc;
+            if ((rc = dalloc(h, &h->spec_w, n))) return rc;
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->rstream, hipStreamNonBlocking));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_red, hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->ev_dec, hipEventDisableTiming));
         }
         if ((rc = dalloc(h, &h->col_hist, (size_t)c.gx))) return rc;
         HIP_TRY(h, hipHostMalloc((void **)&h->col_hist_host, sizeof(int) * (size_t)c.gx, hipHostMallocDefault));
@@ -941,24 +951,25 @@ inline bool slab_stream_ordered(const SphHandle *h) { return h->slab && (h->nati
 // sharded DFSPH with the device-side loop control of the single-GPU path (needs the transport's in-place all-reduce of reduce_buf)
 inline bool slab_async(const SphHandle *h) { return h->slab && (h->native || h->comm.allreduce_stream) && h->red_dev && !h->slab_legacy; }
 
-int native_allreduce_stream(SphHandle *h, int n, int op);
+int native_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream = nullptr);
 
-// all-reduce red_dev[0..n) over the slabs, ordered on the handle's stream
-int slab_allreduce_stream(SphHandle *h, int n, int op)
+// all-reduce red_dev[0..n) over the slabs, ordered on `stream` (default: the handle's stream; a stream-ordered CALLBACK transport always uses the handle's)
+int slab_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = h->stream;
     h->comm_stat[4] += 1;
-    if (h->native) return native_allreduce_stream(h, n, op);
+    if (h->native) return native_allreduce_stream(h, n, op, stream);
     const SphComm &cm = h->comm;
     if (cm.on_host) {                                  // host transport: stage through the caller's host buffer
-        HIP_TRY(h, hipMemcpyAsync(cm.reduce_buf, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpyAsync(cm.reduce_buf, h->red_dev, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
     }
     // synchronous discipline on device buffers: the transport works on its own stream, so the pair must be complete before it reads
     // (it returns only when the reduced values are in place)
-    if (!cm.on_host && !cm.stream_ordered) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!cm.on_host && !cm.stream_ordered) HIP_TRY(h, hipStreamSynchronize(stream));
     int rc = cm.allreduce_stream(cm.user, n, op);
     if (rc) return comm_fail(h, "allreduce_stream", rc);
-    if (cm.on_host) HIP_TRY(h, hipMemcpyAsync(h->red_dev, cm.reduce_buf, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    if (cm.on_host) HIP_TRY(h, hipMemcpyAsync(h->red_dev, cm.reduce_buf, sizeof(double) * n, hipMemcpyHostToDevice, stream));
     return SPH_OK;
 }
 
@@ -1056,9 +1067,9 @@ int native_exchange_counts_n(SphHandle *h, int n, const int32_t *sl, const int32
 }
 int native_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr) { return native_exchange_counts_n(h, 1, &sl, &sr, rl, rr); }
 
-int native_allreduce_stream(SphHandle *h, int n, int op)
+int native_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream)
 {
-    NCCL_TRY(h, rccl().AllReduce(h->red_dev, h->red_dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->nccl, h->stream));
+    NCCL_TRY(h, rccl().AllReduce(h->red_dev, h->red_dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->nccl, stream ? stream : h->stream));
     return SPH_OK;
 }
 
@@ -1972,7 +1983,7 @@ inline FinFuse fin_fuse(const SphHandle *h, int fin_mode)
 {
     return FinFuse{(fin_mode >= 0 && fin_fusable(h)) ? h->fin_ticket : nullptr, fin_mode, partial_group(h), partial_count(h), h->nblocks};
 }
-void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     ProfScope ps(h, K_D_DIV_RESIDUAL);
@@ -1982,17 +1993,17 @@ void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff, un);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
-                  (const float4 *)wall_cache(h), tp, ff);
+                  (const float4 *)wall_cache(h), tp, ff, un);
 }
 
 template <int MODE>
-void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate)
+void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate, SpecSave sv = SpecSave{nullptr, nullptr})
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
@@ -2001,13 +2012,13 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
                            h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tile_phase(h, 0));
+                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tile_phase(h, 0), sv);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_correct, MODE, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0));
+                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0), sv);
 }
 
 void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -2031,6 +2042,28 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = 
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, ff);
 }
 
+// The same in two halves, for the handles that hide the all-reduce (step_dfsph_device_loops): this slab's (sum, count) on the handle's stream ...
+int launch_finalize_reduce(SphHandle *h, int mode)
+{
+    ProfScope ps(h, K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
+    HIP_TRY(h, hipEventRecord(h->ev_red, h->stream));
+    return SPH_OK;
+}
+// ... and the all-reduce + the decision of evaluation `eval` on the third stream; whoever needs the decision waits for ev_dec
+int launch_finalize_decide(SphHandle *h, int mode, int eval)
+{
+    hipStream_t r = h->rstream;
+    HIP_TRY(h, hipStreamWaitEvent(r, h->ev_red, 0));
+    int rc = slab_allreduce_stream(h, 2, 0, r);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, K_FINALIZE, r);
+        hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, r, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h), eval);
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_dec, r));
+    return SPH_OK;
+}
 int launch_finalize(SphHandle *h, int mode)
 {
     if (slab_async(h)) {       // this slab's (sum, count) -> all-reduce over the slabs -> the loop decision, all on the stream
@@ -2152,17 +2185,17 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const bool ovl = two && slab_can_overlap(h);
     auto ghosts_v = [&](float4 *V) -> int { return (h->slab && !two) ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
     // a residual sweep and the refresh of what it produced on the ghosts
-    auto residual_sweep = [&](bool dens, int gate) -> int {
+    auto residual_sweep = [&](bool dens, int gate, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}) -> int {
         int r = SPH_OK;
         if (ovl) {
-            if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1);
+            if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1, -1, un);
             HIP_TRY(h, hipEventRecord(h->ev_edge, s));
-            if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2);       // enqueued before the host turns to the transfer
+            if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2, -1, un);       // enqueued before the host turns to the transfer
             if ((r = slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, true))) return r;
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_halo, 0));                                       // the next sweep reads the ghosts
             return SPH_OK;
         }
-        if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate);
+        if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate, 0, -1, un);
         if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
         return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
     };
@@ -2177,8 +2210,34 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         if ((r = residual_sweep(dens, gate))) return r;
         return launch_finalize(h, fin_mode);
     };
+    // Hiding the all-reduce (two-column handles whose halo may run on its own stream, `ovl`).  What a solver iteration still waited for was the
+    // two-double all-reduce of its residual, because the decision it feeds gates the next sweep.  The reduction and the decision kernel now run on a
+    // third stream while the NEXT sweep runs on the handle's:
+    //   density loop     that sweep is the correction D7 of the SAME iteration, which the reference runs whatever the new mean says
+    //                    (dfsph_solver.py:227-231: the condition is tested at the loop's head): no speculation at all;
+    //   divergence loop  that sweep is the correction D4 of the NEXT iteration (:402-408), which the decision may cancel: it runs ahead, keeps what
+    //                    it overwrote (SpecSave), and if the decision closed the loop the following residual launch -- gated off -- puts it back
+    //                    (SpecUndo).  Wrong at most once per step; never in a loop that runs into its cap of 15.
+    // A sweep that is enqueued behind evaluation e's reduction must not read the gate evaluation e is about to write: it reads the decision of
+    // e - 1 from DevScalars.gate_hist[(e - 1) & 1].  Bit-identical to the plain order by construction (tests/test_slab_gpu.py).
+    const bool spec = ovl && slab_async(h) && h->rstream;
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
+    if (spec) {
+        if ((rc = residual_sweep(false, GATE_NONE))) return rc;                      // :398, evaluation 1
+        if ((rc = launch_finalize_reduce(h, FIN_DIV_FIRST))) return rc;
+        for (int e = 1; e <= 15; ++e) {
+            // the correction of evaluation e first (the GPU works on it while the host may block in a synchronous all-reduce) ...
+            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w});   // :402-405
+            // ... then evaluation e's reduction and decision on the third stream
+            if ((rc = launch_finalize_decide(h, e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e))) return rc;
+            HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
+            if ((rc = residual_sweep(false, GATE_DIV, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e}))) return rc;   // :408, evaluation e + 1
+            if ((rc = launch_finalize_reduce(h, FIN_DIV_LOOP))) return rc;
+        }
+        if ((rc = launch_finalize_decide(h, FIN_DIV_LOOP, 16))) return rc;
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
+    } else {
     if ((rc = residual(false, GATE_NONE, FIN_DIV_FIRST))) return rc;                 // :398
     // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
     // and the host does not need the outcome before the density loop's first read-back
@@ -2187,11 +2246,23 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         if ((rc = residual(false, GATE_DIV, FIN_DIV_LOOP))) return rc;                    // :408
     }
+    }
     if ((rc = dfsph_ext_and_dt(h))) return rc;
     // ---- correct_density_error, :221-233: first chunk = last step's iteration count (it changes slowly), then two at a time ----
     bool first = true;
+    int d = 0;                                                                       // evaluations of the density loop so far
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
+            if (spec) {
+                ++d;
+                if ((rc = residual_sweep(true, GATE_DENS))) return rc;               // :227, evaluation d
+                if ((rc = launch_finalize_reduce(h, FIN_DENS))) return rc;
+                // D7 of iteration d runs iff iteration d runs: the decision of evaluation d - 1 (gate_hist starts open)
+                launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1));   // :229
+                if ((rc = launch_finalize_decide(h, FIN_DENS, d))) return rc;
+                HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
+                continue;
+            }
             if ((rc = residual(true, GATE_DENS, FIN_DENS))) return rc;               // :227
             launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
@@ -2802,6 +2873,9 @@ void sph_destroy(SphHandle *h)
     if (h->ev_edge) (void)hipEventDestroy(h->ev_edge);
     if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
     if (h->xstream) { (void)hipStreamSynchronize(h->xstream); (void)hipStreamDestroy(h->xstream); }
+    if (h->ev_red) (void)hipEventDestroy(h->ev_red);
+    if (h->ev_dec) (void)hipEventDestroy(h->ev_dec);
+    if (h->rstream) { (void)hipStreamSynchronize(h->rstream); (void)hipStreamDestroy(h->rstream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -3092,7 +3166,11 @@ int sph_slab_info(SphHandle *h, int32_t *out)
     if (!h || !out) return SPH_E_INVALID;
     out[0] = h->n_owned; out[1] = h->slab ? h->c.n - h->n_owned : 0;
     out[2] = h->geom.x_lo; out[3] = h->slab ? h->geom.x_hi : h->c.gx; out[4] = h->ncap;
-    out[5] = h->n_recuts; out[6] = h->rebalance_every; out[7] = 0;
+    out[5] = h->n_recuts; out[6] = h->rebalance_every;
+    // the halo protocol in force: ghost columns per side | 16 if the residual sweeps run edge tiles first with the halo on its own stream | 32 if the
+    // residual's all-reduce and loop decision run on a third stream under the next correction sweep (both need a transport that can: slab_can_overlap)
+    out[7] = !h->slab ? 0 : h->geom.layers | ((h->geom.layers == 2 && h->comm_set && slab_can_overlap(h)) ? 16 : 0) |
+                            ((h->geom.layers == 2 && h->comm_set && slab_can_overlap(h) && slab_async(h) && h->rstream && is_dfsph(h)) ? 32 : 0);
     return SPH_OK;
 }
 

@@ -128,10 +128,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp, FinFuse ff)
+                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp, FinFuse ff,
+                                                        SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
 {
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); return; }
+    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
                                                        float *__restrict__ warm, const DevScalars *__restrict__ ds,
                                                        const float4 *Vin, float4 *Vout, int gate,
                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
-                                                       int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, TilePhase tp)
+                                                       int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, TilePhase tp,
+                                                       SpecSave sv = SpecSave{nullptr, nullptr})
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) return;
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     }
     if (!live) return;
     float4 v = Vin[i];
+    if (MODE == CORR_DIV && sv.v) { sv.v[i] = v; sv.w[i] = warm[i]; }             // (see k_correct: the undo of a correction that ran ahead of the loop decision)
     v.x -= (ax + gx) * dt; v.y -= (ay + gy) * dt; v.z -= (az + gz) * dt;         // :324 / :312 / :189
     v.w = rho_i;
     Vout[i] = v;

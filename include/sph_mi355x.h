@@ -289,7 +289,9 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);
  * keeps >= 2 columns and old_cuts[k-1] < new_cuts[k] < old_cuts[k+1] (a particle's new owner is its rank or a direct neighbour) */
 int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts);
 /* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity,
- * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = 0 */
+ * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = the halo protocol in force: ghost columns per side (1 or 2)
+ * | 16 if the dfsph residual sweeps run their edge tiles first with the halo on its own stream | 32 if the residual's all-reduce and loop decision run
+ * on a third stream under the next correction sweep (both need the native transport or a synchronous one) */
 int sph_slab_info(SphHandle *h, int32_t *out8);
 /* What the halo transport was asked to do since the last reset (whichever transport drives it: native RCCL, callbacks over RCCL or gloo):
  * out[0] point-to-point groups (a send / recv pair with each slab neighbour), out[1] bytes sent, out[2] bytes received, out[3] count
