@@ -136,6 +136,7 @@ class SphComm(ctypes.Structure):
         ("allreduce_stream", ALLREDUCE_STREAM_FN),
         ("reduce_buf", ctypes.c_void_p),
         ("exchange_counts_n", EXCHANGE_COUNTS_N_FN),
+        ("reduce_capacity", ctypes.c_size_t),
     ]
 
 

@@ -1966,7 +1966,7 @@ __global__ __launch_bounds__(kBlock) void k_density(Consts c, const float4 *__re
     float rho_i = c.boundary_handle ? rho + rho_b * c.rho0 : rho;   // solver_base.py:49,51
     if (!owner) return;
     rho_out[i] = rho_i;
-    if (RIGID) rho_orig[id[i]] = rho_i;
+    if (RIGID) { const int raw = id[i]; rho_orig[raw < 0 ? ~raw : raw] = rho_i; }      // (by the true id: an inner ghost of a slab handle carries ~id)
     const float4 vi = V[i];
     if (DFSPH) {
         float den;

@@ -1076,6 +1076,9 @@ int native_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream)
 // neighbour counts / host-side all-reduce through whichever transport the handle has
 // n ints to each neighbour, n from each (absent neighbour: zeros): one host round trip where the transport can (native RCCL, a SphComm with
 // exchange_counts_n), n of them through a plain exchange_counts
+// doubles the transport's reduce buffer must hold on this handle (a rigid body's by-id sums: 4 per sample)
+inline size_t slab_reduce_need(const SphHandle *h) { return h->rigid ? 4 * (size_t)h->Nr + 8 : 4; }
+
 int slab_exchange_counts_n(SphHandle *h, int n, const int32_t *sl, const int32_t *sr, int32_t *rl, int32_t *rr)
 {
     if (n > kCountInts) return fail(h, SPH_E_INVALID, "count exchange of %d ints", n);
@@ -1372,7 +1375,7 @@ inline RigidView rigid_view_or_none(const SphHandle *h) { return rigid_coupled(h
 // the tolerance-grade sweeps (sph_relaxed_kernels.h) run on this handle
 // (with a coupled body -- rx_split -- they cover the workgroups with 16-bit lists, i.e. without a rigid sample in reach, and the exact RIGID sweeps the thin
 // shell around the body: two launches per sweep over the two halves of tile_order)
-inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && h->wall_grad && (!rigid_coupled(h) || h->tile_order); }
+inline bool use_relaxed(const SphHandle *h) { return h->relaxed && h->staged && h->c.kr_split && h->wall_grad && (!rigid_coupled(h) || (h->tile_order && !h->slab)); }
 inline bool rx_split(const SphHandle *h) { return use_relaxed(h) && rigid_coupled(h); }
 // dfsph handles the tolerance-grade kernels of sph_relaxed_kernels.h do not cover because their sweeps are not staged (scenes below 131 k particles in
 // the reference's cell order: plain and quad sweeps): the exact sweeps with the kernel functions KF<true> -- same lists, same order of the sums
@@ -1483,8 +1486,10 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->rcell_start, (size_t)c.S + 2))) return rc;
     if ((rc = dalloc(h, &h->rforce, 3 * nr))) return rc;
     if ((rc = dalloc(h, &h->rvert, 3 * (size_t)(Nv > 0 ? Nv : 1)))) return rc;
-    if ((rc = dalloc(h, &h->pos_orig, (size_t)h->c.stride))) return rc;
-    if ((rc = dalloc(h, &h->rho_orig, (size_t)h->c.stride))) return rc;
+    // (indexed by ORIGINAL particle id: on a slab handle that is the whole scene's id range, whatever this rank holds)
+    const size_t by_id = std::max((size_t)h->c.stride, (size_t)h->N);
+    if ((rc = dalloc(h, &h->pos_orig, by_id))) return rc;
+    if ((rc = dalloc(h, &h->rho_orig, by_id))) return rc;
     if ((rc = dalloc(h, &h->ncount, (size_t)h->c.stride))) return rc;
     if ((rc = dalloc(h, &h->rred, kRigidParts))) return rc;
     if ((rc = dalloc(h, &h->rvmax_part, kRigidParts))) return rc;
@@ -1505,7 +1510,7 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if (Nv > 0) HIP_TRY(h, hipMemcpyAsync(h->rvert, rvert.data(), sizeof(float) * 3 * (size_t)Nv, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rforce, 0, sizeof(float) * 3 * nr, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)c.S + 2), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->rho_orig, 0, sizeof(float) * (size_t)h->c.stride, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rho_orig, 0, sizeof(float) * by_id, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->ncount, 0, sizeof(int) * (size_t)h->c.stride, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->rigid = true;
@@ -1768,6 +1773,13 @@ int stage_sort_and_lists(SphHandle *h)
             hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
     }
+    if (h->slab && rigid_coupled(h)) {      // fluid positions by original id < Nr, from whichever rank owns them (the get_neighbour_count quirk)
+        ProfScope ps(h, K_RIGID);
+        HIP_TRY(h, hipMemsetAsync(h->red_dev, 0, sizeof(double) * 4 * (size_t)h->Nr, s));
+        hipLaunchKernelGGL(k_collect_by_id, g, b, 0, s, c.n, h->id[h->icur], h->P[h->pcur], (const float *)nullptr, h->Nr, h->red_dev);
+        if ((rc = slab_allreduce_stream(h, 4 * h->Nr, 0))) return rc;
+        hipLaunchKernelGGL(k_spread_by_id, grid_for(h->Nr), b, 0, s, h->Nr, h->red_dev, h->pos_orig, (float *)nullptr);
+    }
     if (rigid_coupled(h) && (rc = stage_sort_rigid(h))) return rc;
     {
         ProfScope ps(h, K_BUILD_NL);
@@ -1892,6 +1904,14 @@ int stage_density(SphHandle *h)
         h->pcur ^= 1; h->vcur ^= 1;   // P = (pos, rho), V = (vel, p/rho^2)
     }
     HIP_TRY(h, hipGetLastError());
+    if (h->slab && dfsph && rigid_coupled(h)) {      // fluid densities by original id < Nr (the viscosity quirk), summed over the owners
+        ProfScope ps(h, K_RIGID);
+        HIP_TRY(h, hipMemsetAsync(h->red_dev, 0, sizeof(double) * (size_t)h->Nr, s));
+        hipLaunchKernelGGL(k_collect_by_id, grid_for(c.n), dim3(kBlock), 0, s, c.n, h->id[h->icur], (const float4 *)nullptr, h->rho, h->Nr, h->red_dev);
+        int rc = slab_allreduce_stream(h, h->Nr, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_spread_by_id, grid_for(h->Nr), dim3(kBlock), 0, s, h->Nr, h->red_dev, (float4 *)nullptr, h->rho_orig);
+    }
     if (h->slab && dfsph && h->geom.layers == 2) {
         // two ghost columns: the inner one computed rho, alpha and its warm-start k / rho itself (same inputs, same order as on its owner); the
         // outer one is only ever read as a neighbour of the warm start: k / rho
@@ -2087,7 +2107,7 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
     const Consts &c = h->c;
     ProfScope ps(h, K_RIGID);
     hipLaunchKernelGGL(k_rigid_force, grid_for(h->Nr), dim3(kBlock), 0, h->stream, c, h->Nr, h->RPs, h->rid, h->P[h->pcur], h->rnl, h->rcnt, h->rho,
-                       h->rho_adv, h->aux, h->ds, h->rforce, gate);
+                       h->rho_adv, h->aux, h->ds, h->rforce, gate, h->slab ? h->geom.x_lo : -0x7fffffff, h->slab ? h->geom.x_hi : 0x7fffffff);
 }
 
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
@@ -2259,6 +2279,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
                 if ((rc = launch_finalize_reduce(h, FIN_DENS))) return rc;
                 // D7 of iteration d runs iff iteration d runs: the decision of evaluation d - 1 (gate_hist starts open)
                 launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1));   // :229
+                if (rigid_coupled(h)) launch_rigid_force(h, GATE_HIST0 + ((d - 1) & 1));
                 if ((rc = launch_finalize_decide(h, FIN_DENS, d))) return rc;
                 HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
                 continue;
@@ -2825,7 +2846,8 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
 int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out)
 {
     if (!cfg || !rigid || !out) return fail(nullptr, SPH_E_INVALID, "null argument");
-    if (cfg->slab_count > 1) return fail(nullptr, SPH_E_INVALID, "rigid coupling is not available on slab handles");
+    if (cfg->slab_count > 1 && (cfg->solver != SPH_SOLVER_DFSPH || cfg->slab_ghost_layers == 1))
+        return fail(nullptr, SPH_E_INVALID, "a rigid body on slab handles needs dfsph with two ghost columns (the body's fluid neighbours must be resident on the rank that owns its column)");
     if (rigid->n_particles <= 0 || !rigid->points) return fail(nullptr, SPH_E_INVALID, "rigid body has no sample points");
     if (cfg->solver == SPH_SOLVER_PBF) return fail(nullptr, SPH_E_INVALID, "pbf has no rigid coupling (pbf_solver.py has no material branches)");
     g_creating_with_rigid = true;
@@ -2848,6 +2870,13 @@ int sph_rigid_step(SphHandle *h)
     if (!h) return SPH_E_INVALID;
     if (!h->rigid) return fail(h, SPH_E_STATE, "handle has no rigid body");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->slab) {       // every sample's force was summed whole by the rank that owns its column (k_rigid_force): add the ranks' arrays up, x + 0 = x
+        const int n3 = 3 * h->Nr;
+        hipLaunchKernelGGL(k_floats_to_doubles, grid_for(n3), dim3(kBlock), 0, h->stream, n3, h->rforce, h->red_dev);
+        int rc = slab_allreduce_stream(h, n3, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_doubles_to_floats, grid_for(n3), dim3(kBlock), 0, h->stream, n3, h->red_dev, h->rforce);
+    }
     return rigid_step(h);
 }
 
@@ -3084,7 +3113,7 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     }
     h->own_dev_comm = true;
     if (h->own_red) (void)hipFree(h->red_dev);
-    h->red_cap = std::max(1024, h->c.gx + 8);                  // the re-balancing histogram (gx counts) goes through it too
+    h->red_cap = (int)std::max<size_t>(std::max(1024, h->c.gx + 8), slab_reduce_need(h));      // the re-balancing histogram (gx counts) and a rigid body's by-id sums go through it too
     HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * (size_t)h->red_cap));
     h->own_red = true;
     HIP_TRY(h, hipHostMalloc((void **)&h->red_host, sizeof(double) * (size_t)h->red_cap, hipHostMallocDefault));
@@ -3137,8 +3166,14 @@ int sph_set_comm(SphHandle *h, const SphComm *comm)
     h->red_dev = nullptr;
     if (comm->allreduce_stream) {
         if (!comm->reduce_buf) return fail(h, SPH_E_INVALID, "SphComm.allreduce_stream needs reduce_buf");
-        if (comm->on_host) { HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * 4)); h->own_red = true; }
+        const size_t have = comm->reduce_capacity ? comm->reduce_capacity : 4;
+        if (have < slab_reduce_need(h))
+            return fail(h, SPH_E_INVALID, "SphComm.reduce_buf holds %zu doubles, this handle (rigid body of %d samples) needs %zu: set reduce_capacity", have, h->Nr, slab_reduce_need(h));
+        h->red_cap = (int)std::min<size_t>(have, 0x7fffffff);
+        if (comm->on_host) { HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * have)); h->own_red = true; }
         else h->red_dev = comm->reduce_buf;
+    } else if (h->rigid) {
+        return fail(h, SPH_E_INVALID, "a rigid body on a slab handle needs a transport with allreduce_stream");
     }
     if (comm->stream_ordered && comm->on_host) return fail(h, SPH_E_INVALID, "a stream-ordered transport needs device buffers (on_host = 0)");
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_density_rx(Consts c, const float4 *_
         den = (den + gs * (f * f)) + __builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx));    // :45
     }
     rho_out[i] = rho_i;
-    if (rho_orig) rho_orig[id[i]] = rho_i;                                        // (a coupled body's viscosity reads rho by ORIGINAL id, solver_base.py:198-199)
+    if (rho_orig) { const int raw = id[i]; rho_orig[raw < 0 ? ~raw : raw] = rho_i; }                                        // (a coupled body's viscosity reads rho by ORIGINAL id, solver_base.py:198-199)
     const float alpha = fabsf(den) < 1e-6f ? 0.0f : rho_i / den;                  // :48-51
     aux_out[i] = alpha;
     const float4 vi = V[i];

@@ -72,12 +72,17 @@ __global__ __launch_bounds__(kBlock) void k_rigid_force(Consts c, int nr, const 
                                                         const float4 *__restrict__ P, const uint32_t *__restrict__ rnl,
                                                         const int *__restrict__ rcnt, const float *__restrict__ rho,
                                                         const float *__restrict__ rho_adv, const float *__restrict__ alpha,
-                                                        const DevScalars *__restrict__ ds, float *__restrict__ force, int gate)
+                                                        const DevScalars *__restrict__ ds, float *__restrict__ force, int gate,
+                                                        int col_lo = -0x7fffffff, int col_hi = 0x7fffffff)
 {
     if (gate_closed(ds, gate)) return;
     int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= nr) return;
     const float4 pr = RP[r];
+    // slab handles: the body is replicated on every rank and a sample's force is summed WHOLE by the rank that owns the sample's cell column
+    // (all its fluid neighbours are resident there: owned particles and inner ghosts, in the canonical order); the per-sample forces of all ranks
+    // are added up before rigid_solver.step (x + 0 = x: exact)
+    { const int cx = (int)floorf(pr.x / c.hcell); if (cx < col_lo || cx >= col_hi) return; }
     const float dt2 = ds->dt2;
     float fx = 0.f, fy = 0.f, fz = 0.f;
     struct Op { float4 p; float rho, rho_adv, alpha; };

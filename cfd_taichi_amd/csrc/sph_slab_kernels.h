@@ -321,6 +321,38 @@ __global__ __launch_bounds__(kBlock) void k_tile_order(const int *__restrict__ f
     if (threadIdx.x == 0) order[ntiles] = total_s;
 }
 
+// Rigid body on slab handles.  The reference's quirks read FLUID arrays with a rigid particle's local index (get_neighbour_count measures to
+// fluid_particles.pos[particle_j.index], ParticleSystem.py:440-442; viscosity reads rho[particle_j.index], solver_base.py:198-199): positions and densities
+// of the fluid particles with original id < Nr, wherever they are.  Every rank contributes the ones it OWNS to a zeroed array of doubles, the arrays are
+// summed over the slabs (one owner per id: x + 0 + ... = x exactly) and spread into pos_orig / rho_orig.
+__global__ __launch_bounds__(kBlock) void k_collect_by_id(int n, const int *__restrict__ id, const float4 *__restrict__ A4, const float *__restrict__ A1, int nr,
+                                                          double *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int o = id[i];
+    if (o < 0 || o >= nr) return;                            // ghosts (~id) and particles whose id no rigid particle can name
+    if (A4) { const float4 a = A4[i]; out[4 * (size_t)o] = a.x; out[4 * (size_t)o + 1] = a.y; out[4 * (size_t)o + 2] = a.z; out[4 * (size_t)o + 3] = a.w; }
+    else out[o] = (double)A1[i];
+}
+__global__ __launch_bounds__(kBlock) void k_spread_by_id(int nr, const double *__restrict__ in, float4 *__restrict__ D4, float *__restrict__ D1)
+{
+    const int o = blockIdx.x * kBlock + threadIdx.x;
+    if (o >= nr) return;
+    if (D4) D4[o] = make_float4((float)in[4 * (size_t)o], (float)in[4 * (size_t)o + 1], (float)in[4 * (size_t)o + 2], (float)in[4 * (size_t)o + 3]);
+    else D1[o] = (float)in[o];
+}
+__global__ __launch_bounds__(kBlock) void k_floats_to_doubles(int n, const float *__restrict__ in, double *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+__global__ __launch_bounds__(kBlock) void k_doubles_to_floats(int n, const double *__restrict__ in, float *__restrict__ out)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_unsort_ids(int n, const int *__restrict__ id, int *__restrict__ out)
 {
     int s = blockIdx.x * kBlock + threadIdx.x;

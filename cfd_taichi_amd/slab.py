@@ -31,7 +31,7 @@ from . import _native as nat
 class TorchComm:
     """SphComm callbacks on top of torch.distributed (backend nccl = RCCL, or gloo)."""
 
-    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None, stream_ptr=0, stream_ordered=None):
+    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None, stream_ptr=0, stream_ordered=None, reduce_capacity=4):
         """stream_ptr: the library handle's hipStream_t (Simulation.stream_ptr()); with the nccl backend and a stream the
         transport is stream-ordered unless stream_ordered=False / SPH_SLAB_SYNC=1."""
         import os
@@ -47,7 +47,7 @@ class TorchComm:
         self.capacity = int(capacity_bytes)
         self.bufs = {k: torch.empty(self.capacity, dtype=torch.uint8, device=self.device, **kw)
                      for k in ("send_left", "send_right", "recv_left", "recv_right")}
-        self.reduce_t = torch.zeros(4, dtype=torch.float64, device=self.device, **kw)
+        self.reduce_t = torch.zeros(max(4, int(reduce_capacity)), dtype=torch.float64, device=self.device, **kw)
         if stream_ordered is None:
             stream_ordered = os.environ.get("SPH_SLAB_SYNC", "0") != "1"
         self.stream_ordered = bool(stream_ordered and not self.on_host and stream_ptr)
@@ -67,6 +67,7 @@ class TorchComm:
         self.struct.allreduce = self._cb_allreduce
         self.struct.allreduce_stream = self._cb_allreduce_stream
         self.struct.exchange_counts_n = self._cb_counts_n
+        self.struct.reduce_capacity = self.reduce_t.numel()
         self.struct.reduce_buf = self.reduce_t.data_ptr()
         self.struct.stream_ordered = 1 if self.stream_ordered else 0
         for k, t in self.bufs.items():
@@ -220,12 +221,20 @@ class SlabSimulation:
         cfg = nat.config_from_dict(config, solver_name=solver_name, device=device, slab_rank=rank, slab_count=world,
                                    slab_capacity=slab_capacity, slab_rebalance_every=rebalance_every, **native_opts)
         self.solver = {v: k for k, v in nat.SOLVER_IDS.items()}[cfg.solver]
-        self.sim = nat.Simulation(cfg)
+        # a rigid body (config["solid"]): replicated on every rank (dfsph, two ghost columns); the sums that keep the copies identical go through the
+        # transport's reduce buffer, 4 doubles per rigid sample
+        rigid = None
+        if config.get("solid"):
+            from . import mesh
+            rigid = mesh.rigid_from_config(config)
+        self.rigid_active = bool(rigid and rigid.get("active"))
+        self.sim = nat.Simulation(cfg, rigid=rigid)
         if transport == "native":
             self.comm = None
             attach_native(self.sim, rank, capacity_bytes, group)
         else:
-            self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, group=group, stream_ptr=self.sim.stream_ptr())
+            self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, group=group, stream_ptr=self.sim.stream_ptr(),
+                                  reduce_capacity=4 * self.sim.n_rigid + 8 if rigid else 4)
             self.sim.set_comm(self.comm.struct)
         self.n_fluid = self.sim.n_fluid
 
@@ -237,6 +246,8 @@ class SlabSimulation:
             st = None
             for _ in range(nsteps):
                 st = self.sim.step(1)
+                if self.rigid_active:
+                    self.sim.rigid_step()          # main.py:169-171
             return st
         except nat.SphError:
             if self.comm is not None and self.comm.error is not None:

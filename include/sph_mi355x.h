@@ -177,8 +177,9 @@ typedef struct SphHandle SphHandle;
  * wall cell list and wall volumes (:309-335), and allocates every device buffer. */
 int sph_create(const SphConfig *cfg, SphHandle **out);
 /* the same with a rigid body: replaces ParticleSystem(config) with a `solid` block + rigid_solver(ps, config)   main.py:69-71.
- * All four solvers couple to the body (wcsph_solver.py:118-127, dfsph_solver.py:204-212, pcisph_solver.py:200-211, iisph_solver.py:159-168);
- * not available on slab handles. */
+ * All four solvers couple to the body (wcsph_solver.py:118-127, dfsph_solver.py:204-212, pcisph_solver.py:200-211, iisph_solver.py:159-168).
+ * On slab handles: dfsph with two ghost columns only; the body is replicated on every rank, three small all-reduces per step (the fluid positions and
+ * densities the reference's index quirks read, the per-sample forces) keep every rank's copy bit-identical to the one-GPU run. */
 int sph_create_rigid(const SphConfig *cfg, const SphRigid *rigid, SphHandle **out);
 /* replaces rigid_solver.step()   rigid_solver.py:216-232 */
 int sph_rigid_step(SphHandle *h);
@@ -269,6 +270,7 @@ typedef struct SphComm {
     /* optional: exchange_counts with n (<= 8) ints per neighbour in one round trip -- the particle exchange of a step sends
      * (records, ghosts per column, migrants the sender keeps as ghosts per column) in ONE message; NULL: the library calls exchange_counts n times */
     int (*exchange_counts_n)(void *user, int32_t n, const int32_t *send_left, const int32_t *send_right, int32_t *recv_left, int32_t *recv_right);
+    size_t reduce_capacity;     /* doubles reduce_buf holds; 0 = 4.  A slab handle with a rigid body sums arrays of 4 x (rigid sample count) doubles through it */
 } SphComm;
 
 int sph_set_comm(SphHandle *h, const SphComm *comm);

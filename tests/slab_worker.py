@@ -50,6 +50,11 @@ def main():
             stats.append([st.n_div, st.n_dens, st.n_div_evals, float(st.div_first_err), float(st.div_err), float(st.dens_err), float(st.dt)])
     info = sim.sim.slab_info()
     info["owned_max"] = owned_max
+    body = None
+    if cfg.get("solid"):          # every rank holds the whole body: its state must be the same everywhere, and equal to the one-GPU run's
+        body = {"scalars": sim.sim.rigid_scalars(), "pos": sim.sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID).tolist()}
+        bodies = [None] * world if rank == 0 else None
+        dist.gather_object(body, bodies, dst=0)
     infos = [None] * world if rank == 0 else None
     dist.gather_object(info, infos, dst=0)
     pos = sim.gather(nat.F_POS)
@@ -59,7 +64,11 @@ def main():
     if rank == 0:
         if os.environ.get("SLAB_REF_NOSKIP") == "1":      # the one-GPU reference computes every tile in every density iteration
             os.environ["SPH_TILE_SKIP"] = "0"
-        ref = nat.Simulation(nat.config_from_dict(cfg, device=device, arith=args.arith))
+        rigid = None
+        if cfg.get("solid"):
+            from cfd_taichi_amd import mesh
+            rigid = mesh.rigid_from_config(cfg)
+        ref = nat.Simulation(nat.config_from_dict(cfg, device=device, arith=args.arith), rigid=rigid)
         ref_stats = []
         for _ in range(args.steps):
             if dfsph:
@@ -67,6 +76,8 @@ def main():
                 ref_stats.append([st.n_div, st.n_dens, st.n_div_evals, float(st.div_first_err), float(st.div_err), float(st.dens_err), float(st.dt)])
             else:
                 ref.step_wcsph(1)
+            if rigid and rigid.get("active"):
+                ref.rigid_step()
         rp, rv, rr = ref.download(nat.F_POS), ref.download(nat.F_VEL), ref.download(nat.F_RHO)
 
         def rel(a, b):
@@ -76,6 +87,8 @@ def main():
             "pos_equal": bool(np.array_equal(pos, rp)), "vel_equal": bool(np.array_equal(vel, rv)), "rho_equal": bool(np.array_equal(rho, rr)),
             "pos_rel_err": rel(pos, rp), "vel_rel_err": rel(vel, rv),
             "stats_equal": stats == ref_stats, "stats_last": stats[-1] if stats else None, "ref_stats_last": ref_stats[-1] if ref_stats else None,
+            "body_equal": None if body is None else bool(all(b == {"scalars": ref.rigid_scalars(), "pos": ref.download(nat.F_RIGID_POS, nat.SPECIES_RIGID).tolist()} for b in bodies)),
+            "body_centroid": None if body is None else body["scalars"]["centroid"], "body_omega": None if body is None else body["scalars"]["omega"],
             "comm": sim.comm.stats, "lib_comm": sim.sim.comm_stats(), "relaxed": [sim.sim.scalar(nat.S_ARITH_RELAXED), ref.scalar(nat.S_ARITH_RELAXED)],
         }
         with open(args.out, "w") as f:

@@ -38,7 +38,7 @@ def test_struct_layouts(tmp_path):
                                 ("SphStepStats", _native.SphStepStats, ["capped", "div_first_err", "dt", "lost"]),
                                 ("SphRigid", _native.SphRigid, ["points", "vertices", "rho_0", "pos_offset", "attitude_offset", "active"]),
                                 ("SphComm", _native.SphComm, ["exchange_counts", "exchange_buffers", "allreduce", "send_left", "recv_right", "capacity", "on_host",
-                                                              "stream_ordered", "allreduce_stream", "reduce_buf", "exchange_counts_n"])):
+                                                              "stream_ordered", "allreduce_stream", "reduce_buf", "exchange_counts_n", "reduce_capacity"])):
         for f in fields:
             probes.append(("offsetof(%s, %s)" % (struct, f), getattr(cls, f).offset))
     src = tmp_path / "sz.c"

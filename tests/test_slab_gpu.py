@@ -123,6 +123,23 @@ def test_relaxed_arithmetic_on_slabs(tmp_path, scene, world, steps, rebalance):
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "stats_last", "ref_stats_last")}
 
 
+@pytest.mark.parametrize("scene,world,steps,rebalance,overlap", [("dfsph_rigid_small", 2, 60, 0, 0), ("dfsph_rigid_small", 3, 120, 9, 0), ("dfsph_rigid_tilted", 3, 80, 0, 1),
+                                                                  ("dfsph_rigid_tilted", 4, 60, 7, 0)])
+def test_rigid_body_on_slabs(tmp_path, scene, world, steps, rebalance, overlap):
+    """SURVEY 8(e) last bullet, VERDICT r3 missing #5: two-way rigid coupling on a sharded dfsph run.  The body is replicated on every rank; what keeps
+    the copies identical -- and equal to the one-GPU run bit for bit -- are three small sums per step through the transport's reduce buffer: the positions
+    and densities of the fluid particles with original id < Nr (the reference's quirks index FLUID arrays with a rigid particle's local index,
+    ParticleSystem.py:440-442, solver_base.py:198-199) and the per-sample forces, each summed whole by the rank that owns the sample's cell column.
+    Fluid state, iteration counts and residuals, the body's centroid / omega / velocity / inertia and every sample position: equal on all ranks and to one GPU,
+    through wall contact, rotation and re-cuts, on the Morton curve (staged sweeps) too."""
+    r = run_slabs(tmp_path, scene, world, steps, rebalance=rebalance, overlap=overlap, env_extra={"SPH_CELL_ORDER": "morton"} if world == 3 else None)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err")}
+    assert r["stats_equal"], (r["stats_last"], r["ref_stats_last"])
+    assert r["body_equal"], (r["body_centroid"], r["body_omega"])
+    assert sum(s["owned"] for s in r["slabs"]) == r["n"]
+    assert any(abs(v) > 1e-4 for v in r["body_omega"]) or scene == "dfsph_rigid_small"
+
+
 def test_legacy_host_loops_on_slabs(tmp_path):
     """SPH_SLAB_LEGACY=1: the host-driven loops (one read-back + host all-reduce per residual) stay available and agree."""
     r = run_slabs(tmp_path, "dfsph_small", 2, 12, legacy=True)
