@@ -187,6 +187,7 @@ struct SphHandle {
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
     int *counters = nullptr, *counters_host = nullptr;
+    int *class_cnt = nullptr;     // k_classify_*: per-workgroup counts / offsets, kSlabCounted arrays of (capacity / 256) ints
     std::vector<int> init_ids;    // original ids of the particles this handle owns at t = 0
 
     // rigid body (config 5)
@@ -879,6 +880,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         for (int k = 0; k < 4; ++k)
             if ((rc = dalloc(h, &h->edge_list[k], n))) return rc;
         if ((rc = dalloc(h, &h->counters, kSlabCounters))) return rc;
+        if ((rc = dalloc(h, &h->class_cnt, (size_t)kSlabCounted * (n / kBlock + 2)))) return rc;
         HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * kSlabCounters, hipHostMallocDefault));
         // edge / interior split of the residual sweeps (dfsph, two ghost columns): tile flags and the edge-first tile order
         h->overlap = h->geom.layers == 2 && h->cfg.slab_overlap != 1;
@@ -997,9 +999,15 @@ RcclApi &rccl()
 {
     static RcclApi api = [] {
         RcclApi a;
+        // development override (SPH_DEV=1): another library with librccl's entry points -- tests/loopback_rccl.hip drives this transport
+        // with several handles of ONE process on one GPU.  sph_rccl_attach records it in the handle's overrides.
+        if (const char *dev = dev_env(nullptr, "SPH_RCCL_LIB")) {
+            a.lib = dlopen(dev, RTLD_NOW | RTLD_LOCAL);
+            if (!a.lib) { a.why = std::string("SPH_RCCL_LIB: ") + dlerror(); return a; }
+        }
         for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (a.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!a.lib) { a.why = "librccl.so not found"; return a; }
 #define SPH_RCCL_SYM(field, sym) a.field = (decltype(a.field))dlsym(a.lib, sym); if (!a.field) { a.why = std::string("missing symbol ") + sym; return a; }
@@ -1211,11 +1219,13 @@ int slab_exchange_particles(SphHandle *h)
     int own_ghost[2][2] = {{0, 0}, {0, 0}}, own_kept[2][2] = {{0, 0}, {0, 0}};      // [side][column]: ghost copies I sent, leavers I kept as ghosts
     int got_ghost[2][2] = {{0, 0}, {0, 0}}, got_kept[2][2] = {{0, 0}, {0, 0}};      // ... and what the neighbour on that side reported
     auto round = [&](int mode) -> int {
-        HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(int) * kSlabCounters, s));
         {
             ProfScope ps(h, K_SLAB);
-            hipLaunchKernelGGL(k_classify_slab, grid_for(n_res), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
-                               (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, h->counters, h->ds);
+            const int nblk = (int)grid_for(n_res).x;
+            hipLaunchKernelGGL(k_classify_count, dim3(nblk), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->id[h->icur], h->dead, nblk, h->class_cnt);
+            hipLaunchKernelGGL(k_classify_scan, dim3(kSlabCounted), dim3(kScanBlock), 0, s, nblk, h->class_cnt, h->counters);
+            hipLaunchKernelGGL(k_classify_write, dim3(nblk), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
+                               (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, nblk, h->class_cnt, h->ds);
         }
         int r;
         if ((r = read_counters(h))) return r;
@@ -1748,14 +1758,20 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_SLAB);
         // ordered edge lists: list k, column l (0 = next to the cut): ghost-left x_lo - 1 - l, send-left x_lo + l, send-right x_hi - 1 - l, ghost-right x_hi + l
         const SlabGeom &sg = h->geom;
+        LayerJobs jobs;
+        jobs.n = 0;
         for (int k = 0; k < 4; ++k) {
             if (!(k < 2 ? sg.has_left : sg.has_right)) continue;
             for (int l = 0; l < sg.layers; ++l) {
-                const int col = k == 0 ? sg.x_lo - 1 - l : k == 1 ? sg.x_lo + l : k == 2 ? sg.x_hi - 1 - l : sg.x_hi + l;
-                hipLaunchKernelGGL(k_layer_offsets, dim3(1), b, 0, s, c, h->cell_start, col, h->edge_off[2 * k + l]);
-                hipLaunchKernelGGL(k_layer_list, grid_for(c.gy * c.gz), b, 0, s, c, h->cell_start, col, h->edge_off[2 * k + l],
-                                   h->edge_list[k] + (l ? h->edge_n[k][0] : 0));
+                jobs.col[jobs.n] = k == 0 ? sg.x_lo - 1 - l : k == 1 ? sg.x_lo + l : k == 2 ? sg.x_hi - 1 - l : sg.x_hi + l;
+                jobs.off[jobs.n] = h->edge_off[2 * k + l];
+                jobs.list[jobs.n] = h->edge_list[k] + (l ? h->edge_n[k][0] : 0);
+                jobs.n += 1;
             }
+        }
+        if (jobs.n) {
+            hipLaunchKernelGGL(k_layer_offsets, dim3(jobs.n), dim3(kScanBlock), 0, s, c, h->cell_start, jobs);
+            hipLaunchKernelGGL(k_layer_list, dim3(grid_for(c.gy * c.gz).x, jobs.n), b, 0, s, c, h->cell_start, jobs);
         }
         if (dev_env(&h->overrides, "SPH_SLAB_CHECK")) {       // the host's bookkeeping of the column populations against the sorted arrays
             for (int k = 0; k < 4; ++k)
@@ -2205,12 +2221,15 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const bool ovl = two && slab_can_overlap(h);
     auto ghosts_v = [&](float4 *V) -> int { return (h->slab && !two) ? slab_exchange_field(h, 1, nullptr, V, nullptr) : SPH_OK; };
     // a residual sweep and the refresh of what it produced on the ghosts
-    auto residual_sweep = [&](bool dens, int gate, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}) -> int {
+    // reduce_mode >= 0 (the handles that hide the all-reduce): this slab's (sum, count) is reduced right behind the sweep's last tile -- in front of
+    // the halo's enqueue and of the wait for it, which only the NEXT sweep needs
+    auto residual_sweep = [&](bool dens, int gate, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, int reduce_mode = -1) -> int {
         int r = SPH_OK;
         if (ovl) {
             if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1, -1, un);
             HIP_TRY(h, hipEventRecord(h->ev_edge, s));
             if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2, -1, un);       // enqueued before the host turns to the transfer
+            if (reduce_mode >= 0 && (r = launch_finalize_reduce(h, reduce_mode))) return r;
             if ((r = slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, true))) return r;
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_halo, 0));                                       // the next sweep reads the ghosts
             return SPH_OK;
@@ -2244,16 +2263,14 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
     if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
     if (spec) {
-        if ((rc = residual_sweep(false, GATE_NONE))) return rc;                      // :398, evaluation 1
-        if ((rc = launch_finalize_reduce(h, FIN_DIV_FIRST))) return rc;
+        if ((rc = residual_sweep(false, GATE_NONE, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DIV_FIRST))) return rc;     // :398, evaluation 1
         for (int e = 1; e <= 15; ++e) {
             // the correction of evaluation e first (the GPU works on it while the host may block in a synchronous all-reduce) ...
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w});   // :402-405
             // ... then evaluation e's reduction and decision on the third stream
             if ((rc = launch_finalize_decide(h, e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e))) return rc;
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
-            if ((rc = residual_sweep(false, GATE_DIV, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e}))) return rc;   // :408, evaluation e + 1
-            if ((rc = launch_finalize_reduce(h, FIN_DIV_LOOP))) return rc;
+            if ((rc = residual_sweep(false, GATE_DIV, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e}, FIN_DIV_LOOP))) return rc;   // :408, evaluation e + 1
         }
         if ((rc = launch_finalize_decide(h, FIN_DIV_LOOP, 16))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
@@ -2275,8 +2292,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         for (int k = 0; k < chunk; ++k) {
             if (spec) {
                 ++d;
-                if ((rc = residual_sweep(true, GATE_DENS))) return rc;               // :227, evaluation d
-                if ((rc = launch_finalize_reduce(h, FIN_DENS))) return rc;
+                if ((rc = residual_sweep(true, GATE_DENS, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DENS))) return rc;      // :227, evaluation d
                 // D7 of iteration d runs iff iteration d runs: the decision of evaluation d - 1 (gate_hist starts open)
                 launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1));   // :229
                 if (rigid_coupled(h)) launch_rigid_force(h, GATE_HIST0 + ((d - 1) & 1));
@@ -3098,6 +3114,7 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     if (!h || !id128) return SPH_E_INVALID;
     RcclApi &n = rccl();
     if (!n.ok) return fail(h, SPH_E_STATE, "RCCL is not available: %s", n.why.c_str());
+    (void)dev_env(&h->overrides, "SPH_RCCL_LIB");       // reported by sph_overrides() when a stand-in transport library is in force
     if (h->native) return fail(h, SPH_E_STATE, "the native transport is already attached");
     if (capacity_bytes < 4096) return fail(h, SPH_E_INVALID, "halo buffers smaller than 4 KiB");
     HIP_TRY(h, hipSetDevice(h->device));

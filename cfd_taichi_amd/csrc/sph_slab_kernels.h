@@ -86,59 +86,141 @@ __device__ __forceinline__ void wave_count(int *__restrict__ counter, bool want)
 // move whole columns across a slab.  A leaver of a merged step that lands beyond the neighbour's own slab breaks the assumption: it
 // raises overflow bit 2 and the step fails loudly on every rank (check_overflow_all).
 constexpr int kSlabCounters = 16;
+constexpr int kSlabCounted = 11;          // counters a classification fills
 enum { kSlabMigrate = 1, kSlabGhosts = 2, kSlabKeep = 4 };
-__global__ __launch_bounds__(kBlock) void k_classify_slab(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const float4 *__restrict__ V,
-                                                          const float *__restrict__ warm, int *__restrict__ id, int *__restrict__ dead,
-                                                          float4 *__restrict__ send_left, float4 *__restrict__ send_right, int cap_records,
-                                                          int *__restrict__ counters, DevScalars *__restrict__ ds)
+// What becomes of one resident slot.  which[k] = 1 if the slot counts towards counter k.
+struct SlabClass {
+    float4 p;
+    int pid;
+    bool go_left, go_right, dies, to_left, to_right;
+    int gl, gr, kl, kr;       // ghost copy for the left / right neighbour, kept as my ghost on the left / right: column 1 or 2 (0: no)
+    bool beyond;              // merged exchange only: a leaver that lands outside what the neighbour can take (overflow bit 2)
+};
+__device__ __forceinline__ SlabClass classify_slot(const Consts &c, const SlabGeom &g, int mode, int s, const float4 *__restrict__ P, const int *__restrict__ id,
+                                                   const int *__restrict__ dead)
 {
-    const int s = blockIdx.x * kBlock + threadIdx.x;
+    SlabClass k;
     const bool in = s < c.n;
     const bool migrate = (mode & kSlabMigrate) != 0, ghosts = (mode & kSlabGhosts) != 0, keep = (mode & kSlabKeep) != 0;
-    const int pid = in ? id[s] : 0;
+    k.pid = in ? id[s] : 0;
     const bool skip = in && !migrate && dead[s] != 0;        // second round: slots the first round killed
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool go_left = false, go_right = false, dies = false;
-    int gl = 0, gr = 0, kl = 0, kr = 0;                      // ghost copy for the left / right neighbour, kept as my ghost on the left / right: column 1 or 2 (0: no)
+    k.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    k.go_left = k.go_right = k.dies = k.beyond = false;
+    k.gl = k.gr = k.kl = k.kr = 0;
     if (in && !skip) {
-        if (pid < 0) {
-            dies = migrate;                                  // last step's ghost
+        if (k.pid < 0) {
+            k.dies = migrate;                                // last step's ghost
         } else {
-            p = P[s];
+            k.p = P[s];
             // "is an edge particle" must be decided by the cell the sort bins the particle into (the ordered edge lists enumerate CELL LISTS):
             // the reference's 1-D index, ParticleSystem.py:486-494; a particle outside the grid sits in no cell of a slab handle (strict_cells)
             int cx, cy, cz;
-            const int cid = cell_id_of(c, p.x, p.y, p.z, cx, cy, cz);
+            const int cid = cell_id_of(c, k.p.x, k.p.y, k.p.z, cx, cy, cz);
             const int col = cid < c.C ? cid % c.gx : -1;
             if (migrate) {
-                go_left = g.has_left && cx < g.x_lo;
-                go_right = !go_left && g.has_right && cx >= g.x_hi;
+                k.go_left = g.has_left && cx < g.x_lo;
+                k.go_right = !k.go_left && g.has_right && cx >= g.x_hi;
             }
-            if (go_left || go_right) {
+            if (k.go_left || k.go_right) {
                 if (keep && col >= 0) {
-                    if (go_left && col >= g.x_lo - g.layers && col < g.x_lo) kl = g.x_lo - col;
-                    if (go_right && col >= g.x_hi && col < g.x_hi + g.layers) kr = col - g.x_hi + 1;
+                    if (k.go_left && col >= g.x_lo - g.layers && col < g.x_lo) k.kl = g.x_lo - col;
+                    if (k.go_right && col >= g.x_hi && col < g.x_hi + g.layers) k.kr = col - g.x_hi + 1;
                     // merged exchange only: a leaver must land inside the neighbour's slab, clear of the columns it copies to ITS other neighbour
-                    if ((go_left && cx < g.far_left + g.layers && g.far_left > 0) || (go_right && cx >= g.far_right - g.layers && g.far_right < c.gx)) atomicOr(&ds->overflow, 4);
+                    k.beyond = (k.go_left && cx < g.far_left + g.layers && g.far_left > 0) || (k.go_right && cx >= g.far_right - g.layers && g.far_right < c.gx);
                 }
-                dies = kl == 0 && kr == 0;
+                k.dies = k.kl == 0 && k.kr == 0;
             } else if (ghosts && col >= 0) {
-                if (g.has_left && col >= g.x_lo && col < g.x_lo + g.layers) gl = col - g.x_lo + 1;
-                if (g.has_right && col < g.x_hi && col >= g.x_hi - g.layers) gr = g.x_hi - col;
+                if (g.has_left && col >= g.x_lo && col < g.x_lo + g.layers) k.gl = col - g.x_lo + 1;
+                if (g.has_right && col < g.x_hi && col >= g.x_hi - g.layers) k.gr = g.x_hi - col;
             }
         }
     }
-    const bool to_left = go_left || gl != 0, to_right = go_right || gr != 0;
-    const int sl = wave_alloc(&counters[0], to_left);
-    const int sr = wave_alloc(&counters[1], to_right);
-    wave_count(&counters[2], dies);
-    wave_count(&counters[3], gl == 1); wave_count(&counters[4], gl == 2); wave_count(&counters[5], kl == 1); wave_count(&counters[6], kl == 2);
-    wave_count(&counters[7], gr == 1); wave_count(&counters[8], gr == 2); wave_count(&counters[9], kr == 1); wave_count(&counters[10], kr == 2);
-    if (to_left && sl < cap_records) write_record(send_left, sl, p, V[s], warm ? warm[s] : 0.f, go_left ? pid : ~pid);
-    if (to_right && sr < cap_records) write_record(send_right, sr, p, V[s], warm ? warm[s] : 0.f, go_right ? pid : ~pid);
-    if (in && migrate) {
-        dead[s] = dies ? 1 : 0;
-        if (kl != 0 || kr != 0) id[s] = ~pid;
+    k.to_left = k.go_left || k.gl != 0;
+    k.to_right = k.go_right || k.gr != 0;
+    return k;
+}
+__device__ __forceinline__ bool slab_class_counts(const SlabClass &k, int q)
+{
+    switch (q) {
+    case 0: return k.to_left;
+    case 1: return k.to_right;
+    case 2: return k.dies;
+    case 3: return k.gl == 1;
+    case 4: return k.gl == 2;
+    case 5: return k.kl == 1;
+    case 6: return k.kl == 2;
+    case 7: return k.gr == 1;
+    case 8: return k.gr == 2;
+    case 9: return k.kr == 1;
+    default: return k.kr == 2;
+    }
+}
+// The classification runs in three launches WITHOUT same-address atomics.  (One atomicAdd per wave and counter on eleven shared words was
+// 607 us per step on a rank of config 4 at 8 slabs -- ~50 k adds that the memory side serialises at ~12 ns each, DESIGN.md section 6 -- where
+// the passes below take ~25 us together; the record order in the message is now the slot order, i.e. deterministic.)
+//   k_classify_count   per workgroup: how many of its slots count towards each of the eleven counters     -> blk_cnt[q * nblk + blk]
+//   k_classify_scan    one workgroup per counter: exclusive scan over the workgroups (offsets of counters 0 and 1 = the records' places
+//                      in the two messages) and the totals                                                -> blk_cnt in place, counters[q]
+//   k_classify_write   the same classification again; records written at offset of the workgroup + rank inside it; dead[] / id[] updated
+__global__ __launch_bounds__(kBlock) void k_classify_count(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const int *__restrict__ id,
+                                                           const int *__restrict__ dead, int nblk, int *__restrict__ blk_cnt)
+{
+    __shared__ int s_cnt[kBlock / 64][kSlabCounted];
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const SlabClass k = classify_slot(c, g, mode, s, P, id, dead);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kSlabCounted; ++q) {
+        const int n = __popcll(__ballot(slab_class_counts(k, q)));
+        if (lane == 0) s_cnt[w][q] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSlabCounted) {
+        int t = 0;
+        for (int ww = 0; ww < kBlock / 64; ++ww) t += s_cnt[ww][threadIdx.x];
+        blk_cnt[(size_t)threadIdx.x * nblk + blockIdx.x] = t;
+    }
+}
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void k_classify_scan(int nblk, int *__restrict__ blk_cnt, int *__restrict__ counters)
+{
+    __shared__ int s_w[kScanBlock / 64];
+    int *a = blk_cnt + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + kScanBlock - 1) / kScanBlock;
+    const int lo = min((int)threadIdx.x * per, nblk), hi = min(lo + per, nblk);
+    int t = 0;
+    for (int i = lo; i < hi; ++i) t += a[i];
+    const int inc = wave_inclusive_scan(t);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int before = inc - t, total = 0;
+    for (int q = 0; q < kScanBlock / 64; ++q) { if (q < w) before += s_w[q]; total += s_w[q]; }
+    if (blockIdx.x < 2)                               // the two allocating counters: exclusive offsets in place
+        for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = before; before += v; }
+    if (threadIdx.x == 0) counters[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kBlock) void k_classify_write(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const float4 *__restrict__ V,
+                                                           const float *__restrict__ warm, int *__restrict__ id, int *__restrict__ dead,
+                                                           float4 *__restrict__ send_left, float4 *__restrict__ send_right, int cap_records,
+                                                           int nblk, const int *__restrict__ blk_off, DevScalars *__restrict__ ds)
+{
+    __shared__ int s_cnt[kBlock / 64][2];
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    const bool in = s < c.n;
+    const SlabClass k = classify_slot(c, g, mode, s, P, id, dead);
+    if (k.beyond) atomicOr(&ds->overflow, 4);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long ml = __ballot(k.to_left), mr = __ballot(k.to_right);
+    if (lane == 0) { s_cnt[w][0] = __popcll(ml); s_cnt[w][1] = __popcll(mr); }
+    __syncthreads();
+    int sl = blk_off[blockIdx.x] + __popcll(ml & ((1ull << lane) - 1ull)), sr = blk_off[(size_t)nblk + blockIdx.x] + __popcll(mr & ((1ull << lane) - 1ull));
+    for (int q = 0; q < w; ++q) { sl += s_cnt[q][0]; sr += s_cnt[q][1]; }
+    if (k.to_left && sl < cap_records) write_record(send_left, sl, k.p, V[s], warm ? warm[s] : 0.f, k.go_left ? k.pid : ~k.pid);
+    if (k.to_right && sr < cap_records) write_record(send_right, sr, k.p, V[s], warm ? warm[s] : 0.f, k.go_right ? k.pid : ~k.pid);
+    if (in && (mode & kSlabMigrate)) {
+        dead[s] = k.dies ? 1 : 0;
+        if (k.kl != 0 || k.kr != 0) id[s] = ~k.pid;
     }
 }
 
@@ -160,41 +242,47 @@ __global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restr
 // Ordered list of the sorted slots that live in cell column `layer_cx`: cells ascending (y, then z), slots
 // ascending inside a cell.  The sender's list for its edge column and the receiver's list for the matching ghost
 // column enumerate the same particles in the same order, because both sides sort by (cell, true id).
-__global__ __launch_bounds__(kBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, int layer_cx, int *__restrict__ off)
+// All (up to eight) edge columns of a step in one launch each: one workgroup per column scans the column's cells -- counts first (coalesced
+// over the cells), then each thread the offsets of its run of consecutive cells.  (One single-workgroup launch per column, 256 cells per
+// trip, was 56 us x 8 per step on config 4's 153 x 113 cell cut.)
+struct LayerJobs { int n; int col[8]; int *off[8]; int *list[8]; };
+__global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, LayerJobs jobs)
 {
-    // single block: exclusive scan of the per-cell counts of the column, chunks of 256 with a carry
-    __shared__ int wsum[kBlock / 64];
-    __shared__ int carry_s;
+    __shared__ int s_w[kScanBlock / 64];
+    const int layer_cx = jobs.col[blockIdx.x];
+    int *__restrict__ off = jobs.off[blockIdx.x];
     const int ncol = c.gy * c.gz;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < ncol; base += kBlock) {
-        int k = base + threadIdx.x;
+    const bool valid = layer_cx >= 0 && layer_cx < c.gx;
+    for (int k = threadIdx.x; k < ncol; k += kScanBlock) {
         int v = 0;
-        if (k < ncol && layer_cx >= 0 && layer_cx < c.gx) {
-            int y = k / c.gz, z = k - y * c.gz;
+        if (valid) {
+            const int y = k / c.gz, z = k - y * c.gz;
             const int slot = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
             v = cell_start[slot + 1] - cell_start[slot];
         }
-        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        int inc = wave_inclusive_scan(v);
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int q = 0; q < w; ++q) woff += wsum[q];
-        int carry = carry_s;
-        if (k < ncol) off[k] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == kBlock - 1) carry_s = carry + woff + inc;
-        __syncthreads();
+        off[k] = v;
     }
-    if (threadIdx.x == 0) off[ncol] = carry_s;
+    __syncthreads();
+    const int per = (ncol + kScanBlock - 1) / kScanBlock;
+    const int lo = min((int)threadIdx.x * per, ncol), hi = min(lo + per, ncol);
+    int t = 0;
+    for (int i = lo; i < hi; ++i) t += off[i];
+    const int inc = wave_inclusive_scan(t);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int before = inc - t, total = 0;
+    for (int q = 0; q < kScanBlock / 64; ++q) { if (q < w) before += s_w[q]; total += s_w[q]; }
+    for (int i = lo; i < hi; ++i) { const int v = off[i]; off[i] = before; before += v; }
+    if (threadIdx.x == 0) off[ncol] = total;
 }
 
 // (a side's two columns share one list: the second column's entries start at list + count of the first)
-__global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__restrict__ cell_start, int layer_cx, const int *__restrict__ off,
-                                                       int *__restrict__ list)
+__global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__restrict__ cell_start, LayerJobs jobs)
 {
+    const int layer_cx = jobs.col[blockIdx.y];
+    const int *__restrict__ off = jobs.off[blockIdx.y];
+    int *__restrict__ list = jobs.list[blockIdx.y];
     int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= c.gy * c.gz || layer_cx < 0 || layer_cx >= c.gx) return;
     int y = k / c.gz, z = k - y * c.gz;

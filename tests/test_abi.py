@@ -153,3 +153,21 @@ def test_development_overrides_need_sph_dev():
     # every knob of the library goes through the gate: no bare getenv("SPH_...") is left in the product sources
     text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
     assert re.findall(r'[^_a-z]getenv\("SPH_(?!DEV")', text) == []
+
+
+def test_loopback_stand_in_exports_what_the_native_transport_binds():
+    """tests/loopback_rccl.hip (test infrastructure: the in-process stand-in for librccl, loaded through the development override SPH_RCCL_LIB)
+    must export every entry point csrc/sph_mi355x.hip's RcclApi looks up -- otherwise the GPU suite's loopback tests would fall back to nothing."""
+    import ctypes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("loopback_worker", os.path.join(ROOT, "tests", "loopback_worker.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    so = ctypes.CDLL(mod.shim_path(build=True))
+    text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
+    bound = sorted(set(re.findall(r'SPH_RCCL_SYM\([A-Za-z]+, "(nccl[A-Za-z]+)"\)', text)))
+    assert len(bound) == 9, bound
+    for name in bound:
+        assert hasattr(so, name), name
+    # the override is gated like every other: the loader reads SPH_RCCL_LIB through dev_env
+    assert 'dev_env(nullptr, "SPH_RCCL_LIB")' in text

@@ -140,6 +140,42 @@ def test_rigid_body_on_slabs(tmp_path, scene, world, steps, rebalance, overlap):
     assert any(abs(v) > 1e-4 for v in r["body_omega"]) or scene == "dfsph_rigid_small"
 
 
+def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0, arith=0, env_extra=None):
+    out = tmp_path / ("loopback_%s_%d_%d_%d%d%d.json" % (os.path.basename(scene), world, rebalance, layers, overlap, arith))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "loopback_worker.py"), "--scene", scene, "--world", str(world), "--steps", str(steps),
+           "--rebalance", str(rebalance), "--layers", str(layers), "--overlap", str(overlap), "--arith", str(arith), "--out", str(out)]
+    env = dict(os.environ, SPH_SLAB_CHECK="1")
+    env.update(env_extra or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return json.loads(out.read_text())
+
+
+@pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap,order", [
+    ("dfsph_small", 2, 25, 0, 0, 0, "morton"), ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
+    ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 3, 30, 0, 0, 1, None), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, "morton"),
+    ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None)])
+def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps, rebalance, layers, overlap, order):
+    """The discipline a multi-GPU node runs -- the library's NATIVE transport: ncclSend / ncclRecv / ncclAllReduce enqueued by the library itself,
+    no host wait between the sweeps, the halo of the edge tiles on its own stream under the interior tiles, the residual's all-reduce and the loop
+    decision on a third stream under the next correction sweep (the divergence loop's correction running ahead of its decision) -- cannot open two ranks
+    on a one-GPU box with the real librccl.  tests/loopback_rccl.hip stands in for the nine entry points the library binds (development override
+    SPH_RCCL_LIB): the ranks are handles of ONE process stepped by one thread each, transfers are device-to-device copies ordered by HIP events the
+    way RCCL orders its kernels.  What the gloo tests cannot see -- a missing dependency between the three streams, which gloo's host waits paper over
+    -- shows here as a difference to the one-GPU run.  Fluid state, iteration counts, residuals (and the rigid body) bit for bit; re-cuts, both
+    ghost-column protocols, the split on and off, every sharded solver."""
+    r = run_loopback(tmp_path, scene, world, steps, rebalance=rebalance, layers=layers, overlap=overlap, env_extra={"SPH_CELL_ORDER": order} if order else None)
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "slabs")}
+    assert r["stats_equal"] and r["stats_same_on_all_ranks"], (r["stats_last"], r["ref_stats_last"])
+    assert r["body_equal"] in (None, True)
+    assert sum(s["owned"] for s in r["slabs"]) == r["n"]
+    assert all(any(o.startswith("SPH_RCCL_LIB=") for o in s["overrides"]) for s in r["slabs"])          # the stand-in is a named override, never silent
+    if "dfsph" in scene:
+        two = layers != 1
+        for s in r["slabs"]:
+            assert s["ghost_columns"] == (2 if two else 1) and s["halo_overlapped"] == (two and overlap == 0) and s["allreduce_hidden"] == (two and overlap == 0), s
+
+
 def test_legacy_host_loops_on_slabs(tmp_path):
     """SPH_SLAB_LEGACY=1: the host-driven loops (one read-back + host all-reduce per residual) stay available and agree."""
     r = run_slabs(tmp_path, "dfsph_small", 2, 12, legacy=True)
