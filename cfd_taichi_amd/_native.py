@@ -238,7 +238,7 @@ def load(build_if_missing=True):
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.sph_comm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ci]
-    lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     lib.sph_download_local.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.sph_download_ids.argtypes = [vp, vp, ctypes.c_size_t]
     _lib = lib
@@ -313,14 +313,14 @@ def rccl_unique_id():
     return buf.raw
 
 
-def replan_slabs(column_histogram, old_cuts):
-    """Host-only: the re-balancing rule of a slab run (new cuts from a per-column particle histogram)."""
+def replan_slabs(column_histogram, old_cuts, ghost_layers=0):
+    """Host-only: the re-balancing rule of a slab run (new cuts from a per-column particle histogram; ghost_layers > 0 weighs in the ghosts of every cut)."""
     lib = load()
     gx, nslab = len(column_histogram), len(old_cuts) - 1
     hist = (ctypes.c_int64 * gx)(*[int(v) for v in column_histogram])
     old = (ctypes.c_int32 * (nslab + 1))(*[int(v) for v in old_cuts])
     new = (ctypes.c_int32 * (nslab + 1))()
-    rc = lib.sph_replan_slabs(hist, gx, nslab, old, new)
+    rc = lib.sph_replan_slabs(hist, gx, nslab, old, int(ghost_layers), new)
     if rc != SPH_OK:
         raise SphError(rc, (lib.sph_last_error(None) or b"").decode())
     return list(new)

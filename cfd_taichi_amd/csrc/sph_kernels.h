@@ -51,15 +51,26 @@ struct TilePhase { const int *order; int ntiles, phase; };
 // (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
 struct SpecSave { float4 *v; float *w; };
 struct SpecUndo { float4 *v_dst; const float4 *v_src; float *w_dst; const float *w_src; int eval; };
+__device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread);
 __device__ __forceinline__ void spec_undo(const Consts &c, const SpecUndo &un, const DevScalars *__restrict__ ds, const TilePhase &tp)
 {
-    if (!un.v_dst || tp.phase == 2 || ds->stop_at != un.eval) return;          // (a split sweep: its first launch undoes)
-    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (!un.v_dst || tp.phase == 2 || ds->stop_at != un.eval) return;          // (a split sweep over a tile order: its first launch, a full grid, undoes)
+    int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (tp.phase >= 5) {                                                        // a split sweep over tile RANGES: each launch undoes its own tiles
+        const int tile = sweep_tile(tp, false);
+        if (tile < 0) return;
+        i = tile * kBlock + (int)threadIdx.x;
+    }
     if (i < c.n) { un.v_dst[i] = un.v_src[i]; un.w_dst[i] = un.w_src[i]; }
 }
+// phases 5 / 6 (slab handles on the curve, whose storage order keeps the interior columns in front: slab_cell_order): order[0] = the number of
+// tiles that hold interior particles only (k_tile_split).  5 = the tiles from there on (edge columns, ghosts, particles outside the grid),
+// 6 = the interior tiles; the grids are sized by the host's bounds on that number, surplus workgroups leave at once.
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
 {
     if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
+    if (tp.phase == 5) { const int s0 = tp.order[0], ne = tp.ntiles - s0; return (int)blockIdx.x < ne ? s0 + (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ne)) : -1; }
+    if (tp.phase == 6) { const int ni = tp.order[0]; return (int)blockIdx.x < ni ? (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ni)) : -1; }
     if (tp.phase == 3) return spread ? (int)blockIdx.x : tp.order[xcd_sweep_block(blockIdx.x, gridDim.x)];
     const int ne = tp.order[tp.ntiles];
     if (tp.phase == 1) return (int)blockIdx.x < ne ? tp.order[blockIdx.x] : -1;
@@ -118,9 +129,15 @@ __device__ __forceinline__ int slot_of_parts(const Consts &c, SlotPart x, SlotPa
 {
     return (c.tile_rank[x.tile + y.tile + z.tile] << (3 * c.tbits)) | (x.code | y.code | z.code);
 }
+// Slab handles on the curve store their cell columns in GROUPS (Consts.xmap, slab_cell_order() in sph_mi355x.hip): the interior columns along
+// the curve first, then the two columns next to each cut, then the ghost columns, each group in cell tiles of its own -- so that a 256-particle
+// tile never mixes ghosts with owned particles (a ghost's lane does no work in most sweeps: mixed tiles made a sweep cost what the RESIDENT
+// particles cost, a third more than the owned ones on config 4 at 8 slabs) and the tiles that wait for no halo are exactly the interior ones.
+// Returns -1 for a column that is not resident on this slab: callers treat the cell as empty.
 __device__ __forceinline__ int cell_slot_xyz(const Consts &c, int x, int y, int z, int id)
 {
     if (c.order != CELL_ORDER_TILED) return id;
+    if (c.xmap) { x = c.xmap[x]; if (x < 0) return -1; }
     return slot_of_parts(c, slot_part(c, x, 0, 1), slot_part(c, y, 1, c.tnxz), slot_part(c, z, 2, c.tnx));
 }
 
@@ -130,7 +147,8 @@ __device__ __forceinline__ int cell_slot(const Consts &c, int id)
     if (id >= c.C) return c.S;
     if (c.order != CELL_ORDER_TILED) return id;
     const int q = id / c.gx;                                // id = x + z*gx + y*gx*gz     ParticleSystem.py:102
-    return cell_slot_xyz(c, id - q * c.gx, q / c.gz, q % c.gz, id);
+    const int slot = cell_slot_xyz(c, id - q * c.gx, q / c.gz, q % c.gz, id);
+    return slot < 0 ? c.S : slot;                           // (a column this slab does not hold: binned nowhere)
 }
 
 // `dead` (multi-GPU only): slots whose particle left the slab or was last step's ghost take no part in
@@ -670,6 +688,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                             const int x = cx + dx, y = cy + dy, z = cz + dz;
                             if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
                             const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                            if (slot < 0) continue;
                             int hq = stage_hash(slot);
                             for (int probe = 0; probe < kStageHash; ++probe) {
                                 const int was = atomicCAS(&s_key[hq], -1, slot);
@@ -767,8 +786,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) return;   // :453-456
         const int cid = x + y * c.sy + z * c.sz;
         const int slot = cell_slot_xyz(c, x, y, z, cid);
-        const int a = cell_start[slot], nf = min(cell_start[slot + 1] - a, 0xffff);
-        const int lbase = staged ? stage_lookup(s_key, s_base, slot, ds) : 0;
+        int a = 0, nf = 0, lbase = 0;
+        if (slot >= 0) {                                                        // (< 0: a column this slab does not hold -- no fluid there for us)
+            a = cell_start[slot]; nf = min(cell_start[slot + 1] - a, 0xffff);
+            lbase = staged ? stage_lookup(s_key, s_base, slot, ds) : 0;
+        }
         int wa = 0, nw = 0;
         if (c.boundary_handle) { wa = wcell_start[cid]; nw = wcell_start[cid + 1] - wa; }
         e = make_uint4((uint32_t)a, (uint32_t)nf | ((uint32_t)lbase << 16), (uint32_t)wa, (uint32_t)nw);
@@ -886,8 +908,10 @@ __device__ __forceinline__ CellEntry split_cell_entry(const Consts &c, const int
     if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) return e;     // :453-456
     const int cid = x + y * c.sy + z * c.sz;
     e.slot = cell_slot_xyz(c, x, y, z, cid);
-    e.a = cell_start[e.slot];
-    e.nf = cell_start[e.slot + 1] - e.a;
+    if (e.slot >= 0) {
+        e.a = cell_start[e.slot];
+        e.nf = cell_start[e.slot + 1] - e.a;
+    }
     if (c.boundary_handle) { e.wa = wcell_start[cid]; e.nw = wcell_start[cid + 1] - e.wa; }
     return e;
 }
@@ -2130,6 +2154,15 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     const bool split = STAGED && c.kr_split;
     // change propagation in the density loop (stage_sources_flagged); with a body in the lists too: its term is V_r rho0 k_i / rho_i grad W, zero with k_i
     const bool track = MODE == CORR_DENS && STAGED && wave_dirty != nullptr;
+    // Two-column slab handles store the ghost columns in tiles of their own (slab_cell_order): a tile in which nobody has a list -- ghosts of the
+    // outer column -- has nothing to correct and nothing to stage (in place: Vin == Vout there, and nobody reads an outer ghost's velocity)
+    if (c.ghost_walk && Vin == Vout && !__syncthreads_or(live && (cw & 0x7fffffff) != 0)) {
+        if (track) {
+            if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
+            if (live) changed8[i] = 0;
+        }
+        return;
+    }
     bool staged;
     if (track) {
         const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk)
@@ -2276,6 +2309,13 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
         }
     }
     SPH_SWEEP_PROLOGUE_B(QUAD, tile)
+    // ... and a tile without an owned particle -- ghosts only -- computes no residual (the ghosts' values arrive with the halo): no staging, a zero partial
+    if (c.ghost_walk && !__syncthreads_or(live && !ghost)) {
+        if (QUAD) block_partial_mean_quad(blk, 0.0, 0, owner, psum, pcnt, ff.ticket != nullptr);
+        else block_partial_mean(blk, 0.0, 0, psum, pcnt, ff.ticket != nullptr);
+        if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
+        return;
+    }
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")

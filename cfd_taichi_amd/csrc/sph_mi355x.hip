@@ -110,6 +110,7 @@ struct SphHandle {
     std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
+    int *xmap = nullptr;                 // Consts.xmap (slab handles on the curve)
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
     int quad_below = 65536;              // = kQuadBelow (SPH_QUAD_BELOW: experiments)
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
@@ -175,6 +176,10 @@ struct SphHandle {
     hipEvent_t ev_red = nullptr, ev_dec = nullptr;
     float4 *spec_v = nullptr; float *spec_w = nullptr;      // what a divergence correction that ran ahead of its loop decision overwrote (SpecSave / SpecUndo)
     int *tile_flag = nullptr, *tile_order = nullptr;
+    // handles on the curve: the split is two RANGES of tiles (slab_cell_order keeps the interior columns in front): tile_split[0] = interior tiles
+    // (k_tile_split); the host sizes the two launches by its bounds on that number
+    bool range_split = false, slab_groups = false;      // SPH_SLAB_GROUPS=1 (development): the columns stored in groups (slab_cell_order), the split by tile ranges -- measured, no gain: off
+    int *tile_split = nullptr, first_edge_slot = 0, split_lo = 0, split_hi = 0;
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
     // native transport (sph_rccl_attach): the library drives RCCL itself on its stream
@@ -303,6 +308,10 @@ inline float host_cubic_w(float r, float h, float kw)
     return ret;
 }
 
+// ghost cell columns per side: two by default for dfsph (one halo refresh per solver iteration, see step_dfsph_device_loops); the other solvers
+// keep the one-column protocol
+inline int slab_layers_of(const SphConfig &cf) { return cf.slab_ghost_layers == 1 ? 1 : (cf.slab_ghost_layers == 2 || cf.solver == SPH_SOLVER_DFSPH) ? 2 : 1; }
+
 // Every slab is at least three columns wide: with two ghost columns per side the merged particle exchange needs ghost layers + 1 (a particle
 // that arrives from one neighbour must not land in the columns copied to the other, see k_classify_slab).
 constexpr int kMinSlabColumns = 3;
@@ -320,14 +329,62 @@ void cuts_from_histogram(const std::vector<long long> &hist, long long N, int gx
     for (; k < nslab; ++k) cut[k] = gx;
 }
 
+// Cuts that balance what a slab COSTS, not what it owns.  A rank's step is its owned particles plus its ghosts: the ghosts of the inner column run
+// the density pass and every correction sweep, all of them sit in the staged neighbourhoods, the tiles they share with owned particles run at
+// part occupancy, and each cut brings a halo's fixed costs.  Measured on config 4 at 8 slabs (one rank alone on a GPU, tools/loopback_replay.sh):
+// the two end ranks, one cut each, 5.5-5.7 ms per step, the six ranks between them 6.0-6.7 ms at the same owned count -- 200 k more ghosts cost
+// what 200 k owned particles cost.  So: load of slab [y, x) = its particles + the particles of the `layers` columns beyond each cut it has, and
+// the cuts minimise the largest load (then keep the smallest slab as large as they can, then the sum of squares), by dynamic programming over the cut positions (slabs x columns^2 steps, host,
+// identical on every rank: integers only).  lo[k] <= cut[k] <= hi[k]; every slab >= kMinSlabColumns wide.  layers = 0: plain equal counts.
+void balanced_cuts(const std::vector<long long> &hist, int gx, int nslab, int layers, const std::vector<int> &lo, const std::vector<int> &hi, std::vector<int> &cut)
+{
+    std::vector<long long> pre((size_t)gx + 1, 0);
+    for (int x = 0; x < gx; ++x) pre[(size_t)x + 1] = pre[(size_t)x] + hist[(size_t)x];
+    auto load = [&](int r, int y, int x) {
+        long long v = pre[(size_t)x] - pre[(size_t)y];
+        if (r > 0) v += pre[(size_t)y] - pre[(size_t)std::max(y - layers, 0)];
+        if (r < nslab - 1) v += pre[(size_t)std::min(x + layers, gx)] - pre[(size_t)x];
+        return v;
+    };
+    struct Val { long long mx, mn; double sq; int from; };          // largest load, smallest OWNED count (no slab left empty for a tie), sum of squares
+    const Val none{-1, 0, 0.0, -1};
+    std::vector<std::vector<Val>> best((size_t)nslab + 1, std::vector<Val>((size_t)gx + 1, none));
+    best[0][0] = Val{0, 0x7fffffffffffffffLL, 0.0, -1};
+    for (int k = 1; k <= nslab; ++k)
+        for (int x = lo[(size_t)k]; x <= hi[(size_t)k]; ++x) {
+            Val b = none;
+            for (int y = lo[(size_t)k - 1]; y <= std::min(hi[(size_t)k - 1], x - kMinSlabColumns); ++y) {
+                const Val &p = best[(size_t)k - 1][(size_t)y];
+                if (p.mx < 0) continue;
+                const long long l = load(k - 1, y, x);
+                const Val c{std::max(p.mx, l), std::min(p.mn, pre[(size_t)x] - pre[(size_t)y]), p.sq + (double)l * (double)l, y};
+                if (b.mx < 0 || c.mx < b.mx || (c.mx == b.mx && (c.mn > b.mn || (c.mn == b.mn && c.sq < b.sq)))) b = c;
+            }
+            best[(size_t)k][(size_t)x] = b;
+        }
+    cut.assign((size_t)nslab + 1, 0);
+    cut[(size_t)nslab] = gx;
+    for (int k = nslab; k >= 1; --k) cut[(size_t)k - 1] = best[(size_t)k][(size_t)cut[(size_t)k]].from;
+}
+
 // Re-balancing ("re-chosen every M steps because a dam break migrates mass along x"):
 // new equal-count cuts from the current global column histogram, clamped so that (a) every slab keeps >= 2
 // columns and (b) a particle's new owner is its current rank or a direct neighbour -- the migration step only
 // talks to the left and right neighbour.  A particle resident on rank r sits in columns
 // [old[r] - 1, old[r+1]] (it may have crossed one column since the last exchange), hence
 // old[k-1] + 1 <= new[k] <= old[k+1] - 1.
-void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, const std::vector<int> &old_cut, std::vector<int> &cut)
+void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, const std::vector<int> &old_cut, std::vector<int> &cut, int layers = 0)
 {
+    if (layers > 0) {          // by cost (balanced_cuts), within the same bounds
+        std::vector<int> lo((size_t)nslab + 1, 0), hi((size_t)nslab + 1, gx);
+        lo[(size_t)nslab] = gx; hi[0] = 0;
+        for (int k = 1; k < nslab; ++k) {
+            lo[(size_t)k] = std::max(old_cut[(size_t)k - 1] + 1, kMinSlabColumns * k);
+            hi[(size_t)k] = std::min(old_cut[(size_t)k + 1] - 1, gx - kMinSlabColumns * (nslab - k));
+        }
+        balanced_cuts(hist, gx, nslab, layers, lo, hi, cut);
+        return;
+    }
     long long N = 0;
     for (long long v : hist) N += v;
     cuts_from_histogram(hist, N, gx, nslab, cut);
@@ -342,7 +399,7 @@ void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, con
 // Equal-count cuts along the cell x index, computed identically on every rank from the full lattice:
 // slab k owns cell columns [cut[k], cut[k+1]).
 bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, int nslab, std::vector<int> &col, std::vector<int> &cut,
-                    std::string &why)
+                    std::string &why, int layers = 0)
 {
     std::vector<long long> hist((size_t)gx, 0);
     col.resize((size_t)N);
@@ -358,6 +415,13 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
         why = buf;
         return false;
     }
+    if (layers > 0) {                   // by cost: owned particles + the ghosts of every cut (balanced_cuts)
+        std::vector<int> lo((size_t)nslab + 1, 0), hi((size_t)nslab + 1, gx);
+        lo[(size_t)nslab] = gx; hi[0] = 0;
+        for (int k = 1; k < nslab; ++k) { lo[(size_t)k] = kMinSlabColumns * k; hi[(size_t)k] = gx - kMinSlabColumns * (nslab - k); }
+        balanced_cuts(hist, gx, nslab, layers, lo, hi, cut);
+        return true;
+    }
     cuts_from_histogram(hist, N, gx, nslab, cut);
     for (int k = 1; k < nslab; ++k)     // every slab at least kMinSlabColumns wide, even where the fluid is narrow
         cut[k] = std::min(std::max(cut[k], cut[k - 1] + kMinSlabColumns), gx - kMinSlabColumns * (nslab - k));
@@ -365,6 +429,7 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
 }
 
 // this rank's columns, its neighbours' far cuts and the ghost columns whose particles own lists, from h->cuts
+constexpr int kSlabGroupTiles = 6;      // x-tiles in front of a slab handle's interior columns (slab_cell_order)
 void set_slab_geometry(SphHandle *h)
 {
     const std::vector<int> &cut = h->cuts;
@@ -475,6 +540,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         c.tbits = edge >= 16 ? 4 : edge >= 8 ? 3 : 2;
         const int te = 1 << c.tbits;
         c.tnx = (c.gx + te - 1) / te;
+        if (cf.slab_count > 1) c.tnx += kSlabGroupTiles;      // slab handles store their columns in groups (slab_cell_order): six tiles of x in front
         c.tnxz = c.tnx * ((c.gz + te - 1) / te);
         const long long slots = c.order == CELL_ORDER_TILED ? ((long long)c.tnxz * ((c.gy + te - 1) / te)) << (3 * c.tbits) : C;
         if (slots + 2 > 0x7fffffffLL) return fail(h, SPH_E_INVALID, "grid of %lld cell slots is too large", slots);
@@ -553,7 +619,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         if (h->slab_rank < 0 || h->slab_rank >= h->nslab) return fail(h, SPH_E_INVALID, "slab_rank %d out of range [0,%d)", h->slab_rank, h->nslab);
         std::vector<int> col, cut;
         std::string why;
-        if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why)) return fail(h, SPH_E_INVALID, "%s", why.c_str());
+        if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why, slab_layers_of(cf))) return fail(h, SPH_E_INVALID, "%s", why.c_str());
         if (const char *e = dev_env(&h->overrides, "SPH_SLAB_CUTS")) {       // debugging aid: comma-separated interior cuts, e.g. "9,18" for three slabs
             std::vector<int> forced{0};
             for (const char *q = e; *q;) { forced.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
@@ -565,7 +631,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
         // two ghost columns per side by default for dfsph (one halo refresh per solver iteration, see step_dfsph_device_loops); the
         // other solvers keep the one-column protocol
-        h->geom.layers = cf.slab_ghost_layers == 1 ? 1 : (cf.slab_ghost_layers == 2 || cf.solver == SPH_SOLVER_DFSPH) ? 2 : 1;
+        h->geom.layers = slab_layers_of(cf);
         if (h->geom.layers == 2 && cf.solver != SPH_SOLVER_DFSPH) return fail(h, SPH_E_INVALID, "slab_ghost_layers = 2 is the dfsph protocol");
         c.ghost_walk = h->geom.layers == 2 ? 1 : 0;
         set_slab_geometry(h);
@@ -765,18 +831,77 @@ int dcommit(SphHandle *h)
     return SPH_OK;
 }
 
+inline uint64_t morton_spread(uint64_t v)          // 21 bits -> every third bit
+{
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+// Storage order of a slab handle on the curve (cell_slot_xyz in sph_kernels.h).  The columns of the slab are stored in GROUPS, every group in
+// x-tiles of its own:
+//   x-tile 0 / 1   the `layers` ghost columns on the left / right
+//   x-tile 4 / 5   the `layers` owned columns next to the left / right cut          what the neighbours' halos carry: the EDGE tiles
+//   x-tile 6 ...   the interior columns, left to right                               (x-tiles 2 and 3 stay empty)
+// and the tiles are ranked interior first (Morton curve of (tx - 6, ty, tz)), then tile 4, 5, 0, 1, each along the curve of (ty, tz).
+// A 256-particle tile therefore holds ghosts or owned particles, edge columns or interior ones, never a mix (but for the one tile at each group
+// boundary); the residual sweeps find no work in a ghost tile, and the tiles that can run under the halo transfer are all of the interior.
+// (Groups of ONE column -- the two ghost columns apart, so that the outer one's tiles never work at all -- make flat tiles whose neighbourhoods
+// overflow the LDS staging capacity: 10 % of the workgroups unstaged on config 4 at 8 slabs, and the correction sweeps 30 % slower.  Measured, dropped.)  Any bijection is a valid storage order (every sum runs in the reference's
+// cell walk with ascending id inside a cell); columns this slab does not hold map to -1 = no cell.  Recomputed when the cuts move.
+void slab_cell_order(const SphHandle *h, std::vector<int> &xmap, std::vector<int> &rank)
+{
+    const Consts &c = h->c;
+    const SlabGeom &g = h->geom;
+    const int te = 1 << c.tbits, L = g.layers;
+    xmap.assign((size_t)c.gx, -1);
+    auto put = [&](int x, int tile, int code) { if (x >= 0 && x < c.gx) xmap[(size_t)x] = tile * te + code; };
+    if (g.has_left) for (int l = 0; l < L; ++l) put(g.x_lo - L + l, 0, l);
+    if (g.has_right) for (int l = 0; l < L; ++l) put(g.x_hi + l, 1, l);
+    int lo = g.x_lo, hi = g.x_hi;
+    if (g.has_left) for (int l = 0; l < L && lo < hi; ++l, ++lo) put(lo, 4, l);
+    if (g.has_right) { const int nr = std::min(L, hi - lo); for (int l = 0; l < nr; ++l) put(hi - nr + l, 5, l); hi -= nr; }
+    for (int x = lo; x < hi; ++x) put(x, kSlabGroupTiles + (x - lo) / te, (x - lo) % te);
+    const int tnx = c.tnx, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
+    static const int group_of[kSlabGroupTiles] = {3, 4, 5, 6, 1, 2};          // rank of the group of x-tile 0..5 (the interior is group 0)
+    std::vector<std::pair<std::pair<int, uint64_t>, int>> key;
+    key.reserve((size_t)tnx * tnz * tny);
+    for (int ty = 0; ty < tny; ++ty)
+        for (int tz = 0; tz < tnz; ++tz)
+            for (int tx = 0; tx < tnx; ++tx) {
+                const int grp = tx < kSlabGroupTiles ? group_of[tx] : 0;
+                const uint64_t m = morton_spread((uint64_t)(grp ? 0 : tx - kSlabGroupTiles)) | morton_spread((uint64_t)ty) << 1 | morton_spread((uint64_t)tz) << 2;
+                key.push_back({{grp, m}, tx + tz * c.tnx + ty * c.tnxz});
+            }
+    std::sort(key.begin(), key.end());
+    rank.assign(key.size(), 0);
+    for (size_t r = 0; r < key.size(); ++r) rank[(size_t)key[r].second] = (int)r;
+}
+int upload_slab_cell_order(SphHandle *h)
+{
+    std::vector<int> xmap, rank;
+    slab_cell_order(h, xmap, rank);
+    {   // slots in front of the first edge tile = the interior's (k_tile_split)
+        const Consts &c = h->c;
+        const int te = 1 << c.tbits, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
+        h->first_edge_slot = (int)(((long long)(c.tnx - kSlabGroupTiles) * tnz * tny) << (3 * c.tbits));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->xmap, xmap.data(), sizeof(int) * xmap.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->tile_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // (the vectors go out of scope)
+    h->c.tile_rank = h->tile_rank;
+    h->c.xmap = h->xmap;
+    return SPH_OK;
+}
+
 // Consts.tile_rank: position of every tile (index tx + tz*tnx + ty*tnxz) along the Morton curve of (tx, ty, tz)
 std::vector<int> morton_tile_ranks(const Consts &c)
 {
-    auto spread = [](uint64_t v) {          // 21 bits -> every third bit
-        v &= 0x1fffffull;
-        v = (v | v << 32) & 0x1f00000000ffffull;
-        v = (v | v << 16) & 0x1f0000ff0000ffull;
-        v = (v | v << 8) & 0x100f00f00f00f00full;
-        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-        v = (v | v << 2) & 0x1249249249249249ull;
-        return v;
-    };
+    auto spread = morton_spread;
     const int te = 1 << c.tbits, tnx = c.tnx, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
     std::vector<std::pair<uint64_t, int>> key;
     key.reserve((size_t)tnx * tnz * tny);
@@ -799,6 +924,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if (c.order == CELL_ORDER_TILED) {
         tile_rank = morton_tile_ranks(c);
         if ((rc = dalloc(h, &h->tile_rank, tile_rank.size()))) return rc;
+        if (h->slab && (rc = dalloc(h, &h->xmap, (size_t)c.gx))) return rc;
     }
     for (int k = 0; k < 2; ++k) {
         if ((rc = dalloc(h, &h->P[k], n + 64))) return rc;      // k_build_nl reads whole groups of four candidates
@@ -884,6 +1010,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * kSlabCounters, hipHostMallocDefault));
         // edge / interior split of the residual sweeps (dfsph, two ghost columns): tile flags and the edge-first tile order
         h->overlap = h->geom.layers == 2 && h->cfg.slab_overlap != 1;
+        h->range_split = h->overlap && c.order == CELL_ORDER_TILED && h->slab_groups;
+        if (h->range_split && (rc = dalloc(h, &h->tile_split, 4))) return rc;
         if (h->overlap) {
             if ((rc = dalloc(h, &h->tile_flag, (n + kBlock - 1) / kBlock + 1))) return rc;
             if ((rc = dalloc(h, &h->tile_order, (n + kBlock - 1) / kBlock + 2))) return rc;
@@ -909,6 +1037,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
+        if (h->slab && h->slab_groups && (rc = upload_slab_cell_order(h))) return rc;
     }
 
     // upload the scene
@@ -1137,7 +1266,7 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStrea
         if (sr) HIP_TRY(h, hipMemcpyAsync(cm.send_right, h->dsend[1], sr, hipMemcpyDeviceToHost, stream));
     }
     if (!slab_stream_ordered(h)) HIP_TRY(h, hipStreamSynchronize(stream));     // packed data complete before the transport reads it
-    if (sl || sr || rl || rr) { h->comm_stat[0] += 1; h->comm_stat[1] += (long long)(sl + sr); h->comm_stat[2] += (long long)(rl + rr); }
+    h->comm_stat[0] += 1; h->comm_stat[1] += (long long)(sl + sr); h->comm_stat[2] += (long long)(rl + rr);       // (counted even when this rank's share of the exchange is empty)
     int rc;
     if (h->native) {
         if ((rc = native_exchange(h, sl, sr, rl, rr, stream))) return rc;
@@ -1183,11 +1312,12 @@ int slab_rebalance(SphHandle *h)
     std::vector<long long> hist((size_t)c.gx);
     for (int x = 0; x < c.gx; ++x) hist[x] = (long long)v[x];
     std::vector<int> cut;
-    replan_slab_cuts(hist, c.gx, h->nslab, h->cuts, cut);
+    replan_slab_cuts(hist, c.gx, h->nslab, h->cuts, cut, h->geom.layers);
     h->cuts_moved = cut != h->cuts;
     if (h->cuts_moved) {
         h->cuts = cut;
         set_slab_geometry(h);
+        if (h->c.order == CELL_ORDER_TILED && h->slab_groups && (rc = upload_slab_cell_order(h))) return rc;      // the groups of columns follow the cuts
         ++h->n_recuts;
     }
     return SPH_OK;
@@ -1302,7 +1432,7 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
 // the inner ghost column, the owner's k / rho for the outer one -- 4 bytes per ghost (k_pack_resid / k_unpack_resid).  With `overlap` the
 // caller has run the EDGE tiles of the sweep only: the pack waits for them (ev_edge) on the halo's own stream, and whoever reads the ghosts
 // next waits for ev_halo -- the interior tiles of the sweep run under the transfer.
-int slab_exchange_resid(SphHandle *h, bool dens, float *val, bool overlap)
+int slab_exchange_resid(SphHandle *h, bool dens, float *val, bool overlap, bool wait_edge = true)
 {
     hipStream_t s = overlap ? h->xstream : h->stream;
     const dim3 b(kBlock);
@@ -1310,7 +1440,7 @@ int slab_exchange_resid(SphHandle *h, bool dens, float *val, bool overlap)
     const int nrl = h->edge_n[0][0] + h->edge_n[0][1], nrr = h->edge_n[3][0] + h->edge_n[3][1];
     float *S = h->c.kr_split ? h->krho : nullptr;
     float4 *P = h->P[1 - h->pcur];
-    if (overlap) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_edge, 0));
+    if (overlap && wait_edge) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_edge, 0));
     {
         ProfScope ps(h, K_SLAB, s);
         if (nsl + nsr)
@@ -1784,7 +1914,16 @@ int stage_sort_and_lists(SphHandle *h)
                         return fail(h, SPH_E_STATE, "slab %d step %d: edge list %d column %d holds %d particles, the exchange counted %d", h->slab_rank, h->simulate_cnt, k, l, tot, h->edge_n[k][l]);
                 }
         }
-        if (h->overlap) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
+        if (h->range_split) {
+            // the interior particles are the first of the sorted arrays; how many: everything resident but the eight edge / ghost columns and
+            // whoever sits outside the grid.  The last is known on the device only: the host bounds it (what the last read-back said + 8192)
+            int edge = 0;
+            for (int k = 0; k < 4; ++k) edge += h->edge_n[k][0] + h->edge_n[k][1];
+            const int hi = std::max(0, c.n - edge), lo = std::max(0, hi - (h->ds_host->lost + 8192));
+            h->split_hi = (hi + kBlock - 1) / kBlock;
+            h->split_lo = lo / kBlock;
+            hipLaunchKernelGGL(k_tile_split, dim3(1), dim3(1), 0, s, h->cell_start, h->first_edge_slot, h->split_lo, h->tile_split, h->ds);
+        } else if (h->overlap) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
             hipLaunchKernelGGL(k_tile_flags, g, b, 0, s, c, h->geom, h->P[h->pcur], h->tile_flag);
             hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
@@ -1856,6 +1995,8 @@ int check_overflow(SphHandle *h)
         (void)hipMemsetAsync(&h->ds->overflow, 0, sizeof(int), h->stream);
         if (h->ds_host->overflow & 2)
             return fail(h, SPH_E_OVERFLOW, "internal: a cell was missing from a workgroup's staging plan (run with SPH_STAGE=0 and report)");
+        if (h->ds_host->overflow & 8)
+            return fail(h, SPH_E_OVERFLOW, "more than 8192 particles left the grid in one step: the split of the residual sweeps no longer covers every tile");
         if (h->ds_host->overflow & 4)
             return fail(h, SPH_E_OVERFLOW, "a particle crossed a whole slab in one step (it left its slab and landed beyond the neighbour's): the one-message particle "
                                            "exchange assumes a fraction of a cell per step -- lower delta_time or use fewer, wider slabs");
@@ -2011,7 +2152,14 @@ inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 inline TilePhase tile_phase(const SphHandle *h, int phase)
 {
     if (phase == 0 && h->tile_perm && h->nblocks >= 64) return TilePhase{h->tile_perm, h->nblocks, 3};      // one GPU, staged: heavy tiles first within each XCD's eighth
+    if (phase != 0 && h->range_split) return TilePhase{h->tile_split, h->nblocks, phase == 1 ? 5 : 6};
     return TilePhase{h->tile_order, h->nblocks, phase};
+}
+// particles a split launch's grid must cover (grid_for): all of them, or the host's bound on its range of tiles
+inline int phase_n(const SphHandle *h, int phase)
+{
+    if (phase == 0 || !h->range_split) return h->c.n;
+    return std::max(1, phase == 1 ? h->nblocks - h->split_lo : h->split_hi) * kBlock;
 }
 // fin_mode >= 0: the loop decision k_finalize_mean would take after this sweep is taken by the sweep's last workgroup (fin_fused)
 inline bool fin_fusable(const SphHandle *h) { return h->fin_ticket != nullptr; }
@@ -2019,20 +2167,21 @@ inline FinFuse fin_fuse(const SphHandle *h, int fin_mode)
 {
     return FinFuse{(fin_mode >= 0 && fin_fusable(h)) ? h->fin_ticket : nullptr, fin_mode, partial_group(h), partial_count(h), h->nblocks};
 }
-void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
-    ProfScope ps(h, K_D_DIV_RESIDUAL);
+    if (!st) st = h->stream;
+    ProfScope ps(h, K_D_DIV_RESIDUAL, st);
     const bool split = rx_split(h);
     const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
     const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
-        hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->V[h->vcur],
+        hipLaunchKernelGGL(k_residual_rx<false>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->V[h->vcur],
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff, un);
         if (!split) return;
     }
-    SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
                   (const float4 *)wall_cache(h), tp, ff, un);
@@ -2057,10 +2206,11 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
                   (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0), sv);
 }
 
-void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
+void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, hipStream_t st = nullptr)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
-    ProfScope ps(h, K_D_DENS_RESIDUAL);
+    if (!st) st = h->stream;
+    ProfScope ps(h, K_D_DENS_RESIDUAL, st);
     const bool split = rx_split(h);
     const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
     const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
@@ -2069,11 +2219,11 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = 
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
-        hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c, h->P[h->pcur], h->VA[0],
+        hipLaunchKernelGGL(k_residual_rx<true>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->VA[0],
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr, ff);
         if (!split) return;
     }
-    SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), h->stream, c,
+    SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, ff);
 }
@@ -2825,6 +2975,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); h->slab_groups = e && atoi(e) == 1; }
     { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
@@ -3074,7 +3225,7 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts)
     if (rc) { g_create_error = tmp.err; return rc; }
     std::vector<int> col, cut;
     std::string why;
-    if (!plan_slab_cuts(sc.fluid_pos, tmp.N, tmp.c.h, tmp.c.gx, nslab, col, cut, why)) return fail(nullptr, SPH_E_INVALID, "%s", why.c_str());
+    if (!plan_slab_cuts(sc.fluid_pos, tmp.N, tmp.c.h, tmp.c.gx, nslab, col, cut, why, slab_layers_of(*cfg))) return fail(nullptr, SPH_E_INVALID, "%s", why.c_str());
     for (int k = 0; k <= nslab; ++k) cuts[k] = cut[k];
     for (int k = 0; k < nslab; ++k) counts[k] = 0;
     for (int i = 0; i < tmp.N; ++i)
@@ -3083,16 +3234,16 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts)
     return SPH_OK;
 }
 
-int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts)
+int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t ghost_layers, int32_t *new_cuts)
 {
-    if (!column_histogram || !old_cuts || !new_cuts || grid_x < 2 || slab_count < 1 || grid_x < kMinSlabColumns * slab_count)
+    if (!column_histogram || !old_cuts || !new_cuts || grid_x < 2 || slab_count < 1 || grid_x < kMinSlabColumns * slab_count || ghost_layers < 0 || ghost_layers > 2)
         return fail(nullptr, SPH_E_INVALID, "bad argument");
     for (int k = 0; k < slab_count; ++k)
         if (old_cuts[k + 1] < old_cuts[k] + kMinSlabColumns || old_cuts[0] != 0 || old_cuts[slab_count] != grid_x)
             return fail(nullptr, SPH_E_INVALID, "old cuts must start at 0, end at grid_x and leave every slab >= %d columns", kMinSlabColumns);
     std::vector<long long> hist(column_histogram, column_histogram + grid_x);
     std::vector<int> oldc(old_cuts, old_cuts + slab_count + 1), cut;
-    replan_slab_cuts(hist, grid_x, slab_count, oldc, cut);
+    replan_slab_cuts(hist, grid_x, slab_count, oldc, cut, ghost_layers);
     for (int k = 0; k <= slab_count; ++k) new_cuts[k] = cut[k];
     return SPH_OK;
 }

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_pbf_xsph(Consts c, PbfConsts k, cons
                 const int x = cx + dx, y = cy + dy, z = cz + dz;
                 if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;          // ParticleSystem.py:453-456
                 const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                if (slot < 0) continue;
                 const int a = cell_start[slot], b = cell_start[slot + 1];
                 if (QUAD) {
                     for (int j0 = a; j0 < b; j0 += 4) {

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_build_rnl(Consts c, int nr, const fl
                 if (x >= c.gx || y >= c.gy || z >= c.gz) continue;
                 if (x < 0 || y < 0 || z < 0) continue;
                 const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                if (slot < 0) continue;
                 const int a = cell_start[slot], b = cell_start[slot + 1];
                 for (int j0 = a; j0 < b; j0 += 4) {
                     const float4 *pb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(P) + (unsigned)j0 * 16u);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const in
         if (valid) {
             const int y = k / c.gz, z = k - y * c.gz;
             const int slot = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
-            v = cell_start[slot + 1] - cell_start[slot];
+            v = slot < 0 ? 0 : cell_start[slot + 1] - cell_start[slot];
         }
         off[k] = v;
     }
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_layer_list(Consts c, const int *__re
     if (k >= c.gy * c.gz || layer_cx < 0 || layer_cx >= c.gx) return;
     int y = k / c.gz, z = k - y * c.gz;
     const int slot = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
+    if (slot < 0) return;
     int a = cell_start[slot], b = cell_start[slot + 1];
     int o = off[k];
     for (int s = a; s < b; ++s) list[o + (s - a)] = s;
@@ -407,6 +408,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_order(const int *__restrict__ f
         }
     }
     if (threadIdx.x == 0) order[ntiles] = total_s;
+}
+
+// Slab handles on the curve keep the interior columns in front of everything else (slab_cell_order): cell_start[first slot of the first edge
+// tile] = particles in interior columns.  The tiles below split[0] hold interior particles only.  The host sized the edge launch by a lower
+// bound of that number: if the bound does not hold (thousands of particles left the grid in one step) the step fails loudly (overflow bit 3).
+__global__ void k_tile_split(const int *__restrict__ cell_start, int first_edge_slot, int lower_bound_tiles, int *__restrict__ split, DevScalars *__restrict__ ds)
+{
+    const int t = cell_start[first_edge_slot] / kBlock;
+    split[0] = t;
+    if (t < lower_bound_tiles) atomicOr(&ds->overflow, 8);
 }
 
 // Rigid body on slab handles.  The reference's quirks read FLUID arrays with a rigid particle's local index (get_neighbour_count measures to

@@ -284,12 +284,14 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes);
 int sph_rccl_selftest(SphHandle *h, double *inout, int32_t n, int32_t op);
 /* the handle's HIP stream (a hipStream_t), for stream-ordered transports */
 int sph_get_stream(SphHandle *h, void **stream);
-/* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the equal-count slabs of the
- * scene's initial lattice, counts[k] = particles slab k owns at t = 0 */
+/* host-only planning (no device needed): cuts[0..slab_count] = cell-column boundaries of the slabs of the scene's initial lattice,
+ * counts[k] = particles slab k owns at t = 0.  The cuts balance what a slab costs: its particles plus the ghosts of each cut it has
+ * (the particles of the solver's ghost columns beyond the cut) -- the largest such load is minimised */
 int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);
-/* host-only: the re-balancing rule.  new_cuts = equal-count cuts of `column_histogram` (grid_x counts), clamped so that every slab
- * keeps >= 2 columns and old_cuts[k-1] < new_cuts[k] < old_cuts[k+1] (a particle's new owner is its rank or a direct neighbour) */
-int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t *new_cuts);
+/* host-only: the re-balancing rule.  new_cuts = cuts of `column_histogram` (grid_x counts) that minimise the largest load (particles + the
+ * particles of `ghost_layers` columns beyond each cut; ghost_layers = 0: plain equal counts), every slab >= 3 columns wide and
+ * old_cuts[k-1] < new_cuts[k] < old_cuts[k+1] (a particle's new owner is its rank or a direct neighbour) */
+int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t ghost_layers, int32_t *new_cuts);
 /* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity,
  * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = the halo protocol in force: ghost columns per side (1 or 2)
  * | 16 if the dfsph residual sweeps run their edge tiles first with the halo on its own stream | 32 if the residual's all-reduce and loop decision run

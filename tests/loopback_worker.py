@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--log-mb", type=int, default=8192)
     ap.add_argument("--save-log", default="", help="with --replay-rank: write the log to this file and stop (the replay runs in a process of its own: --load-log)")
     ap.add_argument("--load-log", default="", help="replay --replay-rank alone against a saved log (one thread, one handle: what a profiler should see)")
+    ap.add_argument("--one-gpu", action="store_true", help="with a replay: time the same steps of the whole scene on a one-GPU handle in the same process")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     os.environ["SPH_DEV"] = "1"
@@ -215,6 +216,23 @@ def main():
             same = state_digest(sims[k]) == state_digest(solo)
         result["replay"] = {"rank": k, "ms_per_step": dt, "log_entries": int(entries), "log_bytes": int(used.value), "same_state_as_in_the_full_run": same, "digest": state_digest(solo),
                             "owned": solo.slab_info()["owned"], "ghosts": solo.slab_info()["ghosts"]}
+        if args.one_gpu:          # the yardstick, same process, same clocks: the whole scene on one handle, same steps
+            for s_ in sims:
+                s_.close()
+            sims = []
+            one = nat.Simulation(nat.config_from_dict(cfg, arith=args.arith), rigid=rigid)
+            sims.append(one)
+            for _ in range(args.steps):
+                one_step(0)
+            one.synchronize()
+            shim.loopback_marker(ctypes.c_void_p(one.stream_ptr()))
+            t0 = time.perf_counter()
+            for _ in range(args.time):
+                one_step(0)
+            one.synchronize()
+            result["one_gpu"] = {"ms_per_step": (time.perf_counter() - t0) * 1e3 / max(args.time, 1), "n": int(one.n_fluid)}
+            shim.loopback_marker(ctypes.c_void_p(one.stream_ptr()))
+            one.synchronize()
     with open(args.out, "w") as f:
         json.dump(result, f)
     for s in sims:

@@ -94,11 +94,14 @@ def test_slab_planner_partitions_the_lattice():
         cuts, counts = nat.plan_slabs(cfg, world)
         assert cuts[0] == 0 and cuts[-1] == 161 and all(b - a >= 3 for a, b in zip(cuts, cuts[1:]))
         assert sum(counts) == 1000000
-        assert max(counts) <= 1.25 * 1000000 / world      # cell-column granularity: 10k particles per column
+        # cell-column granularity: 20k particles per column; the cuts balance particles + ghosts, so the two end slabs (one cut each) own more
+        assert max(counts) <= 1.35 * 1000000 / world
+        if world > 2:
+            assert counts[0] >= max(counts[1:-1]) - 20000 and counts[-1] >= max(counts[1:-1]) - 20000
     with pytest.raises(nat.SphError):
         nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_small")), 6)    # 16 cell columns cannot hold 6 slabs of >= 3 columns
-    cuts, counts = nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_dam_x")), 3)   # fluid narrower than 3 equal-count slabs: widths clamp
-    assert cuts == [0, 3, 6, 21] and sum(counts) == 960
+    cuts, counts = nat.plan_slabs(nat.config_from_dict(scenes.get("dfsph_dam_x")), 3)   # fluid narrower than 3 slabs of >= 3 columns: widths clamp
+    assert cuts[:2] == [0, 3] and 6 <= cuts[2] <= 18 and cuts[3] == 21 and counts == [480, 480, 0]
 
 
 def test_replan_rule_properties():
@@ -132,3 +135,21 @@ def test_replan_rule_properties():
     assert counts == [4000, 4000, 4000, 4000], (cuts, counts)
     with pytest.raises(nat.SphError):
         nat.replan_slabs(hist, [0, 1, gx])
+    # by cost (ghost_layers > 0): a slab pays for its particles AND for the ghost columns beyond each of its cuts, so the two end slabs -- one
+    # cut each -- take more columns than the ones between them; the largest load is what is minimised; same bounds, same fixed-point property
+    cuts = [0, 3, 6, 9, gx]
+    for _ in range(40):
+        cuts = nat.replan_slabs(hist, cuts, ghost_layers=2)
+    assert cuts == nat.replan_slabs(hist, cuts, ghost_layers=2)
+    counts = [int(pre[cuts[k + 1]] - pre[cuts[k]]) for k in range(4)]
+    loads = [counts[k] + (2000 if k > 0 else 0) + (2000 if k < 3 else 0) for k in range(4)]
+    assert counts == [5000, 3000, 3000, 5000] and max(loads) == 7000, (cuts, counts, loads)          # equal counts would cost 8000 on the inner slabs
+    for nslab in (2, 3, 4, 8):
+        old = [round(k * gx / nslab) for k in range(nslab + 1)]
+        for trial in range(20):
+            h2 = np.zeros(gx, dtype=np.int64)
+            lo = int(rng.integers(0, gx - 4)); hi = int(rng.integers(lo + 3, gx))
+            h2[lo:hi] = rng.integers(1, 2000, hi - lo)
+            new = nat.replan_slabs(h2, old, ghost_layers=int(rng.integers(1, 3)))
+            assert new[0] == 0 and new[-1] == gx and all(new[k + 1] >= new[k] + 3 for k in range(nslab)) and all(old[k - 1] < new[k] < old[k + 1] for k in range(1, nslab))
+            old = new

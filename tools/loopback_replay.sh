@@ -14,16 +14,16 @@ log=${TMPDIR:-/tmp}/loopback_${scene}_${world}_${rank}.log
 python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --save-log $log --out ${out}_recorded.json || exit 1
 if [ -n "$prof" ]; then
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --output-format csv -d $R/${out}_trace -o trace -- python3 $R/tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --load-log $log --out $R/$out.json || exit 1
-  cd $R && python3 tools/replay_trace.py ${out}_trace > $out.kernels.txt && rm -rf ${out}_trace && tail -80 $out.kernels.txt
+  rocprofv3 --kernel-trace --output-format csv -d $R/${out}_trace -o trace -- python3 $R/tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --load-log $log --one-gpu --out $R/$out.json || exit 1
+  cd $R && python3 tools/replay_trace.py ${out}_trace 0 3000 > $out.kernels.txt && python3 tools/replay_trace.py ${out}_trace 1 > $out.one_gpu_kernels.txt && rm -rf ${out}_trace && tail -80 $out.kernels.txt && grep -A12 "^kernel " $out.one_gpu_kernels.txt
 else
-  python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --load-log $log --out $out.json || exit 1
+  python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --load-log $log --one-gpu --out $out.json || exit 1
 fi
 rm -f $log
 python3 - <<PY
 import json
 a, b = json.load(open("${out}_recorded.json")), json.load(open("$out.json"))
 same = a["recorded"]["digest"] == b["replay"]["digest"]
-print("$scene, rank $rank of $world: all ranks on one GPU %.2f ms per step; this rank alone %.3f ms per step; same final state: %s" % (a["timing"]["ms_per_step"], b["replay"]["ms_per_step"], same), b["replay"])
+print("$scene, rank $rank of $world: all ranks on one GPU %.2f ms per step; this rank alone %.3f ms per step; the whole scene on one handle %.3f ms per step (= %.2fx); same final state: %s" % (a["timing"]["ms_per_step"], b["replay"]["ms_per_step"], b["one_gpu"]["ms_per_step"], b["one_gpu"]["ms_per_step"] / b["replay"]["ms_per_step"], same), b["replay"])
 assert same
 PY

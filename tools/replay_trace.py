@@ -12,7 +12,9 @@ for f in files:
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "loopback_marker_kernel" in r["Kernel_Name"]]
 assert len(marks) >= 2, "markers not found (%d)" % len(marks)
-a, b = marks[-2], marks[-1]
+# windows: (replay) or (replay, one-GPU yardstick); argv[2] = which pair from the front (default 0 = the replay)
+which = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+a, b = marks[2 * which], marks[2 * which + 1]
 win = rows[a + 1:b]
 span = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e3
 agg = defaultdict(lambda: [0, 0.0])
@@ -20,6 +22,8 @@ busy = 0.0
 for r in win:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     name = r["Kernel_Name"].split("(")[0].replace("void sph::", "").replace("sph::", "")
+    if "k_residual" in name or "k_correct" in name:          # the split launches of a sweep differ in their grids
+        name += " grid %s" % (int(r.get("Grid_Size", r.get("Grid_Size_X", "0")) or 0) // 256)
     agg[name][0] += 1
     agg[name][1] += d
     busy += d
@@ -35,7 +39,6 @@ for s, e in iv:
         cur_e = max(cur_e, e)
 if cur_e is not None:
     union += cur_e - cur_s
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 print("window: %.1f us, %d launches, sum of kernel durations %.1f us, GPU busy (union) %.1f us = %.1f %% of the window" % (span, len(win), busy, union / 1e3, 100.0 * union / 1e3 / span))
 print("%-44s %8s %12s %10s %7s" % ("kernel", "launches", "total us", "avg us", "share"))
 for name, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -58,3 +61,16 @@ print("\nidle gaps > 2 us: %.1f us in total (%.1f %% of the window)" % (tot, 100
 print("%-30s %-30s %7s %10s %8s" % ("after", "before", "count", "total us", "avg us"))
 for (a_, b_), (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
     print("%-30s %-30s %7d %10.1f %8.2f" % (a_, b_, n, t, t / n))
+
+# a slice of the timeline: every launch of ~600 us in the middle of the window, with its queue (= stream)
+if len(sys.argv) > 3:
+    t0 = int(rows[a]["End_Timestamp"]) + int(float(sys.argv[3]) * 1e3)
+    qs = {}
+    print("\ntimeline slice from +%s us (columns: start, end, duration [us]; queue; kernel)" % sys.argv[3])
+    for r in win:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if s_ < t0 or s_ > t0 + 600000:
+            continue
+        q = r.get("Queue_Id", "?")
+        qs.setdefault(q, len(qs))
+        print("%9.1f %9.1f %7.1f  q%d  %s" % ((s_ - t0) / 1e3, (e_ - t0) / 1e3, (e_ - s_) / 1e3, qs[q], r["Kernel_Name"].split("(")[0].replace("void sph::", "").replace("sph::", "")[:40]))
