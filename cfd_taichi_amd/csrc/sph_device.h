@@ -100,7 +100,8 @@ struct DevScalars {
     // evaluation e is also kept in gate_hist[e & 1], so that a sweep enqueued BEHIND the reduction of evaluation e can still read the decision of
     // e - 1 without racing the kernel that takes e; stop_at = the evaluation whose decision closed the divergence loop (the correction sweep that ran
     // ahead of it is undone by the next residual launch)
-    int gate_hist[2], stop_at, pad3;
+    int gate_hist[2], stop_at;
+    int overflow_any;  // slab handles: some slab's overflow flags were set at the last density-loop reduction (summed with the residual pair)
     // Per-build maxima of the list lengths, sharded: workgroup w raises shard w % kNoteShards, the host takes the maximum over the
     // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
     // list build: same-address traffic serialises even when it is only loads.)

@@ -1376,8 +1376,10 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
     __shared__ long long s_cnt[kFinBlock / 64];
     if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);
     if (threadIdx.x != 0) return;
-    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
-    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
+    // (the density loop's reduction carries a third word: this slab's overflow flags -- every slab must see a list overflow on ANY slab at the
+    // same point of the step, and this way that costs no host round trip of its own)
+    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; if (mode == FIN_DENS) red[2] = (double)ds->overflow; return; }
+    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; if (mode == FIN_DENS) ds->overflow_any = red[2] != 0.0 ? 1 : 0; }
     const int was = (mode == FIN_DENS) ? ds->dens_active : ds->div_active;
     fin_decide(ds, mode, s_sum[0], s_cnt[0]);
     if (hist >= 0) {
@@ -1450,7 +1452,7 @@ __device__ __forceinline__ void fin_fused_closed(const FinFuse &ff, DevScalars *
 
 __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 {
-    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0;
+    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0; ds->overflow_any = 0;
     ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
     ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
     ds->gate_hist[0] = 1; ds->gate_hist[1] = 1; ds->stop_at = -1;

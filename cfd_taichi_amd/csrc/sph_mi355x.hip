@@ -1203,6 +1203,32 @@ int native_exchange_counts_n(SphHandle *h, int n, const int32_t *sl, const int32
     return SPH_OK;
 }
 int native_exchange_counts(SphHandle *h, int32_t sl, int32_t sr, int32_t *rl, int32_t *rr) { return native_exchange_counts_n(h, 1, &sl, &sr, rl, rr); }
+// the same with the n ints per side already in cnt_dev[0..n) / cnt_dev[kCountInts..] (k_classify_scan): no upload; the classification's
+// counters come back in the same read-back (counters_host)
+int native_exchange_counts_dev(SphHandle *h, int n, int32_t *rl, int32_t *rr)
+{
+    RcclApi &api = rccl();
+    const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
+    h->comm_stat[3] += 1;
+    HIP_TRY(h, hipMemsetAsync(h->cnt_dev + 2 * kCountInts, 0, sizeof(int) * 2 * kCountInts, h->stream));
+    if (left >= 0 || right >= 0) {
+        NCCL_TRY(h, api.GroupStart());
+        if (left >= 0) {
+            NCCL_TRY(h, api.Send(h->cnt_dev + 0, (size_t)n, ncclInt32, left, h->nccl, h->stream));
+            NCCL_TRY(h, api.Recv(h->cnt_dev + 2 * kCountInts, (size_t)n, ncclInt32, left, h->nccl, h->stream));
+        }
+        if (right >= 0) {
+            NCCL_TRY(h, api.Send(h->cnt_dev + kCountInts, (size_t)n, ncclInt32, right, h->nccl, h->stream));
+            NCCL_TRY(h, api.Recv(h->cnt_dev + 3 * kCountInts, (size_t)n, ncclInt32, right, h->nccl, h->stream));
+        }
+        NCCL_TRY(h, api.GroupEnd());
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->cnt_host, h->cnt_dev, sizeof(int) * 4 * kCountInts, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->counters_host, h->counters, sizeof(int) * kSlabCounters, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k < n; ++k) { rl[k] = h->cnt_host[2 * kCountInts + k]; rr[k] = h->cnt_host[3 * kCountInts + k]; }
+    return SPH_OK;
+}
 
 int native_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream)
 {
@@ -1353,17 +1379,22 @@ int slab_exchange_particles(SphHandle *h)
             ProfScope ps(h, K_SLAB);
             const int nblk = (int)grid_for(n_res).x;
             hipLaunchKernelGGL(k_classify_count, dim3(nblk), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->id[h->icur], h->dead, nblk, h->class_cnt);
-            hipLaunchKernelGGL(k_classify_scan, dim3(kSlabCounted), dim3(kScanBlock), 0, s, nblk, h->class_cnt, h->counters);
+            hipLaunchKernelGGL(k_classify_scan, dim3(kSlabCounted), dim3(kScanBlock), 0, s, nblk, h->class_cnt, h->counters, h->native ? h->cnt_dev : (int *)nullptr);
             hipLaunchKernelGGL(k_classify_write, dim3(nblk), b, 0, s, c, h->geom, mode, h->P[h->pcur], h->V[h->vcur], warm, h->id[h->icur], h->dead,
                                (float4 *)h->dsend[0], (float4 *)h->dsend[1], cap_rec, nblk, h->class_cnt, h->ds);
         }
         int r;
-        if ((r = read_counters(h))) return r;
         const int *ct = h->counters_host;
+        int32_t sl[5], sr[5], rl[5], rr[5];
+        if (h->native) {
+            // the counts go from device to device (k_classify_scan left them in wire order) and come back to the host together with what the
+            // neighbours sent: ONE host round trip per exchange round
+            if ((r = native_exchange_counts_dev(h, 5, rl, rr))) return r;
+        } else if ((r = read_counters(h))) return r;
         if (ct[0] > cap_rec || ct[1] > cap_rec) return fail(h, SPH_E_OVERFLOW, "%d/%d particle records exceed the comm buffer (%d records)", ct[0], ct[1], cap_rec);
         if (mode & kSlabMigrate) ndead = ct[2];
-        int32_t sl[5] = {ct[0], ct[3], ct[4], ct[5], ct[6]}, sr[5] = {ct[1], ct[7], ct[8], ct[9], ct[10]}, rl[5], rr[5];
-        if ((r = slab_exchange_counts_n(h, 5, sl, sr, rl, rr))) return r;
+        { const int32_t a[5] = {ct[0], ct[3], ct[4], ct[5], ct[6]}, b2[5] = {ct[1], ct[7], ct[8], ct[9], ct[10]}; for (int q = 0; q < 5; ++q) { sl[q] = a[q]; sr[q] = b2[q]; } }
+        if (!h->native && (r = slab_exchange_counts_n(h, 5, sl, sr, rl, rr))) return r;
         for (int l = 0; l < 2; ++l) {
             own_ghost[0][l] += sl[1 + l]; own_kept[0][l] += sl[3 + l]; own_ghost[1][l] += sr[1 + l]; own_kept[1][l] += sr[3 + l];
             got_ghost[0][l] += rl[1 + l]; got_kept[0][l] += rl[3 + l]; got_ghost[1][l] += rr[1 + l]; got_kept[1][l] += rr[3 + l];
@@ -2133,10 +2164,12 @@ int step_wcsph_once(SphHandle *h)
 }
 
 // every slab must see a list overflow at the same point, or the others would wait in a collective forever
-int check_overflow_all(SphHandle *h)
+int check_overflow_all(SphHandle *h, bool reduced_on_device = false)
 {
     int ovf = h->ds_host->overflow;
-    if (h->slab) {
+    if (h->slab && reduced_on_device) {          // dfsph device loops: the flags of all slabs came with the density loop's first reduction
+        if (h->ds_host->overflow_any && !ovf) return fail(h, SPH_E_OVERFLOW, "list overflow or exchange failure on another slab");
+    } else if (h->slab) {
         double v[1] = {(double)ovf};
         int rc = slab_allreduce_host(h, v, 1, 1);
         if (rc) return rc;
@@ -2241,7 +2274,7 @@ int launch_finalize_decide(SphHandle *h, int mode, int eval)
 {
     hipStream_t r = h->rstream;
     HIP_TRY(h, hipStreamWaitEvent(r, h->ev_red, 0));
-    int rc = slab_allreduce_stream(h, 2, 0, r);
+    int rc = slab_allreduce_stream(h, mode == FIN_DENS ? 3 : 2, 0, r);       // (the density loop's carries the overflow flags, k_finalize_mean)
     if (rc) return rc;
     {
         ProfScope ps(h, K_FINALIZE, r);
@@ -2257,7 +2290,7 @@ int launch_finalize(SphHandle *h, int mode)
             ProfScope ps(h, K_FINALIZE);
             hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
-        int rc = slab_allreduce_stream(h, 2, 0);
+        int rc = slab_allreduce_stream(h, mode == FIN_DENS ? 3 : 2, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
         hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
@@ -2457,7 +2490,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
-            if ((rc = check_overflow_all(h))) return rc;     // first read-back of the step: list overflow?
+            if ((rc = check_overflow_all(h, slab_async(h)))) return rc;     // first read-back of the step: list overflow?
             first = false;
         }
         if (!h->ds_host->dens_active) break;

@@ -182,7 +182,9 @@ __global__ __launch_bounds__(kBlock) void k_classify_count(Consts c, SlabGeom g,
     }
 }
 constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(kScanBlock) void k_classify_scan(int nblk, int *__restrict__ blk_cnt, int *__restrict__ counters)
+// wire[] (optional; the native transport's device-side count exchange): what goes to the left neighbour at wire[0..5), to the right one at
+// wire[8..13) -- (records, ghost copies of column 1 / 2, leavers kept as ghosts of column 1 / 2), the five ints slab_exchange_particles trades
+__global__ __launch_bounds__(kScanBlock) void k_classify_scan(int nblk, int *__restrict__ blk_cnt, int *__restrict__ counters, int *__restrict__ wire)
 {
     __shared__ int s_w[kScanBlock / 64];
     int *a = blk_cnt + (size_t)blockIdx.x * nblk;
@@ -198,7 +200,12 @@ __global__ __launch_bounds__(kScanBlock) void k_classify_scan(int nblk, int *__r
     for (int q = 0; q < kScanBlock / 64; ++q) { if (q < w) before += s_w[q]; total += s_w[q]; }
     if (blockIdx.x < 2)                               // the two allocating counters: exclusive offsets in place
         for (int i = lo; i < hi; ++i) { const int v = a[i]; a[i] = before; before += v; }
-    if (threadIdx.x == 0) counters[blockIdx.x] = total;
+    if (threadIdx.x == 0) {
+        counters[blockIdx.x] = total;
+        const int q = (int)blockIdx.x;
+        const int slot = q == 0 ? 0 : q == 1 ? 8 : q == 2 ? -1 : q <= 6 ? q - 2 : 8 + q - 6;       // 3..6 -> 1..4, 7..10 -> 9..12
+        if (wire && slot >= 0) wire[slot] = total;
+    }
 }
 __global__ __launch_bounds__(kBlock) void k_classify_write(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                            const float *__restrict__ warm, int *__restrict__ id, int *__restrict__ dead,

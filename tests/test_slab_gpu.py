@@ -54,9 +54,12 @@ def test_slabs_match_single_gpu(tmp_path, scene, world, steps):
     assert r["stats_equal"], (r["stats_last"], r["ref_stats_last"])
     assert sum(s["owned"] for s in r["slabs"]) == r["n"]
     assert all(s["ghosts"] > 0 for s in r["slabs"])
-    assert r["comm"]["exchange_buffers"] > 0 and r["comm"]["allreduce"] > 0
-    if "dfsph" in scene:      # the loops ran with the device-side control: residuals were reduced in place, not through the host callback
-        assert r["comm"]["allreduce_stream"] >= 3 * steps
+    assert r["comm"]["exchange_buffers"] > 0
+    if "dfsph" in scene:      # the loops ran with the device-side control: residuals were reduced in place, not through the host callback --
+        # and the slabs' overflow flags ride on the density loop's reduction: no host all-reduce at all in an ordinary dfsph step
+        assert r["comm"]["allreduce_stream"] >= 3 * steps and r["comm"]["allreduce"] == 0
+    else:
+        assert r["comm"]["allreduce"] > 0
 
 
 @pytest.mark.parametrize("scene,world,steps", [("breaking_dam_30k_iisph", 3, 10), ("breaking_dam_30k_pcisph", 2, 6), ("dfsph_tiny_wall_pcisph", 2, 30),
