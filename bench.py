@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-relaxed", action="store_true", help="N=1 dfsph: skip the tolerance-grade arithmetic leg (the `relaxed` object)")
     ap.add_argument("--allow-overrides", action="store_true", default=os.environ.get("SPH_BENCH_ALLOW_OVERRIDES") == "1",
                     help="print a line although development overrides (SPH_DEV=1 + SPH_* knobs) are in force; they are named in config.overrides")
+    ap.add_argument("--no-overlap-probe", action="store_true", help="N > 1, dfsph: keep the overlapped slab protocol without timing it against the in-order one")
     ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
                     help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
     return ap.parse_args()
@@ -502,7 +503,27 @@ def main():
         """pre-roll (timed on the side as the early phase), warm-up, then EXACTLY args.steps steps between two fences; max over ranks"""
         fence(sim)
         t0 = time.perf_counter()
-        run(args.preroll)
+        probe = 6 if (world > 1 and solver_kind == "dfsph" and args.preroll >= 24 and sim.slab_info()["halo_overlapped"] and not args.no_overlap_probe) else 0
+        run(args.preroll - 2 * probe)
+        if probe:
+            # Which protocol is faster HERE?  The dfsph loops with the halo and the reductions on their own streams, or in order on one stream: the
+            # same bits either way, and the answer depends on the link (with the link time at zero the in-order form wins by 12 % at 1.2 M particles
+            # per rank, DESIGN.md section 6).  The last 2 x 6 steps of the pre-roll time both; every rank takes the same decision (MAX over ranks).
+            times = {}
+            for mode in (True, False):
+                sim.set_slab_overlap(mode)
+                fence(sim)
+                tp = time.perf_counter()
+                run(probe)
+                sim.synchronize()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                times[mode] = float(tt[0].item()) / probe * 1e3
+            keep = times[True] <= times[False]
+            sim.set_slab_overlap(keep)
+            overlap_probe.update({"overlapped_ms_per_step": times[True], "in_order_ms_per_step": times[False], "kept": "overlapped" if keep else "in order",
+                                  "steps": "%d-%d" % (args.preroll - 2 * probe + 1, args.preroll)})
         fence(sim)
         early = time.perf_counter() - t0
         run(args.warmup)
@@ -526,6 +547,7 @@ def main():
             dist.barrier()
         return elapsed, early, stats, state
 
+    overlap_probe = {}
     run = make_run(sim, solver_kind, rigid_active)
     want_relaxed = rank == 0 and world == 1 and solver_kind in ("dfsph", "wcsph") and not has_rigid and not args.no_relaxed and headline_arith == "exact"
     want_state = rank == 0 and world == 1 and not has_rigid and solver_kind in ("dfsph", "wcsph", "pbf") and (not args.no_cpu_baseline or want_relaxed)
@@ -552,6 +574,8 @@ def main():
     if args.preroll > 0:
         out["early_phase"] = {"steps": "1-%d" % args.preroll, "value": n_total * args.preroll / early / 1e6, "ms_per_step": early / args.preroll * 1e3,
                               "note": "the pre-roll from rest (density loop at its minimum of 2 iterations for most of it); not the headline"}
+    if overlap_probe:
+        out["config"]["slab_protocol_probe"] = overlap_probe
     if slab_info is not None:
         out["config"]["rank0_slab"] = slab_info
         cs = comm_stats_timed if comm_stats_timed is not None else sim.comm_stats()

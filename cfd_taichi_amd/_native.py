@@ -36,7 +36,7 @@ EXPORTS = [
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_set_scalar", "sph_synchronize", "sph_overrides", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
-    "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_info", "sph_comm_stats", "sph_download_local", "sph_download_ids",
+    "sph_set_comm", "sph_rccl_unique_id", "sph_rccl_attach", "sph_rccl_selftest", "sph_get_stream", "sph_plan_slabs", "sph_replan_slabs", "sph_slab_set_overlap", "sph_slab_info", "sph_comm_stats", "sph_download_local", "sph_download_ids",
     "sph_create_rigid", "sph_rigid_step",
 ]
 
@@ -237,6 +237,7 @@ def load(build_if_missing=True):
     lib.sph_rccl_selftest.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int32, ctypes.c_int32]
     lib.sph_plan_slabs.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.sph_slab_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.sph_slab_set_overlap.argtypes = [vp, ctypes.c_int32]
     lib.sph_comm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_int64), ci]
     lib.sph_replan_slabs.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     lib.sph_download_local.argtypes = [vp, ci, vp, ctypes.c_size_t]
@@ -487,6 +488,10 @@ class Simulation:
         self._check(self._lib.sph_slab_info(self._h, out))
         return {"owned": out[0], "ghosts": out[1], "x_lo": out[2], "x_hi": out[3], "capacity": out[4], "recuts": out[5],
                 "rebalance_every": out[6], "ghost_columns": out[7] & 15, "halo_overlapped": bool(out[7] & 16), "allreduce_hidden": bool(out[7] & 32)}
+
+    def set_slab_overlap(self, on):
+        """Between steps, on every slab alike: halo and reductions of the dfsph loops on their own streams (True) or in order (False); same bits."""
+        self._check(self._lib.sph_slab_set_overlap(self._h, 1 if on else 0))
 
     def comm_stats(self, reset=False):
         """Transport requests since the last reset: {p2p_groups, bytes_sent, bytes_received, count_exchanges, allreduce_stream, allreduce_host, steps}."""

@@ -1363,9 +1363,10 @@ __device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode
     }
 }
 // hist >= 0: this is evaluation number `hist` of its loop; the decision also goes to gate_hist[hist & 1] (see DevScalars)
-__global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
-                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                             int group = 1, int nparts = 0, int hist = -1)
+// (the work of ONE workgroup of kFinBlock threads: k_finalize_mean, or the last workgroup of k_pack_resid_reduce / k_unpack_resid_decide)
+__device__ __forceinline__ void finalize_mean_block(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                    DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                    int group, int nparts, int hist)
 {
     if (mode == FIN_DIV_LOOP && ds->div_active == 0) { if (hist >= 0 && threadIdx.x == 0 && phase != FINP_REDUCE) ds->gate_hist[hist & 1] = 0; return; }
     if (mode == FIN_DENS && ds->dens_active == 0) {
@@ -1387,6 +1388,12 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
         ds->gate_hist[hist & 1] = now;
         if (mode != FIN_DENS && was != 0 && now == 0) ds->stop_at = hist;
     }
+}
+__global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
+                                                             DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
+                                                             int group = 1, int nparts = 0, int hist = -1)
+{
+    finalize_mean_block(psum, pcnt, nblocks, ds, mode, phase, red, group, nparts, hist);
 }
 
 // ---- the finalize fused into the sweep that produced the partials (VERDICT r3 next #5b) --------------------------------------------------

@@ -178,7 +178,13 @@ struct SphHandle {
     int *tile_flag = nullptr, *tile_order = nullptr;
     // handles on the curve: the split is two RANGES of tiles (slab_cell_order keeps the interior columns in front): tile_split[0] = interior tiles
     // (k_tile_split); the host sizes the two launches by its bounds on that number
-    bool range_split = false, slab_groups = false;      // SPH_SLAB_GROUPS=1 (development): the columns stored in groups (slab_cell_order), the split by tile ranges -- measured, no gain: off
+    bool range_split = false;
+    bool overlap_on = true;       // sph_slab_set_overlap: the split + the hidden all-reduce may be switched off between steps (same bits either way)
+    // storage order of a slab handle's columns on the curve.  0 (default): the global curve as it falls.  Development switches (SPH_SLAB_GROUPS,
+    // slab_cell_order), both measured and no faster: 1 = groups of columns in cell tiles of their own, the split by tile ranges (flat tiles overflow
+    // the staging capacity); 2 = the curve shifted so that a cell tile starts at the slab's outer ghost column (fewer edge tiles, longer interior
+    // launch: the halo's chain hides, the step stays as long -- the joins between the streams cost what the hiding saves)
+    int slab_groups = 0;
     int *tile_split = nullptr, first_edge_slot = 0, split_lo = 0, split_hi = 0;
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
@@ -853,12 +859,24 @@ inline uint64_t morton_spread(uint64_t v)          // 21 bits -> every third bit
 // (Groups of ONE column -- the two ghost columns apart, so that the outer one's tiles never work at all -- make flat tiles whose neighbourhoods
 // overflow the LDS staging capacity: 10 % of the workgroups unstaged on config 4 at 8 slabs, and the correction sweeps 30 % slower.  Measured, dropped.)  Any bijection is a valid storage order (every sum runs in the reference's
 // cell walk with ascending id inside a cell); columns this slab does not hold map to -1 = no cell.  Recomputed when the cuts move.
+std::vector<int> morton_tile_ranks(const Consts &c);
 void slab_cell_order(const SphHandle *h, std::vector<int> &xmap, std::vector<int> &rank)
 {
     const Consts &c = h->c;
     const SlabGeom &g = h->geom;
     const int te = 1 << c.tbits, L = g.layers;
     xmap.assign((size_t)c.gx, -1);
+    if (h->slab_groups == 2) {
+        // ALIGNED: the plain curve, shifted so that a cell tile starts `layers` columns left of the slab.  With tiles of four columns and two ghost
+        // columns the tile at the left cut holds exactly the ghost columns and the two owned columns the left neighbour's halo carries; the right cut
+        // falls where the slab's width puts it.  The tiles that must run before the halo leaves are then half of a rank's tiles instead of three
+        // quarters (config 4 at 8 slabs: edge launch 83 -> 56 us, interior launch 24 -> 53 us, the halo's chain ends under the interior tiles).
+        // MEASURED: the step is as long as before (6.31 against 6.05-6.20 ms on rank 4) -- what follows the sweep waits for two event packets, not
+        // for the halo.  Off by default.
+        for (int x = std::max(g.x_lo - L, 0); x < std::min(g.x_hi + L, c.gx); ++x) xmap[(size_t)x] = x - (g.x_lo - L) + te;          // x_lo - L lands on a multiple of the tile edge
+        rank = morton_tile_ranks(c);
+        return;
+    }
     auto put = [&](int x, int tile, int code) { if (x >= 0 && x < c.gx) xmap[(size_t)x] = tile * te + code; };
     if (g.has_left) for (int l = 0; l < L; ++l) put(g.x_lo - L + l, 0, l);
     if (g.has_right) for (int l = 0; l < L; ++l) put(g.x_hi + l, 1, l);
@@ -1010,7 +1028,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * kSlabCounters, hipHostMallocDefault));
         // edge / interior split of the residual sweeps (dfsph, two ghost columns): tile flags and the edge-first tile order
         h->overlap = h->geom.layers == 2 && h->cfg.slab_overlap != 1;
-        h->range_split = h->overlap && c.order == CELL_ORDER_TILED && h->slab_groups;
+        h->range_split = h->overlap && c.order == CELL_ORDER_TILED && h->slab_groups == 1;
         if (h->range_split && (rc = dalloc(h, &h->tile_split, 4))) return rc;
         if (h->overlap) {
             if ((rc = dalloc(h, &h->tile_flag, (n + kBlock - 1) / kBlock + 1))) return rc;
@@ -1306,7 +1324,7 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStrea
     }
     return SPH_OK;
 }
-inline bool slab_can_overlap(const SphHandle *h) { return h->overlap && (h->native || !slab_stream_ordered(h)); }
+inline bool slab_can_overlap(const SphHandle *h) { return h->overlap && h->overlap_on && (h->native || !slab_stream_ordered(h)); }
 
 int read_counters(SphHandle *h)
 {
@@ -1954,7 +1972,7 @@ int stage_sort_and_lists(SphHandle *h)
             h->split_hi = (hi + kBlock - 1) / kBlock;
             h->split_lo = lo / kBlock;
             hipLaunchKernelGGL(k_tile_split, dim3(1), dim3(1), 0, s, h->cell_start, h->first_edge_slot, h->split_lo, h->tile_split, h->ds);
-        } else if (h->overlap) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
+        } else if (h->overlap && h->overlap_on) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
             hipLaunchKernelGGL(k_tile_flags, g, b, 0, s, c, h->geom, h->P[h->pcur], h->tile_flag);
             hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
@@ -2309,6 +2327,34 @@ void launch_rigid_force(SphHandle *h, int gate)            // dfsph_solver.py:21
                        h->rho_adv, h->aux, h->ds, h->rforce, gate, h->slab ? h->geom.x_lo : -0x7fffffff, h->slab ? h->geom.x_hi : 0x7fffffff);
 }
 
+// The in-order protocol of a two-column slab handle: the residual's refresh AND its mean in four enqueues instead of six -- [pack + this slab's
+// (sum, count)] -> the halo transfer -> the all-reduce -> [unpack + the loop decision] (k_pack_resid_reduce / k_unpack_resid_decide).
+int slab_exchange_resid_and_finalize(SphHandle *h, bool dens, float *val, int mode)
+{
+    hipStream_t s = h->stream;
+    const int nsl = h->edge_n[1][0] + h->edge_n[1][1], nsr = h->edge_n[2][0] + h->edge_n[2][1];
+    const int nrl = h->edge_n[0][0] + h->edge_n[0][1], nrr = h->edge_n[3][0] + h->edge_n[3][1];
+    float *S = h->c.kr_split ? h->krho : nullptr;
+    float4 *P = h->P[1 - h->pcur];
+    {
+        ProfScope ps(h, K_SLAB);
+        const ResidLists L{h->edge_list[1], nsl, h->edge_n[1][0], (float *)h->dsend[0], h->edge_list[2], nsr, h->edge_n[2][0], (float *)h->dsend[1]};
+        hipLaunchKernelGGL(k_pack_resid_reduce, dim3((unsigned)((nsl + nsr + kFinBlock - 1) / kFinBlock + 1)), dim3(kFinBlock), 0, s, L, val, P, S,
+                           h->psum, h->pcnt, h->nblocks, h->ds, mode, h->red_dev, partial_group(h), partial_count(h));
+    }
+    int rc = slab_xfer(h, 4 * (size_t)nsl, 4 * (size_t)nsr, 4 * (size_t)nrl, 4 * (size_t)nrr, s);
+    if (rc) return rc;
+    if ((rc = slab_allreduce_stream(h, mode == FIN_DENS ? 3 : 2, 0))) return rc;
+    {
+        ProfScope ps(h, K_SLAB);
+        const ResidLists L{h->edge_list[0], nrl, h->edge_n[0][0], (float *)h->drecv[0], h->edge_list[3], nrr, h->edge_n[3][0], (float *)h->drecv[1]};
+        hipLaunchKernelGGL(k_unpack_resid_decide, dim3((unsigned)((nrl + nrr + kFinBlock - 1) / kFinBlock + 1)), dim3(kFinBlock), 0, s, h->c, L, dens ? 1 : 0, h->aux, h->rho,
+                           val, P, S, h->psum, h->pcnt, h->nblocks, h->ds, mode, h->red_dev, partial_group(h), partial_count(h));
+    }
+    HIP_TRY(h, hipGetLastError());
+    return SPH_OK;
+}
+
 // host-driven evaluation of a mean (sharded runs: the (sum, count) pair is all-reduced over the slabs)
 int reduce_mean_host(SphHandle *h, float dflt, float *mean)
 {
@@ -2428,6 +2474,10 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         if (!h->slab && fin_fusable(h)) {
             if (dens) launch_dens_residual(h, gate, 0, fin_mode); else launch_div_residual(h, gate, 0, fin_mode);
             return SPH_OK;
+        }
+        if (two && !ovl && slab_async(h)) {          // in order: the small launches of the refresh and of the mean ride together
+            if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate);
+            return slab_exchange_resid_and_finalize(h, dens, dens ? h->rho_adv : h->drho, fin_mode);
         }
         if ((r = residual_sweep(dens, gate))) return r;
         return launch_finalize(h, fin_mode);
@@ -3008,7 +3058,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
-    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); h->slab_groups = e && atoi(e) == 1; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); if (e) h->slab_groups = std::min(std::max(atoi(e), 0), 2); }
     { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
@@ -3407,6 +3457,19 @@ int sph_slab_info(SphHandle *h, int32_t *out)
     // residual's all-reduce and loop decision run on a third stream under the next correction sweep (both need a transport that can: slab_can_overlap)
     out[7] = !h->slab ? 0 : h->geom.layers | ((h->geom.layers == 2 && h->comm_set && slab_can_overlap(h)) ? 16 : 0) |
                             ((h->geom.layers == 2 && h->comm_set && slab_can_overlap(h) && slab_async(h) && h->rstream && is_dfsph(h)) ? 32 : 0);
+    return SPH_OK;
+}
+
+// Between steps, on every slab alike: run the dfsph loops with the halo and the reductions on their own streams (1; needs a handle created with
+// slab_overlap != 1) or in order on the handle's stream (0).  The bits do not change; which is faster depends on the link and on the slab's
+// size -- with the link time at zero a rank of 1.2 M particles steps 12 % faster in order, on a slow link the overlap wins:
+// bench.py times both on the node it runs on.
+int sph_slab_set_overlap(SphHandle *h, int32_t on)
+{
+    if (!h) return SPH_E_INVALID;
+    if (!h->slab) return fail(h, SPH_E_STATE, "not a slab handle");
+    if (on && !h->overlap) return fail(h, SPH_E_STATE, "this handle was created without the overlapped protocol (slab_overlap = 1, or one ghost column)");
+    h->overlap_on = on != 0;
     return SPH_OK;
 }
 

@@ -343,35 +343,63 @@ __global__ __launch_bounds__(kBlock) void k_unpack_field(const int *__restrict__
 // whose particles run the correction sweeps themselves and need the residual value (rho_derivative / rho_adv: `val`) -- their k / rho is
 // re-derived on arrival with the very expression of k_residual, from the alpha and rho the ghost computed itself in D1; the entries behind them
 // are the OUTER column, read only as neighbours: they get the owner's k / rho.
+struct ResidLists { const int *list_a; int count_a, n1_a; float *buf_a; const int *list_b; int count_b, n1_b; float *buf_b; };
+__device__ __forceinline__ void pack_resid_entry(const ResidLists &L, int r, const float *__restrict__ val, const float4 *__restrict__ P, const float *__restrict__ S)
+{
+    if (r >= L.count_a + L.count_b) return;
+    const bool b = r >= L.count_a;
+    if (b) r -= L.count_a;
+    const int s = (b ? L.list_b : L.list_a)[r];
+    (b ? L.buf_b : L.buf_a)[r] = r < (b ? L.n1_b : L.n1_a) ? val[s] : (S ? S[s] : P[s].w);
+}
+__device__ __forceinline__ void unpack_resid_entry(const Consts &c, const ResidLists &L, int r, int dens, const float *__restrict__ alpha, const float *__restrict__ rho,
+                                                   const DevScalars *__restrict__ ds, float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S)
+{
+    if (r >= L.count_a + L.count_b) return;
+    const bool b = r >= L.count_a;
+    if (b) r -= L.count_a;
+    const int s = (b ? L.list_b : L.list_a)[r];
+    const float x = (b ? L.buf_b : L.buf_a)[r];
+    float kr = x;
+    if (r < (b ? L.n1_b : L.n1_a)) {
+        val[s] = x;
+        if (dens) kr = ((x - c.rho0) * alpha[s] / ds->dt2) / rho[s];           // dfsph_solver.py:199,203 as k_residual writes it
+        else kr = (x * alpha[s] / ds->dt) / rho[s];                            // :363,367
+    }
+    if (S) S[s] = kr; else P[s].w = kr;
+}
 __global__ __launch_bounds__(kBlock) void k_pack_resid(const int *__restrict__ list_a, int count_a, int n1_a, float *__restrict__ out_a,
                                                        const int *__restrict__ list_b, int count_b, int n1_b, float *__restrict__ out_b,
                                                        const float *__restrict__ val, const float4 *__restrict__ P, const float *__restrict__ S)
 {
-    int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= count_a + count_b) return;
-    const bool b = r >= count_a;
-    if (b) r -= count_a;
-    const int s = (b ? list_b : list_a)[r];
-    (b ? out_b : out_a)[r] = r < (b ? n1_b : n1_a) ? val[s] : (S ? S[s] : P[s].w);
+    pack_resid_entry(ResidLists{list_a, count_a, n1_a, out_a, list_b, count_b, n1_b, out_b}, blockIdx.x * kBlock + threadIdx.x, val, P, S);
+}
+// The in-order protocol (slab_overlap = 1 / sph_slab_set_overlap(h, 0)) runs a solver iteration's small launches back to back on one stream: pack,
+// transfer, unpack, reduce, all-reduce, decide -- ~5 us each at 1.2 M particles per rank, a sixth of the iteration.  Two of them ride along: the
+// slab's (sum, count) is reduced by the LAST workgroup of the pack launch (it only needs the residual sweep, like the pack), and the loop decision
+// is taken by the last workgroup of the unpack launch (it only needs the all-reduce, which is enqueued in front of it).  Same trees, same bits.
+__global__ __launch_bounds__(kFinBlock) void k_pack_resid_reduce(ResidLists L, const float *__restrict__ val, const float4 *__restrict__ P, const float *__restrict__ S,
+                                                                 const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, DevScalars *__restrict__ ds,
+                                                                 int mode, double *__restrict__ red, int group, int nparts)
+{
+    if (blockIdx.x == gridDim.x - 1) { finalize_mean_block(psum, pcnt, nblocks, ds, mode, FINP_REDUCE, red, group, nparts, -1); return; }
+    pack_resid_entry(L, blockIdx.x * kFinBlock + threadIdx.x, val, P, S);
+}
+__global__ __launch_bounds__(kFinBlock) void k_unpack_resid_decide(Consts c, ResidLists L, int dens, const float *__restrict__ alpha, const float *__restrict__ rho,
+                                                                   float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S,
+                                                                   const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, DevScalars *__restrict__ ds,
+                                                                   int mode, double *__restrict__ red, int group, int nparts)
+{
+    if (blockIdx.x == gridDim.x - 1) { finalize_mean_block(psum, pcnt, nblocks, ds, mode, FINP_DECIDE, red, group, nparts, -1); return; }
+    unpack_resid_entry(c, L, blockIdx.x * kFinBlock + threadIdx.x, dens, alpha, rho, ds, val, P, S);
 }
 __global__ __launch_bounds__(kBlock) void k_unpack_resid(Consts c, const int *__restrict__ list_a, int count_a, int n1_a, const float *__restrict__ in_a,
                                                          const int *__restrict__ list_b, int count_b, int n1_b, const float *__restrict__ in_b,
                                                          int dens, const float *__restrict__ alpha, const float *__restrict__ rho, const DevScalars *__restrict__ ds,
                                                          float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S)
 {
-    int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= count_a + count_b) return;
-    const bool b = r >= count_a;
-    if (b) r -= count_a;
-    const int s = (b ? list_b : list_a)[r];
-    const float x = (b ? in_b : in_a)[r];
-    float kr = x;
-    if (r < (b ? n1_b : n1_a)) {
-        val[s] = x;
-        if (dens) kr = ((x - c.rho0) * alpha[s] / ds->dt2) / rho[s];           // dfsph_solver.py:199,203 as k_residual writes it
-        else kr = (x * alpha[s] / ds->dt) / rho[s];                            // :363,367
-    }
-    if (S) S[s] = kr; else P[s].w = kr;
+    unpack_resid_entry(c, ResidLists{list_a, count_a, n1_a, const_cast<float *>(in_a), list_b, count_b, n1_b, const_cast<float *>(in_b)}, blockIdx.x * kBlock + threadIdx.x,
+                       dens, alpha, rho, ds, val, P, S);
 }
 
 // Edge / interior split of the residual sweeps (slab handles, dfsph): a tile is an EDGE tile if one of its particles lies in a column that

@@ -292,6 +292,9 @@ int sph_plan_slabs(const SphConfig *cfg, int32_t *cuts, int32_t *counts);
  * particles of `ghost_layers` columns beyond each cut; ghost_layers = 0: plain equal counts), every slab >= 3 columns wide and
  * old_cuts[k-1] < new_cuts[k] < old_cuts[k+1] (a particle's new owner is its rank or a direct neighbour) */
 int sph_replan_slabs(const int64_t *column_histogram, int32_t grid_x, int32_t slab_count, const int32_t *old_cuts, int32_t ghost_layers, int32_t *new_cuts);
+/* between steps, on every slab alike: 1 = the dfsph solver loops run their halo and reductions on their own streams (the default where the
+ * handle and its transport can), 0 = in order on the handle's stream.  Results are the same bits; which is faster depends on the link */
+int sph_slab_set_overlap(SphHandle *h, int32_t on);
 /* slab bookkeeping: out[0] = owned particles, out[1] = ghosts, out[2] = x_lo, out[3] = x_hi (cell units), out[4] = capacity,
  * out[5] = number of re-balancings that moved a cut, out[6] = slab_rebalance_every, out[7] = the halo protocol in force: ghost columns per side (1 or 2)
  * | 16 if the dfsph residual sweeps run their edge tiles first with the halo on its own stream | 32 if the residual's all-reduce and loop decision run

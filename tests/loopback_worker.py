@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--arith", type=int, default=0)
     ap.add_argument("--time", type=int, default=0, help="time this many further steps after the compared ones (no comparison of those)")
     ap.add_argument("--no-compare", action="store_true")
+    ap.add_argument("--toggle-overlap", type=int, default=0, help="switch the overlapped protocol off / on every this many steps (sph_slab_set_overlap), on every rank alike")
     ap.add_argument("--replay-rank", type=int, default=-1, help="record what this rank receives, then run it ALONE against that log and time it (needs --time)")
     ap.add_argument("--log-mb", type=int, default=8192)
     ap.add_argument("--save-log", default="", help="with --replay-rank: write the log to this file and stop (the replay runs in a process of its own: --load-log)")
@@ -104,7 +105,9 @@ def main():
     def run(r):
         try:
             sims[r].rccl_attach(uid, 64 << 20)              # collective: returns when every rank has joined
-            for _ in range(args.steps):
+            for k in range(args.steps):
+                if args.toggle_overlap and k % args.toggle_overlap == 0:
+                    sims[r].set_slab_overlap((k // args.toggle_overlap) % 2 == 1)
                 st = one_step(r)
                 owned_max[r] = max(owned_max[r], sims[r].slab_info()["owned"])
                 if st is not None:

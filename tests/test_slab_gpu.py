@@ -157,7 +157,9 @@ def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0
 @pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap,order", [
     ("dfsph_small", 2, 25, 0, 0, 0, "morton"), ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
     ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 3, 30, 0, 0, 1, None), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, "morton"),
-    ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None)])
+    ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None),
+    # the two storage orders of a slab's columns that were measured and left off (SPH_SLAB_GROUPS = 1: groups + range split, 2: aligned tiles)
+    ("dfsph_dam_x", 3, 150, 7, 0, 0, "morton+groups1"), ("breaking_dam_30k_dfsph", 4, 30, 3, 0, 0, "morton+groups2")])
 def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps, rebalance, layers, overlap, order):
     """The discipline a multi-GPU node runs -- the library's NATIVE transport: ncclSend / ncclRecv / ncclAllReduce enqueued by the library itself,
     no host wait between the sweeps, the halo of the edge tiles on its own stream under the interior tiles, the residual's all-reduce and the loop
@@ -167,7 +169,12 @@ def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps
     way RCCL orders its kernels.  What the gloo tests cannot see -- a missing dependency between the three streams, which gloo's host waits paper over
     -- shows here as a difference to the one-GPU run.  Fluid state, iteration counts, residuals (and the rigid body) bit for bit; re-cuts, both
     ghost-column protocols, the split on and off, every sharded solver."""
-    r = run_loopback(tmp_path, scene, world, steps, rebalance=rebalance, layers=layers, overlap=overlap, env_extra={"SPH_CELL_ORDER": order} if order else None)
+    env = {}
+    if order:
+        env["SPH_CELL_ORDER"] = order.split("+")[0]
+        if "+groups" in order:
+            env["SPH_SLAB_GROUPS"] = order[-1]
+    r = run_loopback(tmp_path, scene, world, steps, rebalance=rebalance, layers=layers, overlap=overlap, env_extra=env or None)
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "slabs")}
     assert r["stats_equal"] and r["stats_same_on_all_ranks"], (r["stats_last"], r["ref_stats_last"])
     assert r["body_equal"] in (None, True)
@@ -177,6 +184,19 @@ def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps
         two = layers != 1
         for s in r["slabs"]:
             assert s["ghost_columns"] == (2 if two else 1) and s["halo_overlapped"] == (two and overlap == 0) and s["allreduce_hidden"] == (two and overlap == 0), s
+
+
+def test_slab_protocol_can_be_switched_between_steps(tmp_path):
+    """sph_slab_set_overlap: the dfsph loops with the halo and the reductions on their own streams, or in order on the handle's -- switched every
+    seven steps on every rank alike (bench.py times both on the node it runs on and keeps the faster): the same bits as one GPU throughout."""
+    out = tmp_path / "toggle.json"
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "loopback_worker.py"), "--scene", "breaking_dam_30k_dfsph", "--world", "3", "--steps", "45",
+           "--rebalance", "11", "--toggle-overlap", "7", "--out", str(out)]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, SPH_SLAB_CHECK="1", SPH_CELL_ORDER="morton"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = json.loads(out.read_text())
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "stats_last", "ref_stats_last")}
+    assert all(not s["halo_overlapped"] for s in r["slabs"])          # 45 steps: the last switch (step 42) turned it off
 
 
 def test_legacy_host_loops_on_slabs(tmp_path):
