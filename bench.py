@@ -22,6 +22,9 @@ Extra objects on the line:
                 from the device's state at the start of the timed window (same phase of the collapse as `value`).
   relaxed       N = 1, dfsph scenes: the same timed steps from the same state with SphConfig.arith = SPH_ARITH_RELAXED (tolerance-grade sweeps),
                 its throughput, dominant kernel and measured deviation from the exact run; the headline `value` is the exact arithmetic.
+  config.slab_protocol_probe   N > 1, dfsph: the last 2 x 6 steps of the pre-roll time the two slab protocols -- halo and reductions on their own streams
+                under the sweeps, or everything in order on one stream (the same bits) -- and the run keeps the faster on all ranks: with a free link
+                the in-order form wins, on a slow one the overlap; --no-overlap-probe keeps the overlapped one unmeasured.
   strong_scaling_base   N = 1, default workload only: the N > 1 workload (dfsph_10m) on this one GPU with the same flags, so that
                 the strong-scaling series the driver assembles from N = 2, 4, 8 has its one-GPU point.
 """

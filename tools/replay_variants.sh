@@ -9,10 +9,10 @@ cd $R
 export SPH_DEV=1 SPH_SLAB_CHECK=0
 log=${TMPDIR:-/tmp}/loopback_${scene}_${world}_${rank}.log
 out=gpurun_out/${tag}_variants_${scene}_${world}_rank${rank}
-python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --save-log $log --out ${out}_recorded.json || exit 1
+python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --overlap ${LOOPBACK_OVERLAP:-0} --replay-rank $rank --save-log $log --out ${out}_recorded.json || exit 1
 for v in "base:" "$@"; do
   name=${v%%:*}; envs=${v#*:}
-  env $envs python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --replay-rank $rank --load-log $log --out ${out}_$name.json || exit 1
+  env $envs python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --overlap ${LOOPBACK_OVERLAP:-0} --replay-rank $rank --load-log $log --out ${out}_$name.json || exit 1
   python3 - <<PY
 import json
 a, b = json.load(open("${out}_recorded.json")), json.load(open("${out}_$name.json"))
