@@ -571,7 +571,8 @@ def main():
                    "grid": list(sim.grid), "preroll_steps": args.preroll, "arith": headline_arith, "overrides": overrides,
                    "timed_steps": "%d-%d" % (args.preroll + args.warmup + 1, args.preroll + args.warmup + args.steps),
                    "parallelism": "1 GPU" if world == 1 else "%d x-slabs, %s, halo transport: %s, cuts re-balanced every %d steps" % (
-                       world, "2 ghost cell columns per side (one halo refresh per dfsph solver iteration, edge tiles of the residual sweeps first)" if solver_kind == "dfsph"
+                       world, ("2 ghost cell columns per side (one halo refresh per dfsph solver iteration, %s)" % ("edge tiles of the residual sweeps first, halo and reductions on their own streams"
+                                                                                                   if (slab_info or {}).get("halo_overlapped") else "in order on one stream")) if solver_kind == "dfsph"
                        else "1 ghost cell column per side", transport, args.rebalance)},
     }
     if args.preroll > 0:
