@@ -153,3 +153,32 @@ def test_replan_rule_properties():
             new = nat.replan_slabs(h2, old, ghost_layers=int(rng.integers(1, 3)))
             assert new[0] == 0 and new[-1] == gx and all(new[k + 1] >= new[k] + 3 for k in range(nslab)) and all(old[k - 1] < new[k] < old[k + 1] for k in range(1, nslab))
             old = new
+
+
+def test_balanced_cuts_are_optimal_on_small_cases():
+    """The cut planner (balanced_cuts in csrc/sph_mi355x.hip, through sph_replan_slabs): the largest load -- 4 x particles + 5 x the particles of the
+    ghost columns beyond each cut, in quarters of a particle -- is the smallest any admissible set of cuts can reach (brute force over all of them)."""
+    rng = np.random.default_rng(11)
+    gx, nslab = 15, 3
+    old = [0, 5, 10, gx]
+    for layers in (1, 2):
+        for trial in range(40):
+            hist = rng.integers(0, 500, gx).astype(np.int64)
+            hist[rng.integers(0, gx, 3)] = 0
+            pre = np.concatenate([[0], np.cumsum(hist)])
+
+            def load(r, y, x):
+                v = 4 * (pre[x] - pre[y])
+                if r > 0:
+                    v += 5 * (pre[y] - pre[max(y - layers, 0)])
+                if r < nslab - 1:
+                    v += 5 * (pre[min(x + layers, gx)] - pre[x])
+                return int(v)
+            best = None
+            for c1 in range(max(old[0] + 1, 3), min(old[2] - 1, gx - 6) + 1):
+                for c2 in range(max(old[1] + 1, c1 + 3), min(old[3] - 1, gx - 3) + 1):
+                    m = max(load(0, 0, c1), load(1, c1, c2), load(2, c2, gx))
+                    best = m if best is None else min(best, m)
+            new = nat.replan_slabs(hist, old, ghost_layers=layers)
+            got = max(load(0, 0, new[1]), load(1, new[1], new[2]), load(2, new[2], gx))
+            assert got == best, (hist.tolist(), new, got, best)
