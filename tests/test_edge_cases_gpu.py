@@ -144,3 +144,26 @@ def test_environment_knobs_are_development_overrides(monkeypatch, capfd):
     sim.step_dfsph(1)
     assert sim.scalar(nat.S_ARITH_RELAXED) == 1.0
     sim.close()
+
+
+def test_slab_protocol_switch_refuses_what_the_handle_cannot_do():
+    """sph_slab_set_overlap: only slab handles have a protocol, and one created without the overlapped form (slab_overlap = 1, or the one-column
+    protocol of the other solvers) cannot be switched to it; switching it OFF is always allowed."""
+    one = nat.Simulation(nat.config_from_dict(scenes.get("dfsph_small")))
+    with pytest.raises(nat.SphError):
+        one.set_slab_overlap(False)
+    one.close()
+    cfg = scenes.get("dfsph_small")
+    plain = nat.Simulation(nat.config_from_dict(cfg, slab_rank=0, slab_count=2, slab_overlap=1))
+    with pytest.raises(nat.SphError):
+        plain.set_slab_overlap(True)
+    plain.set_slab_overlap(False)
+    plain.close()
+    able = nat.Simulation(nat.config_from_dict(cfg, slab_rank=1, slab_count=2))
+    able.set_slab_overlap(False)
+    able.set_slab_overlap(True)
+    able.close()
+    w = nat.Simulation(nat.config_from_dict(scenes.get("wcsph_small"), slab_rank=0, slab_count=2))
+    with pytest.raises(nat.SphError):
+        w.set_slab_overlap(True)
+    w.close()
