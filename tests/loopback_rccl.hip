@@ -125,9 +125,11 @@ bool wait_for(World &w, std::unique_lock<std::mutex> &lk, Pred p)
 
 #define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "loopback_rccl: %s: %s\n", #x, hipGetErrorString(e_)); return ncclUnhandledCudaError; } } while (0)
 
+void delay_on(hipStream_t stream);
 ncclResult_t run_group(std::vector<PendingOp> &ops)
 {
     if (!ops.empty() && ops[0].comm->replay) {
+        for (PendingOp &op : ops) if (!op.send) { delay_on(op.stream); break; }
         for (PendingOp &op : ops)
             if (!op.send) { ncclResult_t r = replay_into(op.comm, op.buf, op.bytes, op.stream, "receive"); if (r != ncclSuccess) return r; }
         return ncclSuccess;
@@ -189,6 +191,22 @@ ncclResult_t run_group(std::vector<PendingOp> &ops)
 }
 
 __global__ void loopback_marker_kernel(int *p) { if (p) *p = 1; }
+
+// LOOPBACK_LATENCY_US=<n>: every group of point-to-point transfers and every all-reduce is preceded, on its stream, by a kernel that does nothing
+// for n microseconds -- a stand-in for what a real link and a real collective take before the first byte arrives (one workgroup of one wave
+// waiting on the 100 MHz wall clock: bounded by construction).  With it the replay of one rank prices the two slab protocols against a link that
+// is not free (tools/loopback_replay.sh).
+__global__ void loopback_delay_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int g_latency_us = -1;
+void delay_on(hipStream_t stream)
+{
+    if (g_latency_us < 0) { const char *e = getenv("LOOPBACK_LATENCY_US"); g_latency_us = e ? atoi(e) : 0; if (g_latency_us > 1000) g_latency_us = 1000; }
+    if (g_latency_us > 0) hipLaunchKernelGGL(loopback_delay_kernel, dim3(1), dim3(64), 0, stream, (long long)g_latency_us * 100);
+}
 
 template <class T>
 __global__ void k_reduce(T *__restrict__ out, const char *__restrict__ stage, size_t slot_bytes, int ranks, size_t n, int is_max)
@@ -387,7 +405,7 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
     if (!c || (datatype != ncclFloat64 && datatype != ncclInt32) || (op != ncclSum && op != ncclMax)) return ncclInvalidArgument;
     World &w = *c->w;
     const size_t ts = type_size(datatype), bytes = count * ts;
-    if (c->replay) return replay_into(c, recvbuff, bytes, stream, "all-reduce");
+    if (c->replay) { delay_on(stream); return replay_into(c, recvbuff, bytes, stream, "all-reduce"); }
     if (bytes > kStageBytes) return ncclInvalidArgument;
     const long long s = c->ar_seq++;
     const int p = (int)(s & 1), me = c->rank;
