@@ -506,7 +506,15 @@ def main():
         """pre-roll (timed on the side as the early phase), warm-up, then EXACTLY args.steps steps between two fences; max over ranks"""
         fence(sim)
         t0 = time.perf_counter()
-        probe = 6 if (world > 1 and solver_kind == "dfsph" and args.preroll >= 24 and sim.slab_info()["halo_overlapped"] and not args.no_overlap_probe) else 0
+        probe = 0
+        if world > 1 and solver_kind == "dfsph" and args.preroll >= 24 and not args.no_overlap_probe:
+            started = sim.slab_info()["halo_overlapped"]
+            try:                                   # can this handle run both protocols?  (created with the streams of the overlapped one)
+                sim.set_slab_overlap(True)
+                probe = 6 if sim.slab_info()["halo_overlapped"] else 0
+            except nat.SphError:
+                probe = 0
+            sim.set_slab_overlap(started)
         run(args.preroll - 2 * probe)
         if probe:
             # Which protocol is faster HERE?  The dfsph loops with the halo and the reductions on their own streams, or in order on one stream: the

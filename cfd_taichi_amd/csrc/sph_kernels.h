@@ -1364,9 +1364,11 @@ __device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode
 }
 // hist >= 0: this is evaluation number `hist` of its loop; the decision also goes to gate_hist[hist & 1] (see DevScalars)
 // (the work of ONE workgroup of kFinBlock threads: k_finalize_mean, or the last workgroup of k_pack_resid_reduce / k_unpack_resid_decide)
+// gather_n > 0 (FINP_DECIDE only): red holds gather_n slabs' (sum, count, flags) triples, four doubles apart -- gathered with the halo's own
+// transfers instead of all-reduced -- and the decision sums them here, in slab order, on every slab alike
 __device__ __forceinline__ void finalize_mean_block(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                     DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                    int group, int nparts, int hist)
+                                                    int group, int nparts, int hist, int gather_n = 0)
 {
     if (mode == FIN_DIV_LOOP && ds->div_active == 0) { if (hist >= 0 && threadIdx.x == 0 && phase != FINP_REDUCE) ds->gate_hist[hist & 1] = 0; return; }
     if (mode == FIN_DENS && ds->dens_active == 0) {
@@ -1380,7 +1382,12 @@ __device__ __forceinline__ void finalize_mean_block(const double *__restrict__ p
     // (the density loop's reduction carries a third word: this slab's overflow flags -- every slab must see a list overflow on ANY slab at the
     // same point of the step, and this way that costs no host round trip of its own)
     if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; if (mode == FIN_DENS) red[2] = (double)ds->overflow; return; }
-    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; if (mode == FIN_DENS) ds->overflow_any = red[2] != 0.0 ? 1 : 0; }
+    if (phase == FINP_DECIDE) {
+        double rs = red[0], rc = red[1], rf = red[2];
+        for (int r = 1; r < gather_n; ++r) { rs += red[4 * r]; rc += red[4 * r + 1]; rf += red[4 * r + 2]; }
+        s_sum[0] = rs; s_cnt[0] = (long long)rc;
+        if (mode == FIN_DENS) ds->overflow_any = rf != 0.0 ? 1 : 0;
+    }
     const int was = (mode == FIN_DENS) ? ds->dens_active : ds->div_active;
     fin_decide(ds, mode, s_sum[0], s_cnt[0]);
     if (hist >= 0) {

@@ -194,6 +194,8 @@ struct SphHandle {
     int red_cap = 4;              // doubles in red_dev
     int *cnt_dev = nullptr, *cnt_host = nullptr;     // neighbour count exchange: [send_left, send_right, recv_left, recv_right]
     double *red_host = nullptr;   // pinned staging for host-side all-reduces
+    double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
+    bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
     bool own_red = false, slab_legacy = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -1181,13 +1183,20 @@ RcclApi &rccl()
     } while (0)
 
 // exchange_buffers of the native transport: one group of up to four point-to-point transfers, ordered on the handle's stream
-int native_exchange(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr)
+// gather_doubles > 0: the same group also carries this slab's gath_dev slot (that many doubles) to EVERY other slab and theirs back -- the residual's
+// (sum, count, flags) travel with the halo, one start-up latency per solver iteration instead of the halo's plus an all-reduce's
+int native_exchange(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr, int gather_doubles = 0)
 {
     RcclApi &n = rccl();
     if (!stream) stream = h->stream;
     const int left = h->slab_rank > 0 ? h->slab_rank - 1 : -1, right = h->slab_rank < h->nslab - 1 ? h->slab_rank + 1 : -1;
-    if (!((left >= 0 && (sl || rl)) || (right >= 0 && (sr || rr)))) return SPH_OK;
+    if (!gather_doubles && !((left >= 0 && (sl || rl)) || (right >= 0 && (sr || rr)))) return SPH_OK;
     NCCL_TRY(h, n.GroupStart());
+    for (int p = 0; gather_doubles && p < h->nslab; ++p) {
+        if (p == h->slab_rank) continue;
+        NCCL_TRY(h, n.Send(h->gath_dev + 4 * h->slab_rank, (size_t)gather_doubles, ncclDouble, p, h->nccl, stream));
+        NCCL_TRY(h, n.Recv(h->gath_dev + 4 * p, (size_t)gather_doubles, ncclDouble, p, h->nccl, stream));
+    }
     if (left >= 0) {
         if (sl) NCCL_TRY(h, n.Send(h->dsend[0], sl, ncclChar, left, h->nccl, stream));
         if (rl) NCCL_TRY(h, n.Recv(h->drecv[0], rl, ncclChar, left, h->nccl, stream));
@@ -1305,7 +1314,7 @@ int slab_allreduce_host(SphHandle *h, double *v, int n, int op)
 // `stream`: where the packed data was produced and the unpack will run (the handle's stream, or the halo stream of an overlapped refresh).
 // A stream-ordered CALLBACK transport enqueues on the handle's own stream whatever we say, so overlapped refreshes are only taken with the
 // native transport or a synchronous one (slab_can_overlap).
-int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr)
+int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStream_t stream = nullptr, int gather_doubles = 0)
 {
     if (!stream) stream = h->stream;
     const SphComm &cm = h->comm;
@@ -1319,7 +1328,7 @@ int slab_xfer(SphHandle *h, size_t sl, size_t sr, size_t rl, size_t rr, hipStrea
     h->comm_stat[0] += 1; h->comm_stat[1] += (long long)(sl + sr); h->comm_stat[2] += (long long)(rl + rr);       // (counted even when this rank's share of the exchange is empty)
     int rc;
     if (h->native) {
-        if ((rc = native_exchange(h, sl, sr, rl, rr, stream))) return rc;
+        if ((rc = native_exchange(h, sl, sr, rl, rr, stream, gather_doubles))) return rc;
     } else {
         rc = cm.exchange_buffers(cm.user, sl, sr, rl, rr);      // stream-ordered transports enqueue behind the pack kernels instead
         if (rc) return comm_fail(h, "exchange_buffers", rc);
@@ -2342,20 +2351,25 @@ int slab_exchange_resid_and_finalize(SphHandle *h, bool dens, float *val, int mo
     const int nrl = h->edge_n[0][0] + h->edge_n[0][1], nrr = h->edge_n[3][0] + h->edge_n[3][1];
     float *S = h->c.kr_split ? h->krho : nullptr;
     float4 *P = h->P[1 - h->pcur];
+    // native transport: this slab's (sum, count, flags) go to every slab in the halo's own group of transfers and the decision sums the gathered
+    // triples in slab order -- ONE start-up latency per solver iteration where the halo and an all-reduce paid two (what a step costs on a link
+    // that is not free: profiles/r04/loopback/link_latency_sweep.txt)
+    const bool gather = h->native && h->gath_dev && h->opt_gather;
+    if (gather) h->comm_stat[4] += 1;           // (counted with the all-reduces it replaces)
     {
         ProfScope ps(h, K_SLAB);
         const ResidLists L{h->edge_list[1], nsl, h->edge_n[1][0], (float *)h->dsend[0], h->edge_list[2], nsr, h->edge_n[2][0], (float *)h->dsend[1]};
         hipLaunchKernelGGL(k_pack_resid_reduce, dim3((unsigned)((nsl + nsr + kFinBlock - 1) / kFinBlock + 1)), dim3(kFinBlock), 0, s, L, val, P, S,
-                           h->psum, h->pcnt, h->nblocks, h->ds, mode, h->red_dev, partial_group(h), partial_count(h));
+                           h->psum, h->pcnt, h->nblocks, h->ds, mode, gather ? h->gath_dev + 4 * h->slab_rank : h->red_dev, partial_group(h), partial_count(h));
     }
-    int rc = slab_xfer(h, 4 * (size_t)nsl, 4 * (size_t)nsr, 4 * (size_t)nrl, 4 * (size_t)nrr, s);
+    int rc = slab_xfer(h, 4 * (size_t)nsl, 4 * (size_t)nsr, 4 * (size_t)nrl, 4 * (size_t)nrr, s, gather ? 3 : 0);
     if (rc) return rc;
-    if ((rc = slab_allreduce_stream(h, mode == FIN_DENS ? 3 : 2, 0))) return rc;
+    if (!gather && (rc = slab_allreduce_stream(h, mode == FIN_DENS ? 3 : 2, 0))) return rc;
     {
         ProfScope ps(h, K_SLAB);
         const ResidLists L{h->edge_list[0], nrl, h->edge_n[0][0], (float *)h->drecv[0], h->edge_list[3], nrr, h->edge_n[3][0], (float *)h->drecv[1]};
         hipLaunchKernelGGL(k_unpack_resid_decide, dim3((unsigned)((nrl + nrr + kFinBlock - 1) / kFinBlock + 1)), dim3(kFinBlock), 0, s, h->c, L, dens ? 1 : 0, h->aux, h->rho,
-                           val, P, S, h->psum, h->pcnt, h->nblocks, h->ds, mode, h->red_dev, partial_group(h), partial_count(h));
+                           val, P, S, h->psum, h->pcnt, h->nblocks, h->ds, mode, gather ? h->gath_dev : h->red_dev, partial_group(h), partial_count(h), gather ? h->nslab : 0);
     }
     HIP_TRY(h, hipGetLastError());
     return SPH_OK;
@@ -3064,6 +3078,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); if (e) h->slab_groups = std::min(std::max(atoi(e), 0), 2); }
     { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
@@ -3152,6 +3167,7 @@ void sph_destroy(SphHandle *h)
     if (h->cnt_dev) (void)hipFree(h->cnt_dev);
     if (h->cnt_host) (void)hipHostFree(h->cnt_host);
     if (h->red_host) (void)hipHostFree(h->red_host);
+    if (h->gath_dev) (void)hipFree(h->gath_dev);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
@@ -3374,12 +3390,19 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     HIP_TRY(h, hipMalloc((void **)&h->red_dev, sizeof(double) * (size_t)h->red_cap));
     h->own_red = true;
     HIP_TRY(h, hipHostMalloc((void **)&h->red_host, sizeof(double) * (size_t)h->red_cap, hipHostMallocDefault));
+    if (h->gath_dev) (void)hipFree(h->gath_dev);
+    HIP_TRY(h, hipMalloc((void **)&h->gath_dev, sizeof(double) * 4 * (size_t)std::max(world, 1)));
+    HIP_TRY(h, hipMemsetAsync(h->gath_dev, 0, sizeof(double) * 4 * (size_t)std::max(world, 1), h->stream));
     HIP_TRY(h, hipMalloc((void **)&h->cnt_dev, sizeof(int) * 4 * kCountInts));
     HIP_TRY(h, hipHostMalloc((void **)&h->cnt_host, sizeof(int) * 4 * kCountInts, hipHostMallocDefault));
     memset(&h->comm, 0, sizeof(h->comm));
     h->comm.capacity = capacity_bytes;
     h->comm.stream_ordered = 1;
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
+    // the native transport starts in order (one stream; the residual's triple rides with the halo): with transfers and collectives that take
+    // 0-50 us to start it is the faster protocol in every replay (profiles/r04/loopback/link_latency_sweep.txt); slab_overlap = 2 starts overlapped,
+    // sph_slab_set_overlap switches between steps (bench.py times both)
+    h->overlap_on = h->cfg.slab_overlap == 2;
     h->native = true;
     h->comm_set = true;
     return SPH_OK;
@@ -3434,6 +3457,7 @@ int sph_set_comm(SphHandle *h, const SphComm *comm)
     }
     if (comm->stream_ordered && comm->on_host) return fail(h, SPH_E_INVALID, "a stream-ordered transport needs device buffers (on_host = 0)");
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
+    h->overlap_on = true;          // (a synchronous transport is slow: the overlapped protocol wins there, profiles/r04/rehearsal_2ranks.json)
     h->comm_set = true;
     return SPH_OK;
 }

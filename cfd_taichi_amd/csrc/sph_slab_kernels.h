@@ -388,9 +388,9 @@ __global__ __launch_bounds__(kFinBlock) void k_pack_resid_reduce(ResidLists L, c
 __global__ __launch_bounds__(kFinBlock) void k_unpack_resid_decide(Consts c, ResidLists L, int dens, const float *__restrict__ alpha, const float *__restrict__ rho,
                                                                    float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S,
                                                                    const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, DevScalars *__restrict__ ds,
-                                                                   int mode, double *__restrict__ red, int group, int nparts)
+                                                                   int mode, double *__restrict__ red, int group, int nparts, int gather_n)
 {
-    if (blockIdx.x == gridDim.x - 1) { finalize_mean_block(psum, pcnt, nblocks, ds, mode, FINP_DECIDE, red, group, nparts, -1); return; }
+    if (blockIdx.x == gridDim.x - 1) { finalize_mean_block(psum, pcnt, nblocks, ds, mode, FINP_DECIDE, red, group, nparts, -1, gather_n); return; }
     unpack_resid_entry(c, L, blockIdx.x * kFinBlock + threadIdx.x, dens, alpha, rho, ds, val, P, S);
 }
 __global__ __launch_bounds__(kBlock) void k_unpack_resid(Consts c, const int *__restrict__ list_a, int count_a, int n1_a, const float *__restrict__ in_a,

@@ -69,8 +69,12 @@ typedef struct SphConfig {
     int32_t slab_ghost_layers;  /* slab handles: ghost cell columns per side.  0 = default: 2 for dfsph (the correction sweeps run on the inner
                                    ghost column too, so a solver iteration needs ONE halo refresh -- the residual's -- instead of two), 1 for
                                    the other solvers; 1 forces the one-column protocol.  Results do not depend on it. */
-    int32_t slab_overlap;       /* slab handles, dfsph: 0 = default (on): the residual sweeps run their edge tiles first and the interior tiles
-                                   while the halo of the edge results travels on a second stream; 1 = off (everything on one stream) */
+    int32_t slab_overlap;       /* slab handles, dfsph: the OVERLAPPED protocol runs the residual sweeps' edge tiles first, the halo of their results on a
+                                   second stream under the interior tiles, and the residual's all-reduce + loop decision on a third under the next
+                                   correction sweep; the IN-ORDER one runs everything on the handle's stream (same bits).  0 = default: the handle can do
+                                   both and starts with the one that measured faster for its transport (native RCCL: in order, with the residual's
+                                   triple riding in the halo's transfers; a synchronous callback transport: overlapped) -- sph_slab_set_overlap switches
+                                   between steps; 1 = in order only (no second / third stream); 2 = start overlapped */
     int32_t reserved[2];
 } SphConfig;
 

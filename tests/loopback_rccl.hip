@@ -126,12 +126,44 @@ bool wait_for(World &w, std::unique_lock<std::mutex> &lk, Pred p)
 #define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "loopback_rccl: %s: %s\n", #x, hipGetErrorString(e_)); return ncclUnhandledCudaError; } } while (0)
 
 void delay_on(hipStream_t stream);
+constexpr int kBatchMax = 24;
+struct CopyBatch { int n; char *dst[kBatchMax]; const char *src[kBatchMax]; size_t bytes[kBatchMax]; };
+__global__ void k_copy_batch(CopyBatch b)
+{
+    const int j = blockIdx.y;
+    char *d = b.dst[j]; const char *s = b.src[j]; const size_t n = b.bytes[j];
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16, start = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15) == 0) {
+        for (size_t o = start; o + 16 <= n; o += stride) *reinterpret_cast<uint4 *>(d + o) = *reinterpret_cast<const uint4 *>(s + o);
+        if (blockIdx.x == 0 && threadIdx.x < (n & 15)) d[(n & ~(size_t)15) + threadIdx.x] = s[(n & ~(size_t)15) + threadIdx.x];
+    } else {
+        for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (size_t)gridDim.x * blockDim.x) d[o] = s[o];
+    }
+}
 ncclResult_t run_group(std::vector<PendingOp> &ops)
 {
     if (!ops.empty() && ops[0].comm->replay) {
-        for (PendingOp &op : ops) if (!op.send) { delay_on(op.stream); break; }
-        for (PendingOp &op : ops)
-            if (!op.send) { ncclResult_t r = replay_into(op.comm, op.buf, op.bytes, op.stream, "receive"); if (r != ncclSuccess) return r; }
+        // one launch for the whole group, as RCCL makes one kernel of a group of transfers (a copy per receive would charge the replay a launch
+        // per message that a real group does not pay)
+        CopyBatch b;
+        b.n = 0;
+        hipStream_t st = nullptr;
+        for (PendingOp &op : ops) {
+            if (op.send) continue;
+            Comm *c = op.comm;
+            if (c->cursor >= g_rec.entries.size() || g_rec.entries[c->cursor].second != op.bytes) {
+                fprintf(stderr, "loopback_rccl replay: receive of %zu bytes at entry %zu does not match the log\n", op.bytes, c->cursor);
+                return ncclInvalidArgument;
+            }
+            if (!st) { st = op.stream; delay_on(st); }
+            if (op.stream != st || b.n == kBatchMax) {          // (never in the library's groups; fall back to plain copies)
+                ncclResult_t r = replay_into(c, op.buf, op.bytes, op.stream, "receive");
+                if (r != ncclSuccess) return r;
+                continue;
+            }
+            b.dst[b.n] = static_cast<char *>(op.buf); b.src[b.n] = g_rec.log + g_rec.entries[c->cursor++].first; b.bytes[b.n] = op.bytes; b.n += 1;
+        }
+        if (b.n) hipLaunchKernelGGL(k_copy_batch, dim3(64, b.n), dim3(256), 0, st, b);
         return ncclSuccess;
     }
     std::vector<std::shared_ptr<SendDesc>> sends;

@@ -155,11 +155,13 @@ def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0
 
 
 @pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap,order", [
-    ("dfsph_small", 2, 25, 0, 0, 0, "morton"), ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
-    ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 3, 30, 0, 0, 1, None), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, "morton"),
+    ("dfsph_small", 2, 25, 0, 0, 2, "morton"), ("dfsph_dam_x", 3, 200, 7, 0, 2, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
+    ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 2, "morton"), ("breaking_dam_30k_dfsph", 3, 30, 0, 0, 1, None), ("dfsph_rigid_tilted", 3, 80, 9, 0, 2, "morton"),
+    # overlap = 0: the native transport STARTS in order, with the residual's (sum, count, flags) gathered from every slab in the halo's own group of transfers
+    ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, None),
     ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None),
     # the two storage orders of a slab's columns that were measured and left off (SPH_SLAB_GROUPS = 1: groups + range split, 2: aligned tiles)
-    ("dfsph_dam_x", 3, 150, 7, 0, 0, "morton+groups1"), ("breaking_dam_30k_dfsph", 4, 30, 3, 0, 0, "morton+groups2")])
+    ("dfsph_dam_x", 3, 150, 7, 0, 2, "morton+groups1"), ("breaking_dam_30k_dfsph", 4, 30, 3, 0, 2, "morton+groups2")])
 def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps, rebalance, layers, overlap, order):
     """The discipline a multi-GPU node runs -- the library's NATIVE transport: ncclSend / ncclRecv / ncclAllReduce enqueued by the library itself,
     no host wait between the sweeps, the halo of the edge tiles on its own stream under the interior tiles, the residual's all-reduce and the loop
@@ -183,7 +185,7 @@ def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps
     if "dfsph" in scene:
         two = layers != 1
         for s in r["slabs"]:
-            assert s["ghost_columns"] == (2 if two else 1) and s["halo_overlapped"] == (two and overlap == 0) and s["allreduce_hidden"] == (two and overlap == 0), s
+            assert s["ghost_columns"] == (2 if two else 1) and s["halo_overlapped"] == (two and overlap == 2) and s["allreduce_hidden"] == (two and overlap == 2), s
 
 
 def test_slab_protocol_can_be_switched_between_steps(tmp_path):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ONE rank of a sharded run alone on the GPU (tests/loopback_rccl.hip record / replay): its device time per step with the link time set to zero,
-# and (7th argument "profile") its kernel profile.  LOOPBACK_OVERLAP=1 in the environment: the in-order protocol (SphConfig.slab_overlap = 1).   bash tools/loopback_replay.sh <tag> <scene> <world> <rank> <preroll> <timed> [profile]
+# and (7th argument "profile") its kernel profile.  LOOPBACK_OVERLAP=2 in the environment: the overlapped protocol (SphConfig.slab_overlap; 0 = the native transport's default, in order).   bash tools/loopback_replay.sh <tag> <scene> <world> <rank> <preroll> <timed> [profile]
 # Phase 1: all ranks in one process (threads), what rank <rank> receives goes to a log file.  Phase 2: a fresh process replays that rank
 # against the log -- one thread, one handle -- and must end in the same state (digest of ids, positions, velocities, densities).
 set -o pipefail
