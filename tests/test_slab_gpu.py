@@ -53,7 +53,9 @@ def test_slabs_match_single_gpu(tmp_path, scene, world, steps):
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"], r
     assert r["stats_equal"], (r["stats_last"], r["ref_stats_last"])
     assert sum(s["owned"] for s in r["slabs"]) == r["n"]
-    assert all(s["ghosts"] > 0 for s in r["slabs"])
+    # (the cuts balance cost -- particles + 5/4 of the ghosts beyond each cut: on a scene of a few fluid columns that can leave a slab out in the empty
+    # part of the box rather than pay for one more pair of cuts)
+    assert sum(1 for s in r["slabs"] if s["ghosts"] > 0) >= 2
     assert r["comm"]["exchange_buffers"] > 0
     if "dfsph" in scene:      # the loops ran with the device-side control: residuals were reduced in place, not through the host callback --
         # and the slabs' overflow flags ride on the density loop's reduction: no host all-reduce at all in an ordinary dfsph step
