@@ -75,7 +75,7 @@ def test_pressure_solvers_on_slabs(tmp_path, scene, world, steps):
     assert sum(s["owned"] for s in r["slabs"]) == r["n"] and r["comm"]["allreduce_stream"] >= steps
 
 
-@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_dam_x", 3, 1300, 7), ("dfsph_tiny_wall_iisph", 3, 600, 9)])
+@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_dam_x", 3, 1000, 7), ("dfsph_tiny_wall_iisph", 3, 600, 9)])
 def test_particles_that_leak_through_walls_near_a_cut(tmp_path, scene, world, steps, rebalance):
     """Long runs in which particles slip through the single-layer walls (the reference's 1-D cell index then WRAPS them into a far
     cell, or drops them) while the cuts follow the flow: such a particle next to a slab edge once desynchronised the ordered edge /
@@ -210,7 +210,7 @@ def test_legacy_host_loops_on_slabs(tmp_path):
     assert r["comm"]["allreduce_stream"] == 0 and r["comm"]["allreduce"] > 12
 
 
-@pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 350, 2), ("wcsph_dam_x", 2, 2000, 1)])
+@pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 260, 2), ("wcsph_dam_x", 2, 1400, 1)])
 def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_recuts):
     """cuts re-chosen every M steps.  The dam runs along x, the cuts follow it, the result stays bit-identical
     and the largest slab stays smaller than with static cuts."""
@@ -253,7 +253,7 @@ def test_headless_runner_on_slabs(tmp_path):
     assert "element vertex 5879" in head
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(4))
 def test_random_scenes_on_slabs(tmp_path, seed):
     """Seeded random scenes (radius, box, water block, dt, wall model, solver) on 2-4 slabs with re-balancing every 3 steps."""
     import json as _json
