@@ -1466,7 +1466,7 @@ int slab_exchange_particles(SphHandle *h)
 
 // refresh one field of the ghosts after the sweep that produced it (mode: see k_pack_field).  cols: how many of the ghost columns per side
 // (1 = the column next to the cut only; the lists hold it first).
-int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho, int cols = 2)
+int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho, int cols = 2, int gather_doubles = 0)
 {
     hipStream_t s = h->stream;
     const dim3 b(kBlock);
@@ -1480,7 +1480,7 @@ int slab_exchange_field(SphHandle *h, int mode, float4 *P, float4 *V, float *rho
             hipLaunchKernelGGL(k_pack_field, grid_for(nsl + nsr), b, 0, s, h->edge_list[1], nsl, (float *)h->dsend[0], h->edge_list[2], nsr,
                                (float *)h->dsend[1], mode, P, V, S);
     }
-    int rc = slab_xfer(h, 4 * fl * nsl, 4 * fl * nsr, 4 * fl * nrl, 4 * fl * nrr);
+    int rc = slab_xfer(h, 4 * fl * nsl, 4 * fl * nsr, 4 * fl * nrl, 4 * fl * nrr, nullptr, gather_doubles);
     if (rc) return rc;
     {
         ProfScope ps(h, K_SLAB);
@@ -2712,6 +2712,27 @@ int step_pbf_once(SphHandle *h)
 // ---------------------------------------------------------------------------------------------
 // PCISPH / IISPH (SURVEY.md section 8f "next": the solvers coupling_demo.json and breaking_dam_30k.json name)
 // ---------------------------------------------------------------------------------------------
+// The pressure refresh of the ghosts and the residual's mean in ONE group of transfers on the native transport (as the dfsph loops do,
+// slab_exchange_resid_and_finalize): this slab's (sum, count) goes to every slab with the ghosts' pressures, the decision sums the gathered pairs.
+int launch_pressure_finalize(SphHandle *h, int mode);
+int slab_refresh_w_and_pressure_finalize(SphHandle *h, float4 *A, int mode)
+{
+    int rc;
+    if (!(h->slab && h->native && h->gath_dev && h->opt_gather)) {
+        if (h->slab && (rc = slab_exchange_field(h, 0, A, nullptr, nullptr))) return rc;
+        return launch_pressure_finalize(h, mode);
+    }
+    {
+        ProfScope ps(h, K_FINALIZE);
+        hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->gath_dev + 4 * h->slab_rank,
+                           partial_group(h), partial_count(h), 0);
+    }
+    h->comm_stat[4] += 1;
+    if ((rc = slab_exchange_field(h, 0, A, nullptr, nullptr, 2, 2))) return rc;
+    ProfScope ps(h, K_FINALIZE);
+    hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->gath_dev, partial_group(h), partial_count(h), h->nslab);
+    return SPH_OK;
+}
 int launch_pressure_finalize(SphHandle *h, int mode)
 {
     if (h->slab) {
@@ -2719,7 +2740,7 @@ int launch_pressure_finalize(SphHandle *h, int mode)
             ProfScope ps(h, K_FINALIZE);
             hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_REDUCE, h->red_dev, partial_group(h), partial_count(h));
         }
-        int rc = slab_allreduce_stream(h, 2, 0);
+        int rc = slab_allreduce_stream(h, 3, 0);
         if (rc) return rc;
         ProfScope ps(h, K_FINALIZE);
         hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->red_dev, partial_group(h), partial_count(h));
@@ -2764,7 +2785,6 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
     }
     // sharded: the ghosts' predicted positions / pressures come from their owners after the sweep that produced them
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
-    auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
     if ((rc = ghosts_xyz(PP))) return rc;
     // tiles without pressure skip update_press_force (k_pci_press): single-GPU staged handles without rigid entries
     int *zero_press = (h->pci_zero_press && h->staged && !h->slab && !rg) ? h->pci_zero_press : nullptr;
@@ -2776,8 +2796,7 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
                        PB[(k + 1) & 1], h->rho_adv, h->psum, h->pcnt, gate, rv, h->stage_src, h->stage_cnt);
     };
     predict_rho(0, GATE_NONE);                              // :53-56
-    if ((rc = ghosts_w(PB[1]))) return rc;
-    if ((rc = launch_pressure_finalize(h, PFIN_PCI_FIRST))) return rc;
+    if ((rc = slab_refresh_w_and_pressure_finalize(h, PB[1], PFIN_PCI_FIRST))) return rc;
     bool first = true;
     for (int k = 1, chunk = std::max(2, h->last_iters); k <= cap; chunk = 2) {
         for (int q = 0; q < chunk && k <= cap; ++q, ++k) {
@@ -2789,12 +2808,11 @@ int step_pcisph_once(SphHandle *h, SphStepStats *st)
             if (rg) launch_rigid_force_p<RF_PCISPH>(h, h->P[h->pcur], PB[k & 1], GATE_DENS);   // :209, every iteration
             if ((rc = ghosts_xyz(PP))) return rc;
             predict_rho(k, GATE_DENS);
-            if ((rc = ghosts_w(PB[(k + 1) & 1]))) return rc;
-            if ((rc = launch_pressure_finalize(h, PFIN_PCI_LOOP))) return rc;
+            if ((rc = slab_refresh_w_and_pressure_finalize(h, PB[(k + 1) & 1], PFIN_PCI_LOOP))) return rc;
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
-            if ((rc = check_overflow_all(h))) return rc;
+            if ((rc = check_overflow_all(h, slab_async(h)))) return rc;      // (the slabs' flags came with the loop's first reduction)
             first = false;
         }
         if (!h->ds_host->dens_active) break;
@@ -2844,7 +2862,6 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
                        h->cnt, VA, DII, rv, h->stage_src, h->stage_cnt);
     }
     auto ghosts_xyz = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 1, nullptr, A, nullptr) : SPH_OK; };
-    auto ghosts_w = [&](float4 *A) -> int { return h->slab ? slab_exchange_field(h, 0, A, nullptr, nullptr) : SPH_OK; };
     if ((rc = ghosts_xyz(VA))) return rc;                   // v_adv and d_ii of the ghosts (their 0.5 p_past travels with the particle)
     if ((rc = ghosts_xyz(DII))) return rc;
     {
@@ -2868,12 +2885,11 @@ int step_iisph_once(SphHandle *h, SphStepStats *st)
                 SPH_LAUNCH_RMX0(k_ii_update_p, rg, sweep_mode(h), relaxed_pressure(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(uint32_t) + 3 * sizeof(float)), s, c, dt, PB[(k - 1) & 1], DII, DIJ, h->WP, h->nl,
                                h->nlb, h->cnt, h->rho, h->rho_adv, h->aux, h->ds, PB[k & 1], h->psum, h->pcnt, GATE_DENS, rv, h->stage_src, h->stage_cnt);
             }
-            if ((rc = ghosts_w(PB[k & 1]))) return rc;
-            if ((rc = launch_pressure_finalize(h, PFIN_II_LOOP))) return rc;
+            if ((rc = slab_refresh_w_and_pressure_finalize(h, PB[k & 1], PFIN_II_LOOP))) return rc;
         }
         if ((rc = read_scalars(h))) return rc;
         if (first) {
-            if ((rc = check_overflow_all(h))) return rc;
+            if ((rc = check_overflow_all(h, slab_async(h)))) return rc;      // (the slabs' flags came with the loop's first reduction)
             first = false;
         }
         if (!h->ds_host->dens_active) break;

@@ -253,15 +253,20 @@ enum { PFIN_PCI_FIRST = 0, PFIN_PCI_LOOP = 1, PFIN_II_LOOP = 2 };
 // group / nparts: as k_finalize_mean (quad sweeps write one partial per 64 particles; a block's partial is the in-order sum of its four)
 __global__ __launch_bounds__(kFinBlock) void k_finalize_pressure(const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks,
                                                                  DevScalars *__restrict__ ds, int mode, int phase, double *__restrict__ red,
-                                                                 int group = 1, int nparts = 0)
+                                                                 int group = 1, int nparts = 0, int gather_n = 0)
 {
     if (mode != PFIN_PCI_FIRST && ds->dens_active == 0) return;
     __shared__ double s_sum[kFinBlock / 64];
     __shared__ long long s_cnt[kFinBlock / 64];
     if (phase != FINP_DECIDE) fin_reduce(psum, pcnt, nblocks, group, nparts, s_sum, s_cnt);      // the reduction of k_finalize_mean (one batch of loads, one barrier)
     if (threadIdx.x != 0) return;
-    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; return; }
-    if (phase == FINP_DECIDE) { s_sum[0] = red[0]; s_cnt[0] = (long long)red[1]; }
+    if (phase == FINP_REDUCE) { red[0] = s_sum[0]; red[1] = (double)s_cnt[0]; red[2] = (double)ds->overflow; return; }      // (third word: the slab's overflow flags, as in k_finalize_mean)
+    if (phase == FINP_DECIDE) {           // gather_n > 0: every slab's (sum, count, flags), four doubles apart, gathered with the last ghost refresh (finalize_mean_block)
+        double rs = red[0], rc = red[1], rf = red[2];
+        for (int r = 1; r < gather_n; ++r) { rs += red[4 * r]; rc += red[4 * r + 1]; rf += red[4 * r + 2]; }
+        s_sum[0] = rs; s_cnt[0] = (long long)rc;
+        ds->overflow_any = rf != 0.0 ? 1 : 0;
+    }
     ds->sum = s_sum[0]; ds->cnt = s_cnt[0];
     const float res = s_cnt[0] > 0 ? (float)(s_sum[0] / (double)s_cnt[0]) : 0.0f;   // pcisph :136-137, iisph :119-120
     const int cap = ds->dens_cap;
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_pressure(const double *_
 
 __global__ void k_pressure_ctrl_begin(DevScalars *__restrict__ ds, int cap)
 {
+    ds->overflow_any = 0;
     ds->dens_active = 1; ds->dens_it = 0; ds->dens_cap = cap; ds->dens_capped = 0; ds->dens_avg = 0.f;
     ds->res_prev = 0.f; ds->res_have_prev = 0; ds->res_diverged = 0;
 }
