@@ -1489,9 +1489,10 @@ __global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict
 }
 
 // the CFL time step from ds->vmax (global maximum)              dfsph_solver.py:104-119
-__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *__restrict__ red)
+__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *__restrict__ red, int gather_n = 0)
 {
-    float max_vel = red ? (float)red[0] : ds->vmax;        // red: the maximum over all slabs
+    float max_vel = red ? (float)red[0] : ds->vmax;        // red: the maximum over all slabs (gather_n > 0: every slab's own, four doubles apart)
+    for (int r = 1; r < gather_n; ++r) max_vel = fmaxf(max_vel, (float)red[4 * r]);
     if (red) ds->vmax = max_vel;
     float max_rigid_vel = ds->rigid_vmax;                         // :104-110 (0 without a rigid body)
     max_vel += max_rigid_vel;

@@ -2412,13 +2412,18 @@ int dfsph_ext_and_dt(SphHandle *h)
         }
     }
     const bool async = slab_async(h);
+    // native transport: this slab's max |v*| goes to every slab in the group of transfers that refreshes v* on the ghosts (one group instead of a
+    // group and an all-reduce, as in the solver loops)
+    const bool gather = async && h->native && h->gath_dev && h->opt_gather;
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, async ? h->red_dev : (double *)nullptr);
+        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, gather ? h->gath_dev + 4 * h->slab_rank : async ? h->red_dev : (double *)nullptr);
     }
     if (h->slab) {
-        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr, 1))) return rc;     // v* of the column next to the cut (all the density residual reads)
-        if (async) {
+        if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr, 1, gather ? 1 : 0))) return rc;     // v* of the column next to the cut (all the density residual reads)
+        if (gather) {
+            h->comm_stat[4] += 1;
+        } else if (async) {
             if ((rc = slab_allreduce_stream(h, 1, 1))) return rc;          // max |v*| over all slabs, stays on the device
         } else {
             if ((rc = read_scalars(h))) return rc;
@@ -2430,7 +2435,7 @@ int dfsph_ext_and_dt(SphHandle *h)
     }
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds, async ? h->red_dev : (const double *)nullptr);   // :112-119
+        hipLaunchKernelGGL(k_apply_dt, dim3(1), dim3(1), 0, s, c, h->ds, gather ? h->gath_dev : async ? h->red_dev : (const double *)nullptr, gather ? h->nslab : 0);   // :112-119
     }
     return SPH_OK;
 }
