@@ -28,6 +28,10 @@ S_DELTA_TIME, S_SIMULATE_CNT, S_PARTICLE_M, S_SUPPORT_RADIUS, S_PS_DELTA_TIME, S
 S_PCISPH_DELTA, S_PCISPH_BETA, S_PCISPH_MAX_INDEX, S_PCISPH_MAX_COUNT = range(6, 10)
 S_ARITH_RELAXED = 30
 S_VERLET_BUILDS = 31
+# `solver.<attribute> = value` (include/sph_mi355x.h SPH_P_*): name of the reference's attribute -> id
+SOLVER_PARAMS = {"density_threshold": 64, "min_iteration_density": 65, "min_iteration_density_divergence": 66, "max_iteration_density_divergence": 67,
+                 "density_divergence_threshold": 68, "warm_start": 69, "adaptive_dt": 70, "max_dt": 71, "min_dt": 72,
+                 "viscosity_c_s": 73, "viscosity_alpha": 74, "viscosity_epsilon": 75, "tension_k": 76}
 VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGID_FORCE, F_RIGID_VERT, F_PRESS_FORCE, F_POS_PREDICT, F_D_II, F_D_IJ,
                  F_PBF_DELTA_POS}
 
@@ -448,6 +452,13 @@ class Simulation:
     def set_dt(self, value):
         """solver.delta_time[None] = value"""
         self._check(self._lib.sph_set_scalar(self._h, S_DELTA_TIME, float(value)))
+
+    def set_param(self, name, value):
+        """solver.<name> = value for the attributes of SOLVER_PARAMS (dfsph_solver.py:21-29, solver_base.py:23-26, wcsph_solver.py:17-20)."""
+        self._check(self._lib.sph_set_scalar(self._h, SOLVER_PARAMS[name], float(value)))
+
+    def param(self, name):
+        return self.scalar(SOLVER_PARAMS[name])
 
     def synchronize(self):
         self._check(self._lib.sph_synchronize(self._h))

@@ -69,6 +69,9 @@ struct Consts {
     // h + skin = hcell and are rebuilt only once a particle has moved more than skin / 2 since the last build (verlet_thr2 = (skin / 2)^2)
     float hcell, verlet_thr2;
     int verlet;
+    // attributes of dfsph_solver.py:26-29 that Taichi bakes into its kernels when they compile (sph_set_scalar(SPH_P_*) before the first step)
+    int warm_start, adaptive_dt;      // :26-27 (read at :396, :404 and :113)
+    float max_dt, min_dt;             // :28-29 (:114-117)
 };
 
 // Run-time scalars that live in device memory (0-d fields of the reference).
@@ -106,6 +109,11 @@ struct DevScalars {
     // shards into max_nbrs / max_wall_nbrs after a read-back.  (Thousands of waves checking ONE word cost 10 us of a 30 k-particle
     // list build: same-address traffic serialises even when it is only loads.)
     int nbr_shard[64], wall_shard[64];
+    // dfsph loop parameters: the attributes dfsph_solver.py:21-25 sets and its Python-scope loops read at every step (:225, :400).  Written by
+    // sph_create (the reference's values) and sph_set_scalar(SPH_P_*); k_ctrl_begin leaves them alone
+    double p_dens_thr;   // density_threshold * rho_0 * 0.01, folded in f64 like the Python expression                 :225
+    double p_div_thr;    // density_divergence_threshold                                                            :400
+    int p_min_dens, p_min_div, p_max_div, p_pad;       // min_iteration_density, min / max_iteration_density_divergence
 };
 constexpr int kNoteShards = 64;
 

@@ -1348,7 +1348,7 @@ __device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode
             if (fabs((double)err - (double)past) < 1e-5) active = 0;    // break before iter_cnt += 1
             else { it += 1; active = 1; }
         }
-        if (active) active = ((it < 1 || (double)err > 10.0) && it < 15) ? 1 : 0;   // :400
+        if (active) active = ((it < ds->p_min_div || (double)err > ds->p_div_thr) && it < ds->p_max_div) ? 1 : 0;   // :400
         ds->div_it = it;
         ds->div_active = active;
     } else {
@@ -1357,7 +1357,7 @@ __device__ __forceinline__ void fin_decide(DevScalars *__restrict__ ds, int mode
         ds->dens_d7_active = 1;                                          // iter_all_vel_adv of this iteration runs (:229)
         const int it = ds->dens_it + 1;                                  // :231
         ds->dens_it = it;
-        int active = (it < 2 || (double)avg - 1000.0 > 0.1 * 1000 * 0.01) ? 1 : 0;      // :225
+        int active = (it < ds->p_min_dens || (double)avg - 1000.0 > ds->p_dens_thr) ? 1 : 0;      // :225
         if (active && it >= ds->dens_cap) { active = 0; ds->dens_capped = 1; }
         ds->dens_active = active;
     }
@@ -1497,12 +1497,14 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
     float max_rigid_vel = ds->rigid_vmax;                         // :104-110 (0 without a rigid body)
     max_vel += max_rigid_vel;
     float max_delta_time = c.dt_cfl_num / max_vel * 0.2f;         // :112
-    float dt;
-    if (max_delta_time > 1e-3f) dt = 1e-3f;                       // :114-117
-    else dt = rmax(max_delta_time, 1e-5f);
-    ds->dt = dt;
-    ds->dt2 = dt * dt;                                            // :118
-    ds->ps_dt = dt;                                               // :119
+    if (c.adaptive_dt) {                                          // :113
+        float dt;
+        if (max_delta_time > c.max_dt) dt = c.max_dt;             // :114-117
+        else dt = rmax(max_delta_time, c.min_dt);
+        ds->dt = dt;
+        ds->dt2 = dt * dt;                                        // :118
+        ds->ps_dt = dt;                                           // :119
+    }
     ds->gate_hist[0] = 1; ds->gate_hist[1] = 1;                   // (between the two solver loops: the density loop's decisions start afresh)
 }
 
@@ -2289,7 +2291,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     v.w = rho_i;
     Vout[i] = v;
     if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
-    if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
+    if (MODE == CORR_DIV && c.warm_start) warm[i] += src[i] * alpha[i];           // :384 (sum_up_stiff runs under warm_start only, :404-405)
 }
 
 // ======================================================================================

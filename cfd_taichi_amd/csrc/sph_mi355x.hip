@@ -77,6 +77,15 @@ struct SphHandle {
     std::string err;
     std::string overrides;       // development overrides in force on this handle (dev_env)
 
+    // the solver attributes a caller of the reference may edit before (or, for the Python-scope loops, between) steps: solver_base.py:23-26,
+    // wcsph_solver.py:17-20, dfsph_solver.py:21-29; sph_set_scalar(SPH_P_*) writes them, apply_params() folds them into Consts / DevScalars
+    struct Params {
+        double density_threshold = 0.1, density_divergence_threshold = 10, max_dt = 1e-3, min_dt = 1e-5;
+        int min_iteration_density = 2, min_iteration_density_divergence = 1, max_iteration_density_divergence = 15;
+        int warm_start = 1, adaptive_dt = 1;
+        double viscosity_c_s = 13, viscosity_alpha = 0.08, viscosity_epsilon = 0.01, tension_k = 0.5;
+    } p;
+
     int N = 0, Nb = 0, Nr = 0;
     int nblocks = 0;
     float dt_wcsph = 0.f;
@@ -458,6 +467,31 @@ struct HostScene {
     std::vector<int> wcell_start;                 // C+1
 };
 
+// The Python scalars of the viscosity / tension expressions folded in f64 and rounded once, as Taichi does with a kernel's compile-time
+// constants (solver_base.py:187-188, :216), and the dfsph attributes its kernels bake in (dfsph_solver.py:113-117, :396, :404)
+void fold_params(SphHandle *h)
+{
+    Consts &c = h->c;
+    const double r = h->cfg.particle_radius, m = 1000 * (r * r * r) * 8;       // ParticleSystem.py:83
+    const double kernel_h = h->cfg.particle_radius * 4;               // solver_base.py:17
+    c.visc_num = (float)(2 * h->p.viscosity_alpha * kernel_h * h->p.viscosity_c_s);
+    c.visc_eps_h2 = (float)(h->p.viscosity_epsilon * kernel_h * kernel_h);
+    c.tens_c = (float)(-h->p.tension_k / m * m);
+    c.warm_start = h->p.warm_start;
+    c.adaptive_dt = h->p.adaptive_dt;
+    c.max_dt = (float)h->p.max_dt;
+    c.min_dt = (float)h->p.min_dt;
+}
+// the loop parameters live next to the loop state on the device (DevScalars.p_*); `ds` = the host mirror to fill
+void loop_params(const SphHandle *h, DevScalars *ds)
+{
+    ds->p_dens_thr = h->p.density_threshold * 1000 * 0.01;           // dfsph_solver.py:225 (rho_0 = 1000, solver_base.py:19)
+    ds->p_div_thr = h->p.density_divergence_threshold;               // :400
+    ds->p_min_dens = h->p.min_iteration_density;
+    ds->p_min_div = h->p.min_iteration_density_divergence;
+    ds->p_max_div = h->p.max_iteration_density_divergence;
+}
+
 int build_scene(SphHandle *h, HostScene &sc)
 {
     const SphConfig &cf = h->cfg;
@@ -524,12 +558,9 @@ int build_scene(SphHandle *h, HostScene &sc)
         c.r2_cut = t;
         if (h->verlet) c.r2_cut = c.hcell * c.hcell;      // Verlet lists: every pair within h + skin
     }
-    const double c_s = cf.solver == SPH_SOLVER_WCSPH ? 10 : 13;      // wcsph_solver.py:18 vs solver_base.py:24
-    const double t_k = cf.solver == SPH_SOLVER_WCSPH ? 0.2 : 0.5;    // wcsph_solver.py:20 vs solver_base.py:26
-    const double kernel_h = r * 4;                                    // solver_base.py:17
-    c.visc_num = (float)(2 * 0.08 * kernel_h * c_s);
-    c.visc_eps_h2 = (float)(0.01 * kernel_h * kernel_h);
-    c.tens_c = (float)(-t_k / m * m);
+    h->p.viscosity_c_s = cf.solver == SPH_SOLVER_WCSPH ? 10 : 13;    // wcsph_solver.py:18 vs solver_base.py:24
+    h->p.tension_k = cf.solver == SPH_SOLVER_WCSPH ? 0.2 : 0.5;      // wcsph_solver.py:20 vs solver_base.py:26
+    fold_params(h);
     c.neg_m = (float)(-m);
     c.dt_cfl_num = (float)(0.4 * r * 2);
     const float clamp_off = cf.solver == SPH_SOLVER_WCSPH ? c.d : (float)r;   // wcsph_solver.py:57 vs dfsph_solver.py:244, pcisph_solver.py:82, iisph_solver.py:201
@@ -1082,6 +1113,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     h->ds_host->dt2 = h->ds_host->dt * h->ds_host->dt;               // dfsph_solver.py:20
     h->ds_host->ps_dt = 0.f;                                         // ParticleSystem.py:37
     h->ds_host->moved = 1;                                           // Verlet handles: the first step builds the lists
+    loop_params(h, h->ds_host);
     HIP_TRY(h, hipMemcpyAsync(h->ds, h->ds_host, sizeof(DevScalars), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->dt_wcsph = (float)h->cfg.delta_time;
@@ -2518,11 +2550,14 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     // A sweep that is enqueued behind evaluation e's reduction must not read the gate evaluation e is about to write: it reads the decision of
     // e - 1 from DevScalars.gate_hist[(e - 1) & 1].  Bit-identical to the plain order by construction (tests/test_slab_gpu.py).
     const bool spec = ovl && slab_async(h) && h->rstream;
-    launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
-    if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
+    const int max_div = h->p.max_iteration_density_divergence;                       // :24 (15)
+    if (h->p.warm_start) {
+        launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);   // :396-397
+        if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
+    }
     if (spec) {
         if ((rc = residual_sweep(false, GATE_NONE, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DIV_FIRST))) return rc;     // :398, evaluation 1
-        for (int e = 1; e <= 15; ++e) {
+        for (int e = 1; e <= max_div; ++e) {
             // the correction of evaluation e first (the GPU works on it while the host may block in a synchronous all-reduce) ...
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w});   // :402-405
             // ... then evaluation e's reduction and decision on the third stream
@@ -2530,13 +2565,13 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
             if ((rc = residual_sweep(false, GATE_DIV, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e}, FIN_DIV_LOOP))) return rc;   // :408, evaluation e + 1
         }
-        if ((rc = launch_finalize_decide(h, FIN_DIV_LOOP, 16))) return rc;
+        if ((rc = launch_finalize_decide(h, max_div == 0 ? FIN_DIV_FIRST : FIN_DIV_LOOP, max_div + 1))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
     } else {
     if ((rc = residual(false, GATE_NONE, FIN_DIV_FIRST))) return rc;                 // :398
-    // all 15 possible iterations are enqueued at once: the ones the reference's loop would not run exit at their first instruction,
-    // and the host does not need the outcome before the density loop's first read-back
-    for (int done = 0; done < 15; ++done) {
+    // all max_iteration_density_divergence (15) possible iterations are enqueued at once: the ones the reference's loop would not run exit at
+    // their first instruction, and the host does not need the outcome before the density loop's first read-back
+    for (int done = 0; done < max_div; ++done) {
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         if ((rc = residual(false, GATE_DIV, FIN_DIV_LOOP))) return rc;                    // :408
@@ -2596,8 +2631,10 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
         if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
         return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
     };
-    launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);       // :396-397
-    if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
+    if (h->p.warm_start) {
+        launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);   // :396-397
+        if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
+    }
     float err = 0.f, past = 0.f;
     auto residual = [&](float *out) -> int {
         launch_div_residual(h, GATE_NONE);
@@ -2613,7 +2650,7 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
     st->n_div_evals = 1;
     st->div_first_err = err;
     int iter_cnt = 0;
-    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {                  // :400
+    while ((iter_cnt < h->p.min_iteration_density_divergence || (double)err > h->p.density_divergence_threshold) && iter_cnt < h->p.max_iteration_density_divergence) {   // :400
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_NONE);
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         past = err;
@@ -2628,7 +2665,7 @@ int step_dfsph_host_loops(SphHandle *h, SphStepStats *st)
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
     double rho_avg = INFINITY;
     int it = 0;
-    while (it < 2 || rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {                         // :225
+    while (it < h->p.min_iteration_density || rho_avg - 1000.0 > h->p.density_threshold * 1000 * 0.01) {     // :225
         if (it >= cap) { st->capped = 1; break; }
         launch_dens_residual(h, GATE_NONE);
         if ((rc = ghosts_k(true))) return rc;
@@ -2733,7 +2770,7 @@ int slab_refresh_w_and_pressure_finalize(SphHandle *h, float4 *A, int mode)
                            partial_group(h), partial_count(h), 0);
     }
     h->comm_stat[4] += 1;
-    if ((rc = slab_exchange_field(h, 0, A, nullptr, nullptr, 2, 2))) return rc;
+    if ((rc = slab_exchange_field(h, 0, A, nullptr, nullptr, 2, 3))) return rc;      // (sum, count, overflow flags): check_overflow_all trusts the gathered flags
     ProfScope ps(h, K_FINALIZE);
     hipLaunchKernelGGL(k_finalize_pressure, dim3(1), dim3(kFinBlock), 0, h->stream, h->psum, h->pcnt, h->nblocks, h->ds, mode, (int)FINP_DECIDE, h->gath_dev, partial_group(h), partial_count(h), h->nslab);
     return SPH_OK;
@@ -3729,6 +3766,19 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PS_DELTA_TIME: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->ps_dt; return SPH_OK; }
     case SPH_S_ARITH_RELAXED: *out = (use_relaxed(h) || h->verlet || relaxed_pressure(h) || relaxed_unstaged(h)) ? 1.0 : 0.0; return SPH_OK;
     case SPH_S_VERLET_BUILDS: { int rc = read_scalars(h); if (rc) return rc; *out = (double)h->ds_host->verlet_builds; return SPH_OK; }      // kr_split is settled by the first list build
+    case SPH_P_DENSITY_THRESHOLD: *out = h->p.density_threshold; return SPH_OK;
+    case SPH_P_MIN_ITERATION_DENSITY: *out = h->p.min_iteration_density; return SPH_OK;
+    case SPH_P_MIN_ITERATION_DENSITY_DIVERGENCE: *out = h->p.min_iteration_density_divergence; return SPH_OK;
+    case SPH_P_MAX_ITERATION_DENSITY_DIVERGENCE: *out = h->p.max_iteration_density_divergence; return SPH_OK;
+    case SPH_P_DENSITY_DIVERGENCE_THRESHOLD: *out = h->p.density_divergence_threshold; return SPH_OK;
+    case SPH_P_WARM_START: *out = h->p.warm_start; return SPH_OK;
+    case SPH_P_ADAPTIVE_DT: *out = h->p.adaptive_dt; return SPH_OK;
+    case SPH_P_MAX_DT: *out = h->p.max_dt; return SPH_OK;
+    case SPH_P_MIN_DT: *out = h->p.min_dt; return SPH_OK;
+    case SPH_P_VISCOSITY_C_S: *out = h->p.viscosity_c_s; return SPH_OK;
+    case SPH_P_VISCOSITY_ALPHA: *out = h->p.viscosity_alpha; return SPH_OK;
+    case SPH_P_VISCOSITY_EPSILON: *out = h->p.viscosity_epsilon; return SPH_OK;
+    case SPH_P_TENSION_K: *out = h->p.tension_k; return SPH_OK;
     default:
         if (h->rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) {
             if (which < SPH_S_RIGID_OMEGA) *out = (double)h->centroid[which - SPH_S_RIGID_CENTROID];
@@ -3742,10 +3792,57 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     }
 }
 
+// the solver attributes a caller of the reference edits on the solver object (SPH_P_*): validated, kept in h->p, folded into the launch constants
+// and the device's loop-control block
+static int set_param(SphHandle *h, int which, double value)
+{
+    SphHandle::Params &p = h->p;
+    const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
+    auto count = [&](int *dst, int lo) -> int {
+        if (!(value >= lo && value <= 100000.0) || value != std::floor(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): an integer >= %d expected, got %g", which, lo, value);
+        *dst = (int)value; return SPH_OK;
+    };
+    auto positive = [&](double *dst, bool zero_ok) -> int {
+        if (!(value > 0.0 || (zero_ok && value == 0.0)) || !std::isfinite(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): a finite value %s 0 expected, got %g", which, zero_ok ? ">=" : ">", value);
+        *dst = value; return SPH_OK;
+    };
+    int rc = SPH_OK;
+    if (which >= SPH_P_DENSITY_THRESHOLD && which <= SPH_P_MIN_DT && !dfsph) return fail(h, SPH_E_STATE, "sph_set_scalar(%d): a dfsph_solver attribute on a handle of another solver", which);
+    switch (which) {
+    case SPH_P_DENSITY_THRESHOLD: rc = positive(&p.density_threshold, true); break;
+    case SPH_P_MIN_ITERATION_DENSITY: rc = count(&p.min_iteration_density, 0); break;
+    case SPH_P_MIN_ITERATION_DENSITY_DIVERGENCE: rc = count(&p.min_iteration_density_divergence, 0); break;
+    case SPH_P_MAX_ITERATION_DENSITY_DIVERGENCE: rc = count(&p.max_iteration_density_divergence, 0); break;
+    case SPH_P_DENSITY_DIVERGENCE_THRESHOLD: rc = positive(&p.density_divergence_threshold, true); break;
+    case SPH_P_WARM_START: p.warm_start = value != 0.0; break;
+    case SPH_P_ADAPTIVE_DT: p.adaptive_dt = value != 0.0; break;
+    case SPH_P_MAX_DT: rc = positive(&p.max_dt, false); break;
+    case SPH_P_MIN_DT: rc = positive(&p.min_dt, false); break;
+    case SPH_P_VISCOSITY_C_S: rc = positive(&p.viscosity_c_s, true); break;
+    case SPH_P_VISCOSITY_ALPHA: rc = positive(&p.viscosity_alpha, true); break;
+    case SPH_P_VISCOSITY_EPSILON: rc = positive(&p.viscosity_epsilon, false); break;
+    case SPH_P_TENSION_K: rc = positive(&p.tension_k, true); break;
+    default: return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
+    }
+    if (rc) return rc;
+    if (h->cfg.solver == SPH_SOLVER_PBF && which >= SPH_P_VISCOSITY_C_S) return fail(h, SPH_E_STATE, "sph_set_scalar(%d): pbf_solver has no such attribute", which);
+    HIP_TRY(h, hipSetDevice(h->device));
+    fold_params(h);
+    if (dfsph) {          // (the mirror's other words are whatever the last read-back left: only the p_* block is written)
+        loop_params(h, h->ds_host);
+        HIP_TRY(h, hipMemcpyAsync(&h->ds->p_dens_thr, &h->ds_host->p_dens_thr, sizeof(DevScalars) - offsetof(DevScalars, p_dens_thr), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    for (int k = 0; k < 8; ++k)                                      // captured wcsph step pairs carry the old constants as launch arguments
+        if (h->wcsph_graph[k]) { (void)hipGraphExecDestroy(h->wcsph_graph[k]); h->wcsph_graph[k] = nullptr; }
+    return SPH_OK;
+}
+
 int sph_set_scalar(SphHandle *h, int which, double value)
 {
     if (!h) return SPH_E_INVALID;
-    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: only SPH_S_DELTA_TIME > 0 can be written");
+    if (which >= SPH_P_DENSITY_THRESHOLD && which <= SPH_P_TENSION_K) return set_param(h, which, value);      // (on slab handles too: every rank sets the same)
+    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: SPH_S_DELTA_TIME > 0 or a solver attribute SPH_P_* can be written");
     if (h->slab) return fail(h, SPH_E_STATE, "sph_set_scalar is not available on slab handles");
     HIP_TRY(h, hipSetDevice(h->device));
     h->dt_wcsph = (float)value;                                      // the launch argument of the fixed-dt solvers

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     v.w = rho_i;
     Vout[i] = v;
     if (MODE == CORR_WARM) warm[i] = 0.0f;                                        // :325
-    if (MODE == CORR_DIV) warm[i] += src[i] * alpha[i];                           // :384
+    if (MODE == CORR_DIV && c.warm_start) warm[i] += src[i] * alpha[i];           // :384 (:404-405)
 }
 
 

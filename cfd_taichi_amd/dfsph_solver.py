@@ -9,6 +9,9 @@ from .solver_base import solver_base
 
 class dfsph_solver(solver_base):
     _kind = "dfsph"
+    _BAKED = solver_base._BAKED + ("adaptive_dt", "max_dt", "min_dt")             # inside @ti.kernel compute_all_vel_adv (dfsph_solver.py:113-117)
+    _LIVE = ("min_iteration_density", "density_threshold", "min_iteration_density_divergence", "max_iteration_density_divergence",
+             "density_divergence_threshold", "warm_start")                         # Python-scope loops (:225, :396-404): read at every step
 
     def __init__(self, particle_system, config, verbose=True, arith=None):
         super().__init__(particle_system, config, arith)
@@ -30,6 +33,7 @@ class dfsph_solver(solver_base):
         self.last_stats = None
 
     def step(self, nsteps=1):
+        self._forward_attributes()
         st = self._sim.step_dfsph(nsteps)
         self.last_stats = st
         if self.verbose:   # the reference prints these every step (:233, :416)

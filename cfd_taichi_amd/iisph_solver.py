@@ -26,6 +26,7 @@ class iisph_solver(solver_base):
         self.last_stats = None
 
     def step(self, nsteps=1):
+        self._forward_attributes()
         st = self._sim.step_iisph(nsteps)
         self.last_stats = st
         if self.verbose:

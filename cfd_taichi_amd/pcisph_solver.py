@@ -26,6 +26,7 @@ class pcisph_solver(solver_base):
         print("PCISPH parameter delta: {}, beta: {}".format(self.delta[None], self.beta))   # :38
 
     def step(self, nsteps=1):
+        self._forward_attributes()
         st = self._sim.step_pcisph(nsteps)
         self.last_stats = st
         if self.verbose:

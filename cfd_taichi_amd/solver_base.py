@@ -6,6 +6,12 @@ from .fields import DeviceField, ScalarField
 
 class solver_base:
     _kind = None   # "wcsph" | "dfsph"
+    # Attributes of the reference's solver objects that a caller may edit after construction (`solver.tension_k = 1.0`).  Taichi bakes a Python
+    # scalar it meets inside a kernel into that kernel when it first compiles -- the first step() -- so _BAKED attributes are forwarded to the
+    # library once, at the first step(), and later edits are ignored as the reference ignores them; _LIVE attributes are read by Python-scope
+    # loops at every step (dfsph_solver.py:225, :396-404) and are forwarded whenever they changed.
+    _BAKED = ("viscosity_c_s", "viscosity_alpha", "viscosity_epsilon", "tension_k")
+    _LIVE = ()
 
     def __init__(self, particle_system, config, arith=None):
         """arith: None keeps the ParticleSystem's arithmetic; "exact" / "relaxed" rebuilds its handle with that one (see ParticleSystem)."""
@@ -31,6 +37,20 @@ class solver_base:
         self.simulate_cnt = ScalarField(lambda: int(self._sim.scalar(nat.S_SIMULATE_CNT)) + self._prologue_cnt)   # :21
         self.rho = DeviceField(self, nat.F_RHO)               # :14
         print("\033[32m[Solver]: {}\033[0m".format(solver_config.get("name")))   # :39
+
+    def _forward_attributes(self):
+        """`solver.<attribute> = value` reaches the library here, at the head of every step() (see _BAKED / _LIVE)."""
+        sent = self.__dict__.setdefault("_sent", {})
+        first = not sent
+        for name in (self._BAKED if first else ()) + self._LIVE:
+            value = float(getattr(self, name))
+            if sent.get(name) != value:
+                if first and value == self._sim.param(name):       # the library starts from the reference's values
+                    sent[name] = value
+                    continue
+                self._sim.set_param(name, value)
+                sent[name] = value
+        sent["_started"] = 1.0
 
     def compute_all_rho(self):
         """solver_base.compute_all_rho (:41-51) as a stand-alone stage (rebuilds the lists if needed)."""

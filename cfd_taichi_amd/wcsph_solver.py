@@ -18,4 +18,5 @@ class wcsph_solver(solver_base):
         self.pressure = DeviceField(self, nat.F_PRESSURE)
 
     def step(self, nsteps=1):
+        self._forward_attributes()
         self._sim.step_wcsph(nsteps)

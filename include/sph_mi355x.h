@@ -174,6 +174,24 @@ typedef struct SphRigid {
 #define SPH_S_VERLET_BUILDS 31    /* diagnostics: list builds so far on a Verlet handle (wcsph under the relaxed arithmetic: the lists carry a skin and are rebuilt on demand) */
 #define SPH_S_ARITH_RELAXED 30    /* diagnostics: 1 if this handle's dfsph sweeps run the tolerance-grade kernels (SphConfig.arith asked AND the handle qualifies) */
 
+/* Solver attributes a caller of the reference edits on the solver object after constructing it -- sph_set_scalar / sph_get_scalar.
+ * The defaults are the reference's.  The dfsph loop attributes (64-68) are read by Python-scope loops at every step (dfsph_solver.py:225, :400)
+ * and may be written between steps; the others are baked into Taichi kernels when they first compile, so the mirror classes
+ * (cfd_taichi_amd/solver_base.py) forward them once, at the first step().  On slab handles every rank must write the same values. */
+#define SPH_P_DENSITY_THRESHOLD 64                 /* dfsph_solver.density_threshold (percent of rho_0)      dfsph_solver.py:22, :225 */
+#define SPH_P_MIN_ITERATION_DENSITY 65             /* dfsph_solver.min_iteration_density                     :21, :225 */
+#define SPH_P_MIN_ITERATION_DENSITY_DIVERGENCE 66  /* dfsph_solver.min_iteration_density_divergence          :23, :400 */
+#define SPH_P_MAX_ITERATION_DENSITY_DIVERGENCE 67  /* dfsph_solver.max_iteration_density_divergence          :24, :400 */
+#define SPH_P_DENSITY_DIVERGENCE_THRESHOLD 68      /* dfsph_solver.density_divergence_threshold              :25, :400 */
+#define SPH_P_WARM_START 69                        /* dfsph_solver.warm_start (0 / 1)                        :26, :396, :404 */
+#define SPH_P_ADAPTIVE_DT 70                       /* dfsph_solver.adaptive_dt (0 / 1)                       :27, :113 */
+#define SPH_P_MAX_DT 71                            /* dfsph_solver.max_dt                                    :28, :114-115 */
+#define SPH_P_MIN_DT 72                            /* dfsph_solver.min_dt                                    :29, :117 */
+#define SPH_P_VISCOSITY_C_S 73                     /* solver.viscosity_c_s      solver_base.py:24 (13), wcsph_solver.py:18 (10); :187 */
+#define SPH_P_VISCOSITY_ALPHA 74                   /* solver.viscosity_alpha    solver_base.py:25, :187 */
+#define SPH_P_VISCOSITY_EPSILON 75                 /* solver.viscosity_epsilon  solver_base.py:23, :188 */
+#define SPH_P_TENSION_K 76                         /* solver.tension_k          solver_base.py:26 (0.5), wcsph_solver.py:20 (0.2); :216 */
+
 typedef struct SphHandle SphHandle;
 
 /* replaces ParticleSystem(config) + <name>_solver(ps, config)   main.py:64-68.
@@ -218,8 +236,9 @@ int sph_compute_alpha(SphHandle *h);
 
 int sph_get_scalar(SphHandle *h, int which, double *out);
 /* `solver.delta_time[None] = value` (the reference's 0-d field is writable, main.py:111; dfsph re-derives it every step from the CFL
- * rule, dfsph_solver.py:112-119, so a written value lasts one step there).  which = SPH_S_DELTA_TIME only; with it a device state
- * (pos, vel, warm_start_k, delta_time) can be moved into another handle, or into the oracle, completely. */
+ * rule, dfsph_solver.py:112-119, so a written value lasts one step there): which = SPH_S_DELTA_TIME; with it a device state
+ * (pos, vel, warm_start_k, delta_time) can be moved into another handle, or into the oracle, completely.
+ * `solver.<attribute> = value`: which = SPH_P_* (above). */
 int sph_set_scalar(SphHandle *h, int which, double value);
 int sph_synchronize(SphHandle *h);
 /* Development overrides in force on this handle: "NAME=value;NAME=value" (empty string: none).  The SPH_* environment knobs of the

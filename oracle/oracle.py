@@ -206,6 +206,10 @@ class Oracle:
         """delta_time, delta_time_2 and ps.delta_time as a dfsph step leaves them: continue from a state produced elsewhere."""
         assert self._lib.orc_set_scalar(self._h, 0, float(value)) == 0
 
+    def set_param(self, which, value):
+        """`solver.<attribute> = value`: which = the SPH_P_* numbers of include/sph_mi355x.h (64..76)."""
+        assert self._lib.orc_set_scalar(self._h, int(which), float(value)) == 0
+
     @property
     def particle_m(self):
         return self._lib.orc_get_scalar(self._h, 2)

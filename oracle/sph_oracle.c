@@ -59,6 +59,11 @@ struct Orc {
     real neg_m;            /* -particle_m                  solver_base.py:189 */
     real dt, dt2, ps_dt;   /* delta_time, delta_time_2, ps.delta_time (0-d f32 fields) */
     real dt_cfl_num;       /* 0.4*r*2 folded in f64        dfsph_solver.py:112 */
+    /* the attributes a caller may edit on the solver object (orc_set_scalar 64..76; the numbering of include/sph_mi355x.h SPH_P_*):
+     * dfsph_solver.py:21-29, solver_base.py:23-26, wcsph_solver.py:17-20.  Python scalars: kept as doubles, folded where the reference folds them */
+    double p_density_threshold, p_density_divergence_threshold, p_max_dt, p_min_dt;
+    int p_min_iteration_density, p_min_iteration_density_divergence, p_max_iteration_density_divergence, p_warm_start, p_adaptive_dt;
+    double p_viscosity_c_s, p_viscosity_alpha, p_viscosity_epsilon, p_tension_k;
     int simulate_cnt;
     int nt;
     /* fluid particles */
@@ -143,6 +148,8 @@ static double sched_sum(Orc *o, const real *v, const unsigned char *take, int n)
     free(part); free(ord);
     return (double)tot;
 }
+static void fold_params(Orc *o);
+
 void orc_set_schedule(Orc *o, unsigned long long seed, int chunk)
 {
     o->sched_seed = seed;
@@ -519,12 +526,13 @@ Orc *orc_create(const OrcConfig *cfg)
     o->rho0 = R(1000);
     o->gravity = R(c->gravity);
     /* per-solver constants: wcsph_solver.py:17-22 vs solver_base.py:23-26 */
-    double c_s = c->solver == 0 ? 10 : 13;
-    double t_k = c->solver == 0 ? 0.2 : 0.5;
-    double kernel_h = r * 4;                /* solver_base.py:17 */
-    o->visc_num = R(2 * 0.08 * kernel_h * c_s);
-    o->visc_eps_h2 = R(0.01 * kernel_h * kernel_h);
-    o->tens_c = R(-t_k / m * m);
+    o->p_viscosity_c_s = c->solver == 0 ? 10 : 13;
+    o->p_tension_k = c->solver == 0 ? 0.2 : 0.5;
+    o->p_viscosity_alpha = 0.08; o->p_viscosity_epsilon = 0.01;
+    o->p_density_threshold = 0.1; o->p_density_divergence_threshold = 10; o->p_max_dt = 1e-3; o->p_min_dt = 1e-5;       /* dfsph_solver.py:21-29 */
+    o->p_min_iteration_density = 2; o->p_min_iteration_density_divergence = 1; o->p_max_iteration_density_divergence = 15;
+    o->p_warm_start = 1; o->p_adaptive_dt = 1;
+    fold_params(o);
     o->neg_m = R(-m);
     o->dt = R(c->delta_time);
     o->dt2 = R((real)R(c->delta_time) * (real)R(c->delta_time));   /* dfsph_solver.py:20: f32 field ** 2 */
@@ -653,10 +661,36 @@ long orc_set(Orc *o, int field, const float *in)
     return n;
 }
 
+/* the Python scalars of the viscosity / tension terms, folded in f64 and rounded once (solver_base.py:187-188, :216) */
+static void fold_params(Orc *o)
+{
+    double r = o->cfg.particle_radius, m = 1000 * (r * r * r) * 8, kernel_h = r * 4;     /* ParticleSystem.py:83, solver_base.py:17 */
+    o->visc_num = R(2 * o->p_viscosity_alpha * kernel_h * o->p_viscosity_c_s);
+    o->visc_eps_h2 = R(o->p_viscosity_epsilon * kernel_h * kernel_h);
+    o->tens_c = R(-o->p_tension_k / m * m);
+}
+
 /* which 0: delta_time (and delta_time_2 = dt * dt, ps.delta_time = dt as compute_all_vel_adv leaves them, dfsph_solver.py:118-119):
- * lets a test or the CPU baseline continue from a state produced elsewhere (positions, velocities, warm_start_k through orc_set) */
+ * lets a test or the CPU baseline continue from a state produced elsewhere (positions, velocities, warm_start_k through orc_set);
+ * which 64..76: `solver.<attribute> = value` (see struct Orc) */
 int orc_set_scalar(Orc *o, int which, double value)
 {
+    switch (which) {
+    case 64: o->p_density_threshold = value; return 0;
+    case 65: o->p_min_iteration_density = (int)value; return 0;
+    case 66: o->p_min_iteration_density_divergence = (int)value; return 0;
+    case 67: o->p_max_iteration_density_divergence = (int)value; return 0;
+    case 68: o->p_density_divergence_threshold = value; return 0;
+    case 69: o->p_warm_start = value != 0.0; return 0;
+    case 70: o->p_adaptive_dt = value != 0.0; return 0;
+    case 71: o->p_max_dt = value; return 0;
+    case 72: o->p_min_dt = value; return 0;
+    case 73: o->p_viscosity_c_s = value; fold_params(o); return 0;
+    case 74: o->p_viscosity_alpha = value; fold_params(o); return 0;
+    case 75: o->p_viscosity_epsilon = value; fold_params(o); return 0;
+    case 76: o->p_tension_k = value; fold_params(o); return 0;
+    default: break;
+    }
     if (which != 0) return -1;
     o->dt = R(value);
     o->dt2 = o->dt * o->dt;
@@ -682,6 +716,19 @@ double orc_get_scalar(const Orc *o, int which)
     case 16: case 17: case 18: return (double)o->r_vel[which - 16];
     case 19: return (double)o->rs_mass;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: return (double)o->inertia_inv[which - 20];
+    case 64: return o->p_density_threshold;
+    case 65: return o->p_min_iteration_density;
+    case 66: return o->p_min_iteration_density_divergence;
+    case 67: return o->p_max_iteration_density_divergence;
+    case 68: return o->p_density_divergence_threshold;
+    case 69: return o->p_warm_start;
+    case 70: return o->p_adaptive_dt;
+    case 71: return o->p_max_dt;
+    case 72: return o->p_min_dt;
+    case 73: return o->p_viscosity_c_s;
+    case 74: return o->p_viscosity_alpha;
+    case 75: return o->p_viscosity_epsilon;
+    case 76: return o->p_tension_k;
     default: return 0;
     }
 }
@@ -1426,13 +1473,14 @@ static void correct_divergence_error(Orc *o, OrcStepStats *st)
 {
     real past = 0;
     int iter_cnt = 0;
-    divergence_warm_start(o);                                                       /* :396-397 */
+    if (o->p_warm_start) divergence_warm_start(o);                                  /* :396-397 */
     real err = derivative_iter_all_rho(o);                                          /* :398 */
     st->n_div_evals = 1;
     st->div_first_err = (float)err;
-    while ((iter_cnt < 1 || (double)err > 10.0) && iter_cnt < 15) {                  /* :400 (host f64 compare) */
+    while ((iter_cnt < o->p_min_iteration_density_divergence || (double)err > o->p_density_divergence_threshold)
+           && iter_cnt < o->p_max_iteration_density_divergence) {                   /* :400 (host f64 compare) */
         divergence_iter_all_vel_adv(o);
-        sum_up_stiff(o);
+        if (o->p_warm_start) sum_up_stiff(o);                                       /* :404-405 */
         past = err;
         err = derivative_iter_all_rho(o);
         st->n_div_evals += 1;
@@ -1480,10 +1528,12 @@ static void compute_all_vel_adv(Orc *o)
     }
     max_vel += max_rigid_vel;
     real max_delta_time = o->dt_cfl_num / max_vel * R(0.2);                         /* :112 */
-    if (max_delta_time > R(1e-3)) o->dt = R(1e-3);                                  /* :114-117 */
-    else o->dt = r_max(max_delta_time, R(1e-5));
-    o->dt2 = o->dt * o->dt;                                                         /* :118 */
-    o->ps_dt = o->dt;                                                               /* :119 */
+    if (o->p_adaptive_dt) {                                                         /* :113 */
+        if (max_delta_time > R(o->p_max_dt)) o->dt = R(o->p_max_dt);                /* :114-117 */
+        else o->dt = r_max(max_delta_time, R(o->p_min_dt));
+        o->dt2 = o->dt * o->dt;                                                     /* :118 */
+        o->ps_dt = o->dt;                                                           /* :119 */
+    }
 }
 
 /* compute_all_rho_adv                                              dfsph_solver.py:124-176 */
@@ -1615,7 +1665,7 @@ int orc_step_dfsph(Orc *o, int nsteps, int max_dens_iter, OrcStepStats *last)
         {                                                              /* correct_density_error :221-233 */
             real rho_avg = INFINITY;
             int iter_cnt = 0;
-            while (iter_cnt < 2 || (double)rho_avg - 1000.0 > 0.1 * 1000 * 0.01) {      /* :225 (host f64) */
+            while (iter_cnt < o->p_min_iteration_density || (double)rho_avg - 1000.0 > o->p_density_threshold * 1000 * 0.01) {      /* :225 (host f64) */
                 if (max_dens_iter > 0 && iter_cnt >= max_dens_iter) { capped = 1; break; }
                 rho_avg = compute_all_rho_adv(o);
                 iter_all_vel_adv(o);

@@ -207,6 +207,7 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
     case SPH_S_PCISPH_MAX_INDEX: *out = orc_get_scalar(h->o, 7); return SPH_OK;
     case SPH_S_PCISPH_MAX_COUNT: *out = orc_get_scalar(h->o, 8); return SPH_OK;
     default:
+        if (which >= SPH_P_DENSITY_THRESHOLD && which <= SPH_P_TENSION_K) { *out = orc_get_scalar(h->o, which); return SPH_OK; }
         if (h->has_rigid && which >= SPH_S_RIGID_CENTROID && which < SPH_S_RIGID_INERTIA_INV + 9) { *out = orc_get_scalar(h->o, which); return SPH_OK; }
         return fail(h, SPH_E_INVALID, "unknown scalar");
     }
@@ -215,7 +216,8 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
 int sph_set_scalar(SphHandle *h, int which, double value)
 {
     if (!h) return SPH_E_INVALID;
-    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: only SPH_S_DELTA_TIME > 0 can be written");
+    if (which >= SPH_P_DENSITY_THRESHOLD && which <= SPH_P_TENSION_K) { orc_set_scalar(h->o, which, value); return SPH_OK; }
+    if (which != SPH_S_DELTA_TIME || !(value > 0.0)) return fail(h, SPH_E_INVALID, "sph_set_scalar: SPH_S_DELTA_TIME > 0 or a solver attribute SPH_P_* can be written");
     orc_set_scalar(h->o, 0, value);
     return SPH_OK;
 }

@@ -61,6 +61,23 @@ def test_oracle_abi_library_exports_the_path_and_matches_its_own_interface():
     o.close()
 
 
+def test_solver_attributes_through_the_abi_on_the_oracle_backend():
+    """sph_set_scalar(SPH_P_*) on the oracle's ABI library = Oracle.set_param on its own interface, and the attributes change what the loops do."""
+    cfg = scenes.get("dfsph_tiny_wall")
+    sim = nat.Simulation(nat.config_from_dict(cfg), lib=nat.bind_core(orc.ABI_LIB))
+    o = orc.Oracle(cfg, num_threads=4)
+    assert sim.param("max_iteration_density_divergence") == 15 and sim.param("tension_k") == 0.5 and sim.param("max_dt") == 1e-3
+    for k, v in (("max_iteration_density_divergence", 2), ("density_divergence_threshold", 1.0), ("min_iteration_density", 5), ("tension_k", 1.5), ("max_dt", 5e-4)):
+        sim.set_param(k, v); o.set_param(nat.SOLVER_PARAMS[k], v)
+        assert sim.param(k) == float(v)
+    for _ in range(12):
+        st = sim.step(1); o.step_dfsph(1, 100)
+        assert (st.n_div, st.n_dens, st.dt) == (o.last_stats.n_div, o.last_stats.n_dens, o.last_stats.dt)
+        assert st.n_div <= 2 and st.n_dens >= 5 and st.dt <= np.float32(5e-4)
+    assert np.array_equal(sim.download(nat.F_POS), o.get(orc.F_POS)) and np.array_equal(sim.download(nat.F_VEL), o.get(orc.F_VEL))
+    sim.close(); o.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene,steps", [("dfsph_small", 12), ("wcsph_tiny_wall", 40), ("dfsph_tiny_wall_pcisph", 15), ("dfsph_tiny_wall_iisph", 15),
                                          ("pbf_tiny_wall", 30), ("dfsph_rigid_small", 25)])

@@ -1,0 +1,148 @@
+"""GPU suite: `solver.<attribute> = value` reaches the kernels (VERDICT r4 missing #4).
+
+The reference's thresholds are Python attributes of the solver object (dfsph_solver.py:21-29, solver_base.py:23-26, wcsph_solver.py:17-20): its
+Python-scope loops read them at every step (:225, :396-404) and Taichi bakes the ones it meets inside a kernel (:113-117, solver_base.py:187-188, :216)
+when that kernel first compiles.  A caller who edits them before the first step() gets the edited behaviour there; here they travel through
+sph_set_scalar(SPH_P_*), and the library given the same values as the oracle stays bit-equal to it -- state, iteration counts, residuals, delta_time.
+"""
+import numpy as np
+import pytest
+
+from cfd_taichi_amd import _native as nat
+from cfd_taichi_amd import scenes
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what):
+    assert a.shape == b.shape and np.array_equal(a, b), "%s differs at %d of %d entries" % (what, int((a != b).sum()), a.size)
+
+
+def lockstep_dfsph(sim, o, steps):
+    counts = []
+    for s in range(steps):
+        st = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        so = o.last_stats
+        assert (st.n_div, st.n_dens, st.n_div_evals) == (so.n_div, so.n_dens, so.n_div_evals), (s, st.n_div, so.n_div, st.n_dens, so.n_dens)
+        assert st.div_first_err == so.div_first_err and st.div_err == so.div_err and st.dens_err == so.dens_err and st.dt == so.dt, s
+        counts.append((st.n_div, st.n_dens, st.dt))
+    for f, fo, what in ((nat.F_POS, orc.F_POS, "pos"), (nat.F_VEL, orc.F_VEL, "vel"), (nat.F_WARM_K, orc.F_WARM_K, "warm_start_k"), (nat.F_RHO_ADV, orc.F_RHO_ADV, "rho_adv")):
+        same(sim.download(f), o.get(fo), what)
+    return counts
+
+
+PARAM_SETS = {
+    # the case VERDICT r4 names: a looser divergence threshold and a shorter cap, set before the first step
+    "div_loop": {"density_divergence_threshold": 300.0, "max_iteration_density_divergence": 4},
+    "div_min": {"min_iteration_density_divergence": 3, "density_divergence_threshold": 1e9},
+    "dens_loop": {"density_threshold": 0.5, "min_iteration_density": 4},
+    "no_warm_start": {"warm_start": 0},
+    "fixed_dt": {"adaptive_dt": 0},
+    "dt_window": {"max_dt": 4e-4, "min_dt": 2e-4},
+    "fluid": {"viscosity_c_s": 20.0, "viscosity_alpha": 0.05, "viscosity_epsilon": 0.02, "tension_k": 1.5},
+    "no_div_loop": {"max_iteration_density_divergence": 0},
+}
+
+
+CASES = [("dfsph_small", 25, None, name) for name in sorted(PARAM_SETS)] \
+    + [("dfsph_small", 25, "morton", name) for name in ("div_loop", "no_warm_start", "fluid", "dt_window")] \
+    + [("dfsph_tiny_wall", 40, None, name) for name in ("dens_loop", "fixed_dt")]
+
+
+@pytest.mark.parametrize("scene,steps,order,name", CASES)
+def test_dfsph_attributes_set_before_the_first_step(scene, steps, order, name, monkeypatch):
+    if order:
+        monkeypatch.setenv("SPH_CELL_ORDER", order)          # the staged sweeps (Morton curve, LDS staging, 16-bit lists) of the large scenes
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, num_threads=8)
+    for k, v in PARAM_SETS[name].items():
+        sim.set_param(k, v)
+        o.set_param(nat.SOLVER_PARAMS[k], v)
+        assert sim.param(k) == float(v)
+    counts = lockstep_dfsph(sim, o, steps)
+    # ... and the edit did something: the same steps with the reference's values differ in the quantity the attribute governs
+    ref = nat.Simulation(nat.config_from_dict(cfg))
+    ref_counts = [(st.n_div, st.n_dens, st.dt) for st in (ref.step_dfsph(1) for _ in range(steps))]
+    assert counts != ref_counts or not np.array_equal(sim.download(nat.F_VEL), ref.download(nat.F_VEL)), name
+    if name == "div_loop":
+        assert max(c[0] for c in counts) <= 4
+    if name == "no_div_loop":
+        assert all(c[0] == 0 for c in counts)
+    if name == "fixed_dt":
+        assert all(c[2] == counts[0][2] for c in counts) and counts[0][2] == np.float32(cfg["solver"]["delta_time"])
+    if name == "dt_window":
+        assert all(np.float32(2e-4) <= c[2] <= np.float32(4e-4) for c in counts)
+    sim.close(); o.close(); ref.close()
+
+
+def test_live_attributes_can_change_between_steps():
+    """The loop attributes are read by Python-scope loops (dfsph_solver.py:225, :400): an edit between two steps takes effect at the next one."""
+    cfg = scenes.get("dfsph_small")
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, num_threads=8)
+    lockstep_dfsph(sim, o, 8)
+    for k, v in (("max_iteration_density_divergence", 3), ("density_threshold", 0.02)):
+        sim.set_param(k, v); o.set_param(nat.SOLVER_PARAMS[k], v)
+    counts = lockstep_dfsph(sim, o, 8)
+    assert max(c[0] for c in counts) <= 3
+    sim.close(); o.close()
+
+
+@pytest.mark.parametrize("scene,steps", [("wcsph_small", 60), ("wcsph_tiny_wall", 100)])
+def test_wcsph_viscosity_and_tension(scene, steps):
+    cfg = scenes.get(scene)
+    sim = nat.Simulation(nat.config_from_dict(cfg))
+    o = orc.Oracle(cfg, num_threads=8)
+    assert sim.param("viscosity_c_s") == 10.0 and sim.param("tension_k") == 0.2          # wcsph_solver.py:18, :20
+    sim.step_wcsph(4); o.step_wcsph(4)                # (captured step pairs carry the constants: an edit must invalidate them)
+    for k, v in (("viscosity_c_s", 30.0), ("tension_k", 2.0), ("viscosity_alpha", 0.2)):
+        sim.set_param(k, v); o.set_param(nat.SOLVER_PARAMS[k], v)
+    sim.step_wcsph(steps); o.step_wcsph(steps)
+    same(sim.download(nat.F_POS), o.get(orc.F_POS), "pos")
+    same(sim.download(nat.F_VEL), o.get(orc.F_VEL), "vel")
+    ref = nat.Simulation(nat.config_from_dict(cfg))
+    ref.step_wcsph(4 + steps)
+    assert not np.array_equal(ref.download(nat.F_VEL), sim.download(nat.F_VEL))
+    sim.close(); o.close(); ref.close()
+
+
+def test_mirror_classes_forward_the_attributes():
+    """The drop-in classes: `solver.density_divergence_threshold = ...` before the first step(), as a caller of the reference would write it."""
+    from cfd_taichi_amd import ParticleSystem, dfsph_solver
+    cfg = scenes.get("dfsph_small")
+    cfg = dict(cfg, solver=dict(cfg["solver"], name="dfsph"))
+    ps = ParticleSystem(cfg)
+    solver = dfsph_solver(ps, cfg, verbose=False)
+    solver.density_divergence_threshold = 300.0
+    solver.max_iteration_density_divergence = 4
+    solver.tension_k = 1.5
+    o = orc.Oracle(cfg, num_threads=8)
+    for k, v in (("density_divergence_threshold", 300.0), ("max_iteration_density_divergence", 4), ("tension_k", 1.5)):
+        o.set_param(nat.SOLVER_PARAMS[k], v)
+    for s in range(10):
+        st = solver.step()
+        o.step_dfsph(1, 100)
+        assert (st.n_div, st.n_dens) == (o.last_stats.n_div, o.last_stats.n_dens) and st.n_div <= 4
+        if s == 4:
+            solver.tension_k = 9.0                      # baked into the reference's kernel at the first step: ignored from then on
+            solver.max_iteration_density_divergence = 2 # read by a Python-scope loop: takes effect
+            o.set_param(nat.SOLVER_PARAMS["max_iteration_density_divergence"], 2)
+    assert st.n_div <= 2
+    same(ps.fluid_particles.pos.to_numpy(), o.get(orc.F_POS), "pos")
+    same(ps.fluid_particles.vel.to_numpy(), o.get(orc.F_VEL), "vel")
+    o.close()
+
+
+def test_bad_values_are_refused():
+    sim = nat.Simulation(nat.config_from_dict(scenes.get("dfsph_small")))
+    for k, v in (("max_dt", 0.0), ("min_dt", -1.0), ("max_iteration_density_divergence", 2.5), ("min_iteration_density", -1), ("viscosity_epsilon", 0.0), ("tension_k", float("nan"))):
+        with pytest.raises(nat.SphError):
+            sim.set_param(k, v)
+    sim.close()
+    w = nat.Simulation(nat.config_from_dict(scenes.get("wcsph_small")))
+    with pytest.raises(nat.SphError):
+        w.set_param("density_threshold", 0.2)             # a dfsph_solver attribute
+    w.close()
