@@ -228,16 +228,11 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
         avg_s = ms / cnt / 1e3
         rx_names = {"dfsph_div_residual": "k_residual_rx<false>", "dfsph_dens_residual": "k_residual_rx<true>", "dfsph_warm_start": "k_correct_rx<0>",
                     "dfsph_div_correct": "k_correct_rx<1>", "dfsph_dens_correct": "k_correct_rx<2>", "wcsph_density": "k_wcsph_density_rx", "wcsph_force": "k_wcsph_force_rx"}
-        traffic = None
-        try:
-            if scene_name == "dfsph_1m":
-                with open(os.path.join(ROOT, "profiles", "r03", "pmc_traffic_relaxed.json")) as f:
-                    traffic = json.load(f)["kernels"][rx_names[dom]]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic, traffic_status = (load_traffic(rx_names.get(dom), path=os.path.join(ROOT, "profiles", "pmc_traffic_relaxed.json"))
+                                   if scene_name == "dfsph_1m" else (None, None))
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ALGO_BYTES[dom] * n / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ALGO_BYTES[dom] * n / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": "profiles/r03/pmc_traffic_relaxed.json (committed rocprofv3 --pmc passes with SPH_ARITH=relaxed; NOT measured in this run)" if traffic else None,
+                           "frac": ALGO_BYTES[dom] * n / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_status": traffic_status,
+                           "traffic_source": "profiles/pmc_traffic_relaxed.json (committed rocprofv3 --pmc passes with SPH_ARITH=relaxed; NOT measured in this run)" if traffic else None,
                            "avg_launch_us": avg_s * 1e6, "launches": cnt, "share_of_gpu_time": ms / tot if tot else None}
         out["kernel_breakdown_us"] = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_step": v[1] / args.steps, "share": v[0] / tot}
                                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
@@ -245,16 +240,28 @@ def relaxed_leg(nat, scenes, scene_name, device, args, state, final_exact, exact
     return out
 
 
-def load_traffic(kernel, key="hbm_bytes_per_launch"):
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def committed_status(data):
+    """"current" when a committed measurement (profiles/pmc_traffic.json, valu_mix.json) was taken on the kernel sources this run executes -- the
+    writers store cfd_taichi_amd.build.sources_sha256() -- "stale" when the sources have changed since, "unknown" for a file without a digest."""
+    from cfd_taichi_amd import build as hip_build
+    sha = data.get("csrc_sha256") if isinstance(data, dict) else None
+    if not sha:
+        return "unknown"
+    return "current" if sha == hip_build.sources_sha256() else "stale"
+
+
+def load_traffic(kernel, key="hbm_bytes_per_launch", path=None):
+    """(HBM bytes per launch from the committed --pmc passes, status) -- (None, None) if absent.  ONE file: profiles/pmc_traffic.json."""
+    path = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     try:
         with open(path) as f:
             data = json.load(f)
-        return data.get("kernels", {}).get(kernel, {}).get(key)
+        v = data.get("kernels", {}).get(kernel, {}).get(key)
+        return v, (committed_status(data) if v is not None else None)
     except Exception:
-        return None
+        return None, None
 
 
 def load_valu_mix(kernel_profile_name):
@@ -264,11 +271,15 @@ def load_valu_mix(kernel_profile_name):
              "dfsph_div_correct": "k_correct<1, false, %s>", "dfsph_dens_correct": "k_correct<2, false, %s>"}
     try:
         with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
-            kernels = json.load(f)["kernels"]
+            data = json.load(f)
+        kernels = data["kernels"]
         pattern = names.get(kernel_profile_name)
         if pattern is None:
             return None
-        return kernels.get(pattern % "1") or kernels.get(pattern % "true")
+        mix = kernels.get(pattern % "1") or kernels.get(pattern % "true")
+        if mix is not None:
+            mix = dict(mix, status=committed_status(data))
+        return mix
     except Exception:
         return None
 
@@ -633,9 +644,11 @@ def main():
         algo = ALGO_BYTES[dom] * n_local
         achieved = algo / avg_s / 1e9
         committed = world == 1 and scene_name == "dfsph_1m"       # the committed PMC passes were taken on this workload
-        traffic = load_traffic(dom) if committed else None
+        traffic, traffic_status = load_traffic(dom) if committed else (None, None)
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           # "current": the passes were taken on the kernel sources this run executes (sha256 of csrc/ + flags stored with them); "stale": not
+                           "traffic_status": traffic_status,
                            "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes of this workload; NOT measured in this run)" if traffic else None,
                            "algorithmic_bytes_per_launch": algo, "avg_launch_us": avg_s * 1e6, "launches": n,
                            "share_of_gpu_time": ms / tot if tot else None, "rank": 0, "particles_on_rank": n_local,
@@ -655,6 +668,7 @@ def main():
             # costs tools/valu_issue.hip measured on this chip -- the time the SIMDs need just to ISSUE the kernel's instructions
             g_inst = mix["wave_insts_per_launch"] / avg_s / 1e9
             out["roofline"]["valu"] = {"wave_insts_per_launch": mix["wave_insts_per_launch"], "plain": mix["plain"], "transcendental": mix["trans"], "other": mix["other"],
+                                       "status": mix.get("status"),
                                        "source": "profiles/valu_mix.json (committed SQ_INSTS_VALU_* passes priced with profiles/valu_issue.json; NOT measured in this run)",
                                        "issue_floor_us": mix["issue_floor_us"], "frac_of_issue_floor": mix["issue_floor_us"] / (avg_s * 1e6),
                                        "achieved": g_inst, "unit": "G wave64-inst/s", "measured_issue_ceiling_plain_fma": load_ceiling(),

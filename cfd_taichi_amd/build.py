@@ -34,6 +34,19 @@ def hipcc():
     raise RuntimeError("hipcc not found: libsph_mi355x.so cannot be built (there is no CPU fallback)")
 
 
+def sources_sha256():
+    """One digest of what the kernels are built from: every file of csrc/, the public header and the compiler flags.  Measurements that are
+    committed and quoted later (profiles/pmc_traffic.json, profiles/valu_mix.json) carry it, and bench.py labels them "stale" when it differs
+    from the sources it runs (tools/pmc_traffic.py, tools/valu_mix.py, bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(os.path.basename(name).encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

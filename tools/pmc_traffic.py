@@ -101,7 +101,10 @@ def main():
                 if vals.get(k):
                     lv = live(vals[k])
                     entry[c.lower() + "_per_launch"] = sum(lv) / len(lv)
-    out = {"n_particles": n, "counter_unit": "KiB", "fetch_correction": fetch_factor, "calibration": calib, "kernels": kernels,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cfd_taichi_amd import build as hip_build
+    # the sources these counters were taken on: bench.py compares with the sources it runs and labels roofline.traffic "stale" on a mismatch
+    out = {"csrc_sha256": hip_build.sources_sha256(), "n_particles": n, "counter_unit": "KiB", "fetch_correction": fetch_factor, "calibration": calib, "kernels": kernels,
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  --pmc WRITE_SIZE (two separate passes)"}
     with open(out_path, "w") as f:
         json.dump(out, f, indent=2)

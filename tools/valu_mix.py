@@ -7,7 +7,9 @@ Cost classes (cycles per wave64 instruction on one SIMD = 4 SIMDs x 256 CUs x 2.
   other    everything else the class counters do not name: v_cmp, v_cndmask, v_max, v_mov, shifts with an SGPR operand ...
            priced as an SGPR-operand instruction                                                -> v_mul_f32_sgpr
 """
-import json, re, sys
+import json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfd_taichi_amd import build as hip_build
 report, issue = sys.argv[1], json.load(open(sys.argv[2]))
 rate = lambda name: issue["results"][name]["4_waves_per_simd"]
 simd_ghz = issue["compute_units"] * 4 * 2.4
@@ -20,7 +22,7 @@ for line in open(report):
         for kv in m.group(2).split():
             k, v = kv.split("=")
             d[k] = float(v) * 32            # the report holds means per (launch, XCD x SE instance): 32 instances per launch
-out = {"issue_cycles_per_instruction": cyc, "source": "SQ_INSTS_VALU_* (rocprofv3 --pmc, %s) priced with tools/valu_issue.hip (profiles/valu_issue.json)" % report, "kernels": {}}
+out = {"csrc_sha256": hip_build.sources_sha256(), "issue_cycles_per_instruction": cyc, "source": "SQ_INSTS_VALU_* (rocprofv3 --pmc, %s) priced with tools/valu_issue.hip (profiles/valu_issue.json)" % report, "kernels": {}}
 for k, d in per.items():
     if "SQ_INSTS_VALU" not in d or "SQ_INSTS_VALU_FMA_F32" not in d:
         continue
