@@ -45,7 +45,9 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 // 19.5 us against a mean of 12.1 at 1 M particles -- start first instead of wherever their index falls, so that the tail of a launch is made
 // of ordinary tiles (profiles/r03/wg_timeline_div_residual.json: a sixth of every sweep was its drain).  MEASURED (round 4): no effect -- the drain
 // of a launch is one workgroup lifetime whatever tiles come last; off by default (SPH_TILE_LPT=<wall weight>), see profiles/r04/null/tile_lpt_ab.txt.
-struct TilePhase { const int *order; int ntiles, phase; };
+struct TilePhase { const int *order; int ntiles, phase; int shift = 0; };
+// shift = 1: workgroup 0 of the launch is not a tile's -- it takes the loop decision of the sweep BEFORE this one (fin_ride_block) -- and workgroup
+// b serves the tile that workgroup b - 1 of a grid one smaller would (phases 0 and 3, one GPU)
 // Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_mi355x.hip: step_dfsph_device_loops): the correction of
 // evaluation e runs before decision e is known and leaves the velocities and warm_start_k it overwrote in SpecSave; if decision e closed the loop
 // (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
@@ -68,6 +70,12 @@ __device__ __forceinline__ void spec_undo(const Consts &c, const SpecUndo &un, c
 // 6 = the interior tiles; the grids are sized by the host's bounds on that number, surplus workgroups leave at once.
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
 {
+    if (tp.shift) {
+        const int b = (int)blockIdx.x - 1, g = (int)gridDim.x - 1;
+        if (b < 0) return -1;
+        if (tp.phase == 3) return spread ? b : tp.order[xcd_sweep_block(b, g)];
+        return spread ? b : xcd_sweep_block(b, g);
+    }
     if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
     if (tp.phase == 5) { const int s0 = tp.order[0], ne = tp.ntiles - s0; return (int)blockIdx.x < ne ? s0 + (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ne)) : -1; }
     if (tp.phase == 6) { const int ni = tp.order[0]; return (int)blockIdx.x < ni ? (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ni)) : -1; }
@@ -1200,18 +1208,7 @@ __device__ __forceinline__ void for_wall_cache(const float4 *__restrict__ base, 
 }
 
 // block partial of (sum over lanes with flag, count) in a fixed order -> deterministic
-// `through`: the partial is stored write-through at agent scope (sc1) -- the fused finalize (fin_fused) reads it from another XCD inside the same launch
-__device__ __forceinline__ void store_partial(double *__restrict__ psum, int *__restrict__ pcnt, int e, double t, int n, bool through)
-{
-    if (through) {
-        __hip_atomic_store(&psum[e], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&pcnt[e], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        psum[e] = t;
-        pcnt[e] = n;
-    }
-}
-__device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt, bool through = false)
+__device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, double *__restrict__ psum, int *__restrict__ pcnt)
 {
     __shared__ double s_sum[kBlock / 64];
     __shared__ int s_cnt[kBlock / 64];
@@ -1223,14 +1220,14 @@ __device__ __forceinline__ void block_partial_mean(int blk, double v, int flag, 
     if (threadIdx.x == 0) {
         double t = 0.0; int n = 0;
         for (int k = 0; k < kBlock / 64; ++k) { t += s_sum[k]; n += s_cnt[k]; }
-        store_partial(psum, pcnt, blk, t, n, through);
+        psum[blk] = t; pcnt[blk] = n;
     }
 }
 // QUAD sweeps: a workgroup holds 64 particles, one per quad -- exactly one WAVE of a one-lane-per-particle workgroup.  Its partial is
 // that wave's butterfly: the owners' values go through LDS into particle order and wave 0 reduces them with the same tree.
 // psum / pcnt then hold one entry per 64 particles; k_finalize_mean (group = 4) first adds four consecutive entries in order, which is
 // the serial sum over the four waves of the 256-particle block above: same bits.
-__device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int flag, bool owner_lane, double *__restrict__ psum, int *__restrict__ pcnt, bool through = false)
+__device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int flag, bool owner_lane, double *__restrict__ psum, int *__restrict__ pcnt)
 {
     __shared__ double s_v[kBlock / 4];
     __shared__ int s_f[kBlock / 4];
@@ -1239,7 +1236,7 @@ __device__ __forceinline__ void block_partial_mean_quad(int blk, double v, int f
     if (threadIdx.x < 64) {
         const double ws = wave_sum(s_v[threadIdx.x]);
         const int wc = wave_sum(s_f[threadIdx.x]);
-        if (threadIdx.x == 0) store_partial(psum, pcnt, blk, ws, wc, through);
+        if (threadIdx.x == 0) { psum[blk] = ws; pcnt[blk] = wc; }
     }
 }
 
@@ -1271,30 +1268,17 @@ enum { FINP_ALL = 0, FINP_REDUCE = 1, FINP_DECIDE = 2 };
 constexpr int kFinBlock = 1024;
 // group = 4: psum / pcnt hold one entry per 64 particles (QUAD sweeps, block_partial_mean_quad); `nblocks` still counts blocks of 256 particles and
 // `nparts` the entries: a block's partial is the in-order sum of its (up to) four entries.
-// THROUGH: the partials are read with agent-scope (sc1) loads -- inside the launch that produced them (fin_fused)
-template <bool THROUGH>
-__device__ __forceinline__ void load_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, double &v, int &m)
-{
-    if (THROUGH) {
-        v = __hip_atomic_load(&psum[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m = __hip_atomic_load(&pcnt[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        v = psum[e]; m = pcnt[e];
-    }
-}
-template <bool THROUGH = false>
 __device__ __forceinline__ void fin_partial(const double *__restrict__ psum, const int *__restrict__ pcnt, int e, int nblocks, int group, int nparts, double &v, int &m)
 {
     v = 0.0; m = 0;
     if (e >= nblocks) return;
-    if (group == 1) { load_partial<THROUGH>(psum, pcnt, e, v, m); return; }
+    if (group == 1) { v = psum[e]; m = pcnt[e]; return; }
     for (int u = 0; u < group; ++u) {
         const int k = e * group + u;
-        if (k < nparts) { double pv; int pm; load_partial<THROUGH>(psum, pcnt, k, pv, pm); v += pv; m += pm; }          // 0.0 + w0 = w0: the serial sum over the block's waves
+        if (k < nparts) { v += psum[k]; m += pcnt[k]; }          // 0.0 + w0 = w0: the serial sum over the block's waves
     }
 }
 // what "virtual thread" vt of a kFinBlock-thread workgroup adds up: the partials vt, vt + kFinBlock, ... in ascending order
-template <bool THROUGH>
 __device__ __forceinline__ void fin_thread_sum(const double *__restrict__ psum, const int *__restrict__ pcnt, int vt, int nblocks, int group, int nparts, double &t, int &n)
 {
     t = 0.0; n = 0;
@@ -1302,14 +1286,14 @@ __device__ __forceinline__ void fin_thread_sum(const double *__restrict__ psum, 
     for (; k + 3 * kFinBlock < nblocks; k += 4 * kFinBlock) {
         double v[4]; int m[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fin_partial<THROUGH>(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }
     }
     {   // the rest, still as one batch of (predicated) loads
         double v[4]; int m[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fin_partial<THROUGH>(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
+        for (int u = 0; u < 4; ++u) fin_partial(psum, pcnt, k + u * kFinBlock, nblocks, group, nparts, v[u], m[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) { t += v[u]; n += m[u]; }       // + 0.0 leaves a non-negative-zero sum unchanged
     }
@@ -1319,7 +1303,7 @@ __device__ __forceinline__ void fin_reduce(const double *__restrict__ psum, cons
                                            double *__restrict__ s_sum, long long *__restrict__ s_cnt)
 {
     double t; int n;
-    fin_thread_sum<false>(psum, pcnt, threadIdx.x, nblocks, group, nparts, t, n);
+    fin_thread_sum(psum, pcnt, threadIdx.x, nblocks, group, nparts, t, n);
     const double ws = wave_sum(t);
     const int wn = wave_sum(n);
     if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = ws; s_cnt[threadIdx.x >> 6] = wn; }
@@ -1403,64 +1387,43 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
     finalize_mean_block(psum, pcnt, nblocks, ds, mode, phase, red, group, nparts, hist);
 }
 
-// ---- the finalize fused into the sweep that produced the partials (VERDICT r3 next #5b) --------------------------------------------------
-// Between two sweeps of a solver loop sat a single-workgroup launch (k_finalize_mean: 4.2 us at 1 M particles, 4.7 us of a 22 us iteration at
-// 30 k).  Three earlier fusions lost to the agent-scope RELEASE fence they needed (it writes back the XCD's whole L2).  This one has no fence:
-//   * the lane that stores a workgroup's partial stores it write-through (sc1: store_partial), waits for the store (s_waitcnt vmcnt(0)) and
-//     takes a ticket with an agent-scope atomic add that returns -- on one of kFinShards counters, each on a cache line of its own (thousands
-//     of workgroups on ONE word serialise at ~12 ns each); the workgroup whose add completes a shard adds to a second-level counter, and the
-//     one whose add completes THAT is the last workgroup of the launch: every partial was in memory before the add it follows;
-//   * the last workgroup reads all partials with sc1 loads (they bypass the non-coherent L2) in k_finalize_mean's own order -- its 256 threads
-//     play four "virtual threads" of the 1024-thread tree each -- and takes the decision; it zeroes the tickets for the next launch.
-// MEASURED (round 4, profiles/r04/null/fin_fuse_ab.txt): bit-identical in every lock-step case, and slower than the launch it replaces -- config 1
-// dfsph 44.9 -> 42.4 Mparticle-steps/s, dfsph_1m 330.9 -> 321.5: the chain store-ack, ticket, second-level ticket, sc1 loads is four dependent
-// trips to the memory side (~1.5-2 us each) where a kernel boundary costs ~4.3 us.  Off by default (SPH_FIN_FUSE=1 turns it on: tests, A/B).
-// No workgroup ever waits for another: nothing can hang.  Workgroups that skip their tile (change propagation) take a ticket all the same;
-// their partial of an earlier launch is in memory.  Valid hand-off form: MI355X_MICROARCH.md "Inter-workgroup visibility", first table row.
-constexpr int kFinShards = 64, kFinTicketStride = 32;          // (32 ints = 128 B per shard counter)
-constexpr int kFinTicketInts = (kFinShards + 1) * kFinTicketStride;
-struct FinFuse { int *ticket; int mode, group, nparts, nblocks; };      // ticket == nullptr: the separate k_finalize_mean launch follows
-__device__ __forceinline__ void fin_fused(const FinFuse &ff, const double *__restrict__ psum, const int *__restrict__ pcnt, DevScalars *__restrict__ ds)
+// ---- the loop decision riding in the NEXT sweep (one GPU) -----------------------------------------------------------------
+// Between a residual sweep and the correction sweep behind it sat a single-workgroup launch, k_finalize_mean: 31 per step at dfsph_1m, 4.4 us
+// each on the critical path (tools/fin_probe.py).  The correction sweep does not NEED that decision to start -- the slab path's overlapped
+// protocol already runs it ahead (step_dfsph_device_loops): in the density loop D7 of iteration d runs iff iteration d runs, which the decision
+// of evaluation d - 1 says (gate_hist); in the divergence loop D4 of iteration e runs ahead of decision e, keeps what it overwrites (SpecSave)
+// and is undone by the gated residual launch behind it if decision e closed the loop (SpecUndo).  So the decision can be taken INSIDE the
+// correction launch: one extra workgroup (workgroup 0, dispatched first) plays k_finalize_mean while the other ~3900 sweep their tiles.  It
+// reads the partials of the residual launch before (complete: a kernel boundary lies in between) and writes only words of DevScalars that no
+// tile of this launch reads (they read gate_hist[(e - 1) & 1], dt, dt2).  Same reduction tree as k_finalize_mean: its kBlock threads play four
+// of the kFinBlock "virtual threads" each, so the f64 sum has the same bits.
+struct FinRide { const double *psum; const int *pcnt; DevScalars *ds; int nblocks, mode, group, nparts, hist; };      // mode < 0: nobody rides
+constexpr FinRide kNoRide{nullptr, nullptr, nullptr, 0, -1, 1, 0, -1};
+__device__ __forceinline__ void fin_ride_block(const FinRide &fr)
 {
-    __shared__ int s_last;
-    __shared__ double s_fsum[kFinBlock / 64];
-    __shared__ long long s_fcnt[kFinBlock / 64];
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this lane's partial store (if any) has reached memory
-        int last = 0;
-        const int shard = (int)(blockIdx.x & (kFinShards - 1));
-        const int expect = ((int)gridDim.x + kFinShards - 1 - shard) / kFinShards;
-        const int old = __hip_atomic_fetch_add(&ff.ticket[shard * kFinTicketStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == expect - 1) {
-            const int nsh = (int)gridDim.x < kFinShards ? (int)gridDim.x : kFinShards;
-            const int old2 = __hip_atomic_fetch_add(&ff.ticket[kFinShards * kFinTicketStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = old2 == nsh - 1 ? 1 : 0;
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the last workgroup of the launch: k_finalize_mean's tree with kBlock threads
+    DevScalars *ds = fr.ds;
+    // (an iteration the loop does not run: what finalize_mean_block does for it)
+    if (fr.mode == FIN_DIV_LOOP && ds->div_active == 0) { if (threadIdx.x == 0) ds->gate_hist[fr.hist & 1] = 0; return; }
+    if (fr.mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0) { ds->dens_d7_active = 0; ds->gate_hist[fr.hist & 1] = 0; } return; }
+    __shared__ double s_rsum[kFinBlock / 64];
+    __shared__ long long s_rcnt[kFinBlock / 64];
 #pragma unroll
     for (int j = 0; j < kFinBlock / kBlock; ++j) {
         double t; int n;
-        fin_thread_sum<true>(psum, pcnt, (int)threadIdx.x + j * kBlock, ff.nblocks, ff.group, ff.nparts, t, n);
+        fin_thread_sum(fr.psum, fr.pcnt, (int)threadIdx.x + j * kBlock, fr.nblocks, fr.group, fr.nparts, t, n);
         const double ws = wave_sum(t);
         const int wn = wave_sum(n);
-        if ((threadIdx.x & 63) == 0) { s_fsum[(threadIdx.x >> 6) + j * (kBlock / 64)] = ws; s_fcnt[(threadIdx.x >> 6) + j * (kBlock / 64)] = wn; }
+        if ((threadIdx.x & 63) == 0) { s_rsum[(threadIdx.x >> 6) + j * (kBlock / 64)] = ws; s_rcnt[(threadIdx.x >> 6) + j * (kBlock / 64)] = wn; }
     }
-    if (threadIdx.x <= kFinShards) __hip_atomic_store(&ff.ticket[threadIdx.x * kFinTicketStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tt = 0.0; long long nn = 0;
-        for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_fsum[w]; nn += s_fcnt[w]; }
-        fin_decide(ds, ff.mode, tt, nn);
-    }
-}
-// a fused launch whose gate is closed: what k_finalize_mean does for an iteration the loop does not run
-__device__ __forceinline__ void fin_fused_closed(const FinFuse &ff, DevScalars *__restrict__ ds)
-{
-    if (ff.ticket && ff.mode == FIN_DENS && blockIdx.x == 0 && threadIdx.x == 0) ds->dens_d7_active = 0;
+    if (threadIdx.x != 0) return;
+    double tt = 0.0; long long nn = 0;
+    for (int w = 0; w < kFinBlock / 64; ++w) { tt += s_rsum[w]; nn += s_rcnt[w]; }
+    const int was = (fr.mode == FIN_DENS) ? ds->dens_active : ds->div_active;
+    fin_decide(ds, fr.mode, tt, nn);
+    const int now = (fr.mode == FIN_DENS) ? ds->dens_active : ds->div_active;
+    ds->gate_hist[fr.hist & 1] = now;
+    if (fr.mode != FIN_DENS && was != 0 && now == 0) ds->stop_at = fr.hist;
 }
 
 
@@ -2158,11 +2121,12 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
                                                     int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc,
-                                                    TilePhase tp, SpecSave sv = SpecSave{nullptr, nullptr})
+                                                    TilePhase tp, SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
+    if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // the loop decision of the residual sweep before (whatever the gate says)
     if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
@@ -2310,36 +2274,32 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                      const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
-                                                     const float4 *__restrict__ wall_gc, TilePhase tp, FinFuse ff, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
+                                                     const float4 *__restrict__ wall_gc, TilePhase tp, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }
+    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
     if (spread) {                                                    // change propagation, see stage_sources_flagged
         const int sw = stage_cnt[tile];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {           // rho*, k / rho and the block partial of the last iteration stand
-            if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
-            return;
-        }
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) return;     // rho*, k / rho and the block partial of the last iteration stand
     }
     SPH_SWEEP_PROLOGUE_B(QUAD, tile)
     // ... and a tile without an owned particle -- ghosts only -- computes no residual (the ghosts' values arrive with the halo): no staging, a zero partial
     if (c.ghost_walk && !__syncthreads_or(live && !ghost)) {
-        if (QUAD) block_partial_mean_quad(blk, 0.0, 0, owner, psum, pcnt, ff.ticket != nullptr);
-        else block_partial_mean(blk, 0.0, 0, psum, pcnt, ff.ticket != nullptr);
-        if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
+        if (QUAD) block_partial_mean_quad(blk, 0.0, 0, owner, psum, pcnt);
+        else block_partial_mean(blk, 0.0, 0, psum, pcnt);
         return;
     }
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
         const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) { if (ff.ticket) fin_fused(ff, psum, pcnt, ds); return; }
+        if (verdict == 2) return;
         staged = verdict == 1;
     } else {
         staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
@@ -2416,9 +2376,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             else Pout[i] = make_float4(pi.x, pi.y, pi.z, kr);
         }
     }
-    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt, ff.ticket != nullptr);
-    else block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);
-    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
+    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
+    else block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // ======================================================================================

@@ -135,10 +135,6 @@ struct SphHandle {
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
     int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press); iisph: "d_ij holds zeros" (k_ii_dij)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
-    // dfsph: tickets of the finalize fused into the residual sweeps (sph_kernels.h: fin_fused).  Bit-identical, and SLOWER than the separate
-    // single-workgroup launch at every size measured (round 4: 0.945x at 30 k particles, 0.97x at 1 M): off unless SPH_FIN_FUSE=1 (A/B, tests)
-    int *fin_ticket = nullptr;
-    bool opt_fin_fuse = false;
     // staged dfsph sweeps on one GPU: each XCD's eighth of the tiles heavy tiles first (sph_kernels.h: TilePhase phase 3, k_tile_perm).  Bit-identical and
     // WITHOUT effect on the sweeps at any weighting of the wall entries (round 4, profiles/r04/null/tile_lpt_ab.txt): off unless SPH_TILE_LPT=<wall weight>
     int *tile_cost = nullptr, *tile_perm = nullptr;
@@ -205,6 +201,7 @@ struct SphHandle {
     double *red_host = nullptr;   // pinned staging for host-side all-reduces
     double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
     bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
+    bool opt_fin_ride = true;     // SPH_FIN_RIDE=0: one GPU, the loop decisions in launches of their own again (A/B)
     bool own_red = false, slab_legacy = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -1051,8 +1048,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->wcell_start, (size_t)c.C + 1))) return rc;
     h->nblocks = (c.n + kBlock - 1) / kBlock;
     const size_t nblocks_cap = (n + 63) / 64;    // quad sweeps: one partial per 64 particles; others one per 256 (a few KB either way, and no second predicate to keep in step with sweep_mode)
-    if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_fin_fuse)
-        if ((rc = dalloc(h, &h->fin_ticket, kFinTicketInts))) return rc;
     if ((rc = dalloc(h, &h->psum, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pcnt, nblocks_cap))) return rc;
     if ((rc = dalloc(h, &h->pmax, nblocks_cap))) return rc;
@@ -1083,6 +1078,11 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         }
         if ((rc = dalloc(h, &h->col_hist, (size_t)c.gx))) return rc;
         HIP_TRY(h, hipHostMalloc((void **)&h->col_hist_host, sizeof(int) * (size_t)c.gx, hipHostMallocDefault));
+    }
+    // one GPU, dfsph: the divergence correction runs ahead of its loop decision, which rides in the same launch (fin_ride_block): what it overwrites
+    if (!h->slab && is_dfsph(h) && h->opt_fin_ride) {
+        if ((rc = dalloc(h, &h->spec_v, n))) return rc;
+        if ((rc = dalloc(h, &h->spec_w, n))) return rc;
     }
     if ((rc = dalloc(h, &h->ds, 1))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
@@ -2259,71 +2259,71 @@ inline int phase_n(const SphHandle *h, int phase)
     if (phase == 0 || !h->range_split) return h->c.n;
     return std::max(1, phase == 1 ? h->nblocks - h->split_lo : h->split_hi) * kBlock;
 }
-// fin_mode >= 0: the loop decision k_finalize_mean would take after this sweep is taken by the sweep's last workgroup (fin_fused)
-inline bool fin_fusable(const SphHandle *h) { return h->fin_ticket != nullptr; }
-inline FinFuse fin_fuse(const SphHandle *h, int fin_mode)
-{
-    return FinFuse{(fin_mode >= 0 && fin_fusable(h)) ? h->fin_ticket : nullptr, fin_mode, partial_group(h), partial_count(h), h->nblocks};
-}
-void launch_div_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
+void launch_div_residual(SphHandle *h, int gate, int phase = 0, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
     if (!st) st = h->stream;
     ProfScope ps(h, K_D_DIV_RESIDUAL, st);
     const bool split = rx_split(h);
     const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
-    const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<false>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->V[h->vcur],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, ff, un);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, un);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
-                  (const float4 *)wall_cache(h), tp, ff, un);
+                  (const float4 *)wall_cache(h), tp, un);
 }
 
+// ride_mode >= 0 (one GPU, fin_rides): workgroup 0 of the launch takes the loop decision of evaluation `ride_eval` -- the residual sweep enqueued
+// before this one -- and the grid is one workgroup larger (fin_ride_block in sph_kernels.h)
+inline bool fin_rides(const SphHandle *h) { return !h->slab && h->spec_v != nullptr && !rx_split(h); }
 template <int MODE>
-void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate, SpecSave sv = SpecSave{nullptr, nullptr})
+void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate, SpecSave sv = SpecSave{nullptr, nullptr}, int ride_mode = -1, int ride_eval = -1)
 {
     const Consts &c = h->c;
     ProfScope ps(h, kid);
     int *wdirty = (MODE == CORR_DENS && tile_skip(h) && !h->tune_all) ? h->wave_dirty : nullptr;      // change propagation in the density loop
     const bool split = rx_split(h);
+    const bool ride = ride_mode >= 0;
+    const FinRide fr = ride ? FinRide{h->psum, h->pcnt, h->ds, h->nblocks, ride_mode, partial_group(h), partial_count(h), ride_eval} : kNoRide;
+    TilePhase tp0 = tile_phase(h, 0);
+    tp0.shift = ride ? 1 : 0;
+    const int n_grid = c.n + (ride ? (sweep_mode(h) == SWEEP_QUAD ? 64 : kBlock) : 0);           // one more workgroup
     if (use_relaxed(h)) {
-        hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
+        hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(split ? c.n : n_grid), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
                            h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tile_phase(h, 0), sv);
+                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tp0, sv, split ? kNoRide : fr);
         if (!split) return;
     }
-    SPH_LAUNCH_RMX(k_correct, MODE, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4)), h->stream, c,
+    SPH_LAUNCH_RMX(k_correct, MODE, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), split ? c.n : n_grid, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, 0), sv);
+                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tp0, sv, split ? kNoRide : fr);
 }
 
-void launch_dens_residual(SphHandle *h, int gate, int phase = 0, int fin_mode = -1, hipStream_t st = nullptr)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
+void launch_dens_residual(SphHandle *h, int gate, int phase = 0, hipStream_t st = nullptr)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
 {
     const Consts &c = h->c;
     if (!st) st = h->stream;
     ProfScope ps(h, K_D_DENS_RESIDUAL, st);
     const bool split = rx_split(h);
     const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
-    const FinFuse ff = fin_fuse(h, split ? -1 : fin_mode);
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr, ff);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, ff);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp);
 }
 
 // The same in two halves, for the handles that hide the all-reduce (step_dfsph_device_loops): this slab's (sum, count) on the handle's stream ...
@@ -2512,26 +2512,21 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     auto residual_sweep = [&](bool dens, int gate, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, int reduce_mode = -1) -> int {
         int r = SPH_OK;
         if (ovl) {
-            if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1, -1, un);
+            if (dens) launch_dens_residual(h, gate, 1); else launch_div_residual(h, gate, 1, un);
             HIP_TRY(h, hipEventRecord(h->ev_edge, s));
-            if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2, -1, un);       // enqueued before the host turns to the transfer
+            if (dens) launch_dens_residual(h, gate, 2); else launch_div_residual(h, gate, 2, un);       // enqueued before the host turns to the transfer
             if (reduce_mode >= 0 && (r = launch_finalize_reduce(h, reduce_mode))) return r;
             if ((r = slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, true))) return r;
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_halo, 0));                                       // the next sweep reads the ghosts
             return SPH_OK;
         }
-        if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate, 0, -1, un);
+        if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate, 0, un);
         if (two) return slab_exchange_resid(h, dens, dens ? h->rho_adv : h->drho, false);
         return h->slab ? slab_exchange_field(h, 0, h->P[1 - h->pcur], nullptr, nullptr) : SPH_OK;
     };
-    // ... followed by the loop decision: taken by the sweep's own last workgroup on one GPU (fin_fused), by k_finalize_mean around the
-    // all-reduce on slabs
+    // ... followed by the loop decision in a launch of its own (k_finalize_mean; around the all-reduce on slabs)
     auto residual = [&](bool dens, int gate, int fin_mode) -> int {
         int r = SPH_OK;
-        if (!h->slab && fin_fusable(h)) {
-            if (dens) launch_dens_residual(h, gate, 0, fin_mode); else launch_div_residual(h, gate, 0, fin_mode);
-            return SPH_OK;
-        }
         if (two && !ovl && slab_async(h)) {          // in order: the small launches of the refresh and of the mean ride together
             if (dens) launch_dens_residual(h, gate); else launch_div_residual(h, gate);
             return slab_exchange_resid_and_finalize(h, dens, dens ? h->rho_adv : h->drho, fin_mode);
@@ -2555,7 +2550,22 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
         launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);   // :396-397
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
     }
-    if (spec) {
+    // One GPU: the same reordering without a second stream -- the decision of evaluation e is taken by workgroup 0 of the correction launch that
+    // runs ahead of it (launch_correct's ride_mode / fin_ride_block): no single-workgroup launch between two sweeps any more.
+    const bool ride = fin_rides(h);
+    if (ride) {
+        launch_div_residual(h, GATE_NONE);                                                                                   // :398, evaluation 1
+        for (int e = 1; e <= max_div; ++e) {
+            launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w},
+                                     e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e);                                              // :402-405 + decision e
+            launch_div_residual(h, GATE_DIV, 0, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e});     // :408, evaluation e + 1
+        }
+        {   // the decision of the last evaluation has no correction launch to ride in
+            ProfScope ps(h, K_FINALIZE);
+            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, s, h->psum, h->pcnt, h->nblocks, h->ds, max_div == 0 ? (int)FIN_DIV_FIRST : (int)FIN_DIV_LOOP, (int)FINP_ALL,
+                               (double *)nullptr, partial_group(h), partial_count(h), max_div + 1);
+        }
+    } else if (spec) {
         if ((rc = residual_sweep(false, GATE_NONE, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DIV_FIRST))) return rc;     // :398, evaluation 1
         for (int e = 1; e <= max_div; ++e) {
             // the correction of evaluation e first (the GPU works on it while the host may block in a synchronous all-reduce) ...
@@ -2583,6 +2593,14 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     int d = 0;                                                                       // evaluations of the density loop so far
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
+            if (ride) {
+                ++d;
+                launch_dens_residual(h, GATE_DENS);                                                                          // :227, evaluation d
+                // D7 of iteration d runs iff iteration d runs (the decision of evaluation d - 1; gate_hist starts open) and carries decision d
+                launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1), SpecSave{nullptr, nullptr}, FIN_DENS, d);   // :229
+                if (rigid_coupled(h)) launch_rigid_force(h, GATE_HIST0 + ((d - 1) & 1));
+                continue;
+            }
             if (spec) {
                 ++d;
                 if ((rc = residual_sweep(true, GATE_DENS, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DENS))) return rc;      // :227, evaluation d
@@ -3137,13 +3155,13 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_FIN_RIDE"); h->opt_fin_ride = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); if (e) h->slab_groups = std::min(std::max(atoi(e), 0), 2); }
     { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_FIN_FUSE"); h->opt_fin_fuse = e && atoi(e) == 1; }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_LPT"); h->opt_tile_lpt = e && atoi(e) > 0; if (h->opt_tile_lpt) h->tile_wall_weight = atoi(e); }
     { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }

@@ -128,20 +128,17 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         DevScalars *__restrict__ ds, float *__restrict__ out,
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
-                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp, FinFuse ff,
+                                                        const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp,
                                                         SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
 {
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }
+    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
         const int sw = stage_cnt[tile];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) {
-            if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
-            return;
-        }
+        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) return;
     }
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE_B(false, tile)
@@ -150,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     bool staged;
     if (spread) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
         const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) { if (ff.ticket) fin_fused(ff, psum, pcnt, ds); return; }
+        if (verdict == 2) return;
         staged = verdict == 1;
     } else {
         staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
@@ -198,8 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
             krho[i] = kr;
         }
     }
-    block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);
-    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);
+    block_partial_mean(blk, (double)val, flag, psum, pcnt);
 }
 
 // D2 / D4 / D7 (k_correct)                                       dfsph_solver.py:314-355, 302-312 + 357-391, 178-219
@@ -212,9 +208,10 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
                                                        const float4 *Vin, float4 *Vout, int gate,
                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
                                                        int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, TilePhase tp,
-                                                       SpecSave sv = SpecSave{nullptr, nullptr})
+                                                       SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide)
 {
     extern __shared__ float4 s_operand[];
+    if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // (see k_correct: the loop decision rides in this launch)
     if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
     const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
