@@ -40,14 +40,9 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 
 // Edge / interior split of a sweep (slab handles; the order comes from k_tile_order in sph_slab_kernels.h): phase 0 = every tile in one launch,
 // 1 = the edge tiles (tile_order[0 .. n_edge)), 2 = the interior ones; both split launches have the full grid, surplus workgroups leave at once.
-// phase 3 (one GPU): every tile in one launch, each XCD's contiguous eighth taken heavy tiles first (k_tile_perm): order[] is a permutation
-// WITHIN the eighths, so every XCD keeps its brick of the domain and its L2 working set, and the tiles that live longest -- floor and wall tiles:
-// 19.5 us against a mean of 12.1 at 1 M particles -- start first instead of wherever their index falls, so that the tail of a launch is made
-// of ordinary tiles (profiles/r03/wg_timeline_div_residual.json: a sixth of every sweep was its drain).  MEASURED (round 4): no effect -- the drain
-// of a launch is one workgroup lifetime whatever tiles come last; off by default (SPH_TILE_LPT=<wall weight>), see profiles/r04/null/tile_lpt_ab.txt.
 struct TilePhase { const int *order; int ntiles, phase; int shift = 0; };
 // shift = 1: workgroup 0 of the launch is not a tile's -- it takes the loop decision of the sweep BEFORE this one (fin_ride_block) -- and workgroup
-// b serves the tile that workgroup b - 1 of a grid one smaller would (phases 0 and 3, one GPU)
+// b serves the tile that workgroup b - 1 of a grid one smaller would (phase 0, one GPU)
 // Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_mi355x.hip: step_dfsph_device_loops): the correction of
 // evaluation e runs before decision e is known and leaves the velocities and warm_start_k it overwrote in SpecSave; if decision e closed the loop
 // (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
@@ -57,29 +52,17 @@ __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread);
 __device__ __forceinline__ void spec_undo(const Consts &c, const SpecUndo &un, const DevScalars *__restrict__ ds, const TilePhase &tp)
 {
     if (!un.v_dst || tp.phase == 2 || ds->stop_at != un.eval) return;          // (a split sweep over a tile order: its first launch, a full grid, undoes)
-    int i = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (tp.phase >= 5) {                                                        // a split sweep over tile RANGES: each launch undoes its own tiles
-        const int tile = sweep_tile(tp, false);
-        if (tile < 0) return;
-        i = tile * kBlock + (int)threadIdx.x;
-    }
+    const int i = (int)(blockIdx.x * kBlock + threadIdx.x);
     if (i < c.n) { un.v_dst[i] = un.v_src[i]; un.w_dst[i] = un.w_src[i]; }
 }
-// phases 5 / 6 (slab handles on the curve, whose storage order keeps the interior columns in front: slab_cell_order): order[0] = the number of
-// tiles that hold interior particles only (k_tile_split).  5 = the tiles from there on (edge columns, ghosts, particles outside the grid),
-// 6 = the interior tiles; the grids are sized by the host's bounds on that number, surplus workgroups leave at once.
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
 {
     if (tp.shift) {
         const int b = (int)blockIdx.x - 1, g = (int)gridDim.x - 1;
         if (b < 0) return -1;
-        if (tp.phase == 3) return spread ? b : tp.order[xcd_sweep_block(b, g)];
         return spread ? b : xcd_sweep_block(b, g);
     }
     if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
-    if (tp.phase == 5) { const int s0 = tp.order[0], ne = tp.ntiles - s0; return (int)blockIdx.x < ne ? s0 + (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ne)) : -1; }
-    if (tp.phase == 6) { const int ni = tp.order[0]; return (int)blockIdx.x < ni ? (spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, ni)) : -1; }
-    if (tp.phase == 3) return spread ? (int)blockIdx.x : tp.order[xcd_sweep_block(blockIdx.x, gridDim.x)];
     const int ne = tp.order[tp.ntiles];
     if (tp.phase == 1) return (int)blockIdx.x < ne ? tp.order[blockIdx.x] : -1;
     const int ni = tp.ntiles - ne;
@@ -137,15 +120,9 @@ __device__ __forceinline__ int slot_of_parts(const Consts &c, SlotPart x, SlotPa
 {
     return (c.tile_rank[x.tile + y.tile + z.tile] << (3 * c.tbits)) | (x.code | y.code | z.code);
 }
-// Slab handles on the curve store their cell columns in GROUPS (Consts.xmap, slab_cell_order() in sph_mi355x.hip): the interior columns along
-// the curve first, then the two columns next to each cut, then the ghost columns, each group in cell tiles of its own -- so that a 256-particle
-// tile never mixes ghosts with owned particles (a ghost's lane does no work in most sweeps: mixed tiles made a sweep cost what the RESIDENT
-// particles cost, a third more than the owned ones on config 4 at 8 slabs) and the tiles that wait for no halo are exactly the interior ones.
-// Returns -1 for a column that is not resident on this slab: callers treat the cell as empty.
 __device__ __forceinline__ int cell_slot_xyz(const Consts &c, int x, int y, int z, int id)
 {
     if (c.order != CELL_ORDER_TILED) return id;
-    if (c.xmap) { x = c.xmap[x]; if (x < 0) return -1; }
     return slot_of_parts(c, slot_part(c, x, 0, 1), slot_part(c, y, 1, c.tnxz), slot_part(c, z, 2, c.tnx));
 }
 
@@ -1073,55 +1050,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_flags_exact(const int *__restri
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t < ntiles) flag[t] = stage_lists16(stage_cnt, t) ? 0 : 1;
-}
-
-// ---- heavy tiles first (TilePhase phase 3) -------------------------------------------------------------------------------------
-// cost of a tile = the list entries its 256 particles walk (fluid + wall), known once k_build_nl has run
-__global__ __launch_bounds__(kBlock) void k_tile_cost(Consts c, const int *__restrict__ cnt, int *__restrict__ cost, int wall_weight)
-{
-    __shared__ int s_w[kBlock / 64];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    int v = 0;
-    if (i < c.n) { const int cw = cnt[i]; v = cw < 0 ? 0 : (cw & 0xffff) + wall_weight * ((cw >> 16) & 0x7fff); }
-    const int ws = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = ws;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < kBlock / 64; ++k) t += s_w[k]; cost[blockIdx.x] = t; }
-}
-// one workgroup per XCD eighth [start, start + len) of the tiles (the partition xcd_block makes): a stable partition, the tiles whose cost exceeds
-// 1.2 x the eighth's mean first, the others behind them, both in their original (spatial) order
-__global__ __launch_bounds__(kBlock) void k_tile_perm(const int *__restrict__ cost, int ntiles, int *__restrict__ perm)
-{
-    __shared__ int wsum[kBlock / 64];
-    __shared__ long long s_tot;
-    __shared__ int carry_s, heavy_s;
-    const int q = ntiles >> 3, r = ntiles & 7, x = (int)blockIdx.x;
-    const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, len = q + (x < r ? 1 : 0);
-    if (threadIdx.x == 0) { s_tot = 0; carry_s = 0; }
-    __syncthreads();
-    long long mine = 0;
-    for (int k = threadIdx.x; k < len; k += kBlock) mine += cost[start + k];
-    atomicAdd((unsigned long long *)&s_tot, (unsigned long long)mine);
-    __syncthreads();
-    const long long tot = s_tot;
-    for (int pass = 0; pass < 2; ++pass) {          // pass 0 counts the heavy tiles, pass 1 places both kinds
-        if (pass == 1) { if (threadIdx.x == 0) { heavy_s = carry_s; carry_s = 0; } __syncthreads(); }
-        for (int base = 0; base < len; base += kBlock) {
-            const int k = base + (int)threadIdx.x;
-            const int hv = (k < len && (long long)cost[start + k] * 5 * len > tot * 6) ? 1 : 0;
-            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-            const int inc = wave_inclusive_scan(hv);
-            if (lane == 63) wsum[w] = inc;
-            __syncthreads();
-            int woff = 0;
-            for (int u = 0; u < w; ++u) woff += wsum[u];
-            const int before = carry_s + woff + inc - hv;
-            if (pass == 1 && k < len) perm[start + (hv ? before : heavy_s + (k - before))] = start + k;
-            __syncthreads();
-            if (threadIdx.x == kBlock - 1) carry_s = before + hv;
-            __syncthreads();
-        }
-    }
 }
 
 // ======================================================================================

@@ -104,7 +104,7 @@ struct SphHandle {
     float *rho = nullptr, *aux = nullptr /* pressure | alpha | a_ii */, *drho = nullptr, *rho_adv = nullptr, *krho = nullptr /* k / rho (kr_split) */;
     float4 *X[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pcisph: EF, PF, PP, PB0, PB1; iisph: DII, DIJ, f_press, PB0, PB1
     int pb_final = 0;            // which PB holds press_iter / p_iter after the last step
-    unsigned sweep_lds = 0;      // experiment knob SPH_SWEEP_LDS: dynamic LDS bytes per block on the DFSPH sweeps (caps the waves per CU)
+    unsigned sweep_lds = 0;      // sph_tune_time: dynamic LDS bytes per block on the unstaged DFSPH sweeps (caps the waves per CU)
     int last_iters = 2;          // iteration count of the last step's density / pressure loop: size of the next step's first chunk
     float pci_delta = 0.f, pci_beta = 0.f;   // pcisph_solver.py:23-24, :47
     int pci_max_index = -1, pci_max_count = -1;
@@ -119,9 +119,8 @@ struct SphHandle {
     std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
-    int *xmap = nullptr;                 // Consts.xmap (slab handles on the curve)
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
-    int quad_below = 65536;              // = kQuadBelow (SPH_QUAD_BELOW: experiments)
+    int quad_below = 65536;              // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
     int opt_bnl_split = -1;              // SPH_BNL_SPLIT=0 | 3 | 9 at sph_create: never / always k_build_nl_split with that many waves (A/B, tests); -1: by size
     bool opt_nl16 = true, opt_kr_split = true;   // SPH_NL16=0 / SPH_KR_SPLIT=0 at sph_create (A/B, tests)
@@ -135,11 +134,6 @@ struct SphHandle {
     unsigned char *changed8 = nullptr;           // ... and per particle (the second, exact level of the residual sweep's check)
     int *pci_zero_press = nullptr;               // pcisph: per tile, "press_force / pos_predict hold the zero-pressure values" (k_pci_press); iisph: "d_ij holds zeros" (k_ii_dij)
     bool opt_tile_skip = true, dens_first = true, tune_all = false;
-    // staged dfsph sweeps on one GPU: each XCD's eighth of the tiles heavy tiles first (sph_kernels.h: TilePhase phase 3, k_tile_perm).  Bit-identical and
-    // WITHOUT effect on the sweeps at any weighting of the wall entries (round 4, profiles/r04/null/tile_lpt_ab.txt): off unless SPH_TILE_LPT=<wall weight>
-    int *tile_cost = nullptr, *tile_perm = nullptr;
-    bool opt_tile_lpt = false;
-    int tile_wall_weight = 1;
     bool verlet = false;                         // wcsph under the relaxed arithmetic: lists with a skin, rebuilt on demand (sph_relaxed_kernels.h)
     float4 *x0 = nullptr;                        //   ... positions at the last list build
     // slab handles: what the transport was asked to do since the last sph_comm_stats(reset): [0] point-to-point groups (a send / recv
@@ -181,16 +175,7 @@ struct SphHandle {
     hipEvent_t ev_red = nullptr, ev_dec = nullptr;
     float4 *spec_v = nullptr; float *spec_w = nullptr;      // what a divergence correction that ran ahead of its loop decision overwrote (SpecSave / SpecUndo)
     int *tile_flag = nullptr, *tile_order = nullptr;
-    // handles on the curve: the split is two RANGES of tiles (slab_cell_order keeps the interior columns in front): tile_split[0] = interior tiles
-    // (k_tile_split); the host sizes the two launches by its bounds on that number
-    bool range_split = false;
     bool overlap_on = true;       // sph_slab_set_overlap: the split + the hidden all-reduce may be switched off between steps (same bits either way)
-    // storage order of a slab handle's columns on the curve.  0 (default): the global curve as it falls.  Development switches (SPH_SLAB_GROUPS,
-    // slab_cell_order), both measured and no faster: 1 = groups of columns in cell tiles of their own, the split by tile ranges (flat tiles overflow
-    // the staging capacity); 2 = the curve shifted so that a cell tile starts at the slab's outer ghost column (fewer edge tiles, longer interior
-    // launch: the halo's chain hides, the step stays as long -- the joins between the streams cost what the hiding saves)
-    int slab_groups = 0;
-    int *tile_split = nullptr, first_edge_slot = 0, split_lo = 0, split_hi = 0;
     std::vector<int> cuts;        // all slabs' cell-column cuts (identical on every rank)
     double *red_dev = nullptr;    // (sum, count) / max of this slab on its way through allreduce_stream
     // native transport (sph_rccl_attach): the library drives RCCL itself on its stream
@@ -201,8 +186,7 @@ struct SphHandle {
     double *red_host = nullptr;   // pinned staging for host-side all-reduces
     double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
     bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
-    bool opt_fin_ride = true;     // SPH_FIN_RIDE=0: one GPU, the loop decisions in launches of their own again (A/B)
-    bool own_red = false, slab_legacy = false;
+    bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
     int *counters = nullptr, *counters_host = nullptr;
@@ -236,7 +220,6 @@ struct SphHandle {
     // hipGraph replay of WCSPH step pairs (launch-bound at small N): one executable graph per buffer parity
     hipGraphExec_t wcsph_graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool graphs_enabled = true;
-    bool host_loops = false;        // SPH_HOST_LOOPS=1: run the DFSPH loops on the host even on a single GPU (A/B, debugging)
     long long graph_launches = 0;
 
     // profiling
@@ -378,9 +361,17 @@ void balanced_cuts(const std::vector<long long> &hist, int gx, int nslab, int la
             }
             best[(size_t)k][(size_t)x] = b;
         }
-    cut.assign((size_t)nslab + 1, 0);
-    cut[(size_t)nslab] = gx;
-    for (int k = nslab; k >= 1; --k) cut[(size_t)k - 1] = best[(size_t)k][(size_t)cut[(size_t)k]].from;
+    // no assignment within the bounds (the callers' bounds always admit one: every slab >= kMinSlabColumns wide is checked where the cuts are
+    // first planned): keep what the caller had rather than walk back through an empty table
+    if (best[(size_t)nslab][(size_t)gx].mx < 0) return;
+    std::vector<int> found((size_t)nslab + 1, 0);
+    found[(size_t)nslab] = gx;
+    for (int k = nslab; k >= 1; --k) {
+        const int from = best[(size_t)k][(size_t)found[(size_t)k]].from;
+        if (from < 0) return;
+        found[(size_t)k - 1] = from;
+    }
+    cut = found;
 }
 
 // Re-balancing ("re-chosen every M steps because a dam break migrates mass along x"):
@@ -398,6 +389,7 @@ void replan_slab_cuts(const std::vector<long long> &hist, int gx, int nslab, con
             lo[(size_t)k] = std::max(old_cut[(size_t)k - 1] + 1, kMinSlabColumns * k);
             hi[(size_t)k] = std::min(old_cut[(size_t)k + 1] - 1, gx - kMinSlabColumns * (nslab - k));
         }
+        cut = old_cut;                  // (kept if no assignment fits the bounds)
         balanced_cuts(hist, gx, nslab, layers, lo, hi, cut);
         return;
     }
@@ -435,7 +427,9 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
         std::vector<int> lo((size_t)nslab + 1, 0), hi((size_t)nslab + 1, gx);
         lo[(size_t)nslab] = gx; hi[0] = 0;
         for (int k = 1; k < nslab; ++k) { lo[(size_t)k] = kMinSlabColumns * k; hi[(size_t)k] = gx - kMinSlabColumns * (nslab - k); }
+        cut.clear();
         balanced_cuts(hist, gx, nslab, layers, lo, hi, cut);
+        if ((int)cut.size() != nslab + 1) { why = "no slab cuts of at least three columns each fit this grid"; return false; }
         return true;
     }
     cuts_from_histogram(hist, N, gx, nslab, cut);
@@ -445,7 +439,6 @@ bool plan_slab_cuts(const std::vector<float> &pos, int N, float hcell, int gx, i
 }
 
 // this rank's columns, its neighbours' far cuts and the ghost columns whose particles own lists, from h->cuts
-constexpr int kSlabGroupTiles = 6;      // x-tiles in front of a slab handle's interior columns (slab_cell_order)
 void set_slab_geometry(SphHandle *h)
 {
     const std::vector<int> &cut = h->cuts;
@@ -578,7 +571,6 @@ int build_scene(SphHandle *h, HostScene &sc)
         c.tbits = edge >= 16 ? 4 : edge >= 8 ? 3 : 2;
         const int te = 1 << c.tbits;
         c.tnx = (c.gx + te - 1) / te;
-        if (cf.slab_count > 1) c.tnx += kSlabGroupTiles;      // slab handles store their columns in groups (slab_cell_order): six tiles of x in front
         c.tnxz = c.tnx * ((c.gz + te - 1) / te);
         const long long slots = c.order == CELL_ORDER_TILED ? ((long long)c.tnxz * ((c.gy + te - 1) / te)) << (3 * c.tbits) : C;
         if (slots + 2 > 0x7fffffffLL) return fail(h, SPH_E_INVALID, "grid of %lld cell slots is too large", slots);
@@ -601,8 +593,7 @@ int build_scene(SphHandle *h, HostScene &sc)
         // hash then sees a fraction of its inputs and the read latency of a sweep depends on where the allocator put the list
         // (measured: 833 vs 1090 cycles per request, sweeps 110 vs 145 us for identical handles).  An odd number of row groups
         // per tile walks the rows of consecutive tiles through all residues.
-        const char *e = dev_env(&h->overrides, "SPH_NL_PITCH_PAD");
-        const int pad = e ? atoi(e) & ~3 : 4;
+        const int pad = 4;
         // (every tile also keeps at least one spare group beyond kmax entries: the walks read one group ahead, NlWriter::flush)
         c.kpitch = c.kmax + (((c.kmax >> 2) & 1) ? 2 * pad : pad);
         c.kbpitch = c.kbmax + (((c.kbmax >> 2) & 1) ? 2 * pad : pad);
@@ -658,12 +649,6 @@ int build_scene(SphHandle *h, HostScene &sc)
         std::vector<int> col, cut;
         std::string why;
         if (!plan_slab_cuts(sc.fluid_pos, N, c.h, c.gx, h->nslab, col, cut, why, slab_layers_of(cf))) return fail(h, SPH_E_INVALID, "%s", why.c_str());
-        if (const char *e = dev_env(&h->overrides, "SPH_SLAB_CUTS")) {       // debugging aid: comma-separated interior cuts, e.g. "9,18" for three slabs
-            std::vector<int> forced{0};
-            for (const char *q = e; *q;) { forced.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-            forced.push_back(c.gx);
-            if ((int)forced.size() == h->nslab + 1) cut = forced;
-        }
         h->cuts = cut;
         h->rebalance_every = cf.slab_rebalance_every > 0 ? cf.slab_rebalance_every : 0;
         h->geom.has_left = h->slab_rank > 0; h->geom.has_right = h->slab_rank < h->nslab - 1;
@@ -816,7 +801,6 @@ int build_scene(SphHandle *h, HostScene &sc)
         else if ((rx) && !(rg) && (mode) == SWEEP_PLAIN) hipLaunchKernelGGL((K<false, SWEEP_PLAIN, true>), grid_for(n), dim3(kBlock), lds, s, __VA_ARGS__); \
         else SPH_LAUNCH_RM0(K, rg, mode, n, lds, s, __VA_ARGS__);                                                                         \
     } while (0)
-constexpr int kQuadBelow = 65536;          // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
 constexpr int kBnlSplit9Below = 65536, kBnlSplitBelow = 100000;   // k_build_nl_split with nine / three waves per 64 particles up to these sizes (unstaged handles)
 // dynamic LDS of a staged sweep: bytes per staged particle x capacity (else the occupancy-experiment knob)
 inline int sweep_mode(const SphHandle *h)
@@ -864,7 +848,6 @@ int dcommit(SphHandle *h)
     h->arenas.push_back(base);
     for (size_t k = 0; k < h->plan.size(); ++k) *h->plan[k].first = base + off[k];
     HIP_TRY(h, hipMemsetAsync(base, 0, cur, h->stream));
-    if (dev_env(&h->overrides, "SPH_ALLOC_DEBUG")) fprintf(stderr, "[alloc] handle %p: arena of %zu MiB at %p, %zu arrays\n", (void *)h, cur >> 20, (void *)base, h->plan.size());
     h->plan.clear();
     return SPH_OK;
 }
@@ -878,78 +861,6 @@ inline uint64_t morton_spread(uint64_t v)          // 21 bits -> every third bit
     v = (v | v << 4) & 0x10c30c30c30c30c3ull;
     v = (v | v << 2) & 0x1249249249249249ull;
     return v;
-}
-
-// Storage order of a slab handle on the curve (cell_slot_xyz in sph_kernels.h).  The columns of the slab are stored in GROUPS, every group in
-// x-tiles of its own:
-//   x-tile 0 / 1   the `layers` ghost columns on the left / right
-//   x-tile 4 / 5   the `layers` owned columns next to the left / right cut          what the neighbours' halos carry: the EDGE tiles
-//   x-tile 6 ...   the interior columns, left to right                               (x-tiles 2 and 3 stay empty)
-// and the tiles are ranked interior first (Morton curve of (tx - 6, ty, tz)), then tile 4, 5, 0, 1, each along the curve of (ty, tz).
-// A 256-particle tile therefore holds ghosts or owned particles, edge columns or interior ones, never a mix (but for the one tile at each group
-// boundary); the residual sweeps find no work in a ghost tile, and the tiles that can run under the halo transfer are all of the interior.
-// (Groups of ONE column -- the two ghost columns apart, so that the outer one's tiles never work at all -- make flat tiles whose neighbourhoods
-// overflow the LDS staging capacity: 10 % of the workgroups unstaged on config 4 at 8 slabs, and the correction sweeps 30 % slower.  Measured, dropped.)  Any bijection is a valid storage order (every sum runs in the reference's
-// cell walk with ascending id inside a cell); columns this slab does not hold map to -1 = no cell.  Recomputed when the cuts move.
-std::vector<int> morton_tile_ranks(const Consts &c);
-void slab_cell_order(const SphHandle *h, std::vector<int> &xmap, std::vector<int> &rank)
-{
-    const Consts &c = h->c;
-    const SlabGeom &g = h->geom;
-    const int te = 1 << c.tbits, L = g.layers;
-    xmap.assign((size_t)c.gx, -1);
-    if (h->slab_groups == 2) {
-        // ALIGNED: the plain curve, shifted so that a cell tile starts `layers` columns left of the slab.  With tiles of four columns and two ghost
-        // columns the tile at the left cut holds exactly the ghost columns and the two owned columns the left neighbour's halo carries; the right cut
-        // falls where the slab's width puts it.  The tiles that must run before the halo leaves are then half of a rank's tiles instead of three
-        // quarters (config 4 at 8 slabs: edge launch 83 -> 56 us, interior launch 24 -> 53 us, the halo's chain ends under the interior tiles).
-        // MEASURED: the step is as long as before (6.31 against 6.05-6.20 ms on rank 4) -- what follows the sweep waits for two event packets, not
-        // for the halo.  Off by default.
-        for (int x = std::max(g.x_lo - L, 0); x < std::min(g.x_hi + L, c.gx); ++x) xmap[(size_t)x] = x - (g.x_lo - L) + te;          // x_lo - L lands on a multiple of the tile edge
-        // (where in a tile the ghost columns land makes no difference to the in-order protocol either: 5.43-5.54 ms on rank 2 of 8 for all four offsets)
-        rank = morton_tile_ranks(c);
-        return;
-    }
-    auto put = [&](int x, int tile, int code) { if (x >= 0 && x < c.gx) xmap[(size_t)x] = tile * te + code; };
-    if (g.has_left) for (int l = 0; l < L; ++l) put(g.x_lo - L + l, 0, l);
-    if (g.has_right) for (int l = 0; l < L; ++l) put(g.x_hi + l, 1, l);
-    int lo = g.x_lo, hi = g.x_hi;
-    if (g.has_left) for (int l = 0; l < L && lo < hi; ++l, ++lo) put(lo, 4, l);
-    if (g.has_right) { const int nr = std::min(L, hi - lo); for (int l = 0; l < nr; ++l) put(hi - nr + l, 5, l); hi -= nr; }
-    for (int x = lo; x < hi; ++x) put(x, kSlabGroupTiles + (x - lo) / te, (x - lo) % te);
-    // (a third order -- the ghost columns apart, ALL owned columns together in x-tiles of equal width, so that the residual sweeps meet no ghost
-    // lane -- was measured too: in order 5.55 against 5.40 ms on rank 2 of 8, overlapped 6.25 against 6.40: the flat ghost tiles cost the
-    // correction sweeps what the residual sweeps gain.  Not kept.)
-    const int tnx = c.tnx, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
-    static const int group_of[kSlabGroupTiles] = {3, 4, 5, 6, 1, 2};          // rank of the group of x-tile 0..5 (the interior is group 0)
-    std::vector<std::pair<std::pair<int, uint64_t>, int>> key;
-    key.reserve((size_t)tnx * tnz * tny);
-    for (int ty = 0; ty < tny; ++ty)
-        for (int tz = 0; tz < tnz; ++tz)
-            for (int tx = 0; tx < tnx; ++tx) {
-                const int grp = tx < kSlabGroupTiles ? group_of[tx] : 0;
-                const uint64_t m = morton_spread((uint64_t)(grp ? 0 : tx - kSlabGroupTiles)) | morton_spread((uint64_t)ty) << 1 | morton_spread((uint64_t)tz) << 2;
-                key.push_back({{grp, m}, tx + tz * c.tnx + ty * c.tnxz});
-            }
-    std::sort(key.begin(), key.end());
-    rank.assign(key.size(), 0);
-    for (size_t r = 0; r < key.size(); ++r) rank[(size_t)key[r].second] = (int)r;
-}
-int upload_slab_cell_order(SphHandle *h)
-{
-    std::vector<int> xmap, rank;
-    slab_cell_order(h, xmap, rank);
-    {   // slots in front of the first edge tile = the interior's (k_tile_split)
-        const Consts &c = h->c;
-        const int te = 1 << c.tbits, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
-        h->first_edge_slot = (int)(((long long)(c.tnx - kSlabGroupTiles) * tnz * tny) << (3 * c.tbits));
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->xmap, xmap.data(), sizeof(int) * xmap.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->tile_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));       // (the vectors go out of scope)
-    h->c.tile_rank = h->tile_rank;
-    h->c.xmap = h->xmap;
-    return SPH_OK;
 }
 
 // Consts.tile_rank: position of every tile (index tx + tz*tnx + ty*tnxz) along the Morton curve of (tx, ty, tz)
@@ -978,7 +889,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if (c.order == CELL_ORDER_TILED) {
         tile_rank = morton_tile_ranks(c);
         if ((rc = dalloc(h, &h->tile_rank, tile_rank.size()))) return rc;
-        if (h->slab && (rc = dalloc(h, &h->xmap, (size_t)c.gx))) return rc;
     }
     for (int k = 0; k < 2; ++k) {
         if ((rc = dalloc(h, &h->P[k], n + 64))) return rc;      // k_build_nl reads whole groups of four candidates
@@ -1011,10 +921,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
-            if (h->cfg.solver == SPH_SOLVER_DFSPH && !h->slab && h->opt_tile_lpt) {
-                if ((rc = dalloc(h, &h->tile_cost, (n + kBlock - 1) / kBlock + 8))) return rc;
-                if ((rc = dalloc(h, &h->tile_perm, (n + kBlock - 1) / kBlock + 8))) return rc;
-            }
             if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
@@ -1062,8 +968,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipHostMalloc((void **)&h->counters_host, sizeof(int) * kSlabCounters, hipHostMallocDefault));
         // edge / interior split of the residual sweeps (dfsph, two ghost columns): tile flags and the edge-first tile order
         h->overlap = h->geom.layers == 2 && h->cfg.slab_overlap != 1;
-        h->range_split = h->overlap && c.order == CELL_ORDER_TILED && h->slab_groups == 1;
-        if (h->range_split && (rc = dalloc(h, &h->tile_split, 4))) return rc;
         if (h->overlap) {
             if ((rc = dalloc(h, &h->tile_flag, (n + kBlock - 1) / kBlock + 1))) return rc;
             if ((rc = dalloc(h, &h->tile_order, (n + kBlock - 1) / kBlock + 2))) return rc;
@@ -1080,7 +984,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipHostMalloc((void **)&h->col_hist_host, sizeof(int) * (size_t)c.gx, hipHostMallocDefault));
     }
     // one GPU, dfsph: the divergence correction runs ahead of its loop decision, which rides in the same launch (fin_ride_block): what it overwrites
-    if (!h->slab && is_dfsph(h) && h->opt_fin_ride) {
+    if (!h->slab && is_dfsph(h)) {
         if ((rc = dalloc(h, &h->spec_v, n))) return rc;
         if ((rc = dalloc(h, &h->spec_w, n))) return rc;
     }
@@ -1094,7 +998,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
-        if (h->slab && h->slab_groups && (rc = upload_slab_cell_order(h))) return rc;
     }
 
     // upload the scene
@@ -1138,7 +1041,7 @@ int read_scalars(SphHandle *h)
 int comm_fail(SphHandle *h, const char *what, int rc) { return fail(h, SPH_E_STATE, "comm callback %s failed (%d)", what, rc); }
 inline bool slab_stream_ordered(const SphHandle *h) { return h->slab && (h->native || (!h->comm.on_host && h->comm.stream_ordered)); }
 // sharded DFSPH with the device-side loop control of the single-GPU path (needs the transport's in-place all-reduce of reduce_buf)
-inline bool slab_async(const SphHandle *h) { return h->slab && (h->native || h->comm.allreduce_stream) && h->red_dev && !h->slab_legacy; }
+inline bool slab_async(const SphHandle *h) { return h->slab && (h->native || h->comm.allreduce_stream) && h->red_dev; }
 
 int native_allreduce_stream(SphHandle *h, int n, int op, hipStream_t stream = nullptr);
 
@@ -1408,7 +1311,6 @@ int slab_rebalance(SphHandle *h)
     if (h->cuts_moved) {
         h->cuts = cut;
         set_slab_geometry(h);
-        if (h->c.order == CELL_ORDER_TILED && h->slab_groups && (rc = upload_slab_cell_order(h))) return rc;      // the groups of columns follow the cuts
         ++h->n_recuts;
     }
     return SPH_OK;
@@ -2010,16 +1912,7 @@ int stage_sort_and_lists(SphHandle *h)
                         return fail(h, SPH_E_STATE, "slab %d step %d: edge list %d column %d holds %d particles, the exchange counted %d", h->slab_rank, h->simulate_cnt, k, l, tot, h->edge_n[k][l]);
                 }
         }
-        if (h->range_split) {
-            // the interior particles are the first of the sorted arrays; how many: everything resident but the eight edge / ghost columns and
-            // whoever sits outside the grid.  The last is known on the device only: the host bounds it (what the last read-back said + 8192)
-            int edge = 0;
-            for (int k = 0; k < 4; ++k) edge += h->edge_n[k][0] + h->edge_n[k][1];
-            const int hi = std::max(0, c.n - edge), lo = std::max(0, hi - (h->ds_host->lost + 8192));
-            h->split_hi = (hi + kBlock - 1) / kBlock;
-            h->split_lo = lo / kBlock;
-            hipLaunchKernelGGL(k_tile_split, dim3(1), dim3(1), 0, s, h->cell_start, h->first_edge_slot, h->split_lo, h->tile_split, h->ds);
-        } else if (h->overlap && h->overlap_on) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
+        if (h->overlap && h->overlap_on) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
             hipLaunchKernelGGL(k_tile_flags, g, b, 0, s, c, h->geom, h->P[h->pcur], h->tile_flag);
             hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
@@ -2057,11 +1950,6 @@ int stage_sort_and_lists(SphHandle *h)
         hipLaunchKernelGGL(k_tile_flags_exact, grid_for(h->nblocks), b, 0, s, h->stage_cnt, h->nblocks, h->tile_flag);
         hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
     }
-    if (h->tile_perm && h->nblocks >= 64) {      // heavy tiles first within each XCD's eighth, for the sweeps of this step (TilePhase phase 3)
-        ProfScope ps(h, K_BUILD_NL);
-        hipLaunchKernelGGL(k_tile_cost, dim3(h->nblocks), b, 0, s, c, h->cnt, h->tile_cost, h->tile_wall_weight);
-        hipLaunchKernelGGL(k_tile_perm, dim3(8), b, 0, s, h->tile_cost, h->nblocks, h->tile_perm);
-    }
     if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
         ProfScope ps(h, K_RIGID);
         hipLaunchKernelGGL(k_build_rnl, grid_for(h->Nr), b, 0, s, c, h->Nr, h->RPs, h->P[h->pcur], h->cell_start, h->rnl, h->rcnt, h->ds);
@@ -2071,14 +1959,6 @@ int stage_sort_and_lists(SphHandle *h)
         hipLaunchKernelGGL(k_rx_wall_grad, g, b, 0, s, c, h->P[h->pcur], h->WP, h->nlb, h->cnt, h->wall_grad, h->wall_gsq);
     }
     HIP_TRY(h, hipGetLastError());
-    if (h->staged && dev_env(&h->overrides, "SPH_STAGE_DEBUG")) {
-        std::vector<int> sc((size_t)h->nblocks);
-        HIP_TRY(h, hipMemcpyAsync(sc.data(), h->stage_cnt, sizeof(int) * sc.size(), hipMemcpyDeviceToHost, s));
-        HIP_TRY(h, hipStreamSynchronize(s));
-        long long tot = 0; int bad = 0, mx = 0;
-        for (int v : sc) { if (v < 0) ++bad; else { tot += v & 0xffff; mx = std::max(mx, v & 0xffff); } }
-        fprintf(stderr, "[stage] %d workgroups, %d unstaged, mean %.0f max %d staged particles\n", h->nblocks, bad, sc.size() > (size_t)bad ? (double)tot / (sc.size() - bad) : 0.0, mx);
-    }
     h->nl_valid = true;
     h->density_valid = false;
     return SPH_OK;
@@ -2091,8 +1971,6 @@ int check_overflow(SphHandle *h)
         (void)hipMemsetAsync(&h->ds->overflow, 0, sizeof(int), h->stream);
         if (h->ds_host->overflow & 2)
             return fail(h, SPH_E_OVERFLOW, "internal: a cell was missing from a workgroup's staging plan (run with SPH_STAGE=0 and report)");
-        if (h->ds_host->overflow & 8)
-            return fail(h, SPH_E_OVERFLOW, "more than 8192 particles left the grid in one step: the split of the residual sweeps no longer covers every tile");
         if (h->ds_host->overflow & 4)
             return fail(h, SPH_E_OVERFLOW, "a particle crossed a whole slab in one step (it left its slab and landed beyond the neighbour's): the one-message particle "
                                            "exchange assumes a fraction of a cell per step -- lower delta_time or use fewer, wider slabs");
@@ -2249,15 +2127,7 @@ inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline TilePhase tile_phase(const SphHandle *h, int phase)
 {
-    if (phase == 0 && h->tile_perm && h->nblocks >= 64) return TilePhase{h->tile_perm, h->nblocks, 3};      // one GPU, staged: heavy tiles first within each XCD's eighth
-    if (phase != 0 && h->range_split) return TilePhase{h->tile_split, h->nblocks, phase == 1 ? 5 : 6};
     return TilePhase{h->tile_order, h->nblocks, phase};
-}
-// particles a split launch's grid must cover (grid_for): all of them, or the host's bound on its range of tiles
-inline int phase_n(const SphHandle *h, int phase)
-{
-    if (phase == 0 || !h->range_split) return h->c.n;
-    return std::max(1, phase == 1 ? h->nblocks - h->split_lo : h->split_hi) * kBlock;
 }
 void launch_div_residual(SphHandle *h, int gate, int phase = 0, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
@@ -2268,11 +2138,11 @@ void launch_div_residual(SphHandle *h, int gate, int phase = 0, SpecUndo un = Sp
     const TilePhase tp = split ? TilePhase{h->tile_order, h->nblocks, 1} : tile_phase(h, phase);
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
-        hipLaunchKernelGGL(k_residual_rx<false>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->V[h->vcur],
+        hipLaunchKernelGGL(k_residual_rx<false>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->V[h->vcur],
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->drho, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1, tpr, un);
         if (!split) return;
     }
-    SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
+    SPH_LAUNCH_RMX(k_residual, false, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->V[h->vcur], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->drho, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, (const int *)nullptr, (const unsigned char *)nullptr, 1,
                   (const float4 *)wall_cache(h), tp, un);
@@ -2317,11 +2187,11 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, hipStream_t st 
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
-        hipLaunchKernelGGL(k_residual_rx<true>, grid_for(phase_n(h, phase)), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->VA[0],
+        hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->VA[0],
                            h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr);
         if (!split) return;
     }
-    SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), phase_n(h, phase), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
+    SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
                   rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp);
 }
@@ -2710,7 +2580,7 @@ int step_dfsph_once(SphHandle *h, SphStepStats *st)
     h->comm_stat[6] += 1;
     if ((rc = stage_sort_and_lists(h))) return rc;          // :139-141 (reset() is the no-op override, dfsph_solver.py:418-421)
     if ((rc = stage_density(h))) return rc;                 // initialize(): dfsph_solver.py:423-426
-    const bool host_loops = h->host_loops || (h->slab && !slab_async(h));
+    const bool host_loops = h->slab && !slab_async(h);      // a transport without allreduce_stream
     return host_loops ? step_dfsph_host_loops(h, st) : step_dfsph_device_loops(h, st);
 }
 
@@ -3153,19 +3023,13 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     SphHandle *h = new SphHandle();
     h->cfg = *cfg;
     h->device = cfg->device;
-    { const char *e = dev_env(&h->overrides, "SPH_HOST_LOOPS"); h->host_loops = e && e[0] == '1'; }
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_FIN_RIDE"); h->opt_fin_ride = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GROUPS"); if (e) h->slab_groups = std::min(std::max(atoi(e), 0), 2); }
-    { const char *e = dev_env(&h->overrides, "SPH_SWEEP_LDS"); h->sweep_lds = e ? (unsigned)atoi(e) : 0u; }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_TILE_LPT"); h->opt_tile_lpt = e && atoi(e) > 0; if (h->opt_tile_lpt) h->tile_wall_weight = atoi(e); }
     { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_QUAD_BELOW"); h->quad_below = e ? atoi(e) : kQuadBelow; }
     { const char *e = dev_env(&h->overrides, "SPH_BNL_SPLIT"); const int v = e ? atoi(e) : -1; h->opt_bnl_split = (v == 0 || v == 3 || v == 9) ? v : -1; }
     int rc = SPH_OK;
     do {
@@ -3474,7 +3338,6 @@ int sph_rccl_attach(SphHandle *h, const void *id128, size_t capacity_bytes)
     memset(&h->comm, 0, sizeof(h->comm));
     h->comm.capacity = capacity_bytes;
     h->comm.stream_ordered = 1;
-    { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
     // the native transport starts in order (one stream; the residual's triple rides with the halo): with transfers and collectives that take
     // 0-50 us to start it is the faster protocol in every replay (profiles/r04/loopback/link_latency_sweep.txt); slab_overlap = 2 starts overlapped,
     // sph_slab_set_overlap switches between steps (bench.py times both)
@@ -3532,7 +3395,6 @@ int sph_set_comm(SphHandle *h, const SphComm *comm)
         return fail(h, SPH_E_INVALID, "a rigid body on a slab handle needs a transport with allreduce_stream");
     }
     if (comm->stream_ordered && comm->on_host) return fail(h, SPH_E_INVALID, "a stream-ordered transport needs device buffers (on_host = 0)");
-    { const char *e = dev_env(&h->overrides, "SPH_SLAB_LEGACY"); h->slab_legacy = e && e[0] == '1'; }
     h->overlap_on = true;          // (a synchronous transport is slow: the overlapped protocol wins there, profiles/r04/rehearsal_2ranks.json)
     h->comm_set = true;
     return SPH_OK;

@@ -445,16 +445,6 @@ __global__ __launch_bounds__(kBlock) void k_tile_order(const int *__restrict__ f
     if (threadIdx.x == 0) order[ntiles] = total_s;
 }
 
-// Slab handles on the curve keep the interior columns in front of everything else (slab_cell_order): cell_start[first slot of the first edge
-// tile] = particles in interior columns.  The tiles below split[0] hold interior particles only.  The host sized the edge launch by a lower
-// bound of that number: if the bound does not hold (thousands of particles left the grid in one step) the step fails loudly (overflow bit 3).
-__global__ void k_tile_split(const int *__restrict__ cell_start, int first_edge_slot, int lower_bound_tiles, int *__restrict__ split, DevScalars *__restrict__ ds)
-{
-    const int t = cell_start[first_edge_slot] / kBlock;
-    split[0] = t;
-    if (t < lower_bound_tiles) atomicOr(&ds->overflow, 8);
-}
-
 // Rigid body on slab handles.  The reference's quirks read FLUID arrays with a rigid particle's local index (get_neighbour_count measures to
 // fluid_particles.pos[particle_j.index], ParticleSystem.py:440-442; viscosity reads rho[particle_j.index], solver_base.py:198-199): positions and densities
 // of the fluid particles with original id < Nr, wherever they are.  Every rank contributes the ones it OWNS to a zeroed array of doubles, the arrays are

@@ -45,7 +45,7 @@ def main_sharded(args, config):
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
     else:
         dist.init_process_group("gloo")
-    transport = os.environ.get("SPH_RUN_TRANSPORT", "native" if own_gpu else "torch")
+    transport = args.transport or ("native" if own_gpu else "torch")
     sim = SlabSimulation(config, rank, world, device=device, transport=transport, rebalance_every=50, arith=nat.arith_id(args.arith))
     scene_config, solver_config = config["scene"], config["solver"]
     iter_cnt = solver_config.get("iter_cnt")
@@ -84,6 +84,7 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=0, help="stop after this many frames (0 = use --until)")
     ap.add_argument("--ply-dir", default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--transport", default=None, choices=["native", "torch"], help="sharded runs: the library's own RCCL communicator (default with one GPU per rank) or torch.distributed callbacks")
     ap.add_argument("--arith", default=None, choices=["exact", "relaxed"],
                     help="exact (default): the reference's f32 operations in its order; relaxed: the tolerance-grade sweeps (SphConfig.arith)")
     args = ap.parse_args(argv)

@@ -31,8 +31,10 @@ from . import _native as nat
 class TorchComm:
     """SphComm callbacks on top of torch.distributed (backend nccl = RCCL, or gloo)."""
 
-    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None, stream_ptr=0, stream_ordered=None, reduce_capacity=4):
-        """stream_ptr: the library handle's hipStream_t (Simulation.stream_ptr()); with the nccl backend and a stream the
+    def __init__(self, rank, world, device=0, capacity_bytes=64 << 20, group=None, stream_ptr=0, stream_ordered=None, reduce_capacity=4, host_loops=False):
+        """host_loops: offer no allreduce_stream -- the library then runs the dfsph loops on the host, one read-back and one host all-reduce per
+        residual (the minimal SphComm of include/sph_mi355x.h; pcisph / iisph need allreduce_stream).
+        stream_ptr: the library handle's hipStream_t (Simulation.stream_ptr()); with the nccl backend and a stream the
         transport is stream-ordered unless stream_ordered=False / SPH_SLAB_SYNC=1."""
         import os
         import torch
@@ -65,7 +67,8 @@ class TorchComm:
         self.struct.exchange_counts = self._cb_counts
         self.struct.exchange_buffers = self._cb_buffers
         self.struct.allreduce = self._cb_allreduce
-        self.struct.allreduce_stream = self._cb_allreduce_stream
+        if not host_loops:
+            self.struct.allreduce_stream = self._cb_allreduce_stream
         self.struct.exchange_counts_n = self._cb_counts_n
         self.struct.reduce_capacity = self.reduce_t.numel()
         self.struct.reduce_buf = self.reduce_t.data_ptr()
@@ -214,7 +217,7 @@ class SlabSimulation:
     """One rank's share of a sharded simulation: a slab handle plus its transport."""
 
     def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, rebalance_every=0,
-                 transport="torch", group=None, **native_opts):
+                 transport="torch", group=None, host_loops=False, **native_opts):
         """transport: "torch" (TorchComm callbacks: RCCL through torch.distributed, or gloo) or "native" (the library opens its
         own RCCL communicator and issues the transfers itself; one GPU per rank required)."""
         self.rank, self.world = rank, world
@@ -234,7 +237,7 @@ class SlabSimulation:
             attach_native(self.sim, rank, capacity_bytes, group)
         else:
             self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, group=group, stream_ptr=self.sim.stream_ptr(),
-                                  reduce_capacity=4 * self.sim.n_rigid + 8 if rigid else 4)
+                                  reduce_capacity=4 * self.sim.n_rigid + 8 if rigid else 4, host_loops=host_loops)
             self.sim.set_comm(self.comm.struct)
         self.n_fluid = self.sim.n_fluid
 

@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--save-log", default="", help="with --replay-rank: write the log to this file and stop (the replay runs in a process of its own: --load-log)")
     ap.add_argument("--load-log", default="", help="replay --replay-rank alone against a saved log (one thread, one handle: what a profiler should see)")
     ap.add_argument("--one-gpu", action="store_true", help="with a replay: time the same steps of the whole scene on a one-GPU handle in the same process")
+    ap.add_argument("--overflow-rank", type=int, default=-1, help="this rank's handle gets --max-neighbors list rows: its lists overflow, and EVERY rank must fail the step")
+    ap.add_argument("--max-neighbors", type=int, default=0)
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     os.environ["SPH_DEV"] = "1"
@@ -60,7 +62,8 @@ def main():
         rigid = mesh.rigid_from_config(cfg)
     active = bool(rigid and rigid.get("active"))
     sims = [] if args.load_log else [nat.Simulation(nat.config_from_dict(cfg, slab_rank=r, slab_count=world, slab_rebalance_every=args.rebalance,
-                                                                          slab_ghost_layers=args.layers, slab_overlap=args.overlap, arith=args.arith), rigid=rigid)
+                                                                          slab_ghost_layers=args.layers, slab_overlap=args.overlap, arith=args.arith,
+                                                                          max_neighbors=args.max_neighbors if r == args.overflow_rank else 0), rigid=rigid)
                                      for r in range(world)]
     wcsph = nat.config_from_dict(cfg).solver == nat.SOLVER_IDS["wcsph"]
     uid = nat.rccl_unique_id()
@@ -88,6 +91,7 @@ def main():
         return h.hexdigest()
     stats = [[] for _ in range(world)]
     errors = [None] * world
+    codes = [0] * world
     owned_max = [0] * world
     start = threading.Barrier(world)
     timing = {}
@@ -124,6 +128,7 @@ def main():
                     timing["ms_per_step"] = (time.perf_counter() - t0) * 1e3 / args.time
         except BaseException as e:  # noqa: BLE001 - reported by the main thread; the other ranks run into the stand-in's bounded waits
             errors[r] = repr(e)
+            codes[r] = getattr(e, "code", None)
             try:
                 start.abort()
             except Exception:  # noqa: BLE001
@@ -134,6 +139,12 @@ def main():
         t.start()
     for t in threads:
         t.join()
+    if args.overflow_rank >= 0:        # every rank must have failed its step, with the overflow code, and none may hang (the caller's timeout)
+        with open(args.out, "w") as f:
+            json.dump({"codes": codes, "errors": errors, "steps_done": [len(s) for s in stats]}, f)
+        for s in sims:
+            s.close()
+        return
     if any(errors):
         print("loopback worker failed:", errors, file=sys.stderr)
         sys.exit(1)

@@ -66,7 +66,7 @@ def stuck_particles_near_body(sim, h):
 # config 5
 # --------------------------------------------------------------------------------------------------------------------
 def test_config5_coupling_demo_dfsph_against_oracle():
-    """The reference's coupling_demo geometry under DFSPH, 30 coupled steps (solver.step + rigid_solver.step, main.py:166-171):
+    """The reference's coupling_demo geometry under DFSPH, 16 coupled steps (30 until round 5; the long run is tools/soak_rigid.py's) (solver.step + rigid_solver.step, main.py:166-171):
     fluid state, force on the body, body state, iteration counts, residuals and the cap flag equal to the oracle's, bit for bit."""
     cfg = scenes.get("coupling_demo_dfsph")
     rg = mesh.rigid_from_config(cfg)
@@ -75,7 +75,7 @@ def test_config5_coupling_demo_dfsph_against_oracle():
     assert (sim.n_fluid, sim.n_wall, tuple(sim.grid)) == (55200, 52002, (51, 71, 26))        # SURVEY.md 8c KAT
     assert (sim.n_fluid, sim.n_wall, sim.n_rigid) == (o.N, o.Nb, o.Nr) and sim.n_rigid > 3000
     capped_steps, n_dens = 0, []
-    for s in range(30):
+    for s in range(16):
         st = sim.step_dfsph(1)
         o.step_dfsph(1, 100)
         so = o.last_stats
@@ -100,7 +100,7 @@ def test_config5_coupling_demo_dfsph_against_oracle():
     same(sim.download(nat.F_RIGID_POS, nat.SPECIES_RIGID), o.get(orc.F_RIGID_POS), "rigid positions")
     # the oracle runs into the cap as well: the body is placed inside the water column's face (module docstring)
     assert capped_steps > 0 and max(n_dens) == 100, n_dens
-    print("config 5 (coupling_demo_dfsph): n_dens per step %s, %d of 30 steps at the cap" % (n_dens, capped_steps))
+    print("config 5 (coupling_demo_dfsph): n_dens per step %s, %d of 16 steps at the cap" % (n_dens, capped_steps))
     sim.close(); o.close()
 
 

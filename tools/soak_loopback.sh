@@ -19,5 +19,4 @@ run breaking_dam_30k_dfsph 3 400 10 "--overlap 1" "SPH_CELL_ORDER=morton" || exi
 run dfsph_rigid_tilted 3 300 9 "" "SPH_CELL_ORDER=morton" || exit 1
 run wcsph_dam_x 3 6000 11 "" "" || exit 1
 run dfsph_tiny_wall_iisph 3 1500 9 "" "" || exit 1
-run breaking_dam_30k_dfsph 4 300 6 "" "SPH_CELL_ORDER=morton SPH_SLAB_GROUPS=1" || exit 1
-run breaking_dam_30k_dfsph 4 300 6 "" "SPH_CELL_ORDER=morton SPH_SLAB_GROUPS=2" || exit 1
+run dfsph_1m 8 60 10 "" "" || exit 1

@@ -9,6 +9,8 @@ print({k:r[k] for k in ("pos_equal","vel_equal","rho_equal","stats_equal","pos_r
 PY
 }
 export HSA_ENABLE_IPC_MODE_LEGACY=0 OMP_NUM_THREADS=2 SPH_DEV=1 SPH_SLAB_CHECK=1     # (the host's edge-column bookkeeping is checked against the sorted arrays every step)
+# particles that slip through the single-layer walls next to a cut (the reference's 1-D cell index wraps them into a far cell): the first two runs
+# once desynchronised the ordered edge / ghost lists at steps 874 / 343 (the 1000- and 600-step cases the GPU suite carried until round 5)
 run dfsph_dam_x 3 2500 7
 run dfsph_dam_x 4 1500 5
 run wcsph_dam_x 3 8000 11
