@@ -87,7 +87,8 @@ def main():
         h = hashlib.sha1()
         for field in (nat.F_POS, nat.F_VEL, nat.F_RHO):
             ids, vals = sim.download_local(field)
-            h.update(ids.tobytes()); h.update(vals.tobytes())
+            order = np.argsort(ids, kind="stable")          # by particle id (ghosts: ~id): the digest does not depend on the storage order
+            h.update(ids[order].tobytes()); h.update(vals[order].tobytes())
         return h.hexdigest()
     stats = [[] for _ in range(world)]
     errors = [None] * world
