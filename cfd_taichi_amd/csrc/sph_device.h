@@ -51,7 +51,6 @@ struct Consts {
     int S;                // slots in cell_start[] (>= C: tiles pad each axis to a multiple of the tile edge); slot S = "outside the grid"
     int tbits, tnx, tnxz; // tiles of 2^tbits cells per axis; tile strides: tiles along x, tiles along x times tiles along z
     const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
-    const int *xmap;      // two-column slab handles on the curve: cell column x is stored as column xmap[x] (-1: not resident on this slab); nullptr = x itself
     int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
     int nl16;             // fluid lists of staged workgroups hold 16-bit local indices, eight per 16-byte group (NlWriter)
     int kr_split;         // dfsph sweeps hand k / rho to the next sweep in a 4-byte array instead of a (pos, k / rho) float4 (k_correct)

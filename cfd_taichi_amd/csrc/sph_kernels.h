@@ -120,14 +120,9 @@ __device__ __forceinline__ int slot_of_parts(const Consts &c, SlotPart x, SlotPa
 {
     return (c.tile_rank[x.tile + y.tile + z.tile] << (3 * c.tbits)) | (x.code | y.code | z.code);
 }
-// Two-column slab handles on the curve keep their GHOST columns apart (Consts.xmap, slab_cell_order() in sph_mi355x.hip): the owned columns along
-// the curve first, the four ghost columns in one column of cell tiles behind them -- so that the sweeps in which a ghost's lane has nothing to do
-// (residuals, D5, the integrator: a third of the resident particles are ghosts on config 4 at 8 slabs) meet whole tiles of ghosts, which leave at
-// once, instead of ghosts mixed into three quarters of their tiles.  Returns -1 for a column that is not resident: callers treat the cell as empty.
 __device__ __forceinline__ int cell_slot_xyz(const Consts &c, int x, int y, int z, int id)
 {
     if (c.order != CELL_ORDER_TILED) return id;
-    if (c.xmap) { x = c.xmap[x]; if (x < 0) return -1; }
     return slot_of_parts(c, slot_part(c, x, 0, 1), slot_part(c, y, 1, c.tnxz), slot_part(c, z, 2, c.tnx));
 }
 

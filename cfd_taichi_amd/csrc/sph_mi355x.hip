@@ -119,7 +119,6 @@ struct SphHandle {
     std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
-    int *xmap = nullptr;                 // Consts.xmap (two-column slab handles on the curve: slab_cell_order)
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
     int quad_below = 65536;              // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
@@ -187,7 +186,6 @@ struct SphHandle {
     double *red_host = nullptr;   // pinned staging for host-side all-reduces
     double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
     bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
-    bool opt_ghosts_apart = true; // SPH_SLAB_GHOSTS_APART=0: two-column slab handles on the curve keep the plain curve (A/B, slab_cell_order)
     bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -573,7 +571,6 @@ int build_scene(SphHandle *h, HostScene &sc)
         c.tbits = edge >= 16 ? 4 : edge >= 8 ? 3 : 2;
         const int te = 1 << c.tbits;
         c.tnx = (c.gx + te - 1) / te;
-        if (cf.slab_count > 1) c.tnx += 1;      // slab handles keep their ghost columns in a column of cell tiles of their own (slab_cell_order)
         c.tnxz = c.tnx * ((c.gz + te - 1) / te);
         const long long slots = c.order == CELL_ORDER_TILED ? ((long long)c.tnxz * ((c.gy + te - 1) / te)) << (3 * c.tbits) : C;
         if (slots + 2 > 0x7fffffffLL) return fail(h, SPH_E_INVALID, "grid of %lld cell slots is too large", slots);
@@ -883,51 +880,6 @@ std::vector<int> morton_tile_ranks(const Consts &c)
     return rank;
 }
 
-// Storage order of a two-column slab handle on the curve (cell_slot_xyz in sph_kernels.h): x-tile 0 holds the four ghost columns -- code 0 / 1 the
-// INNER ghost column left / right of the slab, 2 / 3 the outer ones, so that a 2 x 2 x 2 block of the in-tile Morton code (a wave's worth of
-// particles) holds inner ghosts, which run D1 and the correction sweeps, or outer ones, which run nothing -- the owned columns follow from x-tile 1
-// on, left to right (the slab always starts on a tile boundary), and the tiles are ranked owned first, along the Morton curve of (tx - 1, ty, tz),
-// the ghost tiles behind them along the curve of (ty, tz).  Owned particles are then the front of the sorted arrays, and a ghost tile is a full
-// 4 x 4 x 4 tile whose staged neighbourhood is as large as any other's (the orders tried in round 4 put each side's ghosts in FLAT tiles of two
-// columns, which overflowed the LDS staging capacity).  Any bijection is a valid storage order: every sum runs in the reference's cell walk with
-// ascending id inside a cell.  Columns this slab does not hold map to -1 = no cell.  Recomputed when the cuts move.
-inline bool slab_ghosts_apart(const SphHandle *h) { return h->slab && h->c.order == CELL_ORDER_TILED && h->geom.layers == 2 && h->c.tbits >= 2 && h->opt_ghosts_apart; }
-void slab_cell_order(const SphHandle *h, std::vector<int> &xmap, std::vector<int> &rank)
-{
-    const Consts &c = h->c;
-    const SlabGeom &g = h->geom;
-    const int te = 1 << c.tbits;
-    xmap.assign((size_t)c.gx, -1);
-    auto put = [&](int x, int v) { if (x >= 0 && x < c.gx) xmap[(size_t)x] = v; };
-    if (g.has_left) { put(g.x_lo - 1, 0); put(g.x_lo - 2, 2); }
-    if (g.has_right) { put(g.x_hi, 1); put(g.x_hi + 1, 3); }
-    for (int x = g.x_lo; x < g.x_hi; ++x) put(x, te + (x - g.x_lo));
-    const int tnx = c.tnx, tnz = c.tnxz / c.tnx, tny = (c.gy + te - 1) / te;
-    std::vector<std::pair<std::pair<int, uint64_t>, int>> key;
-    key.reserve((size_t)tnx * tnz * tny);
-    for (int ty = 0; ty < tny; ++ty)
-        for (int tz = 0; tz < tnz; ++tz)
-            for (int tx = 0; tx < tnx; ++tx) {
-                const int grp = tx == 0 ? 1 : 0;
-                const uint64_t m = morton_spread((uint64_t)(grp ? 0 : tx - 1)) | morton_spread((uint64_t)ty) << 1 | morton_spread((uint64_t)tz) << 2;
-                key.push_back({{grp, m}, tx + tz * c.tnx + ty * c.tnxz});
-            }
-    std::sort(key.begin(), key.end());
-    rank.assign(key.size(), 0);
-    for (size_t r = 0; r < key.size(); ++r) rank[(size_t)key[r].second] = (int)r;
-}
-int upload_slab_cell_order(SphHandle *h)
-{
-    std::vector<int> xmap, rank;
-    slab_cell_order(h, xmap, rank);
-    HIP_TRY(h, hipMemcpyAsync(h->xmap, xmap.data(), sizeof(int) * xmap.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->tile_rank, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));       // (the vectors go out of scope)
-    h->c.tile_rank = h->tile_rank;
-    h->c.xmap = h->xmap;
-    return SPH_OK;
-}
-
 int alloc_device(SphHandle *h, const HostScene &sc)
 {
     const Consts &c = h->c;
@@ -937,7 +889,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if (c.order == CELL_ORDER_TILED) {
         tile_rank = morton_tile_ranks(c);
         if ((rc = dalloc(h, &h->tile_rank, tile_rank.size()))) return rc;
-        if (h->slab && (rc = dalloc(h, &h->xmap, (size_t)c.gx))) return rc;
     }
     for (int k = 0; k < 2; ++k) {
         if ((rc = dalloc(h, &h->P[k], n + 64))) return rc;      // k_build_nl reads whole groups of four candidates
@@ -1047,7 +998,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
-        if (slab_ghosts_apart(h) && (rc = upload_slab_cell_order(h))) return rc;
     }
 
     // upload the scene
@@ -1361,7 +1311,6 @@ int slab_rebalance(SphHandle *h)
     if (h->cuts_moved) {
         h->cuts = cut;
         set_slab_geometry(h);
-        if (slab_ghosts_apart(h) && (rc = upload_slab_cell_order(h))) return rc;      // the ghost columns follow the cuts
         ++h->n_recuts;
     }
     return SPH_OK;
@@ -3075,7 +3024,6 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_SLAB_GHOSTS_APART"); h->opt_ghosts_apart = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
