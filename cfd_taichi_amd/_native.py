@@ -36,7 +36,7 @@ VECTOR_FIELDS = {F_POS, F_VEL, F_ACC, F_VEL_ADV, F_WALL_POS, F_RIGID_POS, F_RIGI
                  F_PBF_DELTA_POS}
 
 EXPORTS = [
-    "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
+    "sph_abi_version", "sph_set_comm_sized", "sph_create", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha",
     "sph_get_scalar", "sph_set_scalar", "sph_synchronize", "sph_overrides", "sph_profile_enable", "sph_profile_reset", "sph_profile_kernel_count",
     "sph_profile_kernel_name", "sph_profile_get", "sph_selftest_math", "sph_selftest_wave", "sph_tune_time",
@@ -163,8 +163,9 @@ def library_path():
 
 # the per-step path of include/sph_mi355x.h: what any implementation of the ABI exports (the device-specific entry points --
 # slabs / RCCL, profiling, tuning, self-tests -- are bound by load() for libsph_mi355x.so only)
+ABI_VERSION = 5          # include/sph_mi355x.h SPH_ABI_VERSION: checked when a library is bound
 CORE_EXPORTS = [
-    "sph_create", "sph_create_rigid", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
+    "sph_abi_version", "sph_create", "sph_create_rigid", "sph_destroy", "sph_get_sizes", "sph_last_error", "sph_upload", "sph_download",
     "sph_step_wcsph", "sph_step_dfsph", "sph_step_pcisph", "sph_step_iisph", "sph_step_pbf", "sph_rigid_step",
     "sph_build_neighbors", "sph_compute_density", "sph_compute_alpha", "sph_get_scalar", "sph_set_scalar", "sph_synchronize",
 ]
@@ -172,6 +173,11 @@ CORE_EXPORTS = [
 
 def _bind_core(lib):
     vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.sph_abi_version.argtypes = []
+    lib.sph_abi_version.restype = ctypes.c_int32
+    if lib.sph_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s implements version %d of include/sph_mi355x.h, this binding version %d: rebuild (python -m cfd_taichi_amd.build)"
+                           % (getattr(lib, "_name", "library"), lib.sph_abi_version(), ABI_VERSION))
     lib.sph_create.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(vp)]
     lib.sph_create.restype = ci
     lib.sph_create_rigid.argtypes = [ctypes.POINTER(SphConfig), ctypes.POINTER(SphRigid), ctypes.POINTER(vp)]

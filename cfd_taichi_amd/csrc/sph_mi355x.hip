@@ -3360,6 +3360,18 @@ int sph_rccl_selftest(SphHandle *h, double *inout, int32_t n, int32_t op)
     return native_exchange(h, 0, 0, 0, 0);
 }
 
+int32_t sph_abi_version(void) { return SPH_ABI_VERSION; }
+
+int sph_set_comm_sized(SphHandle *h, const SphComm *comm, size_t comm_size)
+{
+    if (!h || !comm) return SPH_E_INVALID;
+    if (comm_size < offsetof(SphComm, allreduce_stream)) return fail(h, SPH_E_INVALID, "SphComm of %zu bytes is older than any this library knows", comm_size);
+    SphComm full;
+    memset(&full, 0, sizeof(full));
+    memcpy(&full, comm, std::min(comm_size, sizeof(full)));
+    return sph_set_comm(h, &full);
+}
+
 int sph_set_comm(SphHandle *h, const SphComm *comm)
 {
     if (!h || !comm) return SPH_E_INVALID;

@@ -25,6 +25,12 @@
 extern "C" {
 #endif
 
+/* Version of this interface.  It changes whenever a struct grows or a signature changes (round 4: sph_replan_slabs gained ghost_layers, SphComm
+ * gained exchange_counts_n / reduce_capacity; round 5: SPH_P_* scalars).  A binding checks sph_abi_version() == SPH_ABI_VERSION when it loads the
+ * library (cfd_taichi_amd/_native.py does) instead of finding out through a misread struct. */
+#define SPH_ABI_VERSION 5
+int32_t sph_abi_version(void);
+
 #define SPH_OK 0
 #define SPH_E_INVALID (-1)   /* bad argument / size mismatch */
 #define SPH_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
@@ -74,7 +80,9 @@ typedef struct SphConfig {
                                    correction sweep; the IN-ORDER one runs everything on the handle's stream (same bits).  0 = default: the handle can do
                                    both and starts with the one that measured faster for its transport (native RCCL: in order, with the residual's
                                    triple riding in the halo's transfers; a synchronous callback transport: overlapped) -- sph_slab_set_overlap switches
-                                   between steps; 1 = in order only (no second / third stream); 2 = start overlapped */
+                                   between steps; 1 = in order only (no second / third stream); 2 = start overlapped.  What "can do both" costs: two more
+                                   HIP streams, four events, a tile order and 20 bytes per particle of slab capacity (what a divergence correction that
+                                   runs ahead of its loop decision overwrites) -- allocated with the handle; pass 1 where that memory matters */
     int32_t reserved[2];
 } SphConfig;
 
@@ -297,6 +305,8 @@ typedef struct SphComm {
 } SphComm;
 
 int sph_set_comm(SphHandle *h, const SphComm *comm);
+/* the same for a caller built against an older, SHORTER SphComm: comm_size = that caller's sizeof(SphComm); the fields it does not have read as 0 / NULL */
+int sph_set_comm_sized(SphHandle *h, const SphComm *comm, size_t comm_size);
 /* Native transport: instead of callbacks, the library itself issues ncclSend / ncclRecv to the left and right slab neighbour and
  * ncclAllReduce of the residual pair on its own stream (librccl is dlopen'ed).  Rank 0 obtains a 128-byte id with
  * sph_rccl_unique_id and the application broadcasts it by any means; every rank then calls sph_rccl_attach (collective:

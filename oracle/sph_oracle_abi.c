@@ -223,3 +223,4 @@ int sph_set_scalar(SphHandle *h, int which, double value)
 }
 
 int sph_synchronize(SphHandle *h) { return h ? SPH_OK : SPH_E_INVALID; }
+int32_t sph_abi_version(void) { return SPH_ABI_VERSION; }

