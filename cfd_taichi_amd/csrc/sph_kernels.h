@@ -40,7 +40,11 @@ __device__ __forceinline__ int xcd_sweep_block(int orig, int nwg)
 
 // Edge / interior split of a sweep (slab handles; the order comes from k_tile_order in sph_slab_kernels.h): phase 0 = every tile in one launch,
 // 1 = the edge tiles (tile_order[0 .. n_edge)), 2 = the interior ones; both split launches have the full grid, surplus workgroups leave at once.
-struct TilePhase { const int *order; int ntiles, phase; int shift = 0; };
+struct TilePhase { const int *order; int ntiles, phase; int shift = 0; const int *sparse = nullptr; int *hot = nullptr; };
+// sparse / hot (one GPU, the density loop's change-propagated launches, in which most workgroups find their tile unchanged and leave): the launches
+// of a step's second density residual note per tile whether it had work (hot[tile]); the host turns that into a permutation with the working tiles
+// first (k_tile_order) and the rest of the loop's launches take their tiles through it (sparse[workgroup]) -- the few hundred workgroups with work
+// start at once instead of wherever their index falls among thousands that leave.  Which workgroup serves which tile cannot change a bit.
 // shift = 1: workgroup 0 of the launch is not a tile's -- it takes the loop decision of the sweep BEFORE this one (fin_ride_block) -- and workgroup
 // b serves the tile that workgroup b - 1 of a grid one smaller would (phase 0, one GPU)
 // Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_mi355x.hip: step_dfsph_device_loops): the correction of
@@ -60,9 +64,9 @@ __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread)
     if (tp.shift) {
         const int b = (int)blockIdx.x - 1, g = (int)gridDim.x - 1;
         if (b < 0) return -1;
-        return spread ? b : xcd_sweep_block(b, g);
+        return spread ? (tp.sparse ? tp.sparse[b] : b) : xcd_sweep_block(b, g);
     }
-    if (tp.phase == 0) return spread ? (int)blockIdx.x : xcd_sweep_block(blockIdx.x, gridDim.x);
+    if (tp.phase == 0) return spread ? (tp.sparse ? tp.sparse[blockIdx.x] : (int)blockIdx.x) : xcd_sweep_block(blockIdx.x, gridDim.x);
     const int ne = tp.order[tp.ntiles];
     if (tp.phase == 1) return (int)blockIdx.x < ne ? tp.order[blockIdx.x] : -1;
     const int ni = tp.ntiles - ne;
@@ -2214,7 +2218,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     if (tile < 0) return;
     if (spread) {                                                    // change propagation, see stage_sources_flagged
         const int sw = stage_cnt[tile];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) return;     // rho*, k / rho and the block partial of the last iteration stand
+        const bool idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
+        if (idle) return;                                            // rho*, k / rho and the block partial of the last iteration stand
     }
     SPH_SWEEP_PROLOGUE_B(QUAD, tile)
     // ... and a tile without an owned particle -- ghosts only -- computes no residual (the ghosts' values arrive with the halo): no staging, a zero partial

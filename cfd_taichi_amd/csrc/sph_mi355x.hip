@@ -186,6 +186,9 @@ struct SphHandle {
     double *red_host = nullptr;   // pinned staging for host-side all-reduces
     double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
     bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
+    // one GPU, density loop: working tiles first in the change-propagated launches (TilePhase.sparse / hot in sph_kernels.h)
+    int *dens_hot = nullptr, *dens_order = nullptr;
+    bool dens_sparse = false;
     bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -921,6 +924,10 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
+                if ((rc = dalloc(h, &h->dens_hot, (n + kBlock - 1) / kBlock + 1))) return rc;
+                if ((rc = dalloc(h, &h->dens_order, (n + kBlock - 1) / kBlock + 2))) return rc;
+            }
             if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
@@ -2127,7 +2134,10 @@ inline bool tile_skip(const SphHandle *h) { return h->wave_dirty && h->staged; }
 // the tolerance-grade sweeps cover kr_split handles (single GPU, staged, 16-bit lists, no rigid entries); all others stay exact
 inline TilePhase tile_phase(const SphHandle *h, int phase)
 {
-    return TilePhase{h->tile_order, h->nblocks, phase};
+    TilePhase tp{h->tile_order, h->nblocks, phase};
+    // (the un-split launches of the density loop; the overlapped slab protocol's split launches keep their edge-first order)
+    if (phase == 0 && h->dens_order && tile_skip(h)) { tp.hot = h->dens_hot; tp.sparse = h->dens_sparse ? h->dens_order : nullptr; }
+    return tp;
 }
 void launch_div_residual(SphHandle *h, int gate, int phase = 0, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
@@ -2366,6 +2376,9 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
     hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     h->dens_first = true;
+    // (one GPU: dens_sparse stays -- the region of the scene that keeps the density loop busy moves slowly, last step's order serves the loop's first
+    // launches; a slab's tiles change with every particle exchange)
+    if (h->slab) h->dens_sparse = false;
     // ---- correct_divergence_error, dfsph_solver.py:393-416 ----
     // On a slab handle every sweep whose output the neighbours read is followed by the refresh of that field on the ghosts (enqueued,
     // not waited for, with a stream-ordered transport); gated sweeps still take part in the exchanges so that all slabs issue the same
@@ -2461,19 +2474,28 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     // ---- correct_density_error, :221-233: first chunk = last step's iteration count (it changes slowly), then two at a time ----
     bool first = true;
     int d = 0;                                                                       // evaluations of the density loop so far
+    // behind the loop's second residual launch -- the first that skips unchanged tiles and notes which did not: the tiles that had work first, for the
+    // rest of the loop's launches (TilePhase.sparse)
+    auto order_working_tiles_first = [&]() {
+        if (d != 2 || !h->dens_order || !tile_skip(h) || h->tune_all) return;
+        ProfScope ps(h, K_BUILD_NL);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kBlock), 0, s, h->dens_hot, h->nblocks, h->dens_order);
+        h->dens_sparse = true;
+    };
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
         for (int k = 0; k < chunk; ++k) {
+            ++d;
             if (ride) {
-                ++d;
                 launch_dens_residual(h, GATE_DENS);                                                                          // :227, evaluation d
+                order_working_tiles_first();
                 // D7 of iteration d runs iff iteration d runs (the decision of evaluation d - 1; gate_hist starts open) and carries decision d
                 launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1), SpecSave{nullptr, nullptr}, FIN_DENS, d);   // :229
                 if (rigid_coupled(h)) launch_rigid_force(h, GATE_HIST0 + ((d - 1) & 1));
                 continue;
             }
             if (spec) {
-                ++d;
                 if ((rc = residual_sweep(true, GATE_DENS, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DENS))) return rc;      // :227, evaluation d
+                order_working_tiles_first();
                 // D7 of iteration d runs iff iteration d runs: the decision of evaluation d - 1 (gate_hist starts open)
                 launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_HIST0 + ((d - 1) & 1));   // :229
                 if (rigid_coupled(h)) launch_rigid_force(h, GATE_HIST0 + ((d - 1) & 1));
@@ -2482,6 +2504,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
                 continue;
             }
             if ((rc = residual(true, GATE_DENS, FIN_DENS))) return rc;               // :227
+            order_working_tiles_first();
             launch_correct<CORR_DENS>(h, K_D_DENS_CORRECT, h->rho_adv, h->VA[0], GATE_DENS_D7);   // :229
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
             if ((rc = ghosts_v(h->VA[0]))) return rc;

@@ -138,7 +138,9 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     if (tile < 0) return;
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
         const int sw = stage_cnt[tile];
-        if (sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty)) return;
+        const bool idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
+        if (idle) return;
     }
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE_B(false, tile)
