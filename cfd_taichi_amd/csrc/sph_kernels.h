@@ -1329,11 +1329,21 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize_mean(const double *__res
 // reads the partials of the residual launch before (complete: a kernel boundary lies in between) and writes only words of DevScalars that no
 // tile of this launch reads (they read gate_hist[(e - 1) & 1], dt, dt2).  Same reduction tree as k_finalize_mean: its kBlock threads play four
 // of the kFinBlock "virtual threads" each, so the f64 sum has the same bits.
+// the loop state of a step's two solver loops, before the first of them starts (k_ctrl_begin; one GPU: workgroup 0 of the warm-start launch, FIN_BEGIN)
+__device__ __forceinline__ void ctrl_begin_body(DevScalars *__restrict__ ds, int dens_cap)
+{
+    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0; ds->overflow_any = 0;
+    ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
+    ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
+    ds->gate_hist[0] = 1; ds->gate_hist[1] = 1; ds->stop_at = -1;
+}
+constexpr int FIN_BEGIN = 4;          // FinRide.mode: no decision to take -- reset the loop state (hist = the density loop's cap)
 struct FinRide { const double *psum; const int *pcnt; DevScalars *ds; int nblocks, mode, group, nparts, hist; };      // mode < 0: nobody rides
 constexpr FinRide kNoRide{nullptr, nullptr, nullptr, 0, -1, 1, 0, -1};
 __device__ __forceinline__ void fin_ride_block(const FinRide &fr)
 {
     DevScalars *ds = fr.ds;
+    if (fr.mode == FIN_BEGIN) { if (threadIdx.x == 0) ctrl_begin_body(ds, fr.hist); return; }
     // (an iteration the loop does not run: what finalize_mean_block does for it)
     if (fr.mode == FIN_DIV_LOOP && ds->div_active == 0) { if (threadIdx.x == 0) ds->gate_hist[fr.hist & 1] = 0; return; }
     if (fr.mode == FIN_DENS && ds->dens_active == 0) { if (threadIdx.x == 0) { ds->dens_d7_active = 0; ds->gate_hist[fr.hist & 1] = 0; } return; }
@@ -1361,30 +1371,11 @@ __device__ __forceinline__ void fin_ride_block(const FinRide &fr)
 
 __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 {
-    ds->div_active = 1; ds->div_it = 0; ds->div_evals = 0; ds->overflow_any = 0;
-    ds->dens_active = 1; ds->dens_d7_active = 0; ds->dens_it = 0; ds->dens_cap = dens_cap; ds->dens_capped = 0;
-    ds->div_err = 0.f; ds->div_past = 0.f; ds->div_first = 0.f; ds->dens_avg = 0.f;
-    ds->gate_hist[0] = 1; ds->gate_hist[1] = 1; ds->stop_at = -1;
-}
-
-// max |v*| over the block partials                              dfsph_solver.py:100-103
-__global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds,
-                                                         double *__restrict__ red)
-{
-    __shared__ float s_max[kBlock];
-    float t = -INFINITY;
-    for (int k = threadIdx.x; k < nblocks; k += kBlock) t = fmaxf(t, pmax[k]);
-    s_max[threadIdx.x] = t;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { ds->vmax = s_max[0]; if (red) red[0] = (double)s_max[0]; }   // red: this slab's maximum, all-reduced next
+    ctrl_begin_body(ds, dens_cap);
 }
 
 // the CFL time step from ds->vmax (global maximum)              dfsph_solver.py:104-119
-__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *__restrict__ red, int gather_n = 0)
+__device__ __forceinline__ void apply_dt_body(const Consts &c, DevScalars *__restrict__ ds, const double *__restrict__ red, int gather_n)
 {
     float max_vel = red ? (float)red[0] : ds->vmax;        // red: the maximum over all slabs (gather_n > 0: every slab's own, four doubles apart)
     for (int r = 1; r < gather_n; ++r) max_vel = fmaxf(max_vel, (float)red[4 * r]);
@@ -1401,6 +1392,33 @@ __global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *
         ds->ps_dt = dt;                                           // :119
     }
     ds->gate_hist[0] = 1; ds->gate_hist[1] = 1;                   // (between the two solver loops: the density loop's decisions start afresh)
+}
+__global__ void k_apply_dt(Consts c, DevScalars *__restrict__ ds, const double *__restrict__ red, int gather_n = 0)
+{
+    apply_dt_body(c, ds, red, gather_n);
+}
+
+// max |v*| over the block partials                              dfsph_solver.py:100-103
+// apply != 0 (one GPU: nothing travels between the maximum and the rule): the same thread goes on to the CFL rule, one launch instead of two
+// fr.mode >= 0 (one GPU): first the loop decision of the divergence loop's LAST evaluation, which has no correction launch to ride in (fin_ride_block)
+__global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict__ pmax, int nblocks, DevScalars *__restrict__ ds,
+                                                         double *__restrict__ red, Consts c, int apply, FinRide fr)
+{
+    if (fr.mode >= 0) { fin_ride_block(fr); __syncthreads(); }
+    __shared__ float s_max[kBlock];
+    float t = -INFINITY;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) t = fmaxf(t, pmax[k]);
+    s_max[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ds->vmax = s_max[0];
+        if (red) red[0] = (double)s_max[0];   // red: this slab's maximum, all-reduced next
+        if (apply) apply_dt_body(c, ds, nullptr, 0);
+    }
 }
 
 // ======================================================================================

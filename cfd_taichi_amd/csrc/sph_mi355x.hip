@@ -187,6 +187,7 @@ struct SphHandle {
     double *gath_dev = nullptr;   // native transport, in-order protocol: every slab's (sum, count, flags), four doubles per slab (native_exchange)
     bool opt_gather = true;       // SPH_SLAB_GATHER=0: the residual pair is all-reduced instead (A/B)
     // one GPU, density loop: working tiles first in the change-propagated launches (TilePhase.sparse / hot in sph_kernels.h)
+    FinRide pending_div = kNoRide;      // one GPU: the divergence loop's last decision, taken by k_finalize_max's launch
     int *dens_hot = nullptr, *dens_order = nullptr;
     bool dens_sparse = false;
     bool own_red = false;
@@ -2329,8 +2330,11 @@ int dfsph_ext_and_dt(SphHandle *h)
     const bool gather = async && h->native && h->gath_dev && h->opt_gather;
     {
         ProfScope ps(h, K_FINALIZE);
-        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, gather ? h->gath_dev + 4 * h->slab_rank : async ? h->red_dev : (double *)nullptr);
+        hipLaunchKernelGGL(k_finalize_max, dim3(1), b, 0, s, h->pmax, partial_count(h), h->ds, gather ? h->gath_dev + 4 * h->slab_rank : async ? h->red_dev : (double *)nullptr,
+                           c, h->slab ? 0 : 1, h->pending_div);
+        h->pending_div = kNoRide;
     }
+    if (!h->slab) return SPH_OK;          // (the maximum's thread applied the CFL rule: :112-119)
     if (h->slab) {
         if ((rc = slab_exchange_field(h, 1, nullptr, h->VA[0], nullptr, 1, gather ? 1 : 0))) return rc;     // v* of the column next to the cut (all the density residual reads)
         if (gather) {
@@ -2374,7 +2378,9 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     int rc;
     hipStream_t s = h->stream;
     const int cap = h->cfg.max_density_iters > 0 ? h->cfg.max_density_iters : 100;
-    hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
+    // (one GPU with the warm start on: workgroup 0 of the warm-start launch resets the loop state instead -- FIN_BEGIN below -- one launch less)
+    const bool begin_rides = fin_rides(h) && h->p.warm_start;
+    if (!begin_rides) hipLaunchKernelGGL(k_ctrl_begin, dim3(1), dim3(1), 0, s, h->ds, cap);
     h->dens_first = true;
     // (one GPU: dens_sparse stays -- the region of the scene that keeps the density loop busy moves slowly, last step's order serves the loop's first
     // launches; a slab's tiles change with every particle exchange)
@@ -2430,7 +2436,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     const bool spec = ovl && slab_async(h) && h->rstream;
     const int max_div = h->p.max_iteration_density_divergence;                       // :24 (15)
     if (h->p.warm_start) {
-        launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE);   // :396-397
+        launch_correct<CORR_WARM>(h, K_D_WARM, nullptr, h->V[h->vcur], GATE_NONE, SpecSave{nullptr, nullptr}, begin_rides ? FIN_BEGIN : -1, cap);   // :396-397
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
     }
     // One GPU: the same reordering without a second stream -- the decision of evaluation e is taken by workgroup 0 of the correction launch that
@@ -2443,11 +2449,9 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
                                      e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e);                                              // :402-405 + decision e
             launch_div_residual(h, GATE_DIV, 0, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e});     // :408, evaluation e + 1
         }
-        {   // the decision of the last evaluation has no correction launch to ride in
-            ProfScope ps(h, K_FINALIZE);
-            hipLaunchKernelGGL(k_finalize_mean, dim3(1), dim3(kFinBlock), 0, s, h->psum, h->pcnt, h->nblocks, h->ds, max_div == 0 ? (int)FIN_DIV_FIRST : (int)FIN_DIV_LOOP, (int)FINP_ALL,
-                               (double *)nullptr, partial_group(h), partial_count(h), max_div + 1);
-        }
+        // the decision of the last evaluation has no correction launch to ride in: it is taken by the launch that reduces max |v*| (dfsph_ext_and_dt;
+        // the sweep in between, D5, writes other partials and reads no loop state)
+        h->pending_div = FinRide{h->psum, h->pcnt, h->ds, h->nblocks, max_div == 0 ? (int)FIN_DIV_FIRST : (int)FIN_DIV_LOOP, partial_group(h), partial_count(h), max_div + 1};
     } else if (spec) {
         if ((rc = residual_sweep(false, GATE_NONE, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DIV_FIRST))) return rc;     // :398, evaluation 1
         for (int e = 1; e <= max_div; ++e) {
@@ -2479,7 +2483,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     auto order_working_tiles_first = [&]() {
         if (d != 2 || !h->dens_order || !tile_skip(h) || h->tune_all) return;
         ProfScope ps(h, K_BUILD_NL);
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kBlock), 0, s, h->dens_hot, h->nblocks, h->dens_order);
+        hipLaunchKernelGGL(k_tile_order_wide, dim3(1), dim3(1024), 0, s, h->dens_hot, h->nblocks, h->dens_order);
         h->dens_sparse = true;
     };
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {
