@@ -276,7 +276,8 @@ def load_valu_mix(kernel_profile_name):
         pattern = names.get(kernel_profile_name)
         if pattern is None:
             return None
-        mix = kernels.get(pattern % "1") or kernels.get(pattern % "true")
+        # (the fourth template argument, RX = the relaxed kernel functions on unstaged handles, arrived in round 4: profiles taken since carry it)
+        mix = kernels.get((pattern % "1")[:-1] + ", false>") or kernels.get(pattern % "1") or kernels.get(pattern % "true")
         if mix is not None:
             mix = dict(mix, status=committed_status(data))
         return mix
