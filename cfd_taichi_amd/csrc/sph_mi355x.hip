@@ -1922,7 +1922,7 @@ int stage_sort_and_lists(SphHandle *h)
         }
         if (h->overlap && h->overlap_on) {       // edge tiles first, then the interior (k_tile_order); tile_order[ntiles] = number of edge tiles
             hipLaunchKernelGGL(k_tile_flags, g, b, 0, s, c, h->geom, h->P[h->pcur], h->tile_flag);
-            hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
+            hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, h->tile_flag, h->nblocks, h->tile_order);
         }
     }
     if (h->slab && rigid_coupled(h)) {      // fluid positions by original id < Nr, from whichever rank owns them (the get_neighbour_count quirk)
@@ -1956,7 +1956,7 @@ int stage_sort_and_lists(SphHandle *h)
     if (rx_split(h)) {       // tiles with a rigid sample in reach (32-bit lists) first: the exact RIGID sweeps take them, the relaxed sweeps the rest
         ProfScope ps(h, K_BUILD_NL);
         hipLaunchKernelGGL(k_tile_flags_exact, grid_for(h->nblocks), b, 0, s, h->stage_cnt, h->nblocks, h->tile_flag);
-        hipLaunchKernelGGL(k_tile_order, dim3(1), b, 0, s, h->tile_flag, h->nblocks, h->tile_order);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, h->tile_flag, h->nblocks, h->tile_order);
     }
     if (rigid_coupled(h)) {      // the body's view of the fluid, for the force kernels of this step
         ProfScope ps(h, K_RIGID);
@@ -2483,7 +2483,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     auto order_working_tiles_first = [&]() {
         if (d != 2 || !h->dens_order || !tile_skip(h) || h->tune_all) return;
         ProfScope ps(h, K_BUILD_NL);
-        hipLaunchKernelGGL(k_tile_order_wide, dim3(1), dim3(1024), 0, s, h->dens_hot, h->nblocks, h->dens_order);
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, h->dens_hot, h->nblocks, h->dens_order);
         h->dens_sparse = true;
     };
     for (int chunk = std::max(2, h->last_iters);; chunk = 2) {

@@ -417,38 +417,11 @@ __global__ __launch_bounds__(kBlock) void k_tile_flags(Consts c, SlabGeom g, con
     e = __syncthreads_or(e);
     if (threadIdx.x == 0) flag[blockIdx.x] = e ? 1 : 0;
 }
-__global__ __launch_bounds__(kBlock) void k_tile_order(const int *__restrict__ flag, int ntiles, int *__restrict__ order)
-{
-    // one workgroup: exclusive scan of the flags in chunks of 256 with a carry
-    __shared__ int wsum[kBlock / 64];
-    __shared__ int carry_s, total_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {          // pass 0 counts the edge tiles, pass 1 places both kinds
-        if (pass == 1) { if (threadIdx.x == 0) { total_s = carry_s; carry_s = 0; } __syncthreads(); }
-        for (int base = 0; base < ntiles; base += kBlock) {
-            const int t = base + threadIdx.x;
-            const int v = t < ntiles ? flag[t] : 0;
-            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-            const int inc = wave_inclusive_scan(v);
-            if (lane == 63) wsum[w] = inc;
-            __syncthreads();
-            int woff = 0;
-            for (int q = 0; q < w; ++q) woff += wsum[q];
-            const int before = carry_s + woff + inc - v;         // edge tiles in front of t
-            if (pass == 1 && t < ntiles) order[v ? before : total_s + (t - before)] = t;
-            __syncthreads();
-            if (threadIdx.x == kBlock - 1) carry_s = before + v;
-            __syncthreads();
-        }
-    }
-    if (threadIdx.x == 0) order[ntiles] = total_s;
-}
-
-// The same permutation (flagged tiles first, both kinds in index order) in ONE pass of one 1024-thread workgroup: every thread takes a run of
-// consecutive tiles, the runs' flag counts are scanned once (wave scans + 16 wave sums), then every thread places its tiles.  Two barriers where
-// k_tile_order takes six per 256 tiles (17 us at 3907 tiles): this one is launched every step (the density loop's working tiles, TilePhase.sparse).
-__global__ __launch_bounds__(1024) void k_tile_order_wide(const int *__restrict__ flag, int ntiles, int *__restrict__ order)
+// order[] = the flagged tiles first, then the others, both in index order; order[ntiles] = number of flagged tiles.  ONE pass of one 1024-thread
+// workgroup: every thread takes a run of consecutive tiles, the runs' flag counts are scanned once (wave scans + 16 wave sums), then every thread
+// places its tiles -- one barrier (the chunked two-pass form this replaces took 17 us at 3907 tiles; this one 5, and it is launched every step for
+// the density loop's working tiles, TilePhase.sparse).
+__global__ __launch_bounds__(1024) void k_tile_order(const int *__restrict__ flag, int ntiles, int *__restrict__ order)
 {
     __shared__ int wsum[16];
     const int per = (ntiles + 1023) / 1024, first = (int)threadIdx.x * per, last = min(first + per, ntiles);
