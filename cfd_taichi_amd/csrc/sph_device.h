@@ -52,7 +52,6 @@ struct Consts {
     int tbits, tnx, tnxz; // tiles of 2^tbits cells per axis; tile strides: tiles along x, tiles along x times tiles along z
     const int *tile_rank; // position of every tile along the Morton curve of the tile coordinates
     int stage_cap;        // LDS staging: particles a workgroup may stage (see the plan in k_build_nl); 0 = staging off
-    const uint32_t *stage_flat; // the staging plan's runs expanded once per step: sorted index of staged element e of tile t at [t * stage_cap + e] (k_stage_flatten); nullptr = expand in every sweep
     int nl16;             // fluid lists of staged workgroups hold 16-bit local indices, eight per 16-byte group (NlWriter)
     int kr_split;         // dfsph sweeps hand k / rho to the next sweep in a 4-byte array instead of a (pos, k / rho) float4 (k_correct)
     // tolerance-grade sweeps (SphConfig.arith = SPH_ARITH_RELAXED, sph_relaxed_kernels.h): m grad W = g x_ij with

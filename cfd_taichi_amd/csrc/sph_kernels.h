@@ -1500,79 +1500,14 @@ __device__ __forceinline__ StageIdx stage_take(const uint32_t *__restrict__ s_id
     __syncthreads();
     return x;
 }
-// ---- the staged set's indices from a FLAT per-step list (round 5) ---------------------------------------------------------------------------
-// stage_expand / stage_take above are two dependent trips before the first gather can be asked for (the count, then the runs) plus an LDS expansion
-// and two barriers, in every one of a step's ~57 sweeps -- although the staged set of a workgroup is the same in all of them.  k_stage_flatten
-// expands the runs ONCE per step into Consts.stage_flat[blk * stage_cap + e] = sorted index of staged element e; a sweep's thread then reads its
-// indices straight from there, coalesced, WITHOUT waiting for the count (entries past the count, and the reads past a tile's capacity into the
-// next tile's entries, are stale but valid indices: what they fetch is never stored) -- one trip instead of two, no expansion, no barrier.
-// stage_flat == nullptr: the run-expanding path (the sweeps that keep the index list in LDS -- D5, the pressure solvers -- always take it).
-__device__ __forceinline__ StageIdx stage_take_flat(const Consts &c, int blk)
-{
-    StageIdx x;
-    const uint32_t *f = c.stage_flat + (size_t)blk * c.stage_cap + threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < kStageBatch; ++u) x.j[0][u] = f[u * kBlock];
-#pragma unroll
-    for (int t = 1; t < kStageTrips; ++t)
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) x.j[t][u] = 0u;
-    return x;
-}
-// (capacities above kStageBatch * kBlock: the second trip's indices, once the count says there is one)
-__device__ __forceinline__ void stage_take_flat_rest(const Consts &c, int blk, int nst, StageIdx &x)
-{
-#pragma unroll
-    for (int t = 1; t < kStageTrips; ++t) {
-        if (t * kStageBatch * kBlock >= nst) continue;      // uniform
-        const uint32_t *f = c.stage_flat + (size_t)blk * c.stage_cap;
-#pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) x.j[t][u] = f[min((int)threadIdx.x + (t * kStageBatch + u) * kBlock, nst - 1)];
-    }
-}
-__device__ __forceinline__ int stage_count(const int *__restrict__ stage_cnt, int blk)
-{
-    const int w = stage_cnt[blk];
-    return w < 0 ? -1 : (w & 0xffff);
-}
-// NST / X: the staged count and this thread's indices, by whichever path the handle has; returns RET_UNSTAGED / RET_EMPTY from the calling function
-#define SPH_STAGE_INDICES(NST, X, RET_UNSTAGED, RET_EMPTY)                                                                   \
-    int NST;                                                                                                                 \
-    StageIdx X;                                                                                                              \
-    if (c.stage_flat) {                                                                                                      \
-        X = stage_take_flat(c, blk);                                                                                         \
-        NST = stage_count(stage_cnt, blk);                                                                                   \
-        if (NST < 0) return RET_UNSTAGED;                                                                                    \
-        if (NST == 0) return RET_EMPTY;                                                                                      \
-        stage_take_flat_rest(c, blk, NST, X);                                                                                \
-    } else {                                                                                                                 \
-        NST = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));                                   \
-        if (NST < 0) return RET_UNSTAGED;                                                                                    \
-        if (NST == 0) return RET_EMPTY;                                                                                      \
-        X = stage_take(reinterpret_cast<const uint32_t *>(s_A), NST);                                                        \
-    }
-// one workgroup per tile, once per step behind k_build_nl: the runs of the staging plan expanded into the flat list
-__global__ __launch_bounds__(kBlock) void k_stage_flatten(const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int stage_cap,
-                                                          uint32_t *__restrict__ flat, const int *__restrict__ gate = nullptr)
-{
-    if (gate && *gate == 0) return;
-    const int blk = blockIdx.x, w = stage_cnt[blk];
-    if (w < 0) return;
-    const int nruns = (w >> 16) & 0x3fff;
-    const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
-    uint32_t *out = flat + (size_t)blk * stage_cap;
-    for (int r = threadIdx.x; r < nruns; r += kBlock) {
-        const uint2 rn = runs[r];
-        const int base = (int)(rn.y & 0xffffu), n = (int)(rn.y >> 16);
-        for (int k = 0; k < n; ++k) out[base + k] = rn.x + (uint32_t)k;
-    }
-}
-
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
                                               const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, false, true)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return false;
+    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
@@ -1596,7 +1531,10 @@ template <bool SCALED>
 __device__ __forceinline__ int stage_operand_w_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, 0, 2)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 2;                                 // a workgroup of ghosts only: nothing staged, nothing to add
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
     int any = 0;
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
@@ -1620,7 +1558,10 @@ __device__ __forceinline__ int stage_operand_w_checked(const Consts &c, float4 *
 __device__ __forceinline__ bool stage_operand_ps_scaled(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
                                                         const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, false, true)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return false;
+    if (nst == 0) return true;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
@@ -1644,16 +1585,19 @@ template <bool SCALED>
 __device__ __forceinline__ int stage_operand_ps_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
                                                         const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, 0, 1)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 1;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
     float sc[kStageTrips][kStageBatch];
     int any = 0;
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         if (t * kStageBatch * kBlock >= nst) break;
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) sc[t][u] = S[x.j[t][u]];                      // (indices past the count: clamped duplicates or stale slots -- not examined)
+        for (int u = 0; u < kStageBatch; ++u) sc[t][u] = S[x.j[t][u]];                      // (clamped indices: duplicates of valid slots)
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) any |= (sc[t][u] != 0.f && (int)threadIdx.x + (t * kStageBatch + u) * kBlock < nst) ? 1 : 0;
+        for (int u = 0; u < kStageBatch; ++u) any |= sc[t][u] != 0.f;
     }
     if (!__syncthreads_or(any)) return 2;
 #pragma unroll
@@ -1755,7 +1699,10 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
                                                  const float4 *__restrict__ A, const float4 *__restrict__ B,
                                                  const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, false, true)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return false;
+    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
@@ -1782,16 +1729,19 @@ __device__ __forceinline__ int stage_operand_pv_checked(const Consts &c, float4 
                                                         const float4 *__restrict__ A, const float4 *__restrict__ B, const unsigned char *__restrict__ changed,
                                                         const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, 0, 1)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return 0;
+    if (nst == 0) return 1;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
     int any = 0;
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         if (t * kStageBatch * kBlock >= nst) break;
         unsigned char f[kStageBatch];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) f[u] = changed[x.j[t][u]];                     // (indices past the count: not examined)
+        for (int u = 0; u < kStageBatch; ++u) f[u] = changed[x.j[t][u]];                     // (clamped indices: duplicates of valid slots)
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) any |= (f[u] != 0 && (int)threadIdx.x + (t * kStageBatch + u) * kBlock < nst) ? 1 : 0;
+        for (int u = 0; u < kStageBatch; ++u) any |= f[u];
     }
     if (!__syncthreads_or(any)) return 2;
 #pragma unroll

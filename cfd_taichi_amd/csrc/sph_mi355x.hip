@@ -141,8 +141,6 @@ struct SphHandle {
     // ordered on the stream, [5] all-reduces through the host, [6] steps
     long long comm_stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint2 *stage_src = nullptr;          // cell runs of every workgroup's staged set (kStageMaxCells per workgroup)
-    uint32_t *stage_flat = nullptr;      // Consts.stage_flat: the runs expanded once per step (k_stage_flatten)
-    bool opt_stage_flat = true;          // SPH_STAGE_FLAT=0: every sweep expands the runs itself (A/B)
     int *stage_cnt = nullptr;
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
     DevScalars *ds = nullptr;    // device
@@ -926,7 +924,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         h->c.stage_cap = h->staged ? std::min(std::max(cap ? atoi(cap) : 1664, 64), 2560) : 0;
         if (h->staged) {
             if ((rc = dalloc(h, &h->stage_src, (n + kBlock - 1) / kBlock * (size_t)kStageMaxCells))) return rc;
-            if (h->opt_stage_flat && is_dfsph(h) && (rc = dalloc(h, &h->stage_flat, (n + kBlock - 1) / kBlock * (size_t)h->c.stage_cap + kStageTrips * kStageBatch * kBlock))) return rc;
             if ((rc = dalloc(h, &h->stage_cnt, (n + kBlock - 1) / kBlock))) return rc;
             if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip) {
                 if ((rc = dalloc(h, &h->dens_hot, (n + kBlock - 1) / kBlock + 1))) return rc;
@@ -1010,7 +1007,6 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
     }
-    h->c.stage_flat = h->stage_flat;
 
     // upload the scene
     std::vector<float4> p4((size_t)h->n_owned);
@@ -1956,8 +1952,6 @@ int stage_sort_and_lists(SphHandle *h)
         else SPH_BNL(false, false);
 #undef SPH_BNL
 #undef SPH_BNL_SPLIT
-        if (h->staged && h->stage_flat)      // the staging plan's runs expanded once for all of this step's sweeps (Consts.stage_flat)
-            hipLaunchKernelGGL(k_stage_flatten, dim3((unsigned)std::max(1, h->nblocks)), b, 0, s, h->stage_src, h->stage_cnt, c.stage_cap, h->stage_flat, gate);
     }
     if (rx_split(h)) {       // tiles with a rigid sample in reach (32-bit lists) first: the exact RIGID sweeps take them, the relaxed sweeps the rest
         ProfScope ps(h, K_BUILD_NL);
@@ -3057,7 +3051,6 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
-    { const char *e = dev_env(&h->overrides, "SPH_STAGE_FLAT"); h->opt_stage_flat = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }

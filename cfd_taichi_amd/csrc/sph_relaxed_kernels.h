@@ -41,7 +41,10 @@ __device__ __forceinline__ float rx_g(const Consts &c, float dx, float dy, float
 __device__ __forceinline__ bool stage_operand_ps(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
                                                  const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
 {
-    SPH_STAGE_INDICES(nst, x, false, true)
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    if (nst < 0) return false;
+    if (nst == 0) return true;
+    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
