@@ -1369,6 +1369,20 @@ __device__ __forceinline__ void fin_ride_block(const FinRide &fr)
 }
 
 
+// The loop-control block handed to the host WITHOUT a copy command and an interrupt: the workgroup writes it to pinned host memory (mapped into the
+// device's address space), fences at system scope and stores a sequence number behind it; the host thread spins on that number (read_scalars_fast
+// in sph_mi355x.hip).  A dfsph step needs the density loop's verdict before it can enqueue the integrator; through hipMemcpyAsync +
+// hipStreamSynchronize that round trip left the GPU idle for 36 us per step (profiles/r05: the gap between the copy and k_dfsph_integrate).
+struct DevScalarsPub { DevScalars ds; unsigned long long seq; };
+__global__ __launch_bounds__(kBlock) void k_publish_scalars(const DevScalars *__restrict__ ds, DevScalarsPub *__restrict__ out, unsigned long long seq)
+{
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ds);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&out->ds);
+    for (int w = threadIdx.x; w < (int)(sizeof(DevScalars) / 4); w += kBlock) dst[w] = src[w];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_ctrl_begin(DevScalars *__restrict__ ds, int dens_cap)
 {
     ctrl_begin_body(ds, dens_cap);

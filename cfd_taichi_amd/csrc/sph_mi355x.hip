@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -145,6 +147,8 @@ struct SphHandle {
     double *psum = nullptr; int *pcnt = nullptr; float *pmax = nullptr;
     DevScalars *ds = nullptr;    // device
     DevScalars *ds_host = nullptr;   // pinned mirror
+    DevScalarsPub *pub_host = nullptr, *pub_dev = nullptr;      // the same block as the device publishes it itself (k_publish_scalars): pinned, mapped
+    unsigned long long pub_seq = 0;
     float *staging = nullptr;    // 3*max(N,Nb) floats, device
     // host copies of the wall particles in original order (for download)
     std::vector<float> wall_pos_host, wall_vol_host;
@@ -998,6 +1002,13 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     }
     if ((rc = dalloc(h, &h->ds, 1))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
+    if (hipHostMalloc((void **)&h->pub_host, sizeof(DevScalarsPub), hipHostMallocMapped) == hipSuccess) {
+        memset(h->pub_host, 0, sizeof(DevScalarsPub));
+        if (hipHostGetDevicePointer((void **)&h->pub_dev, h->pub_host, 0) != hipSuccess) { (void)hipHostFree(h->pub_host); h->pub_host = nullptr; h->pub_dev = nullptr; }
+    } else {
+        (void)hipGetLastError();
+        h->pub_host = nullptr;
+    }
     size_t stg = 3 * std::max(n, (size_t)h->Nb);
     if ((rc = dalloc(h, &h->staging, stg))) return rc;
 
@@ -1031,14 +1042,42 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     return SPH_OK;
 }
 
+// the sharded per-build maxima of the list lengths (note_list_lengths), folded into ds_host after a read-back
+inline void fold_list_maxima(SphHandle *h)
+{
+    for (int k = 0; k < kNoteShards; ++k) {
+        h->ds_host->max_nbrs = std::max(h->ds_host->max_nbrs, h->ds_host->nbr_shard[k]);
+        h->ds_host->max_wall_nbrs = std::max(h->ds_host->max_wall_nbrs, h->ds_host->wall_shard[k]);
+    }
+}
+int read_scalars(SphHandle *h);
+// read_scalars for the read-back a solver loop waits on: the device writes the block to mapped host memory itself and the host spins on its
+// sequence number (k_publish_scalars) -- no copy command, no interrupt.  Falls back to the copy if the block has not arrived after 2 ms.
+int read_scalars_fast(SphHandle *h)
+{
+    if (!h->pub_dev) return read_scalars(h);
+    const unsigned long long seq = ++h->pub_seq;
+    hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(kBlock), 0, h->stream, h->ds, h->pub_dev, seq);
+    volatile unsigned long long *flag = &h->pub_host->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (*flag != seq) {
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));          // (a long chunk, or a launch that failed: the stream's status tells)
+            if (*flag != seq) return read_scalars(h);
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(h->ds_host, &h->pub_host->ds, sizeof(DevScalars));
+    fold_list_maxima(h);
+    return SPH_OK;
+}
 int read_scalars(SphHandle *h)
 {
     HIP_TRY(h, hipMemcpyAsync(h->ds_host, h->ds, sizeof(DevScalars), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (int k = 0; k < kNoteShards; ++k) {      // the sharded per-build maxima of the list lengths (note_list_lengths)
-        h->ds_host->max_nbrs = std::max(h->ds_host->max_nbrs, h->ds_host->nbr_shard[k]);
-        h->ds_host->max_wall_nbrs = std::max(h->ds_host->max_wall_nbrs, h->ds_host->wall_shard[k]);
-    }
+    fold_list_maxima(h);
     return SPH_OK;
 }
 
@@ -2513,7 +2552,7 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
             if (rigid_coupled(h)) launch_rigid_force(h, GATE_DENS_D7);
             if ((rc = ghosts_v(h->VA[0]))) return rc;
         }
-        if ((rc = read_scalars(h))) return rc;
+        if ((rc = read_scalars_fast(h))) return rc;
         if (first) {
             if ((rc = check_overflow_all(h, slab_async(h)))) return rc;     // first read-back of the step: list overflow?
             first = false;
@@ -3138,6 +3177,7 @@ void sph_destroy(SphHandle *h)
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->col_hist_host) (void)hipHostFree(h->col_hist_host);
     if (h->ds_host) (void)hipHostFree(h->ds_host);
+    if (h->pub_host) (void)hipHostFree(h->pub_host);
     if (h->ev_edge) (void)hipEventDestroy(h->ev_edge);
     if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
     if (h->xstream) { (void)hipStreamSynchronize(h->xstream); (void)hipStreamDestroy(h->xstream); }
