@@ -47,7 +47,7 @@ struct TilePhase { const int *order; int ntiles, phase; int shift = 0; const int
 // start at once instead of wherever their index falls among thousands that leave.  Which workgroup serves which tile cannot change a bit.
 // shift = 1: workgroup 0 of the launch is not a tile's -- it takes the loop decision of the sweep BEFORE this one (fin_ride_block) -- and workgroup
 // b serves the tile that workgroup b - 1 of a grid one smaller would (phase 0, one GPU)
-// Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_mi355x.hip: step_dfsph_device_loops): the correction of
+// Slab handles that hide the residual's all-reduce behind the next divergence correction (sph_host_dfsph.h: step_dfsph_device_loops): the correction of
 // evaluation e runs before decision e is known and leaves the velocities and warm_start_k it overwrote in SpecSave; if decision e closed the loop
 // (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
 struct SpecSave { float4 *v; float *w; };
@@ -1371,7 +1371,7 @@ __device__ __forceinline__ void fin_ride_block(const FinRide &fr)
 
 // The loop-control block handed to the host WITHOUT a copy command and an interrupt: the workgroup writes it to pinned host memory (mapped into the
 // device's address space), fences at system scope and stores a sequence number behind it; the host thread spins on that number (read_scalars_fast
-// in sph_mi355x.hip).  A dfsph step needs the density loop's verdict before it can enqueue the integrator; through hipMemcpyAsync +
+// in sph_host_scene.h).  A dfsph step needs the density loop's verdict before it can enqueue the integrator; through hipMemcpyAsync +
 // hipStreamSynchronize that round trip left the GPU idle for 36 us per step (profiles/r05: the gap between the copy and k_dfsph_integrate).
 struct DevScalarsPub { DevScalars ds; unsigned long long seq; };
 __global__ __launch_bounds__(kBlock) void k_publish_scalars(const DevScalars *__restrict__ ds, DevScalarsPub *__restrict__ out, unsigned long long seq)

@@ -157,7 +157,7 @@ def test_development_overrides_need_sph_dev():
 
 def test_loopback_stand_in_exports_what_the_native_transport_binds():
     """tests/loopback_rccl.hip (test infrastructure: the in-process stand-in for librccl, loaded through the development override SPH_RCCL_LIB)
-    must export every entry point csrc/sph_mi355x.hip's RcclApi looks up -- otherwise the GPU suite's loopback tests would fall back to nothing."""
+    must export every entry point the library's RcclApi (csrc/sph_host_transport.h) looks up -- otherwise the GPU suite's loopback tests would fall back to nothing."""
     import ctypes
     import importlib.util
     spec = importlib.util.spec_from_file_location("loopback_worker", os.path.join(ROOT, "tests", "loopback_worker.py"))
@@ -168,7 +168,7 @@ def test_loopback_stand_in_exports_what_the_native_transport_binds():
     except Exception as e:  # noqa: BLE001 - a box without hipcc / the rccl headers: test infrastructure, not the product
         pytest.skip("tests/loopback_rccl.hip does not build here: %s" % e)
     so = ctypes.CDLL(path)
-    text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
+    text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_host_transport.h")).read()          # (a section of sph_mi355x.hip's translation unit)
     bound = sorted(set(re.findall(r'SPH_RCCL_SYM\([A-Za-z]+, "(nccl[A-Za-z]+)"\)', text)))
     assert len(bound) == 9, bound
     for name in bound:

@@ -156,7 +156,7 @@ def test_replan_rule_properties():
 
 
 def test_balanced_cuts_are_optimal_on_small_cases():
-    """The cut planner (balanced_cuts in csrc/sph_mi355x.hip, through sph_replan_slabs): the largest load -- 4 x particles + 5 x the particles of the
+    """The cut planner (balanced_cuts in csrc/sph_host_scene.h, through sph_replan_slabs): the largest load -- 4 x particles + 5 x the particles of the
     ghost columns beyond each cut, in quarters of a particle -- is the smallest any admissible set of cuts can reach (brute force over all of them)."""
     rng = np.random.default_rng(11)
     gx, nslab = 15, 3

@@ -222,7 +222,7 @@ def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_re
         assert a["x_hi"] == b["x_lo"]
     static = run_slabs(tmp_path, scene, world, steps, rebalance=0)
     assert static["pos_equal"]
-    # the cuts balance particles + ghosts (balanced_cuts in sph_mi355x.hip): compare what they balance; every slab keeps >= 3 columns -- ghost
+    # the cuts balance particles + ghosts (balanced_cuts in csrc/sph_host_scene.h): compare what they balance; every slab keeps >= 3 columns -- ghost
     # layers + 1 -- which on these 21-column scenes leaves the re-cut little room: one column's worth of slack
     load = lambda res: max(s["owned"] + s["ghosts"] for s in res["slabs"])   # noqa: E731
     assert load(r) <= load(static) + r["n"] // 8, (r["slabs"], static["slabs"])
