@@ -151,7 +151,8 @@ def test_development_overrides_need_sph_dev():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     # every knob of the library goes through the gate: no bare getenv("SPH_...") is left in the product sources
-    text = open(os.path.join(ROOT, "cfd_taichi_amd", "csrc", "sph_mi355x.hip")).read()
+    csrc = os.path.join(ROOT, "cfd_taichi_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)))
     assert re.findall(r'[^_a-z]getenv\("SPH_(?!DEV")', text) == []
 
 
