@@ -72,15 +72,15 @@ def dfsph_steps_equal(sim, o, nsteps, label):
     return counts
 
 
-def test_dfsph_1m_steps_56_to_58_bit_exact():
+def test_dfsph_1m_steps_56_to_57_bit_exact():
     """Config 3 where the bench times it: the handle of bench.py's default line (Morton order, LDS staging, 16-bit lists, k/rho array),
-    55 steps in, then steps 56-58 against the oracle."""
+    55 steps in, then steps 56-57 against the oracle (tools/soak_oracle.py: every step of the bench's window)."""
     cfg = scenes.get("dfsph_1m")
     sim = nat.Simulation(nat.config_from_dict(cfg))
     pre = [sim.step_dfsph(1) for _ in range(55)]
     assert pre[-1].n_dens >= 8, "expected the collapsing phase (n_dens ~ 12), got n_dens = %d" % pre[-1].n_dens
     o = hand_over_dfsph(sim, cfg)
-    counts = dfsph_steps_equal(sim, o, 3, "dfsph_1m @55")
+    counts = dfsph_steps_equal(sim, o, 2, "dfsph_1m @55")
     assert min(c[1] for c in counts) >= 8
     sim.close(); o.close()
 
@@ -143,19 +143,21 @@ def test_wcsph_250k_steps_151_to_155_bit_exact():
 
 def test_dfsph_rigid_2m_two_coupled_steps_bit_exact():
     """Config 5 at full size against the oracle (round 2 had properties only): 2 coupled steps from rest -- fluid state, force on the
-    body, body state, iteration counts, residuals."""
+    body, body state, iteration counts, residuals.  The density loop's cap is 40 on both sides here (the reference has none; the library's
+    default of 100, which step 2 runs into on this scene, is what tools/soak_oracle.py and test_config5_dfsph_rigid_2m_full_size run with)."""
     cfg = scenes.get("dfsph_rigid_2m")
     rg = mesh.rigid_from_config(cfg)
-    sim = nat.Simulation(nat.config_from_dict(cfg), rigid=rg)
+    sim = nat.Simulation(nat.config_from_dict(cfg, max_density_iters=40), rigid=rg)
     o = orc.Oracle(cfg, num_threads=cores(), rigid=rg)
     assert (sim.n_fluid, sim.n_wall, sim.n_rigid) == (o.N, o.Nb, o.Nr) and sim.n_fluid == 2006400
     for s in range(2):
         t0 = time.time()
         st = sim.step_dfsph(1)
-        o.step_dfsph(1, 100)
+        o.step_dfsph(1, 40)
         so = o.last_stats
         assert (st.n_div, st.n_dens, st.n_div_evals, st.div_first_err, st.div_err, st.dens_err, st.dt) == (
             so.n_div, so.n_dens, so.n_div_evals, so.div_first_err, so.div_err, so.dens_err, so.dt), s
+        assert st.n_dens <= 40 and st.capped == (1 if st.n_dens == 40 and so.dens_err > 1.0 else 0), (s, st.n_dens, st.capped)
         same(sim.download(nat.F_RIGID_FORCE, nat.SPECIES_RIGID), o.get(orc.F_RIGID_FORCE), "force on the body, step %d" % s)
         sim.rigid_step()
         o.rigid_step()

@@ -76,7 +76,7 @@ def test_pressure_solvers_on_slabs(tmp_path, scene, world, steps):
 
 
 @pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap", [
-    ("dfsph_small", 3, 25, 0, 1, 0), ("dfsph_dam_x", 3, 200, 7, 1, 0), ("dfsph_dam_x", 3, 200, 7, 2, 1), ("breaking_dam_30k_dfsph", 4, 12, 3, 2, 0)])
+    ("dfsph_small", 3, 25, 0, 1, 0), ("dfsph_dam_x", 3, 140, 7, 1, 0), ("dfsph_dam_x", 3, 140, 7, 2, 1), ("breaking_dam_30k_dfsph", 4, 12, 3, 2, 0)])
 def test_ghost_column_protocols_agree(tmp_path, scene, world, steps, rebalance, layers, overlap):
     # (with the split on, the residual's all-reduce + loop decision also run on a third stream under the next correction sweep: the density loop's D7
     # needs no speculation, the divergence loop's D4 runs ahead of its decision and is undone when the decision closes the loop -- from rest that is
