@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--one-gpu", action="store_true", help="with a replay: time the same steps of the whole scene on a one-GPU handle in the same process")
     ap.add_argument("--overflow-rank", type=int, default=-1, help="this rank's handle gets --max-neighbors list rows: its lists overflow, and EVERY rank must fail the step")
     ap.add_argument("--max-neighbors", type=int, default=0)
+    ap.add_argument("--param", action="append", default=[], help="name=value: a solver attribute (sph_set_scalar SPH_P_*) set on every slab handle AND on the one-GPU reference")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     os.environ["SPH_DEV"] = "1"
@@ -65,6 +66,10 @@ def main():
                                                                           slab_ghost_layers=args.layers, slab_overlap=args.overlap, arith=args.arith,
                                                                           max_neighbors=args.max_neighbors if r == args.overflow_rank else 0), rigid=rigid)
                                      for r in range(world)]
+    params = [(kv.split("=")[0], float(kv.split("=")[1])) for kv in args.param]
+    for sim_ in sims:
+        for k_, v_ in params:
+            sim_.set_param(k_, v_)
     wcsph = nat.config_from_dict(cfg).solver == nat.SOLVER_IDS["wcsph"]
     uid = nat.rccl_unique_id()
     shim = None
@@ -181,6 +186,8 @@ def main():
         pos, vel, rho = gather(nat.F_POS), gather(nat.F_VEL), gather(nat.F_RHO)
         bodies = [{"scalars": s.rigid_scalars(), "pos": s.download(nat.F_RIGID_POS, nat.SPECIES_RIGID).tolist()} for s in sims] if rigid else None
         ref = nat.Simulation(nat.config_from_dict(cfg, arith=args.arith), rigid=rigid)
+        for k_, v_ in params:
+            ref.set_param(k_, v_)
         ref_stats = []
         for _ in range(args.steps):
             if wcsph:

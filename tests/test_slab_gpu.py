@@ -188,6 +188,23 @@ def test_a_list_overflow_on_one_slab_fails_every_slab(tmp_path, scene, world, ba
     assert len(set(r["steps_done"])) == 1, r          # ... in the same step
 
 
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_solver_attributes_on_slab_handles(tmp_path, overlap):
+    """sph_set_scalar(SPH_P_*) on slab handles (every rank sets the same): a shorter divergence loop, no warm start, a tighter density threshold and another
+    tension -- the in-order protocol (the decision in the unpack launch's last workgroup) and the overlapped one (the correction running ahead of a
+    decision that now closes the loop after at most four iterations: its undo path) against one GPU with the same attributes, bit for bit."""
+    out = tmp_path / "params.json"
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "loopback_worker.py"), "--scene", "breaking_dam_30k_dfsph", "--world", "3", "--steps", "25",
+           "--rebalance", "7", "--overlap", str(overlap), "--out", str(out)]
+    for kv in ("max_iteration_density_divergence=4", "density_divergence_threshold=200", "warm_start=0", "density_threshold=0.05", "tension_k=1.5"):
+        cmd += ["--param", kv]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, SPH_SLAB_CHECK="1", SPH_CELL_ORDER="morton"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = json.loads(out.read_text())
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"] and r["stats_same_on_all_ranks"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "stats_last", "ref_stats_last")}
+    assert r["stats_last"][0] <= 4
+
+
 def test_slab_protocol_can_be_switched_between_steps(tmp_path):
     """sph_slab_set_overlap: the dfsph loops with the halo and the reductions on their own streams, or in order on the handle's -- switched every
     seven steps on every rank alike (bench.py times both on the node it runs on and keeps the faster): the same bits as one GPU throughout."""
