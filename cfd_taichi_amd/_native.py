@@ -241,6 +241,7 @@ def load(build_if_missing=True):
     lib.sph_selftest_wave.argtypes = [ci, ci, vp, vp, ctypes.c_size_t]
     lib.sph_tune_time.argtypes = [vp, ci, ctypes.c_uint, ci, ctypes.POINTER(ctypes.c_double)]
     lib.sph_set_comm.argtypes = [vp, ctypes.POINTER(SphComm)]
+    lib.sph_set_comm_sized.argtypes = [vp, ctypes.POINTER(SphComm), ctypes.c_size_t]
     lib.sph_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     lib.sph_rccl_unique_id.argtypes = [vp]
     lib.sph_rccl_attach.argtypes = [vp, vp, ctypes.c_size_t]
@@ -480,9 +481,14 @@ class Simulation:
         return out
 
     # ---- multi-GPU slab handles ----
-    def set_comm(self, comm):
+    def set_comm(self, comm, struct_size=None):
+        """struct_size: what a caller built against an older, shorter SphComm would pass as sizeof(SphComm) (sph_set_comm_sized): the fields
+        beyond it read as 0 / NULL whatever this structure holds there."""
         self._comm = comm            # keep the callbacks and buffers alive
-        self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
+        if struct_size is None:
+            self._check(self._lib.sph_set_comm(self._h, ctypes.byref(comm)))
+        else:
+            self._check(self._lib.sph_set_comm_sized(self._h, ctypes.byref(comm), int(struct_size)))
 
     def rccl_attach(self, unique_id, capacity_bytes=64 << 20):
         """Collective over all slabs: the library opens its own RCCL communicator (native transport, no callbacks)."""

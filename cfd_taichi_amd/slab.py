@@ -217,7 +217,7 @@ class SlabSimulation:
     """One rank's share of a sharded simulation: a slab handle plus its transport."""
 
     def __init__(self, config, rank, world, device=0, solver_name=None, capacity_bytes=64 << 20, slab_capacity=0, rebalance_every=0,
-                 transport="torch", group=None, host_loops=False, **native_opts):
+                 transport="torch", group=None, host_loops=False, comm_struct_size=None, **native_opts):
         """transport: "torch" (TorchComm callbacks: RCCL through torch.distributed, or gloo) or "native" (the library opens its
         own RCCL communicator and issues the transfers itself; one GPU per rank required)."""
         self.rank, self.world = rank, world
@@ -238,7 +238,7 @@ class SlabSimulation:
         else:
             self.comm = TorchComm(rank, world, device=device, capacity_bytes=capacity_bytes, group=group, stream_ptr=self.sim.stream_ptr(),
                                   reduce_capacity=4 * self.sim.n_rigid + 8 if rigid else 4, host_loops=host_loops)
-            self.sim.set_comm(self.comm.struct)
+            self.sim.set_comm(self.comm.struct, comm_struct_size)
         self.n_fluid = self.sim.n_fluid
 
     def step(self, nsteps=1):

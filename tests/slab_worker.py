@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="SphConfig.slab_ghost_layers (0 = the solver's default)")
     ap.add_argument("--overlap", type=int, default=0, help="SphConfig.slab_overlap (0 = default on, 1 = off)")
     ap.add_argument("--arith", type=int, default=0, help="SphConfig.arith on the slabs AND on the one-GPU reference")
+    ap.add_argument("--old-comm", action="store_true", help="hand the transport over as a caller built against the round-3 SphComm would: without exchange_counts_n / reduce_capacity (sph_set_comm_sized)")
     ap.add_argument("--host-loops", action="store_true", help="a transport without allreduce_stream: the library runs the dfsph loops on the host")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
@@ -40,7 +41,8 @@ def main():
     from cfd_taichi_amd.slab import SlabSimulation
     cfg = json.load(open(args.scene)) if os.path.exists(args.scene) else scenes.get(args.scene)
     sim = SlabSimulation(cfg, rank, world, device=device, rebalance_every=args.rebalance, slab_ghost_layers=args.layers, slab_overlap=args.overlap,
-                         arith=args.arith, host_loops=args.host_loops)
+                         arith=args.arith, host_loops=args.host_loops,
+                         comm_struct_size=nat.SphComm.exchange_counts_n.offset if args.old_comm else None)
     dfsph = sim.solver != "wcsph"      # every solver but wcsph reports per-step statistics
     stats = []
     owned_max = 0

@@ -218,6 +218,20 @@ def test_slab_protocol_can_be_switched_between_steps(tmp_path):
     assert all(not s["halo_overlapped"] for s in r["slabs"])          # 45 steps: the last switch (step 42) turned it off
 
 
+def test_a_caller_with_an_older_sphcomm(tmp_path):
+    """SphComm grew by exchange_counts_n and reduce_capacity; a caller built against the shorter structure passes its own sizeof through
+    sph_set_comm_sized and the library reads the missing fields as NULL / 0 -- the count exchange then goes through exchange_counts, one int at a time."""
+    out = tmp_path / "oldcomm.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "tests", "slab_worker.py"), "--scene", "dfsph_small", "--steps", "12", "--backend", "gloo", "--old-comm", "--out", str(out)]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", SPH_SLAB_CHECK="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r = json.loads(out.read_text())
+    assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], r
+    # five ints per side went out one at a time: five count exchanges per step where the merged form needs one
+    assert r["lib_comm"]["count_exchanges"] >= 5 * 12, r["lib_comm"]
+
+
 def test_legacy_host_loops_on_slabs(tmp_path):
     """A transport without allreduce_stream (the minimal SphComm): the library runs the dfsph loops on the host, one read-back + host all-reduce
     per residual, and agrees."""
