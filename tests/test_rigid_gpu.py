@@ -52,7 +52,7 @@ def test_density_alpha_count_with_rigid_neighbours():
     sim.close(); o.close()
 
 
-@pytest.mark.parametrize("scene,steps", [("dfsph_rigid_small", 120), ("dfsph_rigid_tilted", 60)])
+@pytest.mark.parametrize("scene,steps", [("dfsph_rigid_small", 120), ("dfsph_rigid_tilted", 45)])
 def test_coupled_steps(scene, steps):
     cfg, sim, o = make(scene)
     moved = False

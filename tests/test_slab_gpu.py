@@ -240,7 +240,7 @@ def test_legacy_host_loops_on_slabs(tmp_path):
     assert r["comm"]["allreduce_stream"] == 0 and r["comm"]["allreduce"] > 12
 
 
-@pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 110, 1), ("wcsph_dam_x", 2, 1400, 1)])
+@pytest.mark.parametrize("scene,world,steps,min_recuts", [("dfsph_dam_x", 3, 80, 1), ("wcsph_dam_x", 2, 1400, 1)])
 def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_recuts):
     """cuts re-chosen every M steps.  The dam runs along x, the cuts follow it, the result stays bit-identical
     and the largest slab stays smaller than with static cuts."""
