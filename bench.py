@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-overlap-probe", action="store_true", help="N > 1, dfsph: keep the overlapped slab protocol without timing it against the in-order one")
     ap.add_argument("--rebalance", type=int, default=int(os.environ.get("SPH_REBALANCE_EVERY", "50")),
                     help="N>1: re-cut the x-slabs from the current particle distribution every M steps (0 = static cuts)")
+    ap.add_argument("--first-contact", action="store_true",
+                    help="(internal) N>1: run ONLY the transport probe and the discipline self-check and report each stage on stdout -- the short child job "
+                         "first_contact_probe() starts under a wall-clock limit before the measuring ranks touch RCCL")
     return ap.parse_args()
 
 
@@ -358,7 +361,7 @@ def pick_transport(dist, torch, rank, world, local_rank, gloo):
     return gloo, "gloo (host staged: RCCL probe failed)"
 
 
-def choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance, gloo):
+def choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, rebalance, gloo, note=None):
     """Which RCCL discipline drives the halo: "native" (the library issues ncclSend / ncclRecv / ncclAllReduce itself on its stream),
     "stream" (torch.distributed calls ordered on the library's stream) or "sync" (host waits around every transfer).  The faster ones
     are only used if two steps of the workload give the very bytes the synchronous discipline gives (SHA-1 of every rank's owned
@@ -395,12 +398,190 @@ def choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, to
     ref = digest("sync")
     if ref is None:
         return "sync", "the synchronous discipline itself failed in the self-check on some rank"
+    if note:
+        note("sync_ok")
     wanted = [m for m in os.environ.get("SPH_SLAB_DISCIPLINES", "native,stream").split(",") if m in ("native", "stream")]
     for mode in wanted:
         d = digest(mode)
         if agreed(d is not None and d == ref):
             return mode, "2 steps reproduce the synchronous discipline byte for byte"
     return "sync", "no faster discipline reproduced it"
+
+
+# ---- first contact with real RCCL, bounded ---------------------------------------------------------------------------
+# `bench.py --gpus N` is a chain of code that has never met librccl with more than one rank: the nccl process group, the halo probe, three
+# handle generations of the discipline self-check.  Every step has a sound fallback for an EXCEPTION; none has one for a HANG, and a hang in a
+# measuring rank ends as the driver's timeout with no line at all.  So the chain first runs in a short-lived CHILD job of fresh processes
+# (`bench.py --first-contact`: same ranks, same GPUs, the small dfsph_1m scene) under a wall-clock limit; the child reports every stage it
+# completes on stdout, and what it proved -- not what it hoped -- is handed to the measuring ranks through the environment
+# (FIRST_CONTACT_ENV).  They then only execute what a fresh process has already survived:
+#   child finished              -> its verdict (transport rccl | gloo, discipline native | stream | sync)
+#   stuck after "sync_ok"       -> rccl transport, synchronous discipline (the faster ones hung or never answered)
+#   stuck after "transport"     -> whatever transport the probe chose; over rccl nothing beyond the probe is proven: gloo host staging
+#   stuck before that           -> the nccl process group itself is suspect: gloo backend, gloo host staging
+# The child is a process GROUP of its own and is killed as one on expiry; a rank that has touched the GPU is never re-executed.
+FIRST_CONTACT_ENV = "SPH_BENCH_FIRST_CONTACT"
+FIRST_CONTACT_TAG = "FIRST_CONTACT "
+# seconds a stage may take after the one before it was reported (the first import of torch on a fresh box pages the image in: up to 2 minutes)
+FIRST_CONTACT_LIMITS = {"start": 60.0, "import": 240.0, "init": 90.0, "transport": 60.0, "sync_ok": 90.0, "discipline": 90.0}
+FIRST_CONTACT_TOTAL = 420.0
+FIRST_CONTACT_ORDER = ("start", "import", "init", "transport", "sync_ok", "discipline")
+
+
+def first_contact_verdict(stages, finished, why):
+    """What the measuring ranks may rely on, from the stages the child reported ({stage: payload})."""
+    v = {"backend": "gloo", "transport": "gloo", "discipline": None, "reached": [k for k in FIRST_CONTACT_ORDER if k in stages], "how": why}
+    if finished and "discipline" in stages:
+        v.update(backend="nccl", transport=stages["transport"].get("transport", "gloo"), discipline=stages["discipline"].get("discipline"))
+    elif "sync_ok" in stages and stages.get("transport", {}).get("transport") == "rccl":
+        v.update(backend="nccl", transport="rccl", discipline="sync")
+    elif stages.get("transport", {}).get("transport") == "gloo":
+        v.update(backend="nccl", transport="gloo")
+    return v
+
+
+def first_contact_probe(nproc, rebalance=0, cmd=None, limits=None, total=None):
+    """Start the child job, follow its stage lines under the limits, kill its process group on expiry.  Nothing here imports torch or touches
+    the GPU.  `cmd` replaces the child's command line (tests/test_first_contact.py hangs a stub at every stage)."""
+    import queue
+    import signal
+    import socket
+    import subprocess
+    import threading
+    limits = dict(FIRST_CONTACT_LIMITS, **(limits or {}))
+    total = FIRST_CONTACT_TOTAL if total is None else total
+    if cmd is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__), "--first-contact", "--gpus", str(nproc), "--rebalance", str(rebalance)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                                                 "MASTER_PORT", FIRST_CONTACT_ENV) and not k.startswith("TORCHELASTIC_")}
+    t0 = time.monotonic()
+    print("[bench] first contact with RCCL in a child job (limit %.0f s): %s" % (total, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, start_new_session=True, text=True, bufsize=1)
+    lines = queue.Queue()
+
+    def pump():
+        for line in child.stdout:
+            lines.put(line)
+        lines.put(None)
+
+    threading.Thread(target=pump, daemon=True).start()
+    stages, nxt, finished, why = {}, 0, False, None
+    stage_deadline = t0 + limits[FIRST_CONTACT_ORDER[0]]
+    while True:
+        now = time.monotonic()
+        wait = min(stage_deadline, t0 + total) - now
+        if wait <= 0:
+            why = "no '%s' within %.0f s (child killed after %.0f s)" % (FIRST_CONTACT_ORDER[min(nxt, len(FIRST_CONTACT_ORDER) - 1)],
+                                                                         limits[FIRST_CONTACT_ORDER[min(nxt, len(FIRST_CONTACT_ORDER) - 1)]], now - t0)
+            break
+        try:
+            line = lines.get(timeout=min(wait, 1.0))
+        except queue.Empty:
+            continue
+        if line is None:                        # stdout closed: the child is ending
+            try:
+                rc = child.wait(timeout=max(1.0, min(30.0, t0 + total - time.monotonic())))
+            except subprocess.TimeoutExpired:
+                rc = None
+            finished = rc == 0 and "discipline" in stages
+            why = "child finished in %.0f s" % (time.monotonic() - t0) if finished else "child ended with code %s after '%s'" % (rc, FIRST_CONTACT_ORDER[nxt - 1] if nxt else "nothing")
+            break
+        if not line.startswith(FIRST_CONTACT_TAG):
+            continue
+        try:
+            msg = json.loads(line[len(FIRST_CONTACT_TAG):])
+        except ValueError:
+            continue
+        st = msg.get("stage")
+        if st in FIRST_CONTACT_ORDER:
+            stages[st] = msg
+            nxt = max(nxt, FIRST_CONTACT_ORDER.index(st) + 1)
+            if nxt < len(FIRST_CONTACT_ORDER):
+                stage_deadline = time.monotonic() + limits[FIRST_CONTACT_ORDER[nxt]]
+            else:
+                stage_deadline = time.monotonic() + 30.0          # everything reported: the job only has to exit
+    if child.poll() is None:                    # expiry, or a child that will not end: the whole process group goes
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            child.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+    v = first_contact_verdict(stages, finished, why)
+    v["seconds"] = round(time.monotonic() - t0, 1)
+    print("[bench] first contact: %s" % json.dumps(v), file=sys.stderr, flush=True)
+    return v
+
+
+def first_contact_for_rank(local_rank, world, rebalance):
+    """The ranks were started by somebody else's launcher (the driver's torch.distributed.run): local rank 0 runs the probe before anything in
+    this process has touched torch or the GPU, the others wait for its verdict (one node: a file keyed by the launcher's pid)."""
+    import tempfile
+    started = time.time()
+    path = os.path.join(tempfile.gettempdir(), "sph_first_contact_%d_%s.json" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    if local_rank == 0:
+        v = first_contact_probe(world, rebalance)
+        v["written_at"] = time.time()
+        tmp = path + ".%d" % os.getpid()
+        with open(tmp, "w") as f:
+            json.dump(v, f)
+        os.replace(tmp, path)
+        return v
+    deadline = time.monotonic() + FIRST_CONTACT_TOTAL + 90.0
+    while time.monotonic() < deadline:
+        try:
+            with open(path) as f:
+                v = json.load(f)
+            if v.get("written_at", 0) >= started - 5.0:      # (not a leftover of an earlier job with the same pid and port)
+                return v
+        except (OSError, ValueError):
+            pass
+        time.sleep(0.2)
+    raise SystemExit("[bench] local rank %d: no first-contact verdict from local rank 0 within %.0f s" % (local_rank, FIRST_CONTACT_TOTAL + 90.0))
+
+
+def first_contact_child(args, rank, world, local_rank):
+    """`bench.py --first-contact` under torch.distributed.run: the chain the measuring ranks would otherwise meet for the first time, on the small
+    scene, every completed stage reported by rank 0 as one tagged JSON line on stdout."""
+    def note(stage, **kw):
+        if rank == 0:
+            print(FIRST_CONTACT_TAG + json.dumps(dict(stage=stage, **kw)), flush=True)
+
+    note("start")
+    import torch
+    import torch.distributed as dist
+    note("import")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    side = dist.new_group(backend="gloo")
+    dist.barrier(group=side)
+    note("init")
+    from cfd_taichi_amd import _native as nat
+    from cfd_taichi_amd import scenes
+    transport_group, transport = pick_transport(dist, torch, rank, world, local_rank, side)
+    note("transport", transport="rccl" if transport_group is None else "gloo", detail=transport)
+    discipline, why = None, "host-staged transport: no discipline to choose"
+    if transport_group is None:
+        if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
+            note("sync_ok")
+            discipline, why = "sync", "forced by SPH_SLAB_SYNC=1"
+        else:
+            try:
+                discipline, why = choose_discipline(nat, scenes, "dfsph_1m", world, rank, local_rank, dist, torch, args.rebalance, side, note=note)
+            except Exception as e:  # noqa: BLE001
+                discipline, why = "sync", "the self-check raised %s" % type(e).__name__
+    else:
+        note("sync_ok")
+    dist.barrier(group=side)
+    note("discipline", discipline=discipline, why=why)
+    dist.destroy_process_group()
+    return 0
 
 
 def self_launch(nproc):
@@ -416,8 +597,13 @@ def self_launch(nproc):
             port = str(sk.getsockname()[1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = None
+    if FIRST_CONTACT_ENV not in os.environ and os.environ.get("SPH_BENCH_REHEARSAL") != "1" and "--first-contact" not in sys.argv:
+        rebalance = sys.argv[sys.argv.index("--rebalance") + 1] if "--rebalance" in sys.argv[:-1] else os.environ.get("SPH_REBALANCE_EVERY", "50")
+        env = dict(os.environ)
+        env[FIRST_CONTACT_ENV] = json.dumps(first_contact_probe(nproc, rebalance))
     print("[bench] no launcher in the environment: starting %s" % " ".join(cmd), file=sys.stderr, flush=True)
-    return subprocess.run(cmd).returncode
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -429,11 +615,19 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
         args.gpus = world
+    if args.first_contact:
+        raise SystemExit(first_contact_child(args, rank, world, local_rank) if world > 1 else "[bench] --first-contact needs N > 1 ranks")
+    rehearsal = os.environ.get("SPH_BENCH_REHEARSAL") == "1"   # all ranks on GPU 0 over gloo: lets a 1-GPU box exercise this file
+    # N > 1 on real GPUs: what a short-lived child job has proven about RCCL on this node (first_contact_probe), from whoever launched us or --
+    # under somebody else's launcher -- from local rank 0, before anything in this process touches torch or the GPU
+    contact = None
+    if world > 1 and not rehearsal and os.environ.get("SPH_BENCH_NO_FIRST_CONTACT") != "1":
+        contact = json.loads(os.environ[FIRST_CONTACT_ENV]) if os.environ.get(FIRST_CONTACT_ENV) else first_contact_for_rank(local_rank, world, args.rebalance)
 
     import torch
     dist = None
     transport_group, transport = None, None
-    rehearsal = os.environ.get("SPH_BENCH_REHEARSAL") == "1"   # all ranks on GPU 0 over gloo: lets a 1-GPU box exercise this file
+    host_backend = rehearsal or (contact is not None and contact["backend"] == "gloo")      # control tensors live on the host
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -441,6 +635,18 @@ def main():
             dist.init_process_group(backend="gloo")
             side = dist.new_group(backend="gloo")
             transport_group, transport = None, "gloo (rehearsal on one GPU)"
+        elif contact is not None:
+            torch.cuda.set_device(local_rank)
+            if contact["backend"] == "gloo":
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            side = dist.new_group(backend="gloo")
+            if contact["transport"] == "rccl":
+                transport_group, transport = None, "rccl p2p (device buffers over xGMI)"
+            else:
+                transport_group, transport = side, "gloo (host staged)"
+            transport += "; chosen by a first-contact child job under a time limit (%s; stages reached: %s)" % (contact["how"], ", ".join(contact["reached"]) or "none")
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -459,6 +665,8 @@ def main():
     if world > 1 and transport_group is None and (not rehearsal or os.environ.get("SPH_BENCH_VERIFY") == "1"):      # RCCL device-to-device transport
         if os.environ.get("SPH_SLAB_SYNC", "0") == "1":
             discipline, why = "sync", "forced by SPH_SLAB_SYNC=1"
+        elif contact is not None:          # the measuring ranks never execute a discipline a fresh process has not survived
+            discipline, why = contact["discipline"] or "sync", "first-contact child job: %s" % contact["how"]
         else:
             try:
                 discipline, why = choose_discipline(nat, scenes, scene_name, world, rank, local_rank, dist, torch, args.rebalance, side)
@@ -540,7 +748,7 @@ def main():
                 run(probe)
                 sim.synchronize()
                 torch.cuda.synchronize()
-                tt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+                tt = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device="cpu" if host_backend else "cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 times[mode] = float(tt[0].item()) / probe * 1e3
             keep = times[True] <= times[False]
@@ -564,7 +772,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed, early], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            t = torch.tensor([elapsed, early], dtype=torch.float64, device="cpu" if host_backend else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, early = float(t[0].item()), float(t[1].item())
             dist.barrier()

@@ -113,7 +113,7 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_BUILD_NL);
         // (the per-build maxima were zeroed by k_hash_count; `overflow` stays sticky until check_overflow reports it)
 #define SPH_BNL(R, S) hipLaunchKernelGGL((k_build_nl<R, S>), g, b, 0, s, c, h->P[h->pcur], h->cell_start, h->WP, h->wcell_start, h->id[h->icur], \
-                                             h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt, gate)
+                                             h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, h->stage_src, h->stage_cnt, gate, h->tile_nbr)
 #define SPH_BNL_SPLIT(R, NW) hipLaunchKernelGGL((k_build_nl_split<R, NW>), dim3((unsigned)std::max(1, (c.n + 63) / 64)), dim3(NW * 64), 0, s, c, h->P[h->pcur], \
                                                 h->cell_start, h->WP, h->wcell_start, h->id[h->icur], h->nl, h->nlb, h->cnt, h->ds, rigid_view_or_none(h), h->ncount, gate)
         // small unstaged scenes: one wave per dx-plane (3) or per (dx, dy) column (9) of the same 64 particles.  Measured (tools/split_sweep.sh):
@@ -316,6 +316,15 @@ inline TilePhase tile_phase(const SphHandle *h, int phase)
     if (phase == 0 && h->dens_order && tile_skip(h)) { tp.hot = h->dens_hot; tp.sparse = h->dens_sparse ? h->dens_order : nullptr; }
     return tp;
 }
+// the density loop's sweeps: who must run is said by the sweep before (DensFlow in sph_kernels.h).  Every sweep takes the next stamp and consumes the
+// stamp of the sweep enqueued before it; d6 = the residual sweep (consumes need6 / pushes need7), else the correction sweep
+inline DensFlow dens_flow(SphHandle *h, bool d6)
+{
+    if (!h->tile_nbr || !tile_skip(h) || h->tune_all) return kNoFlow;
+    DensFlow df{h->tile_nbr, d6 ? h->need6 : h->need7, d6 ? h->need7 : h->need6, h->tile_nz, h->dens_bcast, h->flow_last, ++h->flow_stamp, d6 ? 0 : 1, d6 ? 1 : 0};
+    h->flow_last = df.stamp_out;
+    return df;
+}
 void launch_div_residual(SphHandle *h, int gate, int phase = 0, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, hipStream_t st = nullptr)          // derivative_iter_all_rho sweep, dfsph_solver.py:252-277
 {
     const Consts &c = h->c;
@@ -349,17 +358,18 @@ void launch_correct(SphHandle *h, int kid, const float *src, float4 *V, int gate
     const FinRide fr = ride ? FinRide{h->psum, h->pcnt, h->ds, h->nblocks, ride_mode, partial_group(h), partial_count(h), ride_eval} : kNoRide;
     TilePhase tp0 = tile_phase(h, 0);
     tp0.shift = ride ? 1 : 0;
+    const DensFlow df = (MODE == CORR_DENS && wdirty) ? dens_flow(h, false) : kNoFlow;
     const int n_grid = c.n + (ride ? (sweep_mode(h) == SWEEP_QUAD ? 64 : kBlock) : 0);           // one more workgroup
     if (use_relaxed(h)) {
         hipLaunchKernelGGL(k_correct_rx<MODE>, grid_for(split ? c.n : n_grid), dim3(kBlock), sweep_lds(h, sizeof(float4)), h->stream, c, h->P[h->pcur], h->wall_grad, h->nl, h->cnt,
                            h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tp0, sv, split ? kNoRide : fr);
+                           split ? TilePhase{h->tile_order, h->nblocks, 2} : tp0, sv, split ? kNoRide : fr, df);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_correct, MODE, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), split ? c.n : n_grid, sweep_lds(h, sizeof(float4)), h->stream, c,
                   c.kr_split ? h->P[h->pcur] : h->P[1 - h->pcur], h->WP,
                   h->nl, h->nlb, h->cnt, h->rho, h->aux, src, h->warm[h->wcur], h->ds, V, V, rigid_view_or_none(h), gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8,
-                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tp0, sv, split ? kNoRide : fr);
+                  (const float4 *)wall_cache(h), split ? TilePhase{h->tile_order, h->nblocks, 1} : tp0, sv, split ? kNoRide : fr, df);
 }
 
 void launch_dens_residual(SphHandle *h, int gate, int phase = 0, hipStream_t st = nullptr)          // compute_all_rho_adv sweep, dfsph_solver.py:124-141
@@ -372,15 +382,17 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, hipStream_t st 
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
+    const DensFlow df = wdirty ? dens_flow(h, true) : kNoFlow;
+    const SpecUndo no_undo{nullptr, nullptr, nullptr, nullptr, 0};
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
         hipLaunchKernelGGL(k_residual_rx<true>, grid_for(c.n), dim3(kBlock), sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c, h->P[h->pcur], h->VA[0],
-                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr);
+                           h->wall_grad, h->nl, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->psum, h->pcnt, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, tpr, no_undo, df);
         if (!split) return;
     }
     SPH_LAUNCH_RMX(k_residual, true, rigid_coupled(h), sweep_mode(h), relaxed_unstaged(h), c.n, sweep_lds(h, sizeof(float4) + sizeof(float2)), st, c,
                   h->P[h->pcur], h->VA[0], h->WP, h->nl, h->nlb, h->cnt, h->rho, h->aux, h->ds, h->rho_adv, h->P[1 - h->pcur], h->psum, h->pcnt,
-                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp);
+                  rigid_view_or_none(h), h->ncount, gate, h->stage_src, h->stage_cnt, h->krho, wdirty, h->changed8, force_all, (const float4 *)wall_cache(h), tp, no_undo, df);
 }
 
 // The same in two halves, for the handles that hide the all-reduce (step_dfsph_device_loops): this slab's (sum, count) on the handle's stream ...

@@ -646,6 +646,12 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
             }
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip && h->opt_dens_push && !h->slab) {      // DensFlow (one GPU: a ghost's values change behind the rank's back)
+                const size_t nt = (n + kBlock - 1) / kBlock + 1;
+                if ((rc = dalloc(h, &h->tile_nbr, nt * (size_t)kNbrStride))) return rc;
+                if ((rc = dalloc(h, &h->need6, nt)) || (rc = dalloc(h, &h->need7, nt)) || (rc = dalloc(h, &h->tile_nz, nt))) return rc;
+                if ((rc = dalloc(h, &h->dens_bcast, 64))) return rc;
+            }
             if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
                 if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;
             if (h->relaxed && h->cfg.solver == SPH_SOLVER_DFSPH)      // the relaxed sweeps' per-step wall sums (use_relaxed)

@@ -52,6 +52,44 @@ struct TilePhase { const int *order; int ntiles, phase; int shift = 0; const int
 // (DevScalars.stop_at == e), the residual launch that follows -- its gate is closed -- puts them back, every workgroup its own 256 particles.
 struct SpecSave { float4 *v; float *w; };
 struct SpecUndo { float4 *v_dst; const float4 *v_src; float *w_dst; const float *w_src; int eval; };
+
+// ---- the density loop's sparse launches: the PRODUCER says who must run (round 6; one GPU) ---------------------------------------------------
+// With change propagation (stage_sources_flagged below) 70-89 % of the workgroups of a D6 / D7 launch find their tile unchanged -- but each of
+// them read its staging plan, and D7's even gathered 4 bytes per staged particle, to learn that: ~3.3 us per idle workgroup, a third of the launch.
+// The sweep that WRITES the operand knows which of its tiles changed anything, and k_build_nl knows which tiles stage a tile's particles (cell
+// adjacency is symmetric: the tiles whose particles U stages are the tiles that stage U's): nbr[tile * kNbrStride] = count | flags, then the tiles.
+//   D7 (k_correct<DENS>)  a tile that changed a velocity stores this launch's stamp into need6[t] of every tile t that stages its particles;
+//   D6 (k_residual<DENS>) a tile whose own k / rho holds a nonzero (nz[tile], kept across the launches in which it idles) stores its stamp into need7[t].
+// The consumer reads ONE word: need[tile] == the stamp of the launch before it, or it leaves.  A stamp is a per-handle launch counter, so a stale
+// word never matches and nothing is ever cleared.  A tile that passes goes on to the exact per-particle check as before; the flags only say "maybe".
+// Where the symmetry does not hold the flags say "always": a tile with a particle whose coordinates lie outside the grid (binned into a wrapped
+// cell or nowhere: it walks cells it is not stored in) runs in every launch and, as a producer, raises the broadcast word instead (kNbrOdd); so
+// does a tile whose cell set or tile list did not fit (header -1).
+constexpr int kNbrStride = 64;            // ints per tile in DensFlow.nbr: header + up to 63 tiles
+constexpr int kNbrOdd = 1 << 30;
+struct DensFlow {
+    const int *nbr;                       // nullptr: off (slab handles, SPH_DENS_PUSH=0): the consumers read their staging plans as before
+    const int *need_in; int *need_out;    // stamps per tile: what this launch consumes / produces
+    int *nz;                              // per tile: its own k / rho holds a nonzero
+    int *bcast;                           // [0]: "every tile must run D6", [1]: "... D7" (stamps)
+    int stamp_in, stamp_out, bc_in, bc_out;
+};
+constexpr DensFlow kNoFlow{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+// must this tile run?  (uniform per workgroup: three scalar loads, one round trip)
+__device__ __forceinline__ bool flow_needed(const DensFlow &df, int tile)
+{
+    const int hdr = df.nbr[(size_t)tile * kNbrStride];
+    return hdr < 0 || (hdr & kNbrOdd) != 0 || df.need_in[tile] == df.stamp_in || df.bcast[df.bc_in] == df.stamp_in;
+}
+// this tile's output changed (or stands and is not zero): every tile that stages its particles must run the next sweep.  Called by whole waves;
+// `mine` = nbr[tile * kNbrStride + lane], requested at the head of the kernel
+__device__ __forceinline__ void flow_push(const DensFlow &df, int mine)
+{
+    const int lane = threadIdx.x & 63;
+    const int hdr = __shfl(mine, 0, 64);
+    if (hdr < 0 || (hdr & kNbrOdd) != 0) { if (lane == 0) df.bcast[df.bc_out] = df.stamp_out; }
+    if (hdr >= 0 && lane >= 1 && lane <= (hdr & (kNbrStride - 1))) df.need_out[mine] = df.stamp_out;
+}
 __device__ __forceinline__ int sweep_tile(const TilePhase &tp, bool spread);
 __device__ __forceinline__ void spec_undo(const Consts &c, const SpecUndo &un, const DevScalars *__restrict__ ds, const TilePhase &tp)
 {
@@ -615,6 +653,7 @@ constexpr int kStageMaxCells = 640;
 // indices local to its staged set.  Without a rigid body that is every staged workgroup of an nl16 handle; with one, the workgroups whose
 // neighbourhood cells hold no rigid sample (tagged rigid entries need 32 bits) -- all but a thin shell around the body.
 constexpr int kStageLists16 = 1 << 30;
+constexpr int kTileSet = 128;          // open-addressing set of the tiles that hold a workgroup's staged particles (DensFlow.nbr)
 __device__ __forceinline__ bool stage_lists16(const int *__restrict__ stage_cnt, int blk) { return (stage_cnt[blk] & (kStageLists16 | (int)0x80000000)) == kStageLists16; }
 // Consts.stage_cap = staged particles per workgroup (16 B each for one-operand sweeps, 24 B for the residuals); 1664 keeps four
 // workgroups of a residual sweep resident per CU (4 x 39 KiB of the 160 KiB LDS), ~2 % of the workgroups at 1 M particles exceed it.
@@ -643,11 +682,11 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                                                      const int *__restrict__ id, uint32_t *__restrict__ nl,
                                                      uint32_t *__restrict__ nlb, int *__restrict__ cnt, DevScalars *__restrict__ ds,
                                                      RigidView rv, int *__restrict__ ncount, uint2 *__restrict__ stage_runs,
-                                                     int *__restrict__ stage_cnt, const int *__restrict__ gate = nullptr)
+                                                     int *__restrict__ stage_cnt, const int *__restrict__ gate = nullptr, int *__restrict__ tile_nbr = nullptr)
 {
     if (gate && *gate == 0) return;       // Verlet handles: the lists still hold
     __shared__ uint32_t s_stage[4 * kBlock];
-    __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok;
+    __shared__ int s_key[STAGED ? kStageHash : 1], s_base[STAGED ? kStageHash : 1], s_wsum[kBlock / 64], s_wsum_ne[kBlock / 64], s_ncell, s_ok, s_odd;
     __shared__ uint4 s_cell[kBlock / 64][kRunCap * 9];
     __shared__ int s_cslot[RIGID ? kBlock / 64 : 1][RIGID ? kRunCap * 9 : 1], s_runc[kBlock / 64][kRunCap][3];
     const int blk = xcd_block(blockIdx.x, gridDim.x);
@@ -659,10 +698,17 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
     if (STAGED) {
         // (1) the set of cell slots around the cells of this workgroup's own particles
         for (int q = threadIdx.x; q < kStageHash; q += kBlock) s_key[q] = -1;
-        if (threadIdx.x == 0) { s_ncell = 0; s_ok = 1; }
+        // (DensFlow.nbr: the set of TILES that hold those cells' particles, kTileSet slots in the last wave's cell table -- that table is first
+        // written by its own wave in (3), after that wave has read the set back below)
+        int *s_tset = reinterpret_cast<int *>(&s_cell[kBlock / 64 - 1][0]);
+        static_assert(sizeof(s_cell[0]) >= kTileSet * sizeof(int), "the tile set lives in one wave's cell table");
+        if (tile_nbr && threadIdx.x < kTileSet) s_tset[threadIdx.x] = -1;
+        if (threadIdx.x == 0) { s_ncell = 0; s_ok = 1; s_odd = 0; }
         __syncthreads();
         int hcx = 0, hcy = 0, hcz = 0;
         if (i < c.n) cell_id_of(c, P[i].x, P[i].y, P[i].z, hcx, hcy, hcz);
+        // a particle whose coordinates lie outside the grid is stored in a wrapped cell (or nowhere) and walks cells it is not stored in: kNbrOdd
+        if (tile_nbr && i < c.n && (hcx < 0 || hcx >= c.gx || hcy < 0 || hcy >= c.gy || hcz < 0 || hcz >= c.gz)) s_odd = 1;
         if (i < c.n && list_walker(c, id[i], hcx)) {
             const int cx = hcx, cy = hcy, cz = hcz;
             int px, py, pz;
@@ -690,12 +736,13 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         }
         __syncthreads();
         // (2) local base of every cell of the set (table order), the ordered source list, the verdict
-        int own[kStageHash / kBlock], run = 0, rig = 0;
+        int own[kStageHash / kBlock], cfirst[kStageHash / kBlock], run = 0, rig = 0;
         const bool ok = s_ok != 0;
 #pragma unroll
         for (int q = 0; q < kStageHash / kBlock; ++q) {
             const int key = ok ? s_key[threadIdx.x * (kStageHash / kBlock) + q] : -1;
-            own[q] = key >= 0 ? cell_start[key + 1] - cell_start[key] : 0;
+            cfirst[q] = key >= 0 ? cell_start[key] : 0;
+            own[q] = key >= 0 ? cell_start[key + 1] - cfirst[q] : 0;
             run += own[q];
             if (RIGID && key >= 0) rig |= rv.rcell_start[key + 1] - rv.rcell_start[key];      // rigid samples in a cell this workgroup walks
         }
@@ -720,11 +767,21 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             const int e = threadIdx.x * (kStageHash / kBlock) + q;
             s_base[e] = before;
             if (staged && own[q] > 0) {
-                const uint32_t first = (uint32_t)cell_start[s_key[e]];
+                const uint32_t first = (uint32_t)cfirst[q];
                 stage_runs[(size_t)blk * kStageMaxCells + run_idx] = make_uint2(first, (uint32_t)before | ((uint32_t)own[q] << 16));
                 ++run_idx;
             }
             before += own[q];
+            if (tile_nbr && own[q] > 0)           // the tiles this cell's particles lie in (staged or not: the cell set is complete whenever `ok`)
+                for (int t = cfirst[q] / kBlock; t <= (cfirst[q] + own[q] - 1) / kBlock; ++t) {
+                    int hq = (int)(((unsigned)t * 2654435761u) >> 25);
+                    static_assert(kTileSet == 128, "7 hash bits");
+                    for (int probe = 0; probe < kTileSet; ++probe) {
+                        const int was = atomicCAS(&s_tset[hq], -1, t);
+                        if (was == -1 || was == t) break;
+                        hq = (hq + 1) & (kTileSet - 1);
+                    }                   // (a full table drops the tile: the count below then exceeds the row and the header says "unknown")
+                }
         }
         if (threadIdx.x == 0) {
             const bool l16 = staged && c.nl16 != 0 && !near_body;
@@ -732,6 +789,19 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             s_ok = staged ? (l16 ? 3 : 1) : 0;
         }
         __syncthreads();
+        if (tile_nbr && (int)(threadIdx.x >> 6) == kBlock / 64 - 1) {       // the set, compacted into this tile's row (the wave whose table held it)
+            const int ln = threadIdx.x & 63;
+            const int ta = s_tset[ln], tb = s_tset[ln + 64];
+            const int na = (ta >= 0 ? 1 : 0) + (tb >= 0 ? 1 : 0);
+            const int inc = wave_inclusive_scan(na);
+            const int ntile = __shfl(inc, 63, 64);
+            int *row = tile_nbr + (size_t)blk * kNbrStride;
+            const bool fits = ok && ntile <= kNbrStride - 1 && ntile < kTileSet;       // (a full table may have dropped a tile)
+            int pos = inc - na;
+            if (fits && ta >= 0) row[1 + pos++] = ta;
+            if (fits && tb >= 0) row[1 + pos] = tb;
+            if (ln == 0) row[0] = fits ? (ntile | (s_odd ? kNbrOdd : 0)) : -1;
+        }
     }
     constexpr int CHUNK = 4;
     const bool staged = STAGED && s_ok != 0;
@@ -2081,11 +2151,12 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
                                                     const uint32_t *__restrict__ nl, const uint32_t *__restrict__ nlb,
                                                     const int *__restrict__ cnt, const float *__restrict__ rho,
                                                     const float *__restrict__ alpha, const float *__restrict__ src,   // drho (DIV) / rho_adv (DENS)
-                                                    float *__restrict__ warm, const DevScalars *__restrict__ ds,
+                                                    float *__restrict__ warm, const DevScalars *ds,       // (no __restrict__: workgroup 0 writes the same object through fr.ds --
+                                                    // the tile workgroups may read gate_hist[], dt, dt2 and the p_* parameters only, which fin_ride_block never writes)
                                                     const float4 *Vin, float4 *Vout, RigidView rv, int gate,
                                                     const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
                                                     int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, const float4 *__restrict__ wall_gc,
-                                                    TilePhase tp, SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide)
+                                                    TilePhase tp, SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide, DensFlow df = kNoFlow)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
@@ -2096,6 +2167,15 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
     const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
     if (tile < 0) return;
+    // the residual sweep before this launch said which tiles can see a k / rho != 0 (DensFlow): every other tile leaves after ONE word
+    const bool flow = MODE == CORR_DENS && STAGED && wave_dirty != nullptr && df.nbr != nullptr;
+    if (flow && !flow_needed(df, tile)) {                    // v* stays, as verdict 2 below would find out from the staged scalars themselves
+        const int i0 = tile * kBlock + (int)threadIdx.x;
+        if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
+        if (i0 < c.n) changed8[i0] = 0;
+        return;
+    }
+    const int my_nbr = flow ? df.nbr[(size_t)tile * kNbrStride + (threadIdx.x & 63)] : 0;       // requested now, used by the push at the end
     SPH_SWEEP_PROLOGUE_G(QUAD, tile, true)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && c.kr_split;
@@ -2204,6 +2284,7 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
+        if (flow && any != 0ull) flow_push(df, my_nbr);                           // every tile that stages a particle of this one must run the next residual sweep
     }
     if (!owner) return;
     float4 v = Vin[i];
@@ -2238,7 +2319,8 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
                                                      RigidView rv, const int *__restrict__ ncount, int gate,
                                                      const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                      const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all,
-                                                     const float4 *__restrict__ wall_gc, TilePhase tp, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
+                                                     const float4 *__restrict__ wall_gc, TilePhase tp, SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0},
+                                                     DensFlow df = kNoFlow)
 {
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
@@ -2248,12 +2330,21 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
+    const bool flow = DENS && STAGED && df.nbr != nullptr;           // the producer says who must run (DensFlow)
     if (spread) {                                                    // change propagation, see stage_sources_flagged
-        const int sw = stage_cnt[tile];
-        const bool idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        bool idle;
+        if (flow) {
+            idle = !flow_needed(df, tile);                           // ONE word: did the correction sweep before this launch change a velocity this tile stages?
+            // its k / rho stands; where that is not zero, the correction sweep behind this launch must still be told
+            if (idle && df.nz[tile] != 0 && threadIdx.x < 64) flow_push(df, df.nbr[(size_t)tile * kNbrStride + threadIdx.x]);
+        } else {
+            const int sw = stage_cnt[tile];
+            idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        }
         if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
         if (idle) return;                                            // rho*, k / rho and the block partial of the last iteration stand
     }
+    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;      // requested now, used by the push at the end
     SPH_SWEEP_PROLOGUE_B(QUAD, tile)
     // ... and a tile without an owned particle -- ghosts only -- computes no residual (the ghosts' values arrive with the halo): no staging, a zero partial
     if (c.ghost_walk && !__syncthreads_or(live && !ghost)) {
@@ -2265,7 +2356,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     bool staged;
     if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
         const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) return;
+        if (verdict == 2) {                                          // (its k / rho stands like an idle tile's)
+            if (flow && df.nz[blk] != 0 && threadIdx.x < 64) flow_push(df, my_nbr);
+            return;
+        }
         staged = verdict == 1;
     } else {
         staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
@@ -2318,11 +2412,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
             accb += gv.w * dot3(vi.x, vi.y, vi.z, gv.x, gv.y, gv.z);
         });
     else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);
-    float val = 0.f;
+    float val = 0.f, kr = 0.f;
     int flag = 0;
     if (live) {
         const float rho_i = rho[i];
-        float kr;
         if (DENS) {
             const float dt = ds->dt;
             if (c.boundary_handle) val = rmax(rho_i + dt * (acc + accb * c.rho0), c.rho0);   // :135
@@ -2344,6 +2437,11 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     }
     if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);
     else block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (flow) {                                                      // does this tile hold a k / rho != 0?  (a NaN counts)
+        const int nzf = __syncthreads_or((live && !ghost && kr != 0.f) ? 1 : 0);
+        if (threadIdx.x == 0) df.nz[blk] = nzf ? 1 : 0;
+        if (nzf && threadIdx.x < 64) flow_push(df, my_nbr);
+    }
 }
 
 // ======================================================================================

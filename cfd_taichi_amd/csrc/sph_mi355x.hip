@@ -194,6 +194,11 @@ struct SphHandle {
     FinRide pending_div = kNoRide;      // one GPU: the divergence loop's last decision, taken by k_finalize_max's launch
     int *dens_hot = nullptr, *dens_order = nullptr;
     bool dens_sparse = false;
+    // ... and the producer says who must run (DensFlow in sph_kernels.h): the tiles that stage each tile's particles (k_build_nl), the stamps the
+    // density loop's sweeps push to them, per tile "its k / rho holds a nonzero", the two broadcast words.  SPH_DENS_PUSH=0 turns it off (A/B, tests)
+    int *tile_nbr = nullptr, *need6 = nullptr, *need7 = nullptr, *tile_nz = nullptr, *dens_bcast = nullptr;
+    int flow_stamp = 0, flow_last = 0;          // launch counter of the density loop's sweeps; the stamp of the sweep enqueued last
+    bool opt_dens_push = true;
     bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -326,6 +331,7 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_DENS_PUSH"); h->opt_dens_push = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_WALL_CACHE"); h->opt_wall_cache = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_ARITH"); h->relaxed = cfg->arith == SPH_ARITH_RELAXED || (e && (e[0] == 'r' || e[0] == '1')); }
     { const char *e = dev_env(&h->overrides, "SPH_QUAD"); h->opt_quad = !(e && atoi(e) == 0); }

@@ -129,19 +129,27 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         double *__restrict__ psum, int *__restrict__ pcnt, int gate,
                                                         const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, float *__restrict__ krho,
                                                         const int *__restrict__ wave_dirty, const unsigned char *__restrict__ changed8, int force_all, TilePhase tp,
-                                                        SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0})
+                                                        SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, DensFlow df = kNoFlow)
 {
     extern __shared__ float4 s_operand[];
     if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
     const int tile = sweep_tile(tp, spread);
     if (tile < 0) return;
+    const bool flow = DENS && df.nbr != nullptr;                    // the producer says who must run (DensFlow in sph_kernels.h; k_residual is the commented form)
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
-        const int sw = stage_cnt[tile];
-        const bool idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        bool idle;
+        if (flow) {
+            idle = !flow_needed(df, tile);
+            if (idle && df.nz[tile] != 0 && threadIdx.x < 64) flow_push(df, df.nbr[(size_t)tile * kNbrStride + threadIdx.x]);
+        } else {
+            const int sw = stage_cnt[tile];
+            idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
+        }
         if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
         if (idle) return;
     }
+    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;
     const uint32_t *nlb = nullptr;
     SPH_SWEEP_PROLOGUE_B(false, tile)
     (void)nlbp;
@@ -149,7 +157,10 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     bool staged;
     if (spread) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
         const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
-        if (verdict == 2) return;
+        if (verdict == 2) {
+            if (flow && df.nz[blk] != 0 && threadIdx.x < 64) flow_push(df, my_nbr);
+            return;
+        }
         staged = verdict == 1;
     } else {
         staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
@@ -173,10 +184,9 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
             for (int u = 0; u < 8; ++u) pair(a[u], make_float4(a[u].w, b[u].x, b[u].y, 0.f), 0u);
         });
     else for_fluid_nbrs<false, true>(nlp, kfx, P, V, RigidView(), pair);        // a workgroup whose set did not fit: 32-bit global indices, masked tails
-    float val = 0.f;
+    float val = 0.f, kr = 0.f;
     int flag = 0;
     if (live) {
-        float kr;
         float sum = acc;
         if (c.boundary_handle && kb > 0 && !skip) {                               // :300 / :176
             const float4 gw = G[i];
@@ -198,6 +208,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
         }
     }
     block_partial_mean(blk, (double)val, flag, psum, pcnt);
+    if (flow) {
+        const int nzf = __syncthreads_or((live && !ghost && kr != 0.f) ? 1 : 0);
+        if (threadIdx.x == 0) df.nz[blk] = nzf ? 1 : 0;
+        if (nzf && threadIdx.x < 64) flow_push(df, my_nbr);
+    }
 }
 
 // D2 / D4 / D7 (k_correct)                                       dfsph_solver.py:314-355, 302-312 + 357-391, 178-219
@@ -206,11 +221,11 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *__restrict__ P, const float4 *__restrict__ G,
                                                        const uint32_t *__restrict__ nl, const int *__restrict__ cnt, const float *__restrict__ rho,
                                                        const float *__restrict__ alpha, const float *__restrict__ src,
-                                                       float *__restrict__ warm, const DevScalars *__restrict__ ds,
+                                                       float *__restrict__ warm, const DevScalars *ds,       // (no __restrict__: see k_correct)
                                                        const float4 *Vin, float4 *Vout, int gate,
                                                        const uint2 *__restrict__ stage_src, const int *__restrict__ stage_cnt, const float *__restrict__ krho,
                                                        int *__restrict__ wave_dirty, unsigned char *__restrict__ changed8, TilePhase tp,
-                                                       SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide)
+                                                       SpecSave sv = SpecSave{nullptr, nullptr}, FinRide fr = kNoRide, DensFlow df = kNoFlow)
 {
     extern __shared__ float4 s_operand[];
     if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // (see k_correct: the loop decision rides in this launch)
@@ -218,6 +233,14 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
     const uint32_t *nlb = nullptr;
     const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
     if (tile < 0) return;
+    const bool flow = MODE == CORR_DENS && wave_dirty != nullptr && df.nbr != nullptr;      // (DensFlow, see k_correct in sph_kernels.h)
+    if (flow && !flow_needed(df, tile)) {
+        const int i0 = tile * kBlock + (int)threadIdx.x;
+        if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
+        if (i0 < c.n) changed8[i0] = 0;
+        return;
+    }
+    const int my_nbr = flow ? df.nbr[(size_t)tile * kNbrStride + (threadIdx.x & 63)] : 0;
     SPH_SWEEP_PROLOGUE_G(false, tile, true)
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
+        if (flow && any != 0ull) flow_push(df, my_nbr);
     }
     if (!live) return;
     float4 v = Vin[i];

@@ -111,6 +111,8 @@ def test_bench_launches_its_own_ranks_without_touching_the_gpu(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    # (the first-contact child job that self_launch() starts before the ranks has its own suite, tests/test_first_contact.py)
+    monkeypatch.setenv(bench.FIRST_CONTACT_ENV, '{"backend": "nccl", "transport": "rccl", "discipline": "sync", "reached": [], "how": "test"}')
     torch_loaded_before = "torch" in sys.modules
     with pytest.raises(SystemExit) as e:
         bench.main()

@@ -193,21 +193,26 @@ def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, 
     stage_sources_flagged).  With SPH_TILE_SKIP=0 every tile computes in every iteration: same state, iteration counts and residuals,
     in the exact arithmetic and in the relaxed one (whose skipped and computed tiles give the same bits for the same reason), also at a
     capacity where staged and unstaged workgroups mix.  The two must be compared with ==: a skipped correction leaves a velocity
-    component of -0 where the computed one gives v - (-0) = +0."""
+    component of -0 where the computed one gives v - (-0) = +0.
+    Round 6: the sweep that writes an operand tells the tiles that stage it to run (DensFlow) -- the default; SPH_DENS_PUSH=0 is round 3's
+    form, in which every tile reads its staging plan to find out.  All three in lock step."""
     cfg = scenes.get(scene)
     monkeypatch.setenv("SPH_STAGE_CAP", cap)
     monkeypatch.setenv("SPH_CELL_ORDER", "morton")
     sims = []
-    for skip in ("1", "0"):
+    for skip, push in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("SPH_TILE_SKIP", skip)
+        monkeypatch.setenv("SPH_DENS_PUSH", push)
         sims.append(nat.Simulation(nat.config_from_dict(cfg, arith=arith)))
     n_dens = []
     for s_ in range(steps):
-        a, b = sims[0].step_dfsph(1), sims[1].step_dfsph(1)
-        assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (b.n_div, b.n_dens, b.div_err, b.dens_err, b.dt), (scene, s_)
+        a, b, c_ = sims[0].step_dfsph(1), sims[1].step_dfsph(1), sims[2].step_dfsph(1)
+        for o in (b, c_):
+            assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (o.n_div, o.n_dens, o.div_err, o.dens_err, o.dt), (scene, s_)
         n_dens.append(a.n_dens)
     for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K, nat.F_ALPHA):
-        assert np.array_equal(sims[0].download(f), sims[1].download(f)), (scene, f)
+        for o in sims[1:]:
+            assert np.array_equal(sims[0].download(f), o.download(f)), (scene, f)
     assert max(n_dens) >= 3, "the density loop never iterated past its minimum: nothing was exercised"
     for sim in sims:
         sim.close()

@@ -24,7 +24,7 @@ PATCHES = {
     # exact k_residual (sph_kernels.h): the fluid pair loop / the wall loop removed
     "nofluid": [(K, "    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv2(nlp, skip ? 0 : kf, s_operand, s_v2, pair_scaled);",
                  "    else if (staged && (RIGID ? stage_lists16(stage_cnt, blk) : c.nl16 != 0)) for_staged16_nbrs_pv2(nlp, 0, s_operand, s_v2, pair_scaled);")],
-    "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f;")],
+    "nowall": [(K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f, kr = 0.f;", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    float val = 0.f, kr = 0.f;")],
     "nowall_correct": [(K, "    else for_nbrs_p(nlbp, kb, WP, wall);\n    if (track) {       // did any lane", "    else for_nbrs_p(nlbp, 0, WP, wall);\n    if (track) {       // did any lane")],
     # CORRECT variants (speed only): the solver-loop sweeps take their tiles in chunks of C consecutive tiles dealt round-robin over the XCDs
     # instead of one contiguous eighth per XCD (1.5-2 % faster at 16-64, 19 % more HBM traffic: not in the product)
@@ -41,15 +41,15 @@ PATCHES = {
                     "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
     # a CORRECT variant with a side effect: every workgroup of the exact divergence-residual sweep leaves (begin, end, XCC id) of its life in a
     # device array that sph_debug_timeline() copies out (tools/wg_timeline.py): how full is the chip over a launch, where is the tail?
-    "wg_timeline": [(K, "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// ======================================================================================\n// D5:",
-                     "    if (QUAD) block_partial_mean_quad(blk, (double)val, flag, owner, psum, pcnt);\n    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// ======================================================================================\n// D5:"),
+    "wg_timeline": [(K, "    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (flow) {                                                      // does this tile hold",
+                     "    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n    if (flow) {                                                      // does this tile hold"),
                     (K, "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED\n    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
                      "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;\n    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
                     (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
                     (K, "    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID"),
                     (K, "    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);",
                      "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);"),
-                    (K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f;", "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_walls = wall_clock64();\n    float val = 0.f;"),
+                    (K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f, kr = 0.f;", "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_walls = wall_clock64();\n    float val = 0.f, kr = 0.f;"),
                     ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
                      "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # the same stamps in the relaxed divergence-residual sweep (tools/wg_timeline.py with SPH_ARITH=relaxed reads the same array)
@@ -75,9 +75,9 @@ PATCHES = {
                        (R, "    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
                         "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
                        (R, "    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;"),
-                       (R, "    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    const unsigned long long t_walls = t_pairs;\n    float val = 0.f;\n    int flag = 0;\n    if (live) {\n        float kr;\n        float sum = acc;"),
-                       (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n}\n\n// D2 / D4 / D7 (k_correct)",
-                        "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n}\n\n// D2 / D4 / D7 (k_correct)")],
+                       (R, "    float val = 0.f, kr = 0.f;\n    int flag = 0;\n    if (live) {\n        float sum = acc;", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    const unsigned long long t_walls = t_pairs;\n    float val = 0.f, kr = 0.f;\n    int flag = 0;\n    if (live) {\n        float sum = acc;"),
+                       (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (flow) {\n        const int nzf",
+                        "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n    if (flow) {\n        const int nzf")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
                   "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;", 2)],
