@@ -173,7 +173,11 @@ CORE_EXPORTS = [
 
 def _bind_core(lib):
     vp, ci = ctypes.c_void_p, ctypes.c_int
-    lib.sph_abi_version.argtypes = []
+    try:
+        lib.sph_abi_version.argtypes = []
+    except AttributeError:          # a build from before the symbol existed: the very case the check is for
+        raise RuntimeError("%s predates SPH_ABI_VERSION (include/sph_mi355x.h is at version %d): rebuild (python -m cfd_taichi_amd.build)"
+                           % (getattr(lib, "_name", "library"), ABI_VERSION))
     lib.sph_abi_version.restype = ctypes.c_int32
     if lib.sph_abi_version() != ABI_VERSION:
         raise RuntimeError("%s implements version %d of include/sph_mi355x.h, this binding version %d: rebuild (python -m cfd_taichi_amd.build)"

@@ -321,7 +321,8 @@ inline TilePhase tile_phase(const SphHandle *h, int phase)
 inline DensFlow dens_flow(SphHandle *h, bool d6)
 {
     if (!h->tile_nbr || !tile_skip(h) || h->tune_all) return kNoFlow;
-    DensFlow df{h->tile_nbr, d6 ? h->need6 : h->need7, d6 ? h->need7 : h->need6, h->tile_nz, h->dens_bcast, h->flow_last, ++h->flow_stamp, d6 ? 0 : 1, d6 ? 1 : 0};
+    DensFlow df{h->tile_nbr, d6 ? h->need6 : h->need7, d6 ? h->need7 : h->need6, h->tile_nz, h->dens_bcast, h->flow_last, ++h->flow_stamp, d6 ? 0 : 1, d6 ? 1 : 0,
+                d6 ? h->worked6 : h->worked7};
     h->flow_last = df.stamp_out;
     return df;
 }
@@ -630,18 +631,33 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
     // One GPU: the same reordering without a second stream -- the decision of evaluation e is taken by workgroup 0 of the correction launch that
     // runs ahead of it (launch_correct's ride_mode / fin_ride_block): no single-workgroup launch between two sweeps any more.
     const bool ride = fin_rides(h);
+    // All max_iteration_density_divergence (15) possible iterations are enqueued at once -- the ones the reference's loop would not run leave at their first
+    // instruction.  A caller who writes the "no cap" idiom (solver.max_iteration_density_divergence = 1000) must not pay a thousand gated full-grid launches
+    // per step for that: beyond kDivChunk iterations the host looks at the loop state every kDivChunk iterations and stops enqueuing once the loop has
+    // ended.  1 = ended, 0 = go on, < 0 = error
+    constexpr int kDivChunk = 32;
+    auto div_ended = [&](int e) -> int {
+        if (max_div <= kDivChunk || e % kDivChunk != 0 || e >= max_div) return 0;
+        const int r = read_scalars_fast(h);
+        if (r) return r;
+        return h->ds_host->div_active ? 0 : 1;
+    };
     if (ride) {
         launch_div_residual(h, GATE_NONE);                                                                                   // :398, evaluation 1
+        int last_e = max_div;
         for (int e = 1; e <= max_div; ++e) {
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w},
                                      e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e);                                              // :402-405 + decision e
             launch_div_residual(h, GATE_DIV, 0, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e});     // :408, evaluation e + 1
+            if ((rc = div_ended(e)) < 0) return rc;
+            if (rc) { last_e = e; break; }
         }
         // the decision of the last evaluation has no correction launch to ride in: it is taken by the launch that reduces max |v*| (dfsph_ext_and_dt;
         // the sweep in between, D5, writes other partials and reads no loop state)
-        h->pending_div = FinRide{h->psum, h->pcnt, h->ds, h->nblocks, max_div == 0 ? (int)FIN_DIV_FIRST : (int)FIN_DIV_LOOP, partial_group(h), partial_count(h), max_div + 1};
+        h->pending_div = FinRide{h->psum, h->pcnt, h->ds, h->nblocks, max_div == 0 ? (int)FIN_DIV_FIRST : (int)FIN_DIV_LOOP, partial_group(h), partial_count(h), last_e + 1};
     } else if (spec) {
         if ((rc = residual_sweep(false, GATE_NONE, SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, FIN_DIV_FIRST))) return rc;     // :398, evaluation 1
+        int last_spec = max_div;
         for (int e = 1; e <= max_div; ++e) {
             // the correction of evaluation e first (the GPU works on it while the host may block in a synchronous all-reduce) ...
             launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_HIST0 + ((e - 1) & 1), SpecSave{h->spec_v, h->spec_w});   // :402-405
@@ -649,17 +665,20 @@ int step_dfsph_device_loops(SphHandle *h, SphStepStats *st)
             if ((rc = launch_finalize_decide(h, e == 1 ? FIN_DIV_FIRST : FIN_DIV_LOOP, e))) return rc;
             HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
             if ((rc = residual_sweep(false, GATE_DIV, SpecUndo{h->V[h->vcur], h->spec_v, h->warm[h->wcur], h->spec_w, e}, FIN_DIV_LOOP))) return rc;   // :408, evaluation e + 1
+            if ((rc = div_ended(e)) < 0) return rc;
+            if (rc) { last_spec = e; break; }
         }
-        if ((rc = launch_finalize_decide(h, max_div == 0 ? FIN_DIV_FIRST : FIN_DIV_LOOP, max_div + 1))) return rc;
+        if ((rc = launch_finalize_decide(h, max_div == 0 ? FIN_DIV_FIRST : FIN_DIV_LOOP, last_spec + 1))) return rc;
         HIP_TRY(h, hipStreamWaitEvent(s, h->ev_dec, 0));
     } else {
     if ((rc = residual(false, GATE_NONE, FIN_DIV_FIRST))) return rc;                 // :398
-    // all max_iteration_density_divergence (15) possible iterations are enqueued at once: the ones the reference's loop would not run exit at
-    // their first instruction, and the host does not need the outcome before the density loop's first read-back
+    // (enqueued at once, see div_ended above: the host does not need the outcome before the density loop's first read-back)
     for (int done = 0; done < max_div; ++done) {
         launch_correct<CORR_DIV>(h, K_D_DIV_CORRECT, h->drho, h->V[h->vcur], GATE_DIV);   // :402-405
         if ((rc = ghosts_v(h->V[h->vcur]))) return rc;
         if ((rc = residual(false, GATE_DIV, FIN_DIV_LOOP))) return rc;                    // :408
+        if ((rc = div_ended(done + 1)) < 0) return rc;
+        if (rc) break;
     }
     }
     if ((rc = dfsph_ext_and_dt(h))) return rc;

@@ -650,6 +650,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 const size_t nt = (n + kBlock - 1) / kBlock + 1;
                 if ((rc = dalloc(h, &h->tile_nbr, nt * (size_t)kNbrStride))) return rc;
                 if ((rc = dalloc(h, &h->need6, nt)) || (rc = dalloc(h, &h->need7, nt)) || (rc = dalloc(h, &h->tile_nz, nt))) return rc;
+                if ((rc = dalloc(h, &h->worked6, nt)) || (rc = dalloc(h, &h->worked7, nt))) return rc;
                 if ((rc = dalloc(h, &h->dens_bcast, 64))) return rc;
             }
             if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
@@ -717,7 +718,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     }
     if ((rc = dalloc(h, &h->ds, 1))) return rc;
     HIP_TRY(h, hipHostMalloc((void **)&h->ds_host, sizeof(DevScalars), hipHostMallocDefault));
-    if (hipHostMalloc((void **)&h->pub_host, sizeof(DevScalarsPub), hipHostMallocMapped) == hipSuccess) {
+    // (coherent / fine-grained asked for by name: read_scalars_fast spins on a word the device writes while the stream is still busy, and
+    // HIP_HOST_COHERENT=0 in the environment would otherwise make that word visible only after the stream has drained -- ADVICE r5)
+    if (hipHostMalloc((void **)&h->pub_host, sizeof(DevScalarsPub), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
         memset(h->pub_host, 0, sizeof(DevScalarsPub));
         if (hipHostGetDevicePointer((void **)&h->pub_dev, h->pub_host, 0) != hipSuccess) { (void)hipHostFree(h->pub_host); h->pub_host = nullptr; h->pub_dev = nullptr; }
     } else {
@@ -779,10 +782,14 @@ int read_scalars_fast(SphHandle *h)
     while (*flag != seq) {
         if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
             HIP_TRY(h, hipStreamSynchronize(h->stream));          // (a long chunk, or a launch that failed: the stream's status tells)
-            if (*flag != seq) return read_scalars(h);
+            if (*flag != seq) { h->pub_dev = nullptr; return read_scalars(h); }      // the word never arrives on this system: no second 2 ms wait
+            // it arrived only with the drain: either a chunk that really took longer than 2 ms, or writes that are not visible while the stream runs.
+            // Three such waits in a row and the handle goes back to the copy (a step of a large scene does take > 2 ms per chunk: keep trying there)
+            if (++h->pub_late >= 3 && h->c.n < (1 << 21)) h->pub_dev = nullptr;
             break;
         }
     }
+    if (spins > 0 && std::chrono::steady_clock::now() - t0 <= std::chrono::milliseconds(2)) h->pub_late = 0;
     std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(h->ds_host, &h->pub_host->ds, sizeof(DevScalars));
     fold_list_maxima(h);

@@ -65,6 +65,7 @@ struct SpecUndo { float4 *v_dst; const float4 *v_src; float *w_dst; const float 
 // Where the symmetry does not hold the flags say "always": a tile with a particle whose coordinates lie outside the grid (binned into a wrapped
 // cell or nowhere: it walks cells it is not stored in) runs in every launch and, as a producer, raises the broadcast word instead (kNbrOdd); so
 // does a tile whose cell set or tile list did not fit (header -1).
+constexpr int kStageMaxCells = 640;        // cell runs a workgroup's staging plan may hold (see the plan in k_build_nl)
 constexpr int kNbrStride = 64;            // ints per tile in DensFlow.nbr: header + up to 63 tiles
 constexpr int kNbrOdd = 1 << 30;
 struct DensFlow {
@@ -73,13 +74,39 @@ struct DensFlow {
     int *nz;                              // per tile: its own k / rho holds a nonzero
     int *bcast;                           // [0]: "every tile must run D6", [1]: "... D7" (stamps)
     int stamp_in, stamp_out, bc_in, bc_out;
+    int *worked;                          // per tile, this kind of sweep: did the tile do real work in the loop's last iteration?  (a hint, see below)
 };
-constexpr DensFlow kNoFlow{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-// must this tile run?  (uniform per workgroup: three scalar loads, one round trip)
-__device__ __forceinline__ bool flow_needed(const DensFlow &df, int tile)
+constexpr DensFlow kNoFlow{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};
+// A sparse launch is as long as its slowest WORKING workgroup lives (tools/dens_timeline.py, profiles/r06/: the ~400 working tiles all start within
+// 0.6 us, live 17 us on average and 26 us at worst, the ~3500 others are gone after 15 us), and 6 us of such a life was the chain of dependent
+// trips in front of the first pair: gate, tile, need word, stage_cnt, cell runs, the checked scalars, the operands.  Two things shorten it:
+//   * a tile that worked in the last iteration is almost certainly working in this one (the working set of a step barely moves): it skips the
+//     per-particle check and stages its operands in one batch (computing a tile that turns out unchanged gives the bits that stand);
+//   * the workgroups at the head of the working-tiles-first order request stage_cnt and their first cell run together with the need word.
+struct StagePre { int have; int sw; uint2 rn0; };
+constexpr StagePre kNoPre{0, 0, {0u, 0u}};
+// The head of a density-loop workgroup under DensFlow: everything its verdict needs, in ONE batch of independent loads -- a load behind a
+// branch (a short-circuit `||` is one) is a round trip of its own, ~0.8 us in a launch that is as long as its slowest workgroup lives.
+//   need    must this tile run?
+//   direct  it worked in the loop's last iteration (DensFlow.worked): no per-particle check, the operands in one batch
+//   pre     the workgroups at the head of the working-tiles-first order (TilePhase.sparse: worked, then checked, then idle; n2 = sparse[ntiles + 1] =
+//           how many worked when the order was taken, fetched by the caller together with its tile) get their plan's head -- stage_cnt and the
+//           first cell run of every thread -- with the same batch
+struct FlowHead { bool need, direct; StagePre pre; };
+__device__ __forceinline__ FlowHead flow_head(const TilePhase &tp, const DensFlow &df, int tile, int n2, const uint2 *__restrict__ stage_runs,
+                                              const int *__restrict__ stage_cnt)
 {
-    const int hdr = df.nbr[(size_t)tile * kNbrStride];
-    return hdr < 0 || (hdr & kNbrOdd) != 0 || df.need_in[tile] == df.stamp_in || df.bcast[df.bc_in] == df.stamp_in;
+    FlowHead h;
+    h.pre = kNoPre;
+    if ((int)blockIdx.x - (tp.shift ? 1 : 0) < n2) {          // (a run past the plan's end: never looked at)
+        h.pre.rn0 = stage_runs[(size_t)tile * kStageMaxCells + threadIdx.x];
+        h.pre.have = 1;
+    }
+    const int hdr = df.nbr[(size_t)tile * kNbrStride], nd = df.need_in[tile], bc = df.bcast[df.bc_in], wk = df.worked[tile], sw = stage_cnt[tile];
+    h.pre.sw = sw;
+    h.need = (((hdr < 0) ? 1 : 0) | ((hdr & kNbrOdd) != 0 ? 1 : 0) | (nd == df.stamp_in ? 1 : 0) | (bc == df.stamp_in ? 1 : 0)) != 0;
+    h.direct = wk != 0;
+    return h;
 }
 // this tile's output changed (or stands and is not zero): every tile that stages its particles must run the next sweep.  Called by whole waves;
 // `mine` = nbr[tile * kNbrStride + lane], requested at the head of the kernel
@@ -648,7 +675,6 @@ struct NlWriter {
 constexpr int kRunCap = 13;          // runs of equal cell per wave whose 27 cells k_build_nl looks up cooperatively (mean 9, p99 13-16);
                                      // 13: the staged build's LDS stays under 20 KiB, eight workgroups per CU
 constexpr int kStageHash = 1024;       // open-addressing set of the cell slots a workgroup needs
-constexpr int kStageMaxCells = 640;
 // stage_cnt[blk] = staged particles | runs << 16 | kStageLists16 (-1: not staged).  kStageLists16: the fluid lists of this workgroup hold 16-bit
 // indices local to its staged set.  Without a rigid body that is every staged workgroup of an nl16 handle; with one, the workgroups whose
 // neighbourhood cells hold no rigid sample (tagged rigid entries need 32 bits) -- all but a thin shell around the body.
@@ -1523,14 +1549,15 @@ __global__ __launch_bounds__(kBlock) void k_finalize_max(const float *__restrict
 // largest capacity; a clamped index keeps the loads branch-free so that the compiler leaves them in one batch).
 constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip
 constexpr int kStageTrips = 2;          // 2 x 1792 >= the largest capacity (2560)
-__device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, uint32_t *__restrict__ s_idx)
+__device__ __forceinline__ int stage_expand(const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, uint32_t *__restrict__ s_idx,
+                                            const StagePre &pre = kNoPre)
 {
-    const int w = stage_cnt[blk];
+    const int w = pre.have ? pre.sw : stage_cnt[blk];       // (pre: requested by the caller ahead of time, see StagePre)
     if (w < 0) return -1;                                   // uniform per workgroup
     const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;
     const uint2 *runs = stage_runs + (size_t)blk * kStageMaxCells;
     for (int r = threadIdx.x; r < nruns; r += kBlock) {
-        const uint2 rn = runs[r];
+        const uint2 rn = (pre.have && r == (int)threadIdx.x) ? pre.rn0 : runs[r];
         const int base = (int)(rn.y & 0xffffu), n = (int)(rn.y >> 16);
         for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;
     }
@@ -1586,9 +1613,9 @@ __device__ __forceinline__ StageIdx stage_take(const uint32_t *__restrict__ s_id
 }
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
-                                              const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                              const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return false;
     if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -1613,9 +1640,9 @@ __device__ __forceinline__ bool stage_operand(const Consts &c, float4 *__restric
 // float4 (slab handles, SPH_KR_SPLIT=0): the verdict comes with the copy, so a zero tile saves its pair loop, not its gathers.
 template <bool SCALED>
 __device__ __forceinline__ int stage_operand_w_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A,
-                                                       const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                       const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return 0;
     if (nst == 0) return 2;                                 // a workgroup of ghosts only: nothing staged, nothing to add
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -1640,9 +1667,9 @@ __device__ __forceinline__ int stage_operand_w_checked(const Consts &c, float4 *
 // kr_split handles: positions from the step's position array and the per-sweep scalar k / rho from its own 4-byte array (the sweeps
 // then write 4 B per particle for their neighbours instead of a fresh (pos, k / rho) float4: 12 MB less written per launch at 1 M)
 __device__ __forceinline__ bool stage_operand_ps_scaled(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
-                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return false;
     if (nst == 0) return true;
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -1667,9 +1694,9 @@ __device__ __forceinline__ bool stage_operand_ps_scaled(const Consts &c, float4 
 // residual sweep instead of the staged scalars themselves -- no expansion, no gather -- was measured: fewer tiles return, 30.5 -> 35.4 us.)
 template <bool SCALED>
 __device__ __forceinline__ int stage_operand_ps_checked(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
-                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return 0;
     if (nst == 0) return 1;
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -1781,19 +1808,25 @@ __device__ __forceinline__ void for_staged_nbrs_pv(const uint32_t *__restrict__ 
 template <bool SCALED = false>
 __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
                                                  const float4 *__restrict__ A, const float4 *__restrict__ B,
-                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre,
+                                                 const unsigned char *__restrict__ changed = nullptr, int *any_changed = nullptr)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    // changed (optional): the per-particle bytes of the density loop's check, fetched with the operands; *any_changed = is one of the staged set's set?
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return false;
     if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
+    int any = 0;
 #pragma unroll
     for (int t = 0; t < kStageTrips; ++t) {
         const int base = threadIdx.x + t * kStageBatch * kBlock;
         if (t * kStageBatch * kBlock >= nst) break;
         float4 a[kStageBatch], b[kStageBatch];
+        unsigned char f[kStageBatch];
 #pragma unroll
-        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }
+        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; f[u] = changed ? changed[x.j[t][u]] : (unsigned char)0; }
+#pragma unroll
+        for (int u = 0; u < kStageBatch; ++u) any |= f[u];                                   // (clamped indices: duplicates of valid slots)
 #pragma unroll
         for (int u = 0; u < kStageBatch; ++u)
             if (base + u * kBlock < nst) {
@@ -1802,7 +1835,8 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
                 s_B[e] = make_float2(b[u].y, b[u].z);
             }
     }
-    __syncthreads();
+    if (changed) *any_changed = __syncthreads_or(any);
+    else __syncthreads();
     return true;
 }
 // The same with a look at a per-particle byte first: returns 0 = not staged, 1 = staged, 2 = no staged particle has its byte set (nothing was
@@ -1811,9 +1845,9 @@ __device__ __forceinline__ bool stage_operand_pv(const Consts &c, float4 *__rest
 template <bool SCALED>
 __device__ __forceinline__ int stage_operand_pv_checked(const Consts &c, float4 *__restrict__ s_A, float2 *__restrict__ s_B,
                                                         const float4 *__restrict__ A, const float4 *__restrict__ B, const unsigned char *__restrict__ changed,
-                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                        const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return 0;
     if (nst == 0) return 1;
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -2162,20 +2196,29 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
     if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // the loop decision of the residual sweep before (whatever the gate says)
-    if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     // With change propagation most tiles of a launch return at once and the ones that work are neighbours in space (the floor layer):
     // under the XCD-contiguous mapping they would all land on one or two XCDs.  Those launches deal the tiles round-robin instead.
+    // (the tile is looked up BEFORE the gate is tested: two independent scalar loads, one round trip)
     const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
+    const bool flow = MODE == CORR_DENS && STAGED && wave_dirty != nullptr && df.nbr != nullptr;
+    const int n2 = (flow && tp.sparse) ? tp.sparse[tp.ntiles + 1] : 0;           // (see flow_head)
+    if (gate_closed(ds, gate)) return;     // Vin may alias Vout: each thread reads and writes only its own element
     if (tile < 0) return;
     // the residual sweep before this launch said which tiles can see a k / rho != 0 (DensFlow): every other tile leaves after ONE word
-    const bool flow = MODE == CORR_DENS && STAGED && wave_dirty != nullptr && df.nbr != nullptr;
-    if (flow && !flow_needed(df, tile)) {                    // v* stays, as verdict 2 below would find out from the staged scalars themselves
-        const int i0 = tile * kBlock + (int)threadIdx.x;
-        if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
-        if (i0 < c.n) changed8[i0] = 0;
-        return;
+    StagePre pre = kNoPre;
+    bool direct = false;                                     // this tile worked in the last iteration: no per-particle check, the operands in one batch
+    if (flow) {
+        const FlowHead fh = flow_head(tp, df, tile, n2, stage_src, stage_cnt);
+        pre = fh.pre; direct = fh.direct;
+        if (!fh.need) {                                      // v* stays, as verdict 2 below would find out from the staged scalars themselves
+            const int i0 = tile * kBlock + (int)threadIdx.x;
+            if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
+            if (i0 < c.n) changed8[i0] = 0;
+            if (direct && threadIdx.x == 0) df.worked[tile] = 0;
+            return;
+        }
     }
-    const int my_nbr = flow ? df.nbr[(size_t)tile * kNbrStride + (threadIdx.x & 63)] : 0;       // requested now, used by the push at the end
+    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;       // requested now, used by the push at the end
     SPH_SWEEP_PROLOGUE_G(QUAD, tile, true)
     // kr_split: P is the step's position array and k / rho of the neighbours comes from krho[]; else P = (pos, k / rho)
     const bool split = STAGED && c.kr_split;
@@ -2191,9 +2234,9 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         return;
     }
     bool staged;
-    if (track) {
-        const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk)
-                                  : stage_operand_w_checked<true>(c, s_operand, P, stage_src, stage_cnt, blk);
+    if (track && !direct) {
+        const int verdict = split ? stage_operand_ps_checked<true>(c, s_operand, P, krho, stage_src, stage_cnt, blk, pre)
+                                  : stage_operand_w_checked<true>(c, s_operand, P, stage_src, stage_cnt, blk, pre);
         if (verdict == 2) {                                                        // every k / rho this tile can see is 0: v* stays
             // (one-column slab handles: a ghost's v* is refreshed from its owner after this sweep and may change behind this rank's back,
             // whatever this rank can see; on two-column handles the inner ghosts are corrected HERE, from the same inputs as on their owner)
@@ -2205,8 +2248,8 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         }
         staged = verdict == 1;
     } else {
-        staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk)
-                                  : stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk));     // positions * 2^32
+        staged = STAGED && (split ? stage_operand_ps_scaled(c, s_operand, P, krho, stage_src, stage_cnt, blk, pre)
+                                  : stage_operand<true>(c, s_operand, P, stage_src, stage_cnt, blk, pre));     // positions * 2^32
     }
     const float dt = ds->dt;
     const float rho_i = rho[ii];
@@ -2284,7 +2327,11 @@ __global__ __launch_bounds__(kBlock) void k_correct(Consts c, const float4 *__re
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
-        if (flow && any != 0ull) flow_push(df, my_nbr);                           // every tile that stages a particle of this one must run the next residual sweep
+        if (flow) {                                                               // every tile that stages a particle of this one must run the next residual sweep
+            const int moved = __syncthreads_or(changed ? 1 : 0);
+            if (moved && threadIdx.x < 64) flow_push(df, my_nbr);
+            if (threadIdx.x == 0) df.worked[tile] = moved ? 1 : 0;
+        }
     }
     if (!owner) return;
     float4 v = Vin[i];
@@ -2325,23 +2372,29 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;
     using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
     // (see k_correct: round-robin tiles when most of them return at once; the body does not move inside a solver loop, so its terms stand with v*)
     const bool spread = DENS && STAGED && wave_dirty && !force_all;
     const int tile = sweep_tile(tp, spread);
-    if (tile < 0) return;
     const bool flow = DENS && STAGED && df.nbr != nullptr;           // the producer says who must run (DensFlow)
+    const int n2 = (flow && spread && tp.sparse) ? tp.sparse[tp.ntiles + 1] : 0;      // (see flow_head)
+    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
+    if (tile < 0) return;
+    StagePre pre = kNoPre;
+    bool direct = false;                                             // this tile worked in the last iteration: no per-particle check (see StagePre)
     if (spread) {                                                    // change propagation, see stage_sources_flagged
         bool idle;
         if (flow) {
-            idle = !flow_needed(df, tile);                           // ONE word: did the correction sweep before this launch change a velocity this tile stages?
+            const FlowHead fh = flow_head(tp, df, tile, n2, stage_src, stage_cnt);
+            pre = fh.pre; direct = fh.direct;
+            idle = !fh.need;                                         // ONE word: did the correction sweep before this launch change a velocity this tile stages?
             // its k / rho stands; where that is not zero, the correction sweep behind this launch must still be told
             if (idle && df.nz[tile] != 0 && threadIdx.x < 64) flow_push(df, df.nbr[(size_t)tile * kNbrStride + threadIdx.x]);
+            if (idle && direct && threadIdx.x == 0) df.worked[tile] = 0;
         } else {
             const int sw = stage_cnt[tile];
             idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
         }
-        if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
+        if (tp.hot && threadIdx.x == 0 && idle) tp.hot[tile] = 0;    // (hot: 0 = left here, 1 = left after the per-particle check, 2 = worked)
         if (idle) return;                                            // rho*, k / rho and the block partial of the last iteration stand
     }
     const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;      // requested now, used by the push at the end
@@ -2354,15 +2407,25 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     }
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
-    if (spread) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
-        const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
+    if (spread && !direct) {       // second level of the change propagation: did the v* of any staged PARTICLE change?  (the flagged waves said "maybe")
+        const int verdict = stage_operand_pv_checked<true>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk, pre);
         if (verdict == 2) {                                          // (its k / rho stands like an idle tile's)
             if (flow && df.nz[blk] != 0 && threadIdx.x < 64) flow_push(df, my_nbr);
+            if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 1;
             return;
         }
         staged = verdict == 1;
     } else {
-        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32
+        // (a `direct` tile: the bytes of the check ride in the staging batch and say whether it would have passed -- if not, it computes what
+        // stands this once and takes the check again next time)
+        int would = 1;
+        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk, pre, (spread && direct) ? changed8 : nullptr, &would);   // positions * 2^32
+        if (spread && flow && threadIdx.x == 0) df.worked[blk] = would ? 1 : 0;
+        if (spread && tp.hot && threadIdx.x == 0) tp.hot[blk] = would ? 2 : 1;
+    }
+    if (spread && !direct) {
+        if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 2;
+        if (flow && threadIdx.x == 0) df.worked[blk] = 1;
     }
     const float4 vi = V[ii];
     float fa[1] = {0.f};

@@ -149,6 +149,7 @@ struct SphHandle {
     DevScalars *ds_host = nullptr;   // pinned mirror
     DevScalarsPub *pub_host = nullptr, *pub_dev = nullptr;      // the same block as the device publishes it itself (k_publish_scalars): pinned, mapped
     unsigned long long pub_seq = 0;
+    int pub_late = 0;               // read_scalars_fast: consecutive reads whose word arrived only with the stream's drain
     float *staging = nullptr;    // 3*max(N,Nb) floats, device
     // host copies of the wall particles in original order (for download)
     std::vector<float> wall_pos_host, wall_vol_host;
@@ -196,7 +197,7 @@ struct SphHandle {
     bool dens_sparse = false;
     // ... and the producer says who must run (DensFlow in sph_kernels.h): the tiles that stage each tile's particles (k_build_nl), the stamps the
     // density loop's sweeps push to them, per tile "its k / rho holds a nonzero", the two broadcast words.  SPH_DENS_PUSH=0 turns it off (A/B, tests)
-    int *tile_nbr = nullptr, *need6 = nullptr, *need7 = nullptr, *tile_nz = nullptr, *dens_bcast = nullptr;
+    int *tile_nbr = nullptr, *need6 = nullptr, *need7 = nullptr, *tile_nz = nullptr, *dens_bcast = nullptr, *worked6 = nullptr, *worked7 = nullptr;
     int flow_stamp = 0, flow_last = 0;          // launch counter of the density loop's sweeps; the stamp of the sweep enqueued last
     bool opt_dens_push = true;
     bool own_red = false;
@@ -994,36 +995,43 @@ int sph_get_scalar(SphHandle *h, int which, double *out)
 // and the device's loop-control block
 static int set_param(SphHandle *h, int which, double value)
 {
-    SphHandle::Params &p = h->p;
+    // validated into a COPY and committed at the end: a rejected call leaves the handle -- and what sph_get_scalar reports -- as it was
+    SphHandle::Params p = h->p;
     const bool dfsph = h->cfg.solver == SPH_SOLVER_DFSPH;
     auto count = [&](int *dst, int lo) -> int {
         if (!(value >= lo && value <= 100000.0) || value != std::floor(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): an integer >= %d expected, got %g", which, lo, value);
         *dst = (int)value; return SPH_OK;
     };
-    auto positive = [&](double *dst, bool zero_ok) -> int {
-        if (!(value > 0.0 || (zero_ok && value == 0.0)) || !std::isfinite(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): a finite value %s 0 expected, got %g", which, zero_ok ? ">=" : ">", value);
+    // the reference takes whatever the caller assigns; what is refused here is what cannot be computed with: a value that is not finite, a time step bound <= 0
+    auto finite = [&](double *dst) -> int {
+        if (!std::isfinite(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): a finite value expected, got %g", which, value);
+        *dst = value; return SPH_OK;
+    };
+    auto positive = [&](double *dst) -> int {
+        if (!(value > 0.0) || !std::isfinite(value)) return fail(h, SPH_E_INVALID, "sph_set_scalar(%d): a finite value > 0 expected, got %g", which, value);
         *dst = value; return SPH_OK;
     };
     int rc = SPH_OK;
     if (which >= SPH_P_DENSITY_THRESHOLD && which <= SPH_P_MIN_DT && !dfsph) return fail(h, SPH_E_STATE, "sph_set_scalar(%d): a dfsph_solver attribute on a handle of another solver", which);
+    if (h->cfg.solver == SPH_SOLVER_PBF && which >= SPH_P_VISCOSITY_C_S && which <= SPH_P_TENSION_K) return fail(h, SPH_E_STATE, "sph_set_scalar(%d): pbf_solver has no such attribute", which);
     switch (which) {
-    case SPH_P_DENSITY_THRESHOLD: rc = positive(&p.density_threshold, true); break;
+    case SPH_P_DENSITY_THRESHOLD: rc = finite(&p.density_threshold); break;
     case SPH_P_MIN_ITERATION_DENSITY: rc = count(&p.min_iteration_density, 0); break;
     case SPH_P_MIN_ITERATION_DENSITY_DIVERGENCE: rc = count(&p.min_iteration_density_divergence, 0); break;
     case SPH_P_MAX_ITERATION_DENSITY_DIVERGENCE: rc = count(&p.max_iteration_density_divergence, 0); break;
-    case SPH_P_DENSITY_DIVERGENCE_THRESHOLD: rc = positive(&p.density_divergence_threshold, true); break;
+    case SPH_P_DENSITY_DIVERGENCE_THRESHOLD: rc = finite(&p.density_divergence_threshold); break;
     case SPH_P_WARM_START: p.warm_start = value != 0.0; break;
     case SPH_P_ADAPTIVE_DT: p.adaptive_dt = value != 0.0; break;
-    case SPH_P_MAX_DT: rc = positive(&p.max_dt, false); break;
-    case SPH_P_MIN_DT: rc = positive(&p.min_dt, false); break;
-    case SPH_P_VISCOSITY_C_S: rc = positive(&p.viscosity_c_s, true); break;
-    case SPH_P_VISCOSITY_ALPHA: rc = positive(&p.viscosity_alpha, true); break;
-    case SPH_P_VISCOSITY_EPSILON: rc = positive(&p.viscosity_epsilon, false); break;
-    case SPH_P_TENSION_K: rc = positive(&p.tension_k, true); break;
+    case SPH_P_MAX_DT: rc = positive(&p.max_dt); break;
+    case SPH_P_MIN_DT: rc = positive(&p.min_dt); break;
+    case SPH_P_VISCOSITY_C_S: rc = finite(&p.viscosity_c_s); break;
+    case SPH_P_VISCOSITY_ALPHA: rc = finite(&p.viscosity_alpha); break;
+    case SPH_P_VISCOSITY_EPSILON: rc = finite(&p.viscosity_epsilon); break;
+    case SPH_P_TENSION_K: rc = finite(&p.tension_k); break;
     default: return fail(h, SPH_E_INVALID, "unknown scalar %d", which);
     }
     if (rc) return rc;
-    if (h->cfg.solver == SPH_SOLVER_PBF && which >= SPH_P_VISCOSITY_C_S) return fail(h, SPH_E_STATE, "sph_set_scalar(%d): pbf_solver has no such attribute", which);
+    h->p = p;
     HIP_TRY(h, hipSetDevice(h->device));
     fold_params(h);
     if (dfsph) {          // (the mirror's other words are whatever the last read-back left: only the p_* block is written)

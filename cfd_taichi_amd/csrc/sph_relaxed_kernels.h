@@ -39,9 +39,9 @@ __device__ __forceinline__ float rx_g(const Consts &c, float dx, float dy, float
 
 // positions and k / rho of the workgroup's staged set, unscaled (the relaxed counterpart of stage_operand_ps_scaled)
 __device__ __forceinline__ bool stage_operand_ps(const Consts &c, float4 *__restrict__ s_A, const float4 *__restrict__ A, const float *__restrict__ S,
-                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk)
+                                                 const uint2 *__restrict__ stage_runs, const int *__restrict__ stage_cnt, int blk, const StagePre &pre = kNoPre)
 {
-    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));
+    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);
     if (nst < 0) return false;
     if (nst == 0) return true;
     const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);
@@ -132,21 +132,27 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
                                                         SpecUndo un = SpecUndo{nullptr, nullptr, nullptr, nullptr, 0}, DensFlow df = kNoFlow)
 {
     extern __shared__ float4 s_operand[];
-    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
     const bool spread = DENS && wave_dirty && !force_all;           // (round-robin tiles when most of them return at once, see k_correct in sph_kernels.h)
     const int tile = sweep_tile(tp, spread);
-    if (tile < 0) return;
     const bool flow = DENS && df.nbr != nullptr;                    // the producer says who must run (DensFlow in sph_kernels.h; k_residual is the commented form)
+    const int n2 = (flow && spread && tp.sparse) ? tp.sparse[tp.ntiles + 1] : 0;
+    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }
+    if (tile < 0) return;
+    StagePre pre = kNoPre;
+    bool direct = false;
     if (spread) {                                                   // change propagation between the sweeps of the density loop (sph_kernels.h)
         bool idle;
         if (flow) {
-            idle = !flow_needed(df, tile);
+            const FlowHead fh = flow_head(tp, df, tile, n2, stage_src, stage_cnt);
+            pre = fh.pre; direct = fh.direct;
+            idle = !fh.need;
             if (idle && df.nz[tile] != 0 && threadIdx.x < 64) flow_push(df, df.nbr[(size_t)tile * kNbrStride + threadIdx.x]);
+            if (idle && direct && threadIdx.x == 0) df.worked[tile] = 0;
         } else {
             const int sw = stage_cnt[tile];
             idle = sw >= 0 && !stage_sources_flagged(stage_src, sw, tile, wave_dirty);
         }
-        if (tp.hot && threadIdx.x == 0) tp.hot[tile] = idle ? 0 : 1;
+        if (tp.hot && threadIdx.x == 0 && idle) tp.hot[tile] = 0;
         if (idle) return;
     }
     const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;
@@ -155,15 +161,23 @@ __global__ __launch_bounds__(kBlock) void k_residual_rx(Consts c, const float4 *
     (void)nlbp;
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);
     bool staged;
-    if (spread) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
-        const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk);
+    if (spread && !direct) {       // second, exact level of the change propagation (sph_kernels.h: stage_operand_pv_checked)
+        const int verdict = stage_operand_pv_checked<false>(c, s_operand, s_v2, P, V, changed8, stage_src, stage_cnt, blk, pre);
         if (verdict == 2) {
             if (flow && df.nz[blk] != 0 && threadIdx.x < 64) flow_push(df, my_nbr);
+            if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 1;
             return;
         }
         staged = verdict == 1;
     } else {
-        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);
+        int would = 1;                                              // (see k_residual: a `direct` tile learns from the staging batch whether it would have passed the check)
+        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk, pre, (spread && direct) ? changed8 : nullptr, &would);
+        if (spread && flow && threadIdx.x == 0) df.worked[blk] = would ? 1 : 0;
+        if (spread && tp.hot && threadIdx.x == 0) tp.hot[blk] = would ? 2 : 1;
+    }
+    if (spread && !direct) {
+        if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 2;
+        if (flow && threadIdx.x == 0) df.worked[blk] = 1;
     }
     const float4 vi = V[ii];
     float acc = 0.f;
@@ -229,24 +243,32 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
 {
     extern __shared__ float4 s_operand[];
     if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // (see k_correct: the loop decision rides in this launch)
-    if (gate_closed(ds, gate)) return;
     const uint32_t *nlb = nullptr;
     const int tile = sweep_tile(tp, MODE == CORR_DENS && wave_dirty != nullptr);
-    if (tile < 0) return;
     const bool flow = MODE == CORR_DENS && wave_dirty != nullptr && df.nbr != nullptr;      // (DensFlow, see k_correct in sph_kernels.h)
-    if (flow && !flow_needed(df, tile)) {
-        const int i0 = tile * kBlock + (int)threadIdx.x;
-        if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
-        if (i0 < c.n) changed8[i0] = 0;
-        return;
+    const int n2 = (flow && tp.sparse) ? tp.sparse[tp.ntiles + 1] : 0;
+    if (gate_closed(ds, gate)) return;
+    if (tile < 0) return;
+    StagePre pre = kNoPre;
+    bool direct = false;
+    if (flow) {
+        const FlowHead fh = flow_head(tp, df, tile, n2, stage_src, stage_cnt);
+        pre = fh.pre; direct = fh.direct;
+        if (!fh.need) {
+            const int i0 = tile * kBlock + (int)threadIdx.x;
+            if ((threadIdx.x & 63) == 0) wave_dirty[tile * (kBlock / 64) + (threadIdx.x >> 6)] = 0;
+            if (i0 < c.n) changed8[i0] = 0;
+            if (direct && threadIdx.x == 0) df.worked[tile] = 0;
+            return;
+        }
     }
-    const int my_nbr = flow ? df.nbr[(size_t)tile * kNbrStride + (threadIdx.x & 63)] : 0;
+    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;
     SPH_SWEEP_PROLOGUE_G(false, tile, true)
     (void)nlbp;
     const bool track = MODE == CORR_DENS && wave_dirty != nullptr;  // change propagation in the density loop (sph_kernels.h: stage_sources_flagged)
     bool staged;
-    if (track) {
-        const int verdict = stage_operand_ps_checked<false>(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+    if (track && !direct) {
+        const int verdict = stage_operand_ps_checked<false>(c, s_operand, P, krho, stage_src, stage_cnt, blk, pre);
         if (verdict == 2) {
             const bool foreign = live && ghost && !c.ghost_walk;           // (see k_correct in sph_kernels.h)
             const unsigned long long anyg = __ballot(foreign);
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         }
         staged = verdict == 1;
     } else {
-        staged = stage_operand_ps(c, s_operand, P, krho, stage_src, stage_cnt, blk);
+        staged = stage_operand_ps(c, s_operand, P, krho, stage_src, stage_cnt, blk, pre);
     }
     const float dt = ds->dt;
     const float rho_i = rho[ii];
@@ -298,7 +320,11 @@ __global__ __launch_bounds__(kBlock) void k_correct_rx(Consts c, const float4 *_
         const unsigned long long any = __ballot(changed);
         if ((threadIdx.x & 63) == 0) wave_dirty[blk * (kBlock / 64) + (threadIdx.x >> 6)] = any != 0ull ? 1 : 0;
         if (live) changed8[i] = changed ? 1 : 0;
-        if (flow && any != 0ull) flow_push(df, my_nbr);
+        if (flow) {
+            const int moved = __syncthreads_or(changed ? 1 : 0);
+            if (moved && threadIdx.x < 64) flow_push(df, my_nbr);
+            if (threadIdx.x == 0) df.worked[tile] = moved ? 1 : 0;
+        }
     }
     if (!live) return;
     float4 v = Vin[i];

@@ -417,27 +417,32 @@ __global__ __launch_bounds__(kBlock) void k_tile_flags(Consts c, SlabGeom g, con
     e = __syncthreads_or(e);
     if (threadIdx.x == 0) flag[blockIdx.x] = e ? 1 : 0;
 }
-// order[] = the flagged tiles first, then the others, both in index order; order[ntiles] = number of flagged tiles.  ONE pass of one 1024-thread
-// workgroup: every thread takes a run of consecutive tiles, the runs' flag counts are scanned once (wave scans + 16 wave sums), then every thread
-// places its tiles -- one barrier (the chunked two-pass form this replaces took 17 us at 3907 tiles; this one 5, and it is launched every step for
-// the density loop's working tiles, TilePhase.sparse).
+// order[] = the tiles of class 2 first, then class 1 (any other nonzero flag), then the unflagged ones, each in index order; order[ntiles] = number of
+// flagged tiles, order[ntiles + 1] = number of class-2 tiles.  (Slab edge tiles and the rigid shell flag with 1; the density loop's residual sweep
+// with 2 = worked, 1 = left after the per-particle check: TilePhase.hot.)  ONE pass of one 1024-thread workgroup: every thread takes a run of
+// consecutive tiles, the runs' counts are scanned once (wave scans + 16 wave sums), then every thread places its tiles -- one barrier (the chunked
+// two-pass form this replaces took 17 us at 3907 tiles; this one 5, and it is launched every step for the density loop's working tiles).
 __global__ __launch_bounds__(1024) void k_tile_order(const int *__restrict__ flag, int ntiles, int *__restrict__ order)
 {
-    __shared__ int wsum[16];
+    __shared__ int wsum[2][16];
     const int per = (ntiles + 1023) / 1024, first = (int)threadIdx.x * per, last = min(first + per, ntiles);
-    int mine = 0;
-    for (int t = first; t < last; ++t) mine += flag[t] != 0 ? 1 : 0;
-    const int inc = wave_inclusive_scan(mine);
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    int mine2 = 0, mine1 = 0;
+    for (int t = first; t < last; ++t) { const int f = flag[t]; mine2 += f == 2 ? 1 : 0; mine1 += (f != 0 && f != 2) ? 1 : 0; }
+    const int inc2 = wave_inclusive_scan(mine2), inc1 = wave_inclusive_scan(mine1);
+    if ((threadIdx.x & 63) == 63) { wsum[0][threadIdx.x >> 6] = inc2; wsum[1][threadIdx.x >> 6] = inc1; }
     __syncthreads();
-    int before = inc - mine, total = 0;
-    for (int w = 0; w < 16; ++w) { if (w < (int)(threadIdx.x >> 6)) before += wsum[w]; total += wsum[w]; }
-    for (int t = first; t < last; ++t) {
-        const int v = flag[t] != 0 ? 1 : 0;
-        order[v ? before : total + (t - before)] = t;
-        before += v;
+    int before2 = inc2 - mine2, before1 = inc1 - mine1, total2 = 0, total1 = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) { before2 += wsum[0][w]; before1 += wsum[1][w]; }
+        total2 += wsum[0][w]; total1 += wsum[1][w];
     }
-    if (threadIdx.x == 0) order[ntiles] = total;
+    for (int t = first; t < last; ++t) {
+        const int f = flag[t];
+        const int cls = f == 2 ? 2 : (f != 0 ? 1 : 0);
+        order[cls == 2 ? before2 : cls == 1 ? total2 + before1 : total2 + total1 + (t - before2 - before1)] = t;
+        before2 += cls == 2 ? 1 : 0; before1 += cls == 1 ? 1 : 0;
+    }
+    if (threadIdx.x == 0) { order[ntiles] = total2 + total1; order[ntiles + 1] = total2; }
 }
 
 // Rigid body on slab handles.  The reference's quirks read FLUID arrays with a rigid particle's local index (get_neighbour_count measures to

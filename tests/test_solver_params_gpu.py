@@ -43,12 +43,15 @@ PARAM_SETS = {
     "dt_window": {"max_dt": 4e-4, "min_dt": 2e-4},
     "fluid": {"viscosity_c_s": 20.0, "viscosity_alpha": 0.05, "viscosity_epsilon": 0.02, "tension_k": 1.5},
     "no_div_loop": {"max_iteration_density_divergence": 0},
+    # the "no cap" idiom: the library enqueues such a loop in chunks of 32 iterations and looks at the loop state in between
+    "no_cap": {"max_iteration_density_divergence": 1000},
 }
 
 
 CASES = [("dfsph_small", 25, None, name) for name in sorted(PARAM_SETS)] \
     + [("dfsph_small", 25, "morton", name) for name in ("div_loop", "no_warm_start", "fluid", "dt_window")] \
-    + [("dfsph_tiny_wall", 40, None, name) for name in ("dens_loop", "fixed_dt")]
+    + [("dfsph_tiny_wall", 40, None, name) for name in ("dens_loop", "fixed_dt")] \
+    + [("dfsph_small", 10, "morton", "no_cap")]
 
 
 @pytest.mark.parametrize("scene,steps,order,name", CASES)
@@ -73,6 +76,8 @@ def test_dfsph_attributes_set_before_the_first_step(scene, steps, order, name, m
         assert max(c[0] for c in counts) <= 4
     if name == "no_div_loop":
         assert all(c[0] == 0 for c in counts)
+    if name == "no_cap":
+        assert max(c[0] for c in counts) > 32, "the divergence loop never crossed a chunk boundary: %r" % [c[0] for c in counts]
     if name == "fixed_dt":
         assert all(c[2] == np.float32(5e-4) for c in counts) and ref_counts[-1][2] != np.float32(5e-4)
     if name == "dt_window":
@@ -183,10 +188,22 @@ def test_mirror_classes_forward_the_attributes():
 
 def test_bad_values_are_refused():
     sim = nat.Simulation(nat.config_from_dict(scenes.get("dfsph_small")))
-    for k, v in (("max_dt", 0.0), ("min_dt", -1.0), ("max_iteration_density_divergence", 2.5), ("min_iteration_density", -1), ("viscosity_epsilon", 0.0), ("tension_k", float("nan"))):
+    for k, v in (("max_dt", 0.0), ("min_dt", -1.0), ("max_iteration_density_divergence", 2.5), ("min_iteration_density", -1), ("viscosity_epsilon", float("inf")), ("tension_k", float("nan"))):
+        before = sim.param(k)
         with pytest.raises(nat.SphError):
             sim.set_param(k, v)
+        assert sim.param(k) == before, k             # a refused value leaves the attribute as it was
+    # what the reference would run is taken: it assigns Python attributes without looking at them
+    for k, v in (("viscosity_epsilon", 0.0), ("tension_k", -0.25), ("density_threshold", -1.0)):
+        sim.set_param(k, v)
+        assert sim.param(k) == v
     sim.close()
+    b = nat.Simulation(nat.config_from_dict(scenes.get("pbf_tiny_wall")))
+    before = b.param("tension_k")
+    with pytest.raises(nat.SphError):
+        b.set_param("tension_k", 0.3)                 # pbf_solver has no such attribute: refused BEFORE anything is written
+    assert b.param("tension_k") == before
+    b.close()
     w = nat.Simulation(nat.config_from_dict(scenes.get("wcsph_small")))
     with pytest.raises(nat.SphError):
         w.set_param("density_threshold", 0.2)             # a dfsph_solver attribute

@@ -37,14 +37,14 @@ PATCHES = {
     "xcd_chunk128": [(K, "    return xcd_block(orig, nwg);\n}\n\n// Edge / interior split of a sweep",
                     "    const int C = 128, xcd = orig & 7, s = orig >> 3, per = nwg / (8 * C);\n    if (per < 4) return xcd_block(orig, nwg);\n    if (s >= per * C) return orig;\n    return ((s / C) * 8 + xcd) * C + s % C;\n}\n\n// Edge / interior split of a sweep")],
     # exact k_residual: workgroups whose set did not fit the LDS capacity (1-2 % of them at 1 M) return at once: what do they cost the launch?
-    "nounstaged": [(K, "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n    }",
-                    "        staged = STAGED && stage_operand_pv<true>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);   // positions * 2^32\n        if (STAGED && !staged) return;\n    }")],
+    "nounstaged": [(K, "(spread && direct) ? changed8 : nullptr, &would);   // positions * 2^32\n",
+                    "(spread && direct) ? changed8 : nullptr, &would);   // positions * 2^32\n        if (STAGED && !staged) return;\n")],
     # a CORRECT variant with a side effect: every workgroup of the exact divergence-residual sweep leaves (begin, end, XCC id) of its life in a
     # device array that sph_debug_timeline() copies out (tools/wg_timeline.py): how full is the chip over a launch, where is the tail?
     "wg_timeline": [(K, "    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (flow) {                                                      // does this tile hold",
                      "    else block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n    if (flow) {                                                      // does this tile hold"),
-                    (K, "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;                                        // kernel functions of the sweep's arithmetic (sph_device.h); RX: unstaged handles under SPH_ARITH_RELAXED\n    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
-                     "    constexpr bool STAGED = SWEEP == SWEEP_STAGED, QUAD = SWEEP == SWEEP_QUAD;\n    using K = KF<RX>;\n    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
+                    (K, "    extern __shared__ float4 s_operand[];\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
+                     "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
                     (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
                     (K, "    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID"),
                     (K, "    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);",
@@ -54,8 +54,8 @@ PATCHES = {
                      "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # the same stamps in the relaxed divergence-residual sweep (tools/wg_timeline.py with SPH_ARITH=relaxed reads the same array)
     "wg_timeline_rx": [(K, "constexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip", "__device__ unsigned long long g_sub2[16384 * 4];\nconstexpr int kStageBatch = 7;          // 7 x 256 = 1792 >= the default capacity of 1664: one trip"),
-                       (K, "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;",
-                        "    const int w = stage_cnt[blk];\n    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;"),
+                       (K, "    if (w < 0) return -1;                                   // uniform per workgroup\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;",
+                        "    if (w < 0) return -1;                                   // uniform per workgroup\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 0] = wall_clock64();\n    const int nst = w & 0xffff, nruns = (w >> 16) & 0x3fff;"),
                        (K, "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    __syncthreads();\n    return nst;",
                         "        for (int k = 0; k < n; ++k) s_idx[base + k] = rn.x + (uint32_t)k;\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub2[blockIdx.x * 4 + 1] = wall_clock64();\n    __syncthreads();\n    return nst;"),
                        (R, "    const uint32_t *nlb = nullptr;\n    SPH_SWEEP_PROLOGUE_B(false, tile)\n    (void)nlbp;\n    float2 *s_v2",
@@ -63,24 +63,63 @@ PATCHES = {
                        ("sph_mi355x.hip", "int sph_set_scalar(", "int sph_debug_sub2(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_sub2), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_set_scalar("),
                        (K, "// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle",
                         "__device__ unsigned long long g_sub[16384 * 4];\n// both operands of the residual sweeps staged: (x, y, z, vx) and (vy, vz) -- 24 B per staged particle"),
-                       (K, "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));\n    if (nst < 0) return false;\n    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n#pragma unroll\n    for (int t = 0; t < kStageTrips; ++t) {\n        const int base = threadIdx.x + t * kStageBatch * kBlock;\n        if (t * kStageBatch * kBlock >= nst) break;\n        float4 a[kStageBatch], b[kStageBatch];",
-                        "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A));\n    const unsigned long long ts1 = wall_clock64();\n    if (nst < 0) return false;\n    if (nst == 0) return true;\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n    const unsigned long long ts2 = wall_clock64();\n    if (threadIdx.x == 0 && blockIdx.x < 16384) { g_sub[blockIdx.x * 4 + 0] = ts1; g_sub[blockIdx.x * 4 + 1] = ts2; }\n#pragma unroll\n    for (int t = 0; t < kStageTrips; ++t) {\n        const int base = threadIdx.x + t * kStageBatch * kBlock;\n        if (t * kStageBatch * kBlock >= nst) break;\n        float4 a[kStageBatch], b[kStageBatch];"),
-                       (K, "                s_B[e] = make_float2(b[u].y, b[u].z);\n            }\n    }\n    __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first",
-                        "                s_B[e] = make_float2(b[u].y, b[u].z);\n            }\n    }\n    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub[blockIdx.x * 4 + 2] = wall_clock64();\n    __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first"),
+                       (K, "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);\n    if (nst < 0) return false;\n    if (nst == 0) return true;                              // a workgroup of ghosts only (slab handles): nothing to stage, uniform\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n    int any = 0;\n",
+                        "    const int nst = stage_expand(stage_runs, stage_cnt, blk, reinterpret_cast<uint32_t *>(s_A), pre);\n    const unsigned long long ts1 = wall_clock64();\n    if (nst < 0) return false;\n    if (nst == 0) return true;\n    const StageIdx x = stage_take(reinterpret_cast<const uint32_t *>(s_A), nst);\n    const unsigned long long ts2 = wall_clock64();\n    if (threadIdx.x == 0 && blockIdx.x < 16384) { g_sub[blockIdx.x * 4 + 0] = ts1; g_sub[blockIdx.x * 4 + 1] = ts2; }\n    int any = 0;\n"),
+                       (K, "    if (changed) *any_changed = __syncthreads_or(any);\n    else __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first",
+                        "    if (threadIdx.x == 0 && blockIdx.x < 16384) g_sub[blockIdx.x * 4 + 2] = wall_clock64();\n    if (changed) *any_changed = __syncthreads_or(any);\n    else __syncthreads();\n    return true;\n}\n// The same with a look at a per-particle byte first"),
                        ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
                         "int sph_debug_sub(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_sub), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{"),
                        (K, "// D3 / D6: divergence residual and predicted density.", "__device__ unsigned long long g_timeline[16384 * 4];\n// D3 / D6: divergence residual and predicted density."),
                        ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
                         "int sph_debug_timeline(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_timeline), sizeof(unsigned long long) * 4 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{"),
-                       (R, "    extern __shared__ float4 s_operand[];\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
-                        "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    if (gate_closed(ds, gate)) { spec_undo(c, un, ds, tp); return; }\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
+                       (R, "    extern __shared__ float4 s_operand[];\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin",
+                        "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    const bool spread = DENS && wave_dirty && !force_all;           // (round-robin"),
                        (R, "    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;", "    const unsigned long long t_staged = wall_clock64();\n    const float4 vi = V[ii];\n    float acc = 0.f;\n    const bool skip = !DENS && kf < 20;"),
                        (R, "    float val = 0.f, kr = 0.f;\n    int flag = 0;\n    if (live) {\n        float sum = acc;", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pairs = wall_clock64();\n    const unsigned long long t_walls = t_pairs;\n    float val = 0.f, kr = 0.f;\n    int flag = 0;\n    if (live) {\n        float sum = acc;"),
                        (R, "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (flow) {\n        const int nzf",
                         "    block_partial_mean(blk, (double)val, flag, psum, pcnt);\n    if (!DENS && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n        g_timeline[blockIdx.x * 4 + 0] = t_begin; g_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_timeline[blockIdx.x * 4 + 2] = (xcc & 15) | ((t_staged - t_begin) << 8) | ((t_pairs - t_begin) << 24) | ((t_walls - t_begin) << 40); g_timeline[blockIdx.x * 4 + 3] = (unsigned long long)blk;\n    }\n    if (flow) {\n        const int nzf")],
+    # a CORRECT variant with a side effect (round 6): every workgroup of ONE density-loop launch pair -- the residual sweep D6 and the correction sweep D7 whose
+    # DensFlow stamps the host names (sph_debug_dens_capture) -- leaves (begin, end, outcome | XCC id, tile): outcome 0 = left after the need word, 1 = left
+    # after the per-particle check, 2 = worked (tools/dens_timeline.py: where does a sparse launch's time go?)
+    "dens_timeline": [(K, "constexpr DensFlow kNoFlow{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};",
+                       "constexpr DensFlow kNoFlow{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr};\n__device__ unsigned long long g_tl6[16384 * 4], g_tl7[16384 * 4];\n__device__ int g_tl_capture[2];\n"
+                       "__device__ __forceinline__ void tl_note(unsigned long long *buf, int want, const DensFlow &df, unsigned long long t_begin, int outcome, int tile, int extra = 0, unsigned long long ph = 0ull)\n{\n"
+                       "    if (df.nbr == nullptr || df.stamp_out != want || threadIdx.x != 0 || blockIdx.x >= 16384) return;\n"
+                       "    unsigned xcc; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\" : \"=s\"(xcc));\n"
+                       "    buf[blockIdx.x * 4 + 0] = t_begin; buf[blockIdx.x * 4 + 1] = wall_clock64(); buf[blockIdx.x * 4 + 2] = (unsigned long long)outcome | ((unsigned long long)(xcc & 15) << 8) | ((unsigned long long)(unsigned)extra << 32); buf[blockIdx.x * 4 + 3] = (unsigned long long)tile | (ph << 16);\n}\n"),
+                      (K, "    if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }          // the loop decision of the residual sweep before (whatever the gate says)\n",
+                       "    const unsigned long long t_begin = wall_clock64();\n    if (fr.mode >= 0 && blockIdx.x == 0) { fin_ride_block(fr); return; }\n"),
+                      (K, "            if (direct && threadIdx.x == 0) df.worked[tile] = 0;\n            return;\n        }\n    }\n    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;       // requested now, used by the push at the end",
+                       "            if (direct && threadIdx.x == 0) df.worked[tile] = 0;\n            tl_note(g_tl7, g_tl_capture[1], df, t_begin, 0, tile);\n            return;\n        }\n    }\n    const int my_nbr = (flow && threadIdx.x < 64) ? df.nbr[(size_t)tile * kNbrStride + threadIdx.x] : 0;"),
+                      (K, "            if (live) changed8[i] = foreign ? 1 : 0;\n            return;\n        }\n        staged = verdict == 1;",
+                       "            if (live) changed8[i] = foreign ? 1 : 0;\n            if (MODE == CORR_DENS) tl_note(g_tl7, g_tl_capture[1], df, t_begin, 1, tile);\n            return;\n        }\n        staged = verdict == 1;"),
+                      (K, "            if (threadIdx.x == 0) df.worked[tile] = moved ? 1 : 0;\n        }\n    }\n    if (!owner) return;",
+                       "            if (threadIdx.x == 0) df.worked[tile] = moved ? 1 : 0;\n        }\n    }\n    if (MODE == CORR_DENS) { __builtin_amdgcn_s_barrier(); const unsigned long long t_w = wall_clock64(); tl_note(g_tl7, g_tl_capture[1], df, t_begin, 2, tile, STAGED ? stage_cnt[tile] : 0, ((t_st - t_begin) & 0xffff) | (((t_pr - t_begin) & 0xffff) << 16) | (((t_w - t_begin) & 0xffff) << 32)); }\n    if (!owner) return;"),
+                      (K, "    extern __shared__ float4 s_operand[];\n    // (see k_correct: round-robin tiles when most of them return at once; the body",
+                       "    extern __shared__ float4 s_operand[];\n    const unsigned long long t_begin = wall_clock64();\n    // (see k_correct: round-robin tiles when most of them return at once; the body"),
+                      (K, "        if (idle) return;                                            // rho*, k / rho and the block partial of the last iteration stand",
+                       "        if (idle) { tl_note(g_tl6, g_tl_capture[0], df, t_begin, 0, tile); return; }"),
+                      (K, "            if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 1;\n            return;\n        }\n        staged = verdict == 1;",
+                       "            if (tp.hot && threadIdx.x == 0) tp.hot[blk] = 1;\n            tl_note(g_tl6, g_tl_capture[0], df, t_begin, 1, tile);\n            return;\n        }\n        staged = verdict == 1;"),
+                      (K, "    if (flow) {                                                      // does this tile hold a k / rho != 0?  (a NaN counts)",
+                       "    if (DENS) tl_note(g_tl6, g_tl_capture[0], df, t_begin, 2, tile, STAGED ? stage_cnt[tile] : 0, ((t_st - t_begin) & 0xffff) | (((t_pr - t_begin) & 0xffff) << 16) | (((t_w - t_begin) & 0xffff) << 32));\n    if (flow) {                                                      // does this tile hold a k / rho != 0?  (a NaN counts)"),
+                      (K, "    const float dt = ds->dt;\n    const float rho_i = rho[ii];\n    float k_i;\n    if (MODE == CORR_WARM) k_i = warm[ii] / dt;                                   // :333",
+                       "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_st = wall_clock64();\n    const float dt = ds->dt;\n    const float rho_i = rho[ii];\n    float k_i;\n    if (MODE == CORR_WARM) k_i = warm[ii] / dt;                                   // :333"),
+                      (K, "    float wa[3] = {0.f, 0.f, 0.f};\n    float &bx = wa[0], &by = wa[1], &bz = wa[2];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219",
+                       "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pr = wall_clock64();\n    float wa[3] = {0.f, 0.f, 0.f};\n    float &bx = wa[0], &by = wa[1], &bz = wa[2];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        float s = pj.w * k_i / rho_i;                                             // :354 / :390 / :219"),
+                      (K, "    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID", "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_st = wall_clock64();\n    const float4 vi = V[ii];\n    float fa[1] = {0.f};\n    float &acc = fa[0];\n    const int nq = RIGID"),
+                      (K, "    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);",
+                       "    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_pr = wall_clock64();\n    float wa[1] = {0.f};\n    float &accb = wa[0];\n    auto wall = [&](const float4 pj) {\n        float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;\n        float r = K::norm3(dx, dy, dz);\n        F3 g = K::grad_in(c, dx, dy, dz, r);\n        accb += pj.w * dot3(vi.x, vi.y, vi.z, g.x, g.y, g.z);"),
+                      (K, "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    float val = 0.f, kr = 0.f;", "    else for_nbrs_p(nlbp, skip ? 0 : kb, WP, wall);\n    __builtin_amdgcn_s_barrier();\n    const unsigned long long t_w = wall_clock64();\n    float val = 0.f, kr = 0.f;"),
+                      ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
+                       "int sph_debug_flow_stamp(SphHandle *h) { return h->flow_stamp; }\nint sph_debug_dens_capture(int stamp6, int stamp7)\n{\n    int v[2] = {stamp6, stamp7};\n    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sph::g_tl_capture), v, sizeof(v));\n}\n"
+                       "int sph_debug_dens_timeline(int which, unsigned long long *out, int n)\n{\n    return which == 6 ? (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_tl6), sizeof(unsigned long long) * 4 * (size_t)n)\n                      : (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_tl7), sizeof(unsigned long long) * 4 * (size_t)n);\n}\n"
+                       "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
-                  "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;", 2)],
+                  "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;"),
+                 (K, "        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; f[u] = changed ? changed[x.j[t][u]] : (unsigned char)0; }",
+                  "        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; f[u] = 0; }")],
     # k_build_nl: every wave works its 27 cell entries out per lane (a CORRECT variant: tools/soak_libs.py holds it against the default)
     "bnl_notable": [(K, "    const bool table = nruns <= kRunCap;                                       // wave-uniform",
                      "    const bool table = false;")],
@@ -91,8 +130,8 @@ PATCHES = {
     # LDS gathers, same arithmetic, half the list bytes from HBM): what a 2x more compact list encoding could buy at most
     "rx_halflist": [(R, "        if (kk + 8 < cnt) jn = nl_load(base + (size_t)((kk >> 3) + 1) * 256);\n        pair8(g);",
                      "        if (kk + 8 < cnt && ((kk >> 3) & 1)) jn = nl_load(base + (size_t)((kk >> 3) + 1) * 256);\n        pair8(g);")],
-    "rx_nostage": [(R, "        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk);\n    }\n    const float4 vi = V[ii];",
-                    "        staged = true;\n    }\n    const float4 vi = V[ii];"),
+    "rx_nostage": [(R, "        staged = stage_operand_pv<false>(c, s_operand, s_v2, P, V, stage_src, stage_cnt, blk, pre, (spread && direct) ? changed8 : nullptr, &would);\n",
+                    "        staged = true;\n"),
                    (R, "        rx_walk8(nlp, kfx, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];",
                     "        rx_walk8(nlp, 0, [&](const Nl16Group &g) {\n            float4 a[8]; float2 b[8];")],
 }
