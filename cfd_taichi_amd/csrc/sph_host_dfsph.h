@@ -383,7 +383,9 @@ void launch_dens_residual(SphHandle *h, int gate, int phase = 0, hipStream_t st 
     const int *wdirty = tile_skip(h) ? h->wave_dirty : nullptr;
     const int force_all = (h->dens_first || h->tune_all) ? 1 : 0;      // the first compute_all_rho_adv of a step computes every tile
     if (phase != 1) h->dens_first = false;                              // (an edge launch is followed by the interior launch of the same sweep)
-    const DensFlow df = wdirty ? dens_flow(h, true) : kNoFlow;
+    // (the interior launch of a split sweep is the same sweep as its edge launch: the same stamps)
+    const DensFlow df = wdirty ? (phase == 2 ? h->flow_d6 : dens_flow(h, true)) : kNoFlow;
+    h->flow_d6 = df;
     const SpecUndo no_undo{nullptr, nullptr, nullptr, nullptr, 0};
     if (use_relaxed(h)) {
         const TilePhase tpr = split ? TilePhase{h->tile_order, h->nblocks, 2} : tp;
@@ -471,7 +473,8 @@ int slab_exchange_resid_and_finalize(SphHandle *h, bool dens, float *val, int mo
         ProfScope ps(h, K_SLAB);
         const ResidLists L{h->edge_list[0], nrl, h->edge_n[0][0], (float *)h->drecv[0], h->edge_list[3], nrr, h->edge_n[3][0], (float *)h->drecv[1]};
         hipLaunchKernelGGL(k_unpack_resid_decide, dim3((unsigned)((nrl + nrr + kFinBlock - 1) / kFinBlock + 1)), dim3(kFinBlock), 0, s, h->c, L, dens ? 1 : 0, h->aux, h->rho,
-                           val, P, S, h->psum, h->pcnt, h->nblocks, h->ds, mode, gather ? h->gath_dev : h->red_dev, partial_group(h), partial_count(h), gather ? h->nslab : 0);
+                           val, P, S, h->psum, h->pcnt, h->nblocks, h->ds, mode, gather ? h->gath_dev : h->red_dev, partial_group(h), partial_count(h), gather ? h->nslab : 0,
+                           dens ? h->flow_d6 : kNoFlow);
     }
     HIP_TRY(h, hipGetLastError());
     return SPH_OK;

@@ -163,8 +163,8 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     if ((rc = dalloc(h, &h->rcell_of, nr))) return rc;
     if ((rc = dalloc(h, &h->rrank, nr))) return rc;
     if ((rc = dalloc(h, &h->rslot, nr))) return rc;
-    if ((rc = dalloc(h, &h->rcell_count, (size_t)c.S + 2))) return rc;
-    if ((rc = dalloc(h, &h->rcell_start, (size_t)c.S + 2))) return rc;
+    if ((rc = dalloc(h, &h->rcell_count, (size_t)h->S_full + 2))) return rc;      // (S_full: a slab handle's own slots grow and shrink with its cuts)
+    if ((rc = dalloc(h, &h->rcell_start, (size_t)h->S_full + 2))) return rc;
     if ((rc = dalloc(h, &h->rforce, 3 * nr))) return rc;
     if ((rc = dalloc(h, &h->rvert, 3 * (size_t)(Nv > 0 ? Nv : 1)))) return rc;
     // (indexed by ORIGINAL particle id: on a slab handle that is the whole scene's id range, whatever this rank holds)
@@ -190,7 +190,7 @@ int build_rigid(SphHandle *h, const SphRigid *rg)
     HIP_TRY(h, hipMemcpyAsync(h->RPos, rp4.data(), sizeof(float4) * nr, hipMemcpyHostToDevice, h->stream));
     if (Nv > 0) HIP_TRY(h, hipMemcpyAsync(h->rvert, rvert.data(), sizeof(float) * 3 * (size_t)Nv, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rforce, 0, sizeof(float) * 3 * nr, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)c.S + 2), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->rcell_start, 0, sizeof(int) * ((size_t)h->S_full + 2), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->rho_orig, 0, sizeof(float) * by_id, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->ncount, 0, sizeof(int) * (size_t)h->c.stride, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -167,6 +167,31 @@ void set_slab_geometry(SphHandle *h)
     h->c.gw_right = (h->geom.layers == 2 && h->geom.has_right) ? h->geom.x_hi : -1;
 }
 
+// Slab handles on the Morton curve: the cell slots of THIS slab only.  The whole grid's slots were replicated on every rank -- at config 4 on 8 slabs
+// 6.2 M cells scanned, zeroed and walked per step by a rank that holds 17 of 401 columns (k_scan_tiles 26 us against 5 at 1 M on one GPU, k_scan_sums,
+// k_scan_add, k_layer_offsets: ~0.1 ms of a 5 ms step).  The tiles (4 x 4 x 4 cells) that hold one of the slab's columns [x_lo - layers, x_hi + layers)
+// keep their order along the curve and are ranked among themselves; every other tile ranks -1: cell_slot() bins a particle there nowhere and the
+// 27-cell walks skip it (`slot < 0`).  Re-applied when a re-balancing moves the cuts (the cell arrays keep the whole grid's size, S_full).
+int slab_local_grid(SphHandle *h)
+{
+    Consts &c = h->c;
+    if (!h->slab || c.order != CELL_ORDER_TILED || h->tile_rank_full.empty()) return SPH_OK;
+    const int lo = std::max(h->geom.x_lo - h->geom.layers, 0) >> c.tbits, hi = std::min(h->geom.x_hi + h->geom.layers - 1, c.gx - 1) >> c.tbits;
+    std::vector<std::pair<int, int>> held;                   // (rank along the whole grid's curve, tile)
+    for (size_t t = 0; t < h->tile_rank_full.size(); ++t) {
+        const int tx = (int)(t % (size_t)c.tnx);
+        if (tx >= lo && tx <= hi) held.push_back({h->tile_rank_full[t], (int)t});
+    }
+    std::sort(held.begin(), held.end());
+    h->tile_rank_local.assign(h->tile_rank_full.size(), -1);
+    for (size_t r = 0; r < held.size(); ++r) h->tile_rank_local[(size_t)held[r].second] = (int)r;
+    HIP_TRY(h, hipMemcpyAsync(h->tile_rank, h->tile_rank_local.data(), sizeof(int) * h->tile_rank_local.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    c.S = (int)(held.size() << (3 * c.tbits));
+    h->ntiles = (int)(((size_t)c.S + 2 + kScanTile - 1) / kScanTile);
+    return SPH_OK;
+}
+
 struct HostScene {
     std::vector<float> fluid_pos;                 // 3N, original order
     std::vector<float> wall_pos, wall_vol;        // original order
@@ -646,7 +671,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 if ((rc = dalloc(h, &h->wave_dirty, (n + kBlock - 1) / kBlock * (size_t)(kBlock / 64) + 64))) return rc;
                 if ((rc = dalloc(h, &h->changed8, n + 256))) return rc;
             }
-            if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip && h->opt_dens_push && !h->slab) {      // DensFlow (one GPU: a ghost's values change behind the rank's back)
+            // DensFlow: one GPU, and slab handles of the two-column protocol (the inner ghosts' velocities are corrected HERE like everybody's, the ghosts'
+            // k / rho arrives with the residual's refresh, whose unpack kernel pushes for them; a one-column handle's ghosts change behind the rank's back)
+            if (h->cfg.solver == SPH_SOLVER_DFSPH && h->opt_tile_skip && h->opt_dens_push && (!h->slab || h->geom.layers == 2)) {
                 const size_t nt = (n + kBlock - 1) / kBlock + 1;
                 if ((rc = dalloc(h, &h->tile_nbr, nt * (size_t)kNbrStride))) return rc;
                 if ((rc = dalloc(h, &h->need6, nt)) || (rc = dalloc(h, &h->need7, nt)) || (rc = dalloc(h, &h->tile_nz, nt))) return rc;
@@ -674,6 +701,7 @@ int alloc_device(SphHandle *h, const HostScene &sc)
     if ((rc = dalloc(h, &h->rank, n))) return rc;
     if ((rc = dalloc(h, &h->slot_src, n))) return rc;
     const size_t ncell = (size_t)c.S + 2;
+    h->S_full = c.S;
     h->ntiles = (int)((ncell + kScanTile - 1) / kScanTile);
     if ((rc = dalloc(h, &h->cell_count, ncell))) return rc;
     if ((rc = dalloc(h, &h->cell_start, ncell))) return rc;
@@ -735,6 +763,10 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
+        if (h->slab && !dev_env(&h->overrides, "SPH_SLAB_GRID_FULL")) {         // (SPH_SLAB_GRID_FULL=1: the whole grid's slots on every rank, as before round 6 -- A/B, tests)
+            h->tile_rank_full = tile_rank;
+            if ((rc = slab_local_grid(h))) return rc;
+        }
     }
 
     // upload the scene

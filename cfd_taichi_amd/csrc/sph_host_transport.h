@@ -279,6 +279,7 @@ int slab_rebalance(SphHandle *h)
         h->cuts = cut;
         set_slab_geometry(h);
         ++h->n_recuts;
+        if ((rc = slab_local_grid(h))) return rc;            // the slab's cell slots follow its columns
     }
     return SPH_OK;
 }
@@ -418,7 +419,7 @@ int slab_exchange_resid(SphHandle *h, bool dens, float *val, bool overlap, bool 
         ProfScope ps(h, K_SLAB, s);
         if (nrl + nrr)
             hipLaunchKernelGGL(k_unpack_resid, grid_for(nrl + nrr), b, 0, s, h->c, h->edge_list[0], nrl, h->edge_n[0][0], (const float *)h->drecv[0], h->edge_list[3], nrr,
-                               h->edge_n[3][0], (const float *)h->drecv[1], dens ? 1 : 0, h->aux, h->rho, h->ds, val, P, S);
+                               h->edge_n[3][0], (const float *)h->drecv[1], dens ? 1 : 0, h->aux, h->rho, h->ds, val, P, S, dens ? h->flow_d6 : kNoFlow);
     }
     HIP_TRY(h, hipGetLastError());
     if (overlap) HIP_TRY(h, hipEventRecord(h->ev_halo, s));

@@ -697,6 +697,18 @@ __device__ __forceinline__ int stage_lookup(const int *key, const int *base, int
     return 0;
 }
 
+// open-addressing insert into the kTileSet slots of a workgroup's tile set (k_build_nl; -1 = empty).  A full table drops the tile: the count taken
+// afterwards then reaches kTileSet and the row's header says "unknown"
+__device__ __forceinline__ void tile_set_insert(int *s_tset, int t)
+{
+    static_assert(kTileSet == 128, "7 hash bits");
+    int hq = (int)(((unsigned)t * 2654435761u) >> 25);
+    for (int probe = 0; probe < kTileSet; ++probe) {
+        const int was = atomicCAS(&s_tset[hq], -1, t);
+        if (was == -1 || was == t) break;
+        hq = (hq + 1) & (kTileSet - 1);
+    }
+}
 // who owns neighbour lists: every owned particle (id >= 0), and on two-column slab handles the ghosts of the inner ghost column (Consts.gw_*)
 __device__ __forceinline__ bool list_walker(const Consts &c, int id, int cx) { return id >= 0 || (c.ghost_walk && (cx == c.gw_left || cx == c.gw_right)); }
 
@@ -760,6 +772,28 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
                             }
                         }
         }
+        // (DensFlow on slab handles: a particle WITHOUT a list -- a ghost of the outer column -- is still staged by its neighbours' tiles, and the kernel
+        // that unpacks its k / rho pushes on its behalf through THIS tile's row: the tiles around its cell go into the tile set directly)
+        if (tile_nbr && i < c.n && !list_walker(c, id[i], hcx)) {
+            bool head = threadIdx.x == 0;             // the first of a run of particles without a list in the same cell does it for the run
+            if (!head) {
+                int px, py, pz;
+                const float4 pp = P[i - 1];
+                cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz);
+                head = list_walker(c, id[i - 1], px) || px != hcx || py != hcy || pz != hcz;
+            }
+            if (head)
+                for (int dx = -1; dx <= 1; ++dx)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dz = -1; dz <= 1; ++dz) {
+                            const int x = hcx + dx, y = hcy + dy, z = hcz + dz;
+                            if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
+                            const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                            if (slot < 0) continue;
+                            const int a = cell_start[slot], b = cell_start[slot + 1];
+                            for (int t = a / kBlock; b > a && t <= (b - 1) / kBlock; ++t) tile_set_insert(s_tset, t);
+                        }
+        }
         __syncthreads();
         // (2) local base of every cell of the set (table order), the ordered source list, the verdict
         int own[kStageHash / kBlock], cfirst[kStageHash / kBlock], run = 0, rig = 0;
@@ -799,15 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             }
             before += own[q];
             if (tile_nbr && own[q] > 0)           // the tiles this cell's particles lie in (staged or not: the cell set is complete whenever `ok`)
-                for (int t = cfirst[q] / kBlock; t <= (cfirst[q] + own[q] - 1) / kBlock; ++t) {
-                    int hq = (int)(((unsigned)t * 2654435761u) >> 25);
-                    static_assert(kTileSet == 128, "7 hash bits");
-                    for (int probe = 0; probe < kTileSet; ++probe) {
-                        const int was = atomicCAS(&s_tset[hq], -1, t);
-                        if (was == -1 || was == t) break;
-                        hq = (hq + 1) & (kTileSet - 1);
-                    }                   // (a full table drops the tile: the count below then exceeds the row and the header says "unknown")
-                }
+                for (int t = cfirst[q] / kBlock; t <= (cfirst[q] + own[q] - 1) / kBlock; ++t) tile_set_insert(s_tset, t);
         }
         if (threadIdx.x == 0) {
             const bool l16 = staged && c.nl16 != 0 && !near_body;
@@ -2403,6 +2429,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(Consts c, const float4 *__r
     if (c.ghost_walk && !__syncthreads_or(live && !ghost)) {
         if (QUAD) block_partial_mean_quad(blk, 0.0, 0, owner, psum, pcnt);
         else block_partial_mean(blk, 0.0, 0, psum, pcnt);
+        if (flow && threadIdx.x == 0) df.nz[blk] = 0;               // (the ghosts' k / rho is pushed for by the kernel that unpacks it)
         return;
     }
     float2 *s_v2 = reinterpret_cast<float2 *>(s_operand + c.stage_cap);

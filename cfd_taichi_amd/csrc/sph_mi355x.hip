@@ -121,6 +121,10 @@ struct SphHandle {
     std::vector<std::pair<void **, size_t>> plan;   // dalloc() requests not yet committed
     std::vector<char *> arenas;                      // dcommit() allocations
     int *tile_rank = nullptr;            // Consts.tile_rank
+    // slab handles on the Morton curve keep the cell slots of THEIR columns only (slab_local_grid): the whole grid's tile ranks, and the slot count the
+    // cell arrays were allocated for
+    std::vector<int> tile_rank_full, tile_rank_local;
+    int S_full = 0;
     bool staged = false;                 // LDS staging of the sweeps' gather operand (k_build_nl plan)
     int quad_below = 65536;              // quad sweeps (four lanes per particle) for unstaged single-GPU handles of up to this many particles
     bool opt_quad = true;                // SPH_QUAD=0 at sph_create: small scenes keep one lane per particle in the sweeps (A/B, tests)
@@ -199,6 +203,7 @@ struct SphHandle {
     // density loop's sweeps push to them, per tile "its k / rho holds a nonzero", the two broadcast words.  SPH_DENS_PUSH=0 turns it off (A/B, tests)
     int *tile_nbr = nullptr, *need6 = nullptr, *need7 = nullptr, *tile_nz = nullptr, *dens_bcast = nullptr, *worked6 = nullptr, *worked7 = nullptr;
     int flow_stamp = 0, flow_last = 0;          // launch counter of the density loop's sweeps; the stamp of the sweep enqueued last
+    DensFlow flow_d6 = kNoFlow;                 // ... and the residual sweep's whole block: a split sweep's second launch and the kernel that unpacks the ghosts' k / rho push with it
     bool opt_dens_push = true;
     bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;

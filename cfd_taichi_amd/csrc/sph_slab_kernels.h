@@ -352,8 +352,12 @@ __device__ __forceinline__ void pack_resid_entry(const ResidLists &L, int r, con
     const int s = (b ? L.list_b : L.list_a)[r];
     (b ? L.buf_b : L.buf_a)[r] = r < (b ? L.n1_b : L.n1_a) ? val[s] : (S ? S[s] : P[s].w);
 }
+// df (the density loop on a DensFlow handle): the residual sweep pushed "run the correction" to the tiles that stage a k / rho != 0 of its OWN
+// particles; a ghost's k / rho arrives here, so this kernel pushes for it -- through the row of the ghost's tile, which k_build_nl fills for
+// particles without lists too
 __device__ __forceinline__ void unpack_resid_entry(const Consts &c, const ResidLists &L, int r, int dens, const float *__restrict__ alpha, const float *__restrict__ rho,
-                                                   const DevScalars *__restrict__ ds, float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S)
+                                                   const DevScalars *__restrict__ ds, float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S,
+                                                   const DensFlow &df = kNoFlow)
 {
     if (r >= L.count_a + L.count_b) return;
     const bool b = r >= L.count_a;
@@ -367,6 +371,12 @@ __device__ __forceinline__ void unpack_resid_entry(const Consts &c, const ResidL
         else kr = (x * alpha[s] / ds->dt) / rho[s];                            // :363,367
     }
     if (S) S[s] = kr; else P[s].w = kr;
+    if (dens && df.nbr && kr != 0.f) {                       // (a NaN counts; ~1 % of the ghosts)
+        const int *row = df.nbr + (size_t)(s / kBlock) * kNbrStride;
+        const int hdr = row[0];
+        if (hdr < 0 || (hdr & kNbrOdd) != 0) df.bcast[df.bc_out] = df.stamp_out;
+        for (int q = 1; hdr >= 0 && q <= (hdr & (kNbrStride - 1)); ++q) df.need_out[row[q]] = df.stamp_out;
+    }
 }
 __global__ __launch_bounds__(kBlock) void k_pack_resid(const int *__restrict__ list_a, int count_a, int n1_a, float *__restrict__ out_a,
                                                        const int *__restrict__ list_b, int count_b, int n1_b, float *__restrict__ out_b,
@@ -388,18 +398,18 @@ __global__ __launch_bounds__(kFinBlock) void k_pack_resid_reduce(ResidLists L, c
 __global__ __launch_bounds__(kFinBlock) void k_unpack_resid_decide(Consts c, ResidLists L, int dens, const float *__restrict__ alpha, const float *__restrict__ rho,
                                                                    float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S,
                                                                    const double *__restrict__ psum, const int *__restrict__ pcnt, int nblocks, DevScalars *__restrict__ ds,
-                                                                   int mode, double *__restrict__ red, int group, int nparts, int gather_n)
+                                                                   int mode, double *__restrict__ red, int group, int nparts, int gather_n, DensFlow df = kNoFlow)
 {
     if (blockIdx.x == gridDim.x - 1) { finalize_mean_block(psum, pcnt, nblocks, ds, mode, FINP_DECIDE, red, group, nparts, -1, gather_n); return; }
-    unpack_resid_entry(c, L, blockIdx.x * kFinBlock + threadIdx.x, dens, alpha, rho, ds, val, P, S);
+    unpack_resid_entry(c, L, blockIdx.x * kFinBlock + threadIdx.x, dens, alpha, rho, ds, val, P, S, df);
 }
 __global__ __launch_bounds__(kBlock) void k_unpack_resid(Consts c, const int *__restrict__ list_a, int count_a, int n1_a, const float *__restrict__ in_a,
                                                          const int *__restrict__ list_b, int count_b, int n1_b, const float *__restrict__ in_b,
                                                          int dens, const float *__restrict__ alpha, const float *__restrict__ rho, const DevScalars *__restrict__ ds,
-                                                         float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S)
+                                                         float *__restrict__ val, float4 *__restrict__ P, float *__restrict__ S, DensFlow df = kNoFlow)
 {
     unpack_resid_entry(c, ResidLists{list_a, count_a, n1_a, const_cast<float *>(in_a), list_b, count_b, n1_b, const_cast<float *>(in_b)}, blockIdx.x * kBlock + threadIdx.x,
-                       dens, alpha, rho, ds, val, P, S);
+                       dens, alpha, rho, ds, val, P, S, df);
 }
 
 // Edge / interior split of the residual sweeps (slab handles, dfsph): a tile is an EDGE tile if one of its particles lies in a column that

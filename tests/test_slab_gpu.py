@@ -150,7 +150,10 @@ def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0
     ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, None),
     ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None),
     # world = 8, the size BASELINE's scaling target names: slabs of 12-13 owned + 4 ghost cell columns (the narrowest geometry), re-cuts on, both protocols
-    ("dfsph_1m", 8, 6, 2, 0, 0, None), ("dfsph_1m", 8, 4, 2, 0, 2, None)])
+    ("dfsph_1m", 8, 6, 2, 0, 0, None), ("dfsph_1m", 8, 4, 2, 0, 2, None),
+    # BASELINE config 4 in its named shape (VERDICT r5 missing #4): 10 M particles on 8 slabs of 13 owned + 4 ghost cell columns (0.4 M ghosts per interior rank),
+    # native transport in its default form, the cuts re-chosen on the way
+    ("dfsph_10m", 8, 3, 2, 0, 0, None)])
 def test_native_transport_on_the_loopback_stand_in(tmp_path, scene, world, steps, rebalance, layers, overlap, order):
     """The discipline a multi-GPU node runs -- the library's NATIVE transport: ncclSend / ncclRecv / ncclAllReduce enqueued by the library itself,
     no host wait between the sweeps, the halo of the edge tiles on its own stream under the interior tiles, the residual's all-reduce and the loop
