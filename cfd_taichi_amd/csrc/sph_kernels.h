@@ -747,53 +747,62 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
         if (i < c.n) cell_id_of(c, P[i].x, P[i].y, P[i].z, hcx, hcy, hcz);
         // a particle whose coordinates lie outside the grid is stored in a wrapped cell (or nowhere) and walks cells it is not stored in: kNbrOdd
         if (tile_nbr && i < c.n && (hcx < 0 || hcx >= c.gx || hcy < 0 || hcy >= c.gy || hcz < 0 || hcz >= c.gz)) s_odd = 1;
-        if (i < c.n && list_walker(c, id[i], hcx)) {
-            const int cx = hcx, cy = hcy, cz = hcz;
-            int px, py, pz;
-            // the first particle of every run of equal cell COORDINATES inserts the neighbourhood: particles that left the box share a
-            // (wrapped or "outside") cell index with particles whose coordinates, and hence neighbour cells, differ
-            bool head = threadIdx.x == 0 || id[i - 1] < 0;
-            if (!head) { const float4 pp = P[i - 1]; cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz); head = px != cx || py != cy || pz != cz; }
-            if (head)
-                for (int dx = -1; dx <= 1; ++dx)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dz = -1; dz <= 1; ++dz) {
-                            const int x = cx + dx, y = cy + dy, z = cz + dz;
-                            if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
-                            const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
-                            if (slot < 0) continue;
-                            int hq = stage_hash(slot);
-                            for (int probe = 0; probe < kStageHash; ++probe) {
-                                const int was = atomicCAS(&s_key[hq], -1, slot);
-                                if (was == slot) break;
-                                if (was == -1) { if (atomicAdd(&s_ncell, 1) >= kStageMaxCells) s_ok = 0; break; }
-                                if (s_ok == 0) break;
-                                hq = (hq + 1) & (kStageHash - 1);
-                            }
-                        }
-        }
-        // (DensFlow on slab handles: a particle WITHOUT a list -- a ghost of the outer column -- is still staged by its neighbours' tiles, and the kernel
-        // that unpacks its k / rho pushes on its behalf through THIS tile's row: the tiles around its cell go into the tile set directly)
-        if (tile_nbr && i < c.n && !list_walker(c, id[i], hcx)) {
-            bool head = threadIdx.x == 0;             // the first of a run of particles without a list in the same cell does it for the run
-            if (!head) {
+        // The first particle of every run of equal cell COORDINATES contributes the run's 27 cells (particles that left the box share a wrapped or
+        // "outside" cell index with particles whose coordinates, and hence neighbour cells, differ).  Round 6 (tools/bnl_timeline.py): those ~32 heads
+        // used to walk their 27 cells themselves, one dependent trip to the tile-rank table and one LDS atomic chain per cell, while the other 224
+        // lanes waited -- 22 of a workgroup's 75 us.  Now the heads only leave their coordinates in LDS and ALL lanes share the (head, cell) pairs.
+        // kind 1 (DensFlow on slab handles): a run of particles WITHOUT lists -- ghosts of the outer column -- which its neighbours' tiles stage all the
+        // same: the kernel that unpacks its k / rho pushes on its behalf through THIS tile's row, so the tiles around its cell go into the tile set.
+        int *s_head = reinterpret_cast<int *>(s_stage);           // (3 ints per head; the writer's staging rows are zeroed after this phase)
+        static_assert(4 * kBlock >= 3 * kBlock, "one head per thread at most");
+        {
+            const bool in = i < c.n;
+            const bool walks = in && list_walker(c, id[i], hcx);
+            const int kind = walks ? 0 : 1;
+            bool head = in && (walks || tile_nbr != nullptr);
+            if (head && threadIdx.x != 0) {
                 int px, py, pz;
                 const float4 pp = P[i - 1];
                 cell_id_of(c, pp.x, pp.y, pp.z, px, py, pz);
-                head = list_walker(c, id[i - 1], px) || px != hcx || py != hcy || pz != hcz;
+                const bool pwalks = list_walker(c, id[i - 1], px);
+                head = pwalks != walks || px != hcx || py != hcy || pz != hcz;
             }
-            if (head)
-                for (int dx = -1; dx <= 1; ++dx)
-                    for (int dy = -1; dy <= 1; ++dy)
-                        for (int dz = -1; dz <= 1; ++dz) {
-                            const int x = hcx + dx, y = hcy + dy, z = hcz + dz;
-                            if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
-                            const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
-                            if (slot < 0) continue;
-                            const int a = cell_start[slot], b = cell_start[slot + 1];
-                            for (int t = a / kBlock; b > a && t <= (b - 1) / kBlock; ++t) tile_set_insert(s_tset, t);
-                        }
+            const unsigned long long hb = __ballot(head);
+            const int ln = threadIdx.x & 63, wv0 = threadIdx.x >> 6;
+            if (ln == 0) s_wsum[wv0] = __popcll(hb);
+            __syncthreads();
+            int hbase = 0, nheads = 0;
+            for (int k = 0; k < kBlock / 64; ++k) { if (k < wv0) hbase += s_wsum[k]; nheads += s_wsum[k]; }
+            if (head) {
+                const int e = hbase + __popcll(hb & ((1ull << ln) - 1ull));
+                s_head[3 * e] = hcx; s_head[3 * e + 1] = hcy; s_head[3 * e + 2] = (hcz << 1) | kind;
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < nheads * 27; t += kBlock) {
+                const int e = t / 27, o = t - 27 * e;
+                const int o9 = o / 9, o3 = (o - 9 * o9) / 3;
+                const int x = s_head[3 * e] + o9 - 1, y = s_head[3 * e + 1] + o3 - 1, zk = s_head[3 * e + 2], z = (zk >> 1) + (o - 9 * o9 - 3 * o3) - 1;
+                if (x >= c.gx || y >= c.gy || z >= c.gz || x < 0 || y < 0 || z < 0) continue;
+                const int slot = cell_slot_xyz(c, x, y, z, x + y * c.sy + z * c.sz);
+                if (slot < 0) continue;
+                if (zk & 1) {
+                    const int a = cell_start[slot], b = cell_start[slot + 1];
+                    for (int tt = a / kBlock; b > a && tt <= (b - 1) / kBlock; ++tt) tile_set_insert(s_tset, tt);
+                    continue;
+                }
+                int hq = stage_hash(slot);
+                for (int probe = 0; probe < kStageHash; ++probe) {
+                    const int was = atomicCAS(&s_key[hq], -1, slot);
+                    if (was == slot) break;
+                    if (was == -1) { if (atomicAdd(&s_ncell, 1) >= kStageMaxCells) s_ok = 0; break; }
+                    if (s_ok == 0) break;
+                    hq = (hq + 1) & (kStageHash - 1);
+                }
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_stage[q * kBlock + threadIdx.x] = 0;       // (the head list is done with)
         __syncthreads();
         // (2) local base of every cell of the set (table order), the ordered source list, the verdict
         int own[kStageHash / kBlock], cfirst[kStageHash / kBlock], run = 0, rig = 0;

@@ -115,6 +115,23 @@ PATCHES = {
                        "int sph_debug_flow_stamp(SphHandle *h) { return h->flow_stamp; }\nint sph_debug_dens_capture(int stamp6, int stamp7)\n{\n    int v[2] = {stamp6, stamp7};\n    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sph::g_tl_capture), v, sizeof(v));\n}\n"
                        "int sph_debug_dens_timeline(int which, unsigned long long *out, int n)\n{\n    return which == 6 ? (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_tl6), sizeof(unsigned long long) * 4 * (size_t)n)\n                      : (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_tl7), sizeof(unsigned long long) * 4 * (size_t)n);\n}\n"
                        "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
+    # a CORRECT variant with a side effect (round 6): every workgroup of the staged list build leaves the clock of its thread 0 at the
+    # boundaries of its life -- begin, cell set built, plan written (runs, bases, tile row), after each of the three dx planes of the walk, end
+    # (tools/bnl_timeline.py: which phase of k_build_nl is the time?)
+    "bnl_timeline": [(K, "constexpr int kRunCap = 13;", "__device__ unsigned long long g_bnl[16384 * 8];\nconstexpr int kRunCap = 13;"),
+                     (K, "    if (gate && *gate == 0) return;       // Verlet handles: the lists still hold\n    __shared__ uint32_t s_stage[4 * kBlock];",
+                      "    if (gate && *gate == 0) return;       // Verlet handles: the lists still hold\n    const unsigned long long tl0 = wall_clock64();\n    unsigned long long tl1 = tl0, tl2 = tl0, tlp[3] = {tl0, tl0, tl0};\n    __shared__ uint32_t s_stage[4 * kBlock];"),
+                     (K, "        __syncthreads();\n        // (2) local base of every cell of the set (table order), the ordered source list, the verdict",
+                      "        __syncthreads();\n        tl1 = wall_clock64();\n        // (2) local base of every cell of the set (table order), the ordered source list, the verdict"),
+                     (K, "    constexpr int CHUNK = 4;\n    const bool staged = STAGED && s_ok != 0;", "    tl2 = wall_clock64();\n    constexpr int CHUNK = 4;\n    const bool staged = STAGED && s_ok != 0;"),
+                     (K, "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n    }\n    if (walker) {\n        wf.flush(self_local);",
+                      "        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        __builtin_amdgcn_wave_barrier();\n        tlp[dx + 1] = wall_clock64();\n    }\n    if (walker) {\n        wf.flush(self_local);"),
+                     (K, "    note_list_lengths(c, kf, kb, ds);\n}\n\n// ---- the list build for small scenes: one wave per dx-plane",
+                      "    note_list_lengths(c, kf, kb, ds);\n    if (STAGED && threadIdx.x == 0 && blockIdx.x < 16384) {\n        unsigned long long *o = g_bnl + (size_t)blockIdx.x * 8;\n        o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = tlp[0]; o[4] = tlp[1]; o[5] = tlp[2]; o[6] = wall_clock64(); o[7] = (unsigned long long)blk | ((unsigned long long)(unsigned)nruns << 32);\n    }\n}\n\n// ---- the list build for small scenes: one wave per dx-plane"),
+                     ("sph_mi355x.hip", "int sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{",
+                      "int sph_debug_bnl(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_bnl), sizeof(unsigned long long) * 8 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
+    # k_build_nl: eight candidates of a cell per trip instead of four (a CORRECT variant: same lists; round 6 A/B)
+    "bnl_chunk8": [(K, "    constexpr int CHUNK = 4;\n    const bool staged = STAGED && s_ok != 0;", "    constexpr int CHUNK = 8;\n    const bool staged = STAGED && s_ok != 0;")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
                   "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;"),
