@@ -431,7 +431,7 @@ FIRST_CONTACT_ORDER = ("start", "import", "init", "transport", "sync_ok", "disci
 def first_contact_verdict(stages, finished, why):
     """What the measuring ranks may rely on, from the stages the child reported ({stage: payload})."""
     v = {"backend": "gloo", "transport": "gloo", "discipline": None, "reached": [k for k in FIRST_CONTACT_ORDER if k in stages], "how": why}
-    if finished and "discipline" in stages:
+    if "discipline" in stages:             # everything was reported (a child that then fails to EXIT -- e.g. in destroy_process_group -- proved no less)
         v.update(backend="nccl", transport=stages["transport"].get("transport", "gloo"), discipline=stages["discipline"].get("discipline"))
     elif "sync_ok" in stages and stages.get("transport", {}).get("transport") == "rccl":
         v.update(backend="nccl", transport="rccl", discipline="sync")

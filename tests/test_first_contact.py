@@ -64,6 +64,7 @@ def alive(pid):
     ([START, IMPORT, INIT, RCCL, SYNC], "hang", ("nccl", "rccl", "sync")),       # a faster discipline hung: the proven one
     ([START, IMPORT, INIT, RCCL, SYNC], "die", ("nccl", "rccl", "sync")),        # ... or crashed
     ([START, IMPORT, INIT, RCCL, SYNC, NATIVE], "exit", ("nccl", "rccl", "native")),
+    ([START, IMPORT, INIT, RCCL, SYNC, NATIVE], "hang", ("nccl", "rccl", "native")),      # everything reported, then stuck on its way out: proven all the same
 ])
 def test_a_stuck_child_costs_the_limit_and_no_more(bench, tmp_path, stages, then, expect):
     pidfile = str(tmp_path / "pid")
@@ -74,7 +75,7 @@ def test_a_stuck_child_costs_the_limit_and_no_more(bench, tmp_path, stages, then
     assert (v["backend"], v["transport"], v["discipline"]) == expect, v
     assert v["reached"] == [s["stage"] for s in stages]
     assert took < 6.0 + 3.0, took
-    if then == "hang":
+    if then == "hang" and len(stages) < 6:
         assert took >= 1.0 and "killed" in v["how"]
     time.sleep(0.2)
     assert not alive(int(open(pidfile).read())), "the child survived"

@@ -47,6 +47,9 @@ def same(a, b, what):
 
 
 def hand_over_dfsph(sim, cfg):
+    # the parity these tests state is the parity of the PRODUCT DEFAULTS (the handle bench.py times), not of SPH_DEV=1 plus whatever the environment
+    # holds: the suite's conftest enables development overrides for the A/B suites, none may be in force here
+    assert sim.overrides() == [], sim.overrides()
     o = orc.Oracle(cfg, num_threads=cores())
     o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
     o.set(orc.F_WARM_K, sim.download(nat.F_WARM_K)); o.set_dt(sim.scalar(nat.S_DELTA_TIME))
@@ -105,6 +108,7 @@ def test_pressure_solvers_1m_mid_run_bit_exact(scene, solver, pre_steps):
     also last step's pressure (iisph_solver.py:68, 209-210)."""
     cfg = scenes.get(scene)
     sim = nat.Simulation(nat.config_from_dict(cfg))
+    assert sim.overrides() == [], sim.overrides()       # the product defaults, see hand_over_dfsph
     g_step = sim.step_pcisph if solver == "pcisph" else sim.step_iisph
     pre = [g_step(1) for _ in range(pre_steps)]
     assert all(s.lost == 0 for s in pre)           # (pcisph at 1 M runs into the reference's cap of 80 iterations now and then: that is the reference)
@@ -130,6 +134,7 @@ def test_wcsph_250k_steps_151_to_155_bit_exact():
     """Config 2 after 150 steps (the column has started to collapse, cells are ragged), then 5 steps on both."""
     cfg = scenes.get("wcsph_250k")
     sim = nat.Simulation(nat.config_from_dict(cfg))
+    assert sim.overrides() == [], sim.overrides()       # the product defaults, see hand_over_dfsph
     sim.step_wcsph(150)
     o = orc.Oracle(cfg, num_threads=cores())
     o.set(orc.F_POS, sim.download(nat.F_POS)); o.set(orc.F_VEL, sim.download(nat.F_VEL))
@@ -148,6 +153,7 @@ def test_dfsph_rigid_2m_two_coupled_steps_bit_exact():
     cfg = scenes.get("dfsph_rigid_2m")
     rg = mesh.rigid_from_config(cfg)
     sim = nat.Simulation(nat.config_from_dict(cfg, max_density_iters=40), rigid=rg)
+    assert sim.overrides() == [], sim.overrides()       # the product defaults, see hand_over_dfsph
     o = orc.Oracle(cfg, num_threads=cores(), rigid=rg)
     assert (sim.n_fluid, sim.n_wall, sim.n_rigid) == (o.N, o.Nb, o.Nr) and sim.n_fluid == 2006400
     for s in range(2):
