@@ -132,6 +132,8 @@ PATCHES = {
                       "int sph_debug_bnl(unsigned long long *out, int n)\n{\n    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sph::g_bnl), sizeof(unsigned long long) * 8 * (size_t)n);\n}\nint sph_tune_time(SphHandle *h, int which, unsigned lds_bytes, int reps, double *avg_us)\n{")],
     # k_build_nl: eight candidates of a cell per trip instead of four (a CORRECT variant: same lists; round 6 A/B)
     "bnl_chunk8": [(K, "    constexpr int CHUNK = 4;\n    const bool staged = STAGED && s_ok != 0;", "    constexpr int CHUNK = 8;\n    const bool staged = STAGED && s_ok != 0;")],
+    # k_build_nl at eight waves per SIMD (a CORRECT variant; the compiler must fit 96 SGPRs): does residency move the list build?  (round 6 A/B)
+    "bnl_waves8": [(K, "template <bool RIGID, bool STAGED>\n__global__ __launch_bounds__(kBlock) void k_build_nl(", "template <bool RIGID, bool STAGED>\n__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_build_nl(")],
     # the staging gathers of the residual sweeps removed (plan expansion and barriers kept)
     "nogather": [(K, "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = A[x.j[t][u]]; b[u] = B[x.j[t][u]]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;",
                   "        float4 a[kStageBatch], b[kStageBatch];\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u) { a[u] = make_float4((float)x.j[t][u], 0.f, 0.f, 0.f); b[u] = a[u]; }\n#pragma unroll\n        for (int u = 0; u < kStageBatch; ++u)\n            if (base + u * kBlock < nst) {\n                const int e = base + u * kBlock;"),
