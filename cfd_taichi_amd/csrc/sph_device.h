@@ -63,6 +63,7 @@ struct Consts {
     // lists of their own and run D1 and the correction sweeps like owned particles (k_build_nl: "walker"), so that their v / v* never has to
     // be refreshed inside a solver loop; ghost_walk = 1 on such handles
     int gw_left, gw_right, ghost_walk;
+    int nbr_cap;          // DensFlow: tiles a tile's row may name (kNbrStride - 1; SPH_NBR_CAP lowers it so that tests reach the "unknown row" fallback)
     // cell edge of the grid the particles are binned into (cell_id_of).  Equal to h -- the reference's grid, ParticleSystem.py:100-101,490-494 --
     // except on Verlet handles (wcsph under the relaxed arithmetic, sph_relaxed_kernels.h): there the lists hold every pair within
     // h + skin = hcell and are rebuilt only once a particle has moved more than skin / 2 since the last build (verlet_thr2 = (skin / 2)^2)

@@ -679,6 +679,9 @@ int alloc_device(SphHandle *h, const HostScene &sc)
                 if ((rc = dalloc(h, &h->need6, nt)) || (rc = dalloc(h, &h->need7, nt)) || (rc = dalloc(h, &h->tile_nz, nt))) return rc;
                 if ((rc = dalloc(h, &h->worked6, nt)) || (rc = dalloc(h, &h->worked7, nt))) return rc;
                 if ((rc = dalloc(h, &h->dens_bcast, 64))) return rc;
+                // (SPH_NBR_CAP: fewer tiles per row than fit -- most rows then say "unknown" and their tiles take the broadcast / always-run fallback: tests)
+                const char *cap = dev_env(&h->overrides, "SPH_NBR_CAP");
+                h->c.nbr_cap = cap ? std::min(std::max(atoi(cap), 0), kNbrStride - 1) : kNbrStride - 1;
             }
             if ((h->cfg.solver == SPH_SOLVER_PCISPH || h->cfg.solver == SPH_SOLVER_IISPH) && !h->slab && h->opt_tile_skip)
                 if ((rc = dalloc(h, &h->pci_zero_press, (n + kBlock - 1) / kBlock + 64))) return rc;

@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kBlock) void k_build_nl(Consts c, const float4 *__r
             const int inc = wave_inclusive_scan(na);
             const int ntile = __shfl(inc, 63, 64);
             int *row = tile_nbr + (size_t)blk * kNbrStride;
-            const bool fits = ok && ntile <= kNbrStride - 1 && ntile < kTileSet;       // (a full table may have dropped a tile)
+            const bool fits = ok && ntile <= c.nbr_cap && ntile < kTileSet;             // (a full table may have dropped a tile)
             int pos = inc - na;
             if (fits && ta >= 0) row[1 + pos++] = ta;
             if (fits && tb >= 0) row[1 + pos] = tb;

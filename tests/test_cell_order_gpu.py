@@ -200,14 +200,17 @@ def test_density_loop_change_propagation_is_invisible(scene, steps, cap, arith, 
     monkeypatch.setenv("SPH_STAGE_CAP", cap)
     monkeypatch.setenv("SPH_CELL_ORDER", "morton")
     sims = []
-    for skip, push in (("1", "1"), ("1", "0"), ("0", "1")):
+    for skip, push, cap_rows in (("1", "1", None), ("1", "0", None), ("0", "1", None), ("1", "1", "6")):
         monkeypatch.setenv("SPH_TILE_SKIP", skip)
         monkeypatch.setenv("SPH_DENS_PUSH", push)
+        if cap_rows:          # rows of at most six tiles: most tiles' rows say "unknown" -- they always run and, as producers, raise the broadcast word
+            monkeypatch.setenv("SPH_NBR_CAP", cap_rows)
         sims.append(nat.Simulation(nat.config_from_dict(cfg, arith=arith)))
+        monkeypatch.delenv("SPH_NBR_CAP", raising=False)
     n_dens = []
     for s_ in range(steps):
-        a, b, c_ = sims[0].step_dfsph(1), sims[1].step_dfsph(1), sims[2].step_dfsph(1)
-        for o in (b, c_):
+        a, b, c_, d_ = (sm.step_dfsph(1) for sm in sims)
+        for o in (b, c_, d_):
             assert (a.n_div, a.n_dens, a.div_err, a.dens_err, a.dt) == (o.n_div, o.n_dens, o.div_err, o.dens_err, o.dt), (scene, s_)
         n_dens.append(a.n_dens)
     for f in FIELDS + (nat.F_RHO_ADV, nat.F_WARM_K, nat.F_ALPHA):

@@ -15,7 +15,7 @@ python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --ti
 if [ -n "$prof" ]; then
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d $R/${out}_trace -o trace -- python3 $R/tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --overlap ${LOOPBACK_OVERLAP:-0} --rebalance ${LOOPBACK_REBALANCE:-0} --replay-rank $rank --load-log $log --one-gpu --out $R/$out.json || exit 1
-  cd $R && python3 tools/replay_trace.py ${out}_trace 0 3000 > $out.kernels.txt && python3 tools/replay_trace.py ${out}_trace 1 > $out.one_gpu_kernels.txt && rm -rf ${out}_trace && tail -80 $out.kernels.txt && grep -A12 "^kernel " $out.one_gpu_kernels.txt
+  cd $R && python3 tools/replay_trace.py ${out}_trace 0 3000 > $out.kernels.txt && python3 tools/replay_trace.py ${out}_trace 0 @k_dfsph_integrate:10:1800 | sed -n "/^timeline slice/,\$p" > $out.exchange_slice.txt && python3 tools/replay_trace.py ${out}_trace 1 > $out.one_gpu_kernels.txt && rm -rf ${out}_trace && tail -80 $out.kernels.txt && grep -A12 "^kernel " $out.one_gpu_kernels.txt
 else
   python3 tests/loopback_worker.py --scene $scene --world $world --steps $pre --time $timed --no-compare --overlap ${LOOPBACK_OVERLAP:-0} --rebalance ${LOOPBACK_REBALANCE:-0} --replay-rank $rank --load-log $log --one-gpu --out $out.json || exit 1
 fi

@@ -63,13 +63,21 @@ for (a_, b_), (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
     print("%-30s %-30s %7d %10.1f %8.2f" % (a_, b_, n, t, t / n))
 
 # a slice of the timeline: every launch of ~600 us in the middle of the window, with its queue (= stream)
+# (argv[3] = offset in us, or "@kernel:k:length_us" = from the k-th launch of that kernel in the window)
 if len(sys.argv) > 3:
-    t0 = int(rows[a]["End_Timestamp"]) + int(float(sys.argv[3]) * 1e3)
+    length = 600000
+    if sys.argv[3].startswith("@"):
+        kname, kth, lus = sys.argv[3][1:].split(":")
+        hits = [r for r in win if kname in r["Kernel_Name"]]
+        t0 = int(hits[int(kth)]["Start_Timestamp"])
+        length = int(float(lus) * 1e3)
+    else:
+        t0 = int(rows[a]["End_Timestamp"]) + int(float(sys.argv[3]) * 1e3)
     qs = {}
     print("\ntimeline slice from +%s us (columns: start, end, duration [us]; queue; kernel)" % sys.argv[3])
     for r in win:
         s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        if s_ < t0 or s_ > t0 + 600000:
+        if s_ < t0 or s_ > t0 + length:
             continue
         q = r.get("Queue_Id", "?")
         qs.setdefault(q, len(qs))
