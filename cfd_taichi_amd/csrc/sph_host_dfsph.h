@@ -61,12 +61,12 @@ int stage_sort_and_lists(SphHandle *h)
         ProfScope ps(h, K_ORDER_GATHER);
         hipLaunchKernelGGL(k_order_gather, g, b, 0, s, c, h->cell_of, h->cell_start, h->slot_src, h->P[h->pcur], h->V[h->vcur],
                            carry ? h->warm[h->wcur] : (const float *)nullptr, h->id[h->icur], h->P[1 - h->pcur], h->V[1 - h->vcur],
-                           h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr, gate, h->x0);
+                           h->warm[1 - h->wcur], h->id[1 - h->icur], rigid_coupled(h) ? h->pos_orig : (float4 *)nullptr, gate, h->x0,
+                           h->slab ? h->dead : (int *)nullptr);
         h->pcur ^= 1; h->vcur ^= 1; h->icur ^= 1;
         if (carry) h->wcur ^= 1;
     }
     if (h->slab) {
-        HIP_TRY(h, hipMemsetAsync(h->dead, 0, sizeof(int) * (size_t)c.n, s));
         ProfScope ps(h, K_SLAB);
         // ordered edge lists: list k, column l (0 = next to the cut): ghost-left x_lo - 1 - l, send-left x_lo + l, send-right x_hi - 1 - l, ghost-right x_hi + l
         const SlabGeom &sg = h->geom;
@@ -82,10 +82,10 @@ int stage_sort_and_lists(SphHandle *h)
             }
         }
         if (jobs.n) {
-            hipLaunchKernelGGL(k_layer_offsets, dim3(jobs.n), dim3(kScanBlock), 0, s, c, h->cell_start, jobs);
+            hipLaunchKernelGGL(k_layer_offsets, dim3(jobs.n), dim3(kScanBlock), 0, s, c, h->cell_start, jobs, h->opt_layer_generic ? 1 : 0);
             hipLaunchKernelGGL(k_layer_list, dim3(grid_for(c.gy * c.gz).x, jobs.n), b, 0, s, c, h->cell_start, jobs);
         }
-        if (dev_env(&h->overrides, "SPH_SLAB_CHECK")) {       // the host's bookkeeping of the column populations against the sorted arrays
+        if (h->opt_slab_check) {       // the host's bookkeeping of the column populations against the sorted arrays
             for (int k = 0; k < 4; ++k)
                 for (int l = 0; l < sg.layers; ++l) {
                     if (!(k < 2 ? sg.has_left : sg.has_right)) continue;

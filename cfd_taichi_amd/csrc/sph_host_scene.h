@@ -766,7 +766,8 @@ int alloc_device(SphHandle *h, const HostScene &sc)
         HIP_TRY(h, hipMemcpyAsync(h->tile_rank, tile_rank.data(), sizeof(int) * tile_rank.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->c.tile_rank = h->tile_rank;
-        if (h->slab && !dev_env(&h->overrides, "SPH_SLAB_GRID_FULL")) {         // (SPH_SLAB_GRID_FULL=1: the whole grid's slots on every rank, as before round 6 -- A/B, tests)
+        const char *grid_full = dev_env(&h->overrides, "SPH_SLAB_GRID_FULL");
+        if (h->slab && !(grid_full && atoi(grid_full) != 0)) {         // (SPH_SLAB_GRID_FULL=1: the whole grid's slots on every rank, as before round 6 -- A/B, tests)
             h->tile_rank_full = tile_rank;
             if ((rc = slab_local_grid(h))) return rc;
         }

@@ -339,10 +339,12 @@ __global__ __launch_bounds__(kBlock) void k_order_gather(Consts c, const int *__
                                                          const int *__restrict__ id_in, float4 *__restrict__ Pout,
                                                          float4 *__restrict__ Vout, float *__restrict__ warm_out,
                                                          int *__restrict__ id_out, float4 *__restrict__ pos_orig,
-                                                         const int *__restrict__ gate = nullptr, float4 *__restrict__ x0 = nullptr)
+                                                         const int *__restrict__ gate = nullptr, float4 *__restrict__ x0 = nullptr,
+                                                         int *__restrict__ dead = nullptr)
 {
     int d = blockIdx.x * kBlock + threadIdx.x;
     if (d >= c.n) return;
+    if (dead) dead[d] = 0;              // slab handles: every sorted slot is alive (was a memset of its own, two fill launches per step)
     if (gate && *gate == 0) {           // Verlet handles between two builds: the order stands, the arrays only change roles (the host flips its buffer indices every step)
         Pout[d] = Pin[d]; Vout[d] = Vin[d]; id_out[d] = id_in[d];
         if (warm_in) warm_out[d] = warm_in[d];

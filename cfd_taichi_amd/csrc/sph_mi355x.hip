@@ -205,6 +205,8 @@ struct SphHandle {
     int flow_stamp = 0, flow_last = 0;          // launch counter of the density loop's sweeps; the stamp of the sweep enqueued last
     DensFlow flow_d6 = kNoFlow;                 // ... and the residual sweep's whole block: a split sweep's second launch and the kernel that unpacks the ghosts' k / rho push with it
     bool opt_dens_push = true;
+    bool opt_layer_generic = false;  // SPH_LAYER_GENERIC=1: k_layer_offsets in the form columns of more than 18 432 cells take (tests)
+    bool opt_slab_check = false;     // SPH_SLAB_CHECK=1: the host's edge-column bookkeeping against the sorted arrays, every step (tests, soak runs)
     bool own_red = false;
     int rebalance_every = 0, steps_since_rebalance = 0, n_recuts = 0;
     int *col_hist = nullptr, *col_hist_host = nullptr;
@@ -334,6 +336,8 @@ int sph_create(const SphConfig *cfg, SphHandle **out)
     h->cfg = *cfg;
     h->device = cfg->device;
     { const char *e = dev_env(&h->overrides, "SPH_SLAB_GATHER"); h->opt_gather = !(e && atoi(e) == 0); }
+    { const char *e = dev_env(&h->overrides, "SPH_LAYER_GENERIC"); h->opt_layer_generic = e && atoi(e) != 0; }
+    { const char *e = dev_env(&h->overrides, "SPH_SLAB_CHECK"); h->opt_slab_check = e && atoi(e) != 0; }       // ("0" is off: eight blocking read-backs per step otherwise)
     { const char *e = dev_env(&h->overrides, "SPH_NL16"); h->opt_nl16 = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_KR_SPLIT"); h->opt_kr_split = !(e && atoi(e) == 0); }
     { const char *e = dev_env(&h->overrides, "SPH_TILE_SKIP"); h->opt_tile_skip = !(e && atoi(e) == 0); }

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(kScanBlock) void k_classify_scan(int nblk, int *__r
         const int slot = q == 0 ? 0 : q == 1 ? 8 : q == 2 ? -1 : q <= 6 ? q - 2 : 8 + q - 6;       // 3..6 -> 1..4, 7..10 -> 9..12
         if (wire && slot >= 0) wire[slot] = total;
     }
+    if (wire && blockIdx.x == 0 && threadIdx.x < 16) wire[16 + threadIdx.x] = 0;        // what an absent neighbour "sent" (the receive half of the count exchange: wire[16..32))
 }
 __global__ __launch_bounds__(kBlock) void k_classify_write(Consts c, SlabGeom g, int mode, const float4 *__restrict__ P, const float4 *__restrict__ V,
                                                            const float *__restrict__ warm, int *__restrict__ id, int *__restrict__ dead,
@@ -253,13 +254,51 @@ __global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restr
 // over the cells), then each thread the offsets of its run of consecutive cells.  (One single-workgroup launch per column, 256 cells per
 // trip, was 56 us x 8 per step on config 4's 153 x 113 cell cut.)
 struct LayerJobs { int n; int col[8]; int *off[8]; int *list[8]; };
-__global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, LayerJobs jobs)
+// (round 6: up to kLayerDeep * kScanBlock cells per column -- config 4 has 153 x 113 = 17 289 -- every thread keeps the counts of cells t, t + 1024, ...
+// in registers, all their loads in flight at once, and the offsets come from one block-wide scan per round of 1024 cells: loads and stores are
+// coalesced.  The first form gave every thread 17 CONSECUTIVE cells: its 64-lines-per-instruction loads and stores through the one CU of a
+// workgroup were the whole 33 us; 9 us now.  Larger columns keep that form.)
+constexpr int kLayerDeep = 18;
+__global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, LayerJobs jobs, int generic)
 {
     __shared__ int s_w[kScanBlock / 64];
+    __shared__ int s_tot[kLayerDeep][kScanBlock / 64];
     const int layer_cx = jobs.col[blockIdx.x];
     int *__restrict__ off = jobs.off[blockIdx.x];
     const int ncol = c.gy * c.gz;
     const bool valid = layer_cx >= 0 && layer_cx < c.gx;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (ncol <= kLayerDeep * kScanBlock && !generic) {         // (generic: SPH_LAYER_GENERIC=1, so that tests reach the form larger columns take)
+        int slot[kLayerDeep], v[kLayerDeep], inc[kLayerDeep];
+#pragma unroll
+        for (int j = 0; j < kLayerDeep; ++j) {
+            const int k = (int)threadIdx.x + j * kScanBlock;
+            slot[j] = -1;
+            if (valid && k < ncol) {
+                const int y = k / c.gz, z = k - y * c.gz;
+                slot[j] = cell_slot_xyz(c, layer_cx, y, z, layer_cx + y * c.sy + z * c.sz);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kLayerDeep; ++j) v[j] = slot[j] < 0 ? 0 : cell_start[slot[j] + 1] - cell_start[slot[j]];
+#pragma unroll
+        for (int j = 0; j < kLayerDeep; ++j) {
+            inc[j] = wave_inclusive_scan(v[j]);
+            if (lane == 63) s_tot[j][w] = inc[j];
+        }
+        __syncthreads();
+        int carry = 0;                                     // cells of the rounds before j, then of the waves before w in round j
+#pragma unroll
+        for (int j = 0; j < kLayerDeep; ++j) {
+            int before = carry, total = 0;
+            for (int q = 0; q < kScanBlock / 64; ++q) { const int t = s_tot[j][q]; if (q < w) before += t; total += t; }
+            const int k = (int)threadIdx.x + j * kScanBlock;
+            if (k < ncol) off[k] = before + inc[j] - v[j];
+            carry += total;
+        }
+        if (threadIdx.x == 0) off[ncol] = carry;
+        return;
+    }
     for (int k = threadIdx.x; k < ncol; k += kScanBlock) {
         int v = 0;
         if (valid) {
@@ -275,7 +314,6 @@ __global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const in
     int t = 0;
     for (int i = lo; i < hi; ++i) t += off[i];
     const int inc = wave_inclusive_scan(t);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) s_w[w] = inc;
     __syncthreads();
     int before = inc - t, total = 0;

@@ -210,11 +210,12 @@ def test_solver_attributes_on_slab_handles(tmp_path, overlap):
 
 def test_slab_protocol_can_be_switched_between_steps(tmp_path):
     """sph_slab_set_overlap: the dfsph loops with the halo and the reductions on their own streams, or in order on the handle's -- switched every
-    seven steps on every rank alike (bench.py times both on the node it runs on and keeps the faster): the same bits as one GPU throughout."""
+    seven steps on every rank alike (bench.py times both on the node it runs on and keeps the faster): the same bits as one GPU throughout.
+    (SPH_LAYER_GENERIC=1: the edge lists' offsets in the form columns of more than 18 432 cells take, with the host's bookkeeping checked against them.)"""
     out = tmp_path / "toggle.json"
     cmd = [sys.executable, os.path.join(ROOT, "tests", "loopback_worker.py"), "--scene", "breaking_dam_30k_dfsph", "--world", "3", "--steps", "45",
            "--rebalance", "11", "--toggle-overlap", "7", "--out", str(out)]
-    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, SPH_SLAB_CHECK="1", SPH_CELL_ORDER="morton"), capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, SPH_SLAB_CHECK="1", SPH_CELL_ORDER="morton", SPH_LAYER_GENERIC="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     r = json.loads(out.read_text())
     assert r["pos_equal"] and r["vel_equal"] and r["rho_equal"] and r["stats_equal"], {k: r[k] for k in ("pos_rel_err", "vel_rel_err", "stats_last", "ref_stats_last")}
