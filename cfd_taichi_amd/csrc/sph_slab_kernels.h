@@ -256,8 +256,8 @@ __global__ __launch_bounds__(kBlock) void k_append_records(const float4 *__restr
 struct LayerJobs { int n; int col[8]; int *off[8]; int *list[8]; };
 // (round 6: up to kLayerDeep * kScanBlock cells per column -- config 4 has 153 x 113 = 17 289 -- every thread keeps the counts of cells t, t + 1024, ...
 // in registers, all their loads in flight at once, and the offsets come from one block-wide scan per round of 1024 cells: loads and stores are
-// coalesced.  The first form gave every thread 17 CONSECUTIVE cells: its 64-lines-per-instruction loads and stores through the one CU of a
-// workgroup were the whole 33 us; 9 us now.  Larger columns keep that form.)
+// coalesced.  The first form gave every thread 17 CONSECUTIVE cells and read its counts back from memory: 33 us; 21 us now, of which the launch
+// itself is 5.  Larger columns keep that form.)
 constexpr int kLayerDeep = 18;
 __global__ __launch_bounds__(kScanBlock) void k_layer_offsets(Consts c, const int *__restrict__ cell_start, LayerJobs jobs, int generic)
 {
