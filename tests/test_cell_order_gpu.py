@@ -104,7 +104,7 @@ def test_rigid_coupling_on_the_morton_curve(monkeypatch):
     sim.close(); o.close()
 
 
-@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_dam_x", 3, 160, 7), ("dfsph_tiny_wall_iisph", 2, 200, 9)])
+@pytest.mark.parametrize("scene,world,steps,rebalance", [("dfsph_dam_x", 3, 120, 7), ("dfsph_tiny_wall_iisph", 2, 200, 9)])
 def test_slabs_on_the_morton_curve(tmp_path, monkeypatch, scene, world, steps, rebalance):
     """Edge and ghost lists enumerate cell columns in (y, z) order whatever the storage order: slabs still match one GPU."""
     monkeypatch.setenv("SPH_CELL_ORDER", "morton")

@@ -76,7 +76,7 @@ def test_pressure_solvers_on_slabs(tmp_path, scene, world, steps):
 
 
 @pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap", [
-    ("dfsph_small", 3, 25, 0, 1, 0), ("dfsph_dam_x", 3, 140, 7, 1, 0), ("dfsph_dam_x", 3, 140, 7, 2, 1), ("breaking_dam_30k_dfsph", 4, 12, 3, 2, 0)])
+    ("dfsph_small", 3, 25, 0, 1, 0), ("dfsph_dam_x", 3, 100, 7, 1, 0), ("dfsph_dam_x", 3, 100, 7, 2, 1), ("breaking_dam_30k_dfsph", 4, 12, 3, 2, 0)])
 def test_ghost_column_protocols_agree(tmp_path, scene, world, steps, rebalance, layers, overlap):
     # (with the split on, the residual's all-reduce + loop decision also run on a third stream under the next correction sweep: the density loop's D7
     # needs no speculation, the divergence loop's D4 runs ahead of its decision and is undone when the decision closes the loop -- from rest that is
@@ -144,10 +144,10 @@ def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0
 
 
 @pytest.mark.parametrize("scene,world,steps,rebalance,layers,overlap,order", [
-    ("dfsph_small", 2, 25, 0, 0, 2, "morton"), ("dfsph_dam_x", 3, 200, 7, 0, 2, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
+    ("dfsph_small", 2, 25, 0, 0, 2, "morton"), ("dfsph_dam_x", 3, 140, 7, 0, 2, "morton"), ("dfsph_dam_x", 3, 120, 7, 1, 0, "morton"),
     ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 2, "morton"), ("breaking_dam_30k_dfsph", 3, 30, 0, 0, 1, None), ("dfsph_rigid_tilted", 3, 80, 9, 0, 2, "morton"),
     # overlap = 0: the native transport STARTS in order, with the residual's (sum, count, flags) gathered from every slab in the halo's own group of transfers
-    ("dfsph_dam_x", 3, 200, 7, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, None),
+    ("dfsph_dam_x", 3, 140, 7, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, None),
     ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None),
     # world = 8, the size BASELINE's scaling target names: slabs of 12-13 owned + 4 ghost cell columns (the narrowest geometry), re-cuts on, both protocols
     ("dfsph_1m", 8, 6, 2, 0, 0, None), ("dfsph_1m", 8, 4, 2, 0, 2, None),
