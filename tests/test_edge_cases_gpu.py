@@ -65,7 +65,7 @@ def test_coincident_particles_and_cell_faces(solver):
     sim.close(); o.close()
 
 
-@pytest.mark.parametrize("scene,solver,steps", [("dfsph_dam_x", "dfsph", 1000), ("wcsph_dam_x", "wcsph", 5000), ("dfsph_tiny_wall_iisph", "iisph", 800),
+@pytest.mark.parametrize("scene,solver,steps", [("dfsph_dam_x", "dfsph", 700), ("wcsph_dam_x", "wcsph", 5000), ("dfsph_tiny_wall_iisph", "iisph", 800),
                                                 ("dfsph_tiny_wall_pcisph", "pcisph", 500)])
 def test_long_runs_with_wall_leaks_match_oracle(scene, solver, steps):
     """Hundreds to thousands of steps on small scenes whose single-layer walls leak: particles whose 1-D cell index wraps into a far cell

@@ -150,7 +150,7 @@ def run_loopback(tmp_path, scene, world, steps, rebalance=0, layers=0, overlap=0
     ("dfsph_dam_x", 3, 140, 7, 0, 0, "morton"), ("breaking_dam_30k_dfsph", 4, 40, 3, 0, 0, "morton"), ("dfsph_rigid_tilted", 3, 80, 9, 0, 0, None),
     ("wcsph_small", 2, 60, 0, 0, 0, None), ("breaking_dam_30k_iisph", 3, 10, 0, 0, 0, None), ("breaking_dam_30k_pcisph", 2, 6, 0, 0, 0, None),
     # world = 8, the size BASELINE's scaling target names: slabs of 12-13 owned + 4 ghost cell columns (the narrowest geometry), re-cuts on, both protocols
-    ("dfsph_1m", 8, 6, 2, 0, 0, None), ("dfsph_1m", 8, 4, 2, 0, 2, None),
+    ("dfsph_1m", 8, 4, 2, 0, 2, None),          # (in order at world = 8: the 10 M case below)
     # BASELINE config 4 in its named shape (VERDICT r5 missing #4): 10 M particles on 8 slabs of 13 owned + 4 ghost cell columns (0.4 M ghosts per interior rank),
     # native transport in its default form, the cuts re-chosen on the way
     ("dfsph_10m", 8, 3, 2, 0, 0, None)])
@@ -255,6 +255,8 @@ def test_rebalanced_slabs_match_single_gpu(tmp_path, scene, world, steps, min_re
     assert all(s["recuts"] == r["slabs"][0]["recuts"] for s in r["slabs"]) and r["slabs"][0]["recuts"] >= min_recuts, r["slabs"]
     for a, b in zip(r["slabs"][:-1], r["slabs"][1:]):
         assert a["x_hi"] == b["x_lo"]
+    if scene.startswith("wcsph"):       # (the load comparison below on the dfsph scene only: a second 1400-step run buys nothing)
+        return
     static = run_slabs(tmp_path, scene, world, steps, rebalance=0)
     assert static["pos_equal"]
     # the cuts balance particles + ghosts (balanced_cuts in csrc/sph_host_scene.h): compare what they balance; every slab keeps >= 3 columns -- ghost
